@@ -1,0 +1,115 @@
+/* mdl_hip.h — C ABI of libmdl_hip.so, the MI355X (gfx950) message-passing engine for
+ * MatDeepLearn-style crystal-graph networks.
+ *
+ * The reference (Fung-Lab/MatDeepLearn) is pure Python and has NO FFI of its own: every kernel on
+ * its hot path lives in third-party wheels (torch_scatter, torch_geometric on ATen).  Each entry
+ * point below therefore cites the reference call site (paths relative to /root/reference) whose
+ * third-party operator it replaces.  The binding a maintainer adds on the reference side is a
+ * ctypes stub — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (HBM) unless marked "host".  The caller owns every buffer,
+ *     including scratch/outputs; the library never allocates, frees or synchronises.
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - Return value: 0 = ok, negative = error (MDL_E_*); mdl_last_error_string() gives the text
+ *     (thread-local).  No exceptions cross the boundary.
+ *   - dtype: MDL_F32 (parity mode, exact-fp32 MFMA / VALU) or MDL_BF16 (bf16 storage, fp32
+ *     accumulation).  Index arrays are int32.
+ *   - Graph layout: edges are given in CSR order BY TARGET node:
+ *       rowptr[N+1]  first CSR slot of every target node
+ *       src[E]       source node of CSR slot k           (edge_index[0] permuted)
+ *       tgt[E]       target node of CSR slot k           (edge_index[1] permuted, non-decreasing)
+ *       eperm[E]     original edge id of CSR slot k, or NULL when the caller's per-edge arrays
+ *                    (edge_attr, ...) are already stored in CSR order.
+ *   - Stateless and re-entrant; safe to call from one thread per device/stream.
+ */
+#ifndef MDL_HIP_H
+#define MDL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDL_VERSION 100 /* 0.1.0 */
+
+enum { MDL_F32 = 0, MDL_BF16 = 1 };
+enum { MDL_SUM = 0, MDL_MEAN = 1, MDL_MAX = 2 };
+enum {
+    MDL_OK = 0,
+    MDL_E_ARG = -1,     /* bad shape / null pointer / misaligned buffer */
+    MDL_E_UNSUPP = -2,  /* unsupported C / G / dtype combination        */
+    MDL_E_LAUNCH = -3   /* hipGetLastError() after a launch             */
+};
+
+typedef void* mdlStream_t; /* hipStream_t */
+
+int mdl_version(void);
+const char* mdl_last_error_string(void);
+
+/* ---- K1: Gaussian RBF edge expansion ------------------------------------------------------
+ * Replaces GaussianSmearing.forward, matdeeplearn/process/process.py:588-590 (instantiated
+ * (0, 1, graph_edge_length, 0.2) at :500-502, applied per graph at :506-509):
+ *     out[e, k] = exp(coeff * (d[e] - offsets[k])^2)
+ * d: [E] fp32 (normalised distance, process.py:647-653); offsets: [G] fp32 (the linspace buffer);
+ * out: [E, G] row-major with leading dimension ld_out (>= G) in `out_dtype`. */
+int mdl_rbf_expand(const float* d, const float* offsets, float coeff, void* out, int64_t E, int G,
+                   int64_t ld_out, int out_dtype, mdlStream_t stream);
+
+/* ---- CSR helpers ---------------------------------------------------------------------------
+ * rowptr[n] = lower_bound(sorted_index, n) for n in [0, N]; sorted_index: [E] int32 non-decreasing.
+ * Stands in for the implicit index handling inside torch_scatter / PyG propagate. */
+int mdl_csr_rowptr(const int32_t* sorted_index, int64_t E, int64_t N, int32_t* rowptr, mdlStream_t stream);
+
+/* ---- K5: segmented reduce (scatter with a sorted index) -------------------------------------
+ * Replaces torch_scatter.scatter / scatter_mean as called at matdeeplearn/models/megnet.py:86,
+ * 130-132,342-348 and inside PyG global_{mean,add,max}_pool (matdeeplearn/models/cgcnn.py:154):
+ *     out[n, :] = reduce_{k in [rowptr[n], rowptr[n+1])} src[perm ? perm[k] : k, :]
+ * mean divides by max(count,1); empty segments give 0 (also for max).  src: [E, C]; out: [N, C];
+ * argmax: [N, C] int32 (row index into src, -1 for empty; required for MDL_MAX, else may be NULL). */
+int mdl_segment_reduce_fwd(const void* src, const int32_t* rowptr, const int32_t* perm, void* out,
+                           int32_t* argmax, int64_t N, int64_t C, int reduce, int dtype, mdlStream_t stream);
+/* grad_src[perm?perm[k]:k, :] = grad_out[seg[k], :] (/count for mean); for MDL_MAX grad goes to the
+ * argmax row only (grad_src must be zero-filled by the caller).  seg: [E] int32 segment id of slot k. */
+int mdl_segment_reduce_bwd(const void* grad_out, const int32_t* rowptr, const int32_t* seg,
+                           const int32_t* perm, const int32_t* argmax, void* grad_src, int64_t N,
+                           int64_t E, int64_t C, int reduce, int dtype, mdlStream_t stream);
+
+/* ---- K2/K3: fused CGConv ------------------------------------------------------------------
+ * Replaces torch_geometric.nn.CGConv(channels=C, dim=G, aggr, batch_norm=False) as constructed at
+ * matdeeplearn/models/cgcnn.py:80-83 and called at cgcnn.py:136-145:
+ *     z_k   = [ x[tgt_k] | x[src_k] | edge_attr_k ]                      (2C+G)
+ *     m_k   = sigmoid(W_f z_k + b_f) * softplus(W_s z_k + b_s)           (C)
+ *     out_i = x_i + aggr_{k: tgt_k = i} m_k                             aggr in {MDL_MEAN, MDL_SUM}
+ *
+ * Weights are handed over pre-packed (mdl_cgconv_pack_weights) so the per-step cost of converting
+ * the fp32 master weights is one tiny kernel.
+ *   wpack: mdl_cgconv_wpack_bytes(C,G,dtype) bytes; bpack: [2*Cp] fp32, Cp = 32*ceil(C/32).
+ *   w_f, w_s: [C, 2C+G] fp32 row-major (nn.Linear layout, column order target|source|edge);
+ *   b_f, b_s: [C] fp32 or NULL. */
+size_t mdl_cgconv_wpack_bytes(int C, int G, int dtype);
+int mdl_cgconv_pack_weights(const float* w_f, const float* b_f, const float* w_s, const float* b_s, int C,
+                            int G, void* wpack, float* bpack, int dtype, mdlStream_t stream);
+
+/* x: [N, C]; edge_attr: [E, G] (leading dim G); out: [N, C]; all in `dtype`. */
+int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
+                   const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
+                   void* out, int64_t N, int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream);
+
+/* Backward edge pass.  With dpre_k = d loss / d (W z_k + b) in R^{2Cp} (f half | s half):
+ *     r_tgt[i, :] = sum_{k: tgt_k = i} dpre_k      written once per node (no atomics)
+ *     r_src[j, :] += sum_{k: src_k = j} dpre_k     fp32 atomics; caller zero-fills
+ *     dwe[c, g]   += sum_k dpre_k[c] * edge_attr_k[g]   [2Cp, Gp] fp32, Gp = 64*ceil(G/64); caller zero-fills
+ * from which the caller forms (dense GEMMs): dx = g + r_tgt W_tgt + r_src W_src, dW_tgt = r_tgt^T x,
+ * dW_src = r_src^T x, db = colsum(r_tgt).  The gate pre-activations are recomputed, not stored. */
+int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
+                   const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
+                   const void* grad_out, float* r_tgt, float* r_src, float* dwe, int64_t N, int64_t E,
+                   int C, int G, int aggr, int dtype, mdlStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDL_HIP_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of libmdl_hip.so (include/mdl_hip.h).  There is NO CPU fallback: if the HIP
+library is missing, or a tensor is not on a HIP device, the ops raise."""
+import ctypes
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmdl_hip.so")
+
+MDL_F32, MDL_BF16 = 0, 1
+MDL_SUM, MDL_MEAN, MDL_MAX = 0, 1, 2
+REDUCE = {"sum": MDL_SUM, "add": MDL_SUM, "mean": MDL_MEAN, "max": MDL_MAX}
+
+_vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); kept in one table so tests can check it against include/mdl_hip.h
+PROTOTYPES = {
+    "mdl_version": (_i32, []),
+    "mdl_last_error_string": (ctypes.c_char_p, []),
+    "mdl_rbf_expand": (_i32, [_vp, _vp, _f32, _vp, _i64, _i32, _i64, _i32, _vp]),
+    "mdl_csr_rowptr": (_i32, [_vp, _i64, _i64, _vp, _vp]),
+    "mdl_segment_reduce_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "mdl_segment_reduce_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
+    "mdl_cgconv_wpack_bytes": (_sz, [_i32, _i32, _i32]),
+    "mdl_cgconv_pack_weights": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "mdl_cgconv_fwd": (_i32, [_vp] * 9 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mdl_cgconv_bwd": (_i32, [_vp] * 12 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+class MdlError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmdl_hip.so once.  Fails loudly: the product has no other compute path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MdlError(
+                "libmdl_hip.so not found at %s — build it with `python -m matdeeplearn_amd._build` "
+                "(hipcc --offload-arch=gfx950).  matdeeplearn_amd has no CPU/eager fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MdlError("%s failed (%d): %s" % (what, rc, lib().mdl_last_error_string().decode()))
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return MDL_F32
+    if t.dtype == torch.bfloat16:
+        return MDL_BF16
+    raise MdlError("unsupported dtype %s (float32 or bfloat16)" % t.dtype)
+
+
+def require_hip(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MdlError("matdeeplearn_amd ops need tensors on a HIP device (got %s); there is no CPU path — "
+                           "the CPU restatement lives in oracle/ and is test infrastructure only" % t.device)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,690 @@
+// cgconv.hip — K2/K3: fused CGConv forward and backward edge pass for gfx950 (CDNA4, wave64).
+//
+// Replaces torch_geometric.nn.CGConv (2.0.1) as used by /root/reference/matdeeplearn/models/cgcnn.py:80-83
+// (construction) and :136-145 (call):  z = [x_i | x_j | e_ij];  m = sigmoid(W_f z + b_f) * softplus(W_s z + b_s);
+// out_i = x_i + mean_{j->i} m.   The reference path materialises z (E x (2C+G)), both gate
+// pre-activations (E x C each) and the message (E x C) in HBM and aggregates with atomics.  Here
+// nothing per-edge is ever written:
+//
+//   work item  = (group of 32 consecutive TARGET nodes, 32-channel slice)  -> one wave, no barriers
+//   edge tile  = 32 consecutive CSR slots of the group (edges are sorted by target)
+//   pre        = z_tile (32 x KT) * Wpack^T (KT x 64)      MFMA 32x32, K order [e | x_tgt | x_src]
+//                  e_tile: streamed coalesced HBM -> per-wave LDS (the dominant HBM stream)
+//                  x rows: gathered straight into A fragments (L1/L2 hits: neighbours are in-graph)
+//                  Wpack : staged once per workgroup in LDS, read as B fragments
+//   gate       = VALU on the accumulator registers (lane = channel, 16 edge slots per lane)
+//   aggregate  = second MFMA with a one-hot "slot == node" A matrix: the segmented reduction over
+//                the tile's edges lands in a 32-node x 32-channel register accumulator (no atomics,
+//                deterministic), epilogue adds the residual and divides by the in-degree.
+//
+// Backward recomputes pre (no E x 2C activations are stored), expands grad_out to edges with a
+// one-hot MFMA, forms dpre = d/d(pre) on registers and reduces it three ways:
+//   r_tgt (by target: MFMA, registers), r_src (by source: fp32 atomics), dwe = dpre^T e (MFMA).
+// The node-level dense GEMMs (dx, dW_tgt, dW_src) are left to the caller (see include/mdl_hip.h).
+//
+// dtype MDL_BF16: v_mfma_f32_32x32x16_bf16, fast gate math.  MDL_F32 (parity mode):
+// v_mfma_f32_32x32x2_f32 (bit-exact fp32 fma chain), precise gate math.
+//
+// Algorithmic bytes: fwd E*(G*s + C*s + 4) + N*(2*C*s + 4);
+//                                   bwd E*(G*s + 2*C*s + 4) + N*(3*C*s + 4).
+#include <type_traits>
+
+#include "mdl_common.h"
+
+namespace mdl {
+
+struct CgParams {
+    const void* x;
+    const void* ea;
+    const int32_t* rowptr;
+    const int32_t* src;
+    const int32_t* tgt;
+    const int32_t* eperm;
+    const void* wpack;
+    const float* bpack;
+    void* out;          // fwd
+    const void* gout;   // bwd
+    float* r_tgt;       // bwd [N, 2Cp]
+    float* r_src;       // bwd [N, 2Cp]
+    float* dwe;         // bwd [2Cp, GP]
+    int64_t N, E;
+    int C, G, Cp, KE, KT, WS, EKS, NS, GP, aggr;
+    int GW;             // staging words per e row
+    unsigned gw_inv;    // ceil(2^32 / GW)
+    int n_groups;
+    int w_elems;        // 2*Cp*WS
+    int wave_lds_bytes; // per-wave LDS region
+};
+
+struct CgDims {
+    int Cp, KE, KT, WS, EKS, NS, GP;
+};
+
+static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
+
+static CgDims cg_dims(int C, int G, int dtype) {
+    CgDims d;
+    d.Cp = rup(C, 32);
+    d.KE = rup(G, 16);
+    d.KT = d.KE + 2 * d.Cp;
+    d.WS = d.KT + (dtype == MDL_BF16 ? 8 : 1);   // bf16: odd number of 16-B slots; f32: odd dword stride
+    d.EKS = d.KE + (dtype == MDL_BF16 ? 8 : 1);
+    d.NS = d.Cp / 32;
+    d.GP = rup(G, 64);
+    return d;
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA traits
+// ------------------------------------------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int KSTEP = 16;
+    static constexpr bool FAST = true;
+    typedef bf16x8 frag_t;
+    __device__ static __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ frag_t zero() { return frag_t{0, 0, 0, 0, 0, 0, 0, 0}; }
+};
+template <> struct Mma<float> {
+    static constexpr int KSTEP = 2;
+    static constexpr bool FAST = false;
+    typedef float frag_t;
+    __device__ static __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ frag_t zero() { return 0.0f; }
+};
+
+// A/B fragment of a row-major [rows][ld] matrix held in LDS or global memory:
+// lane (i = lane&31, h = lane>>5) takes row i, columns k0 + KSTEP/2*h .. (8 bf16 / 1 float).
+__device__ __forceinline__ bf16x8 ld_frag(const bf16_t* base, int row, int ld, int k0, int h) {
+    return *reinterpret_cast<const bf16x8*>(base + row * ld + k0 + 8 * h);
+}
+__device__ __forceinline__ float ld_frag(const float* base, int row, int ld, int k0, int h) {
+    return base[row * ld + k0 + h];
+}
+
+// x-row fragment gathered from global memory with column bound C (columns >= C read as 0).
+template <int VEC>
+__device__ __forceinline__ bf16x8 ld_xfrag(const bf16_t* rowp, int c0, int h, int C) {
+    const int c = c0 + 8 * h;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (VEC == 8) {
+        if (c < C) v = *reinterpret_cast<const bf16x8*>(rowp + c);
+    } else if (VEC == 4) {
+        bf16x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (c < C) lo = *reinterpret_cast<const bf16x4*>(rowp + c);
+        if (c + 4 < C) hi = *reinterpret_cast<const bf16x4*>(rowp + c + 4);
+        v = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (c + j < C) v[j] = (short)rowp[c + j];
+    }
+    return v;
+}
+template <int VEC>
+__device__ __forceinline__ float ld_xfrag(const float* rowp, int c0, int h, int C) {
+    const int c = c0 + h;
+    return c < C ? rowp[c] : 0.0f;
+}
+
+__device__ __forceinline__ bf16x8 pack_bf16x8(const float* v) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(v[j]);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Shared per-tile machinery
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct WaveCtx {
+    T* et;              // per-wave e tile  [32][EKS]
+    unsigned* tsl;      // per-wave target-slot bytes (32 B) viewed as 8 dwords
+    int* srcl;          // per-wave source ids (32 ints)   (backward only)
+    const T* wbase;     // packed weights (LDS or global)
+};
+
+// Stage the 32 x G edge-feature tile of CSR slots [eb, eb+nv) into the wave's LDS tile.
+template <typename T, int EW>
+__device__ __forceinline__ void stage_e_tile(const CgParams& p, const WaveCtx<T>& w, int lane, int eb, int nv,
+                                             int my_ep) {
+    typedef typename std::conditional<EW * sizeof(T) == 4, unsigned, unsigned short>::type word_t;
+    const int total = 32 * p.GW;
+    const T* ea = static_cast<const T*>(p.ea);
+    for (int q0 = 0; q0 < total; q0 += WAVE) {
+        const int q = q0 + lane;
+        const bool act = q < total;
+        const int row = act ? (int)__umulhi((unsigned)q, p.gw_inv) : 0;
+        const int cw = q - row * p.GW;
+        const int ep = p.eperm ? __shfl(my_ep, row) : eb + row;
+        if (act && row < nv) {
+            const word_t v = *reinterpret_cast<const word_t*>(ea + (int64_t)ep * p.G + cw * EW);
+            *reinterpret_cast<word_t*>(w.et + row * p.EKS + cw * EW) = v;
+        }
+    }
+}
+
+// pre-activation tile: accf/accs (32 edge slots x 32 channels of slice s), bias pre-loaded.
+template <typename T, int VEC>
+__device__ __forceinline__ void pre_tile(const CgParams& p, const WaveCtx<T>& w, int lane, int s, int my_tgt,
+                                         int my_src, f32x16& accf, f32x16& accs) {
+    typedef Mma<T> M;
+    const int i = lane & 31, h = lane >> 5;
+    const int rowf = s * 32 + i, rows = p.Cp + s * 32 + i;
+    const T* xt = static_cast<const T*>(p.x) + (int64_t)my_tgt * p.C;
+    const T* xs = static_cast<const T*>(p.x) + (int64_t)my_src * p.C;
+    // edge features
+    for (int k0 = 0; k0 < p.KE; k0 += M::KSTEP) {
+        typename M::frag_t a = ld_frag(w.et, i, p.EKS, k0, h);
+        accf = M::mma(a, ld_frag(w.wbase, rowf, p.WS, k0, h), accf);
+        accs = M::mma(a, ld_frag(w.wbase, rows, p.WS, k0, h), accs);
+    }
+    // target-node features (x_i)
+    for (int k0 = 0; k0 < p.Cp; k0 += M::KSTEP) {
+        typename M::frag_t a = ld_xfrag<VEC>(xt, k0, h, p.C);
+        accf = M::mma(a, ld_frag(w.wbase, rowf, p.WS, p.KE + k0, h), accf);
+        accs = M::mma(a, ld_frag(w.wbase, rows, p.WS, p.KE + k0, h), accs);
+    }
+    // source-node features (x_j)
+    for (int k0 = 0; k0 < p.Cp; k0 += M::KSTEP) {
+        typename M::frag_t a = ld_xfrag<VEC>(xs, k0, h, p.C);
+        accf = M::mma(a, ld_frag(w.wbase, rowf, p.WS, p.KE + p.Cp + k0, h), accf);
+        accs = M::mma(a, ld_frag(w.wbase, rows, p.WS, p.KE + p.Cp + k0, h), accs);
+    }
+}
+
+// acc[node slot][ch] += sum over the tile's edge slots of onehot(slot -> node slot) * v[edge slot][ch]
+// v is in D layout (lane = channel, register r = edge slot d_row(r, h)); t4 = the lane's 4 dwords of
+// target-slot bytes (byte r&3 of t4[r>>2] is the node slot of edge slot d_row(r,h), 0xff = invalid).
+template <typename T>
+__device__ __forceinline__ void seg_reduce_mma(const f32x16& v, const unsigned t4[4], int ns, f32x16& acc) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a, b;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 8 * ks + q;
+                const unsigned slot = (t4[r >> 2] >> (8 * (r & 3))) & 0xffu;
+                a[q] = (slot == (unsigned)ns) ? (short)0x3F80 : (short)0;
+                b[q] = (short)f2bf(v[r]);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned slot = (t4[r >> 2] >> (8 * (r & 3))) & 0xffu;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32((slot == (unsigned)ns) ? 1.0f : 0.0f, v[r], acc, 0, 0, 0);
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void setup_wave(const CgParams& p, char* smem, bool w_lds, WaveCtx<T>& w) {
+    const int wave = threadIdx.x >> 6;
+    const int w_bytes = w_lds ? ((p.w_elems * (int)sizeof(T) + 15) & ~15) : 0;
+    char* base = smem + w_bytes + wave * p.wave_lds_bytes;
+    w.et = reinterpret_cast<T*>(base);
+    const int et_bytes = (32 * p.EKS * (int)sizeof(T) + 15) & ~15;
+    w.tsl = reinterpret_cast<unsigned*>(base + et_bytes);
+    w.srcl = reinterpret_cast<int*>(base + et_bytes + 32);
+    w.wbase = w_lds ? reinterpret_cast<const T*>(smem) : static_cast<const T*>(p.wpack);
+    if (w_lds) {
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.wpack);
+        f32x4* l = reinterpret_cast<f32x4*>(smem);
+        const int n16 = w_bytes / 16;
+        for (int q = threadIdx.x; q < n16; q += blockDim.x) l[q] = g[q];
+    }
+    // zero the e tile once: padded columns [G, KE) stay 0 forever, rows never hold garbage bits
+    unsigned* z = reinterpret_cast<unsigned*>(base);
+    for (int q = threadIdx.x & 63; q < et_bytes / 4; q += WAVE) z[q] = 0u;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, int EW, bool W_LDS>
+__global__ __launch_bounds__(256, 2) void cgconv_fwd_kernel(CgParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef Mma<T> M;
+    WaveCtx<T> w;
+    setup_wave<T>(p, smem, W_LDS, w);
+
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int total_waves = gridDim.x * (blockDim.x >> 6);
+    const int s = gw % p.NS;
+    const int gstride = total_waves / p.NS;
+    const float bf = p.bpack[s * 32 + i], bs = p.bpack[p.Cp + s * 32 + i];
+    const T* x = static_cast<const T*>(p.x);
+    T* out = static_cast<T*>(p.out);
+
+    for (int g = gw / p.NS; g < p.n_groups; g += gstride) {
+        const int n0 = g * 32;
+        const int n1 = (int)min((int64_t)n0 + 32, p.N);
+        const int e0 = __builtin_amdgcn_readfirstlane(p.rowptr[n0]);
+        const int e1 = __builtin_amdgcn_readfirstlane(p.rowptr[n1]);
+        f32x16 acc_out;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_out[r] = 0.0f;
+
+        for (int eb = e0; eb < e1; eb += 32) {
+            const int nv = min(32, e1 - eb);
+            const bool valid_i = i < nv;
+            const int eid = eb + i;
+            const int my_src = valid_i ? p.src[eid] : n0;
+            const int my_tgt = valid_i ? p.tgt[eid] : n0;
+            const int my_ep = (p.eperm && valid_i) ? p.eperm[eid] : 0;
+            wave_lds_fence();
+            stage_e_tile<T, EW>(p, w, lane, eb, nv, my_ep);
+            if (h == 0) reinterpret_cast<unsigned char*>(w.tsl)[i] = valid_i ? (unsigned char)(my_tgt - n0) : 0xff;
+            wave_lds_fence();
+
+            f32x16 accf, accs;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
+            pre_tile<T, VEC>(p, w, lane, s, my_tgt, my_src, accf, accs);
+
+            unsigned t4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t4[j] = w.tsl[2 * j + h];
+            f32x16 m;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = sigmoidf_<M::FAST>(accf[r]) * softplusf_<M::FAST>(accs[r]);
+                m[r] = (d_row(r, h) < nv) ? v : 0.0f;
+            }
+            seg_reduce_mma<T>(m, t4, i, acc_out);
+        }
+
+        // epilogue: out = x + acc / deg   (rows = node slots in D layout, col = channel)
+        const int ch = s * 32 + i;
+        if (ch < p.C) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + d_row(r, h);
+                if (n < n1) {
+                    float a = acc_out[r];
+                    if (p.aggr == MDL_MEAN) {
+                        const int deg = p.rowptr[n + 1] - p.rowptr[n];
+                        a = a / (float)max(deg, 1);
+                    }
+                    const int64_t o = (int64_t)n * p.C + ch;
+                    Elem<T>::st(out + o, Elem<T>::ld(x + o) + a);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward edge pass
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, int EW, bool W_LDS>
+__global__ __launch_bounds__(256, 2) void cgconv_bwd_kernel(CgParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef Mma<T> M;
+    constexpr bool BF = std::is_same<T, bf16_t>::value;
+    WaveCtx<T> w;
+    setup_wave<T>(p, smem, W_LDS, w);
+
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int total_waves = gridDim.x * (blockDim.x >> 6);
+    const int s = gw % p.NS;
+    const int gstride = total_waves / p.NS;
+    const int ch = s * 32 + i;
+    const float bf = p.bpack[ch], bs = p.bpack[p.Cp + ch];
+    const T* go = static_cast<const T*>(p.gout);
+    const int C2 = 2 * p.Cp;
+
+    // dwe accumulators: [part f|s][n-tile of G]  (rows = channel slot, cols = edge feature)
+    f32x16 dwe_acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dwe_acc[a][b][r] = 0.0f;
+    const int gnt = (p.KE + 31) / 32;  // 1 or 2 column tiles of edge features
+
+    for (int g = gw / p.NS; g < p.n_groups; g += gstride) {
+        const int n0 = g * 32;
+        const int n1 = (int)min((int64_t)n0 + 32, p.N);
+        const int e0 = __builtin_amdgcn_readfirstlane(p.rowptr[n0]);
+        const int e1 = __builtin_amdgcn_readfirstlane(p.rowptr[n1]);
+
+        // B fragments of the (1/deg-scaled) grad_out tile for the one-hot expansion to edges
+        typename M::frag_t gB[BF ? 2 : 16];
+        {
+            constexpr int NF = BF ? 2 : 16, PER = BF ? 8 : 1;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                float v[PER];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const int ns = BF ? (16 * f + 8 * h + q) : (2 * f + h);
+                    const int n = n0 + ns;
+                    float gv = 0.0f;
+                    if (n < n1 && ch < p.C) {
+                        gv = Elem<T>::ld(go + (int64_t)n * p.C + ch);
+                        if (p.aggr == MDL_MEAN) gv = gv / (float)max(p.rowptr[n + 1] - p.rowptr[n], 1);
+                    }
+                    v[q] = gv;
+                }
+                if constexpr (BF) gB[f] = pack_bf16x8(v); else gB[f] = v[0];
+            }
+        }
+
+        f32x16 Rf, Rs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Rf[r] = 0.0f; Rs[r] = 0.0f; }
+
+        for (int eb = e0; eb < e1; eb += 32) {
+            const int nv = min(32, e1 - eb);
+            const bool valid_i = i < nv;
+            const int eid = eb + i;
+            const int my_src = valid_i ? p.src[eid] : n0;
+            const int my_tgt = valid_i ? p.tgt[eid] : n0;
+            const int my_ep = (p.eperm && valid_i) ? p.eperm[eid] : 0;
+            const int my_ts = valid_i ? (my_tgt - n0) : 0xff;
+            wave_lds_fence();
+            stage_e_tile<T, EW>(p, w, lane, eb, nv, my_ep);
+            if (h == 0) {
+                reinterpret_cast<unsigned char*>(w.tsl)[i] = (unsigned char)my_ts;
+                w.srcl[i] = my_src;
+            }
+            wave_lds_fence();
+
+            f32x16 accf, accs;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
+            pre_tile<T, VEC>(p, w, lane, s, my_tgt, my_src, accf, accs);
+
+            // dm[edge slot][ch] = grad_out[tgt(edge)][ch] / deg : one-hot(edge -> node slot) x gB
+            f32x16 dm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dm[r] = 0.0f;
+            if constexpr (BF) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 a;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = (my_ts == 16 * ks + 8 * h + q) ? (short)0x3F80 : (short)0;
+                    dm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, gB[ks], dm, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int f = 0; f < 16; ++f)
+                    dm = __builtin_amdgcn_mfma_f32_32x32x2f32((my_ts == 2 * f + h) ? 1.0f : 0.0f, gB[f], dm, 0, 0, 0);
+            }
+
+            // gate derivative -> dpre (in place in accf/accs)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = accf[r], sv = accs[r];
+                const float sf = sigmoidf_<M::FAST>(f);
+                const float sp = softplusf_<M::FAST>(sv);
+                const float ss = sigmoidf_<M::FAST>(sv);
+                const bool ok = d_row(r, h) < nv;
+                accf[r] = ok ? dm[r] * sp * sf * (1.0f - sf) : 0.0f;
+                accs[r] = ok ? dm[r] * sf * ss : 0.0f;
+            }
+
+            unsigned t4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t4[j] = w.tsl[2 * j + h];
+            seg_reduce_mma<T>(accf, t4, i, Rf);
+            seg_reduce_mma<T>(accs, t4, i, Rs);
+
+            // r_src: scatter dpre to the SOURCE node of every edge slot (fp32 hardware atomics)
+            if (ch < p.C) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int slot = d_row(r, h);
+                    if (slot < nv) {
+                        const int sj = w.srcl[slot];
+                        float* dst = p.r_src + (int64_t)sj * C2 + ch;
+                        unsafeAtomicAdd(dst, accf[r]);
+                        unsafeAtomicAdd(dst + p.Cp, accs[r]);
+                    }
+                }
+            }
+
+            // dwe[ch][gcol] += sum_slot dpre[slot][ch] * e[slot][gcol]
+            //   A = dpre^T (lane = channel, k = edge slots: own registers), B = e tile column (LDS)
+            for (int nt = 0; nt < gnt; ++nt) {
+                const int gcol = nt * 32 + i;
+                if constexpr (BF) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        bf16x8 af, as, b;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int r = 8 * ks + q;
+                            af[q] = (short)f2bf(accf[r]);
+                            as[q] = (short)f2bf(accs[r]);
+                            b[q] = (gcol < p.KE) ? (short)w.et[d_row(r, h) * p.EKS + gcol] : (short)0;
+                        }
+                        dwe_acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, dwe_acc[0][nt], 0, 0, 0);
+                        dwe_acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as, b, dwe_acc[1][nt], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float b = (gcol < p.KE) ? w.et[d_row(r, h) * p.EKS + gcol] : 0.0f;
+                        dwe_acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(accf[r], b, dwe_acc[0][nt], 0, 0, 0);
+                        dwe_acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(accs[r], b, dwe_acc[1][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // r_tgt rows of this group (each written exactly once)
+        if (ch < p.Cp) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + d_row(r, h);
+                if (n < n1) {
+                    float* dst = p.r_tgt + (int64_t)n * C2 + ch;
+                    dst[0] = Rf[r];
+                    dst[p.Cp] = Rs[r];
+                }
+            }
+        }
+    }
+
+    // flush the wave's dwe partial sums: D rows = channel slot d_row(r,h) of slice s, cols = feature
+    for (int nt = 0; nt < gnt; ++nt) {
+        const int gcol = nt * 32 + i;
+        if (gcol < p.G) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = s * 32 + d_row(r, h);
+                unsafeAtomicAdd(p.dwe + (int64_t)c * p.GP + gcol, dwe_acc[0][nt][r]);
+                unsafeAtomicAdd(p.dwe + (int64_t)(p.Cp + c) * p.GP + gcol, dwe_acc[1][nt][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight packing: nn.Linear [C, 2C+G] (target|source|edge) -> [2Cp][WS] with K order [e|x_tgt|x_src]
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cgconv_pack_kernel(const float* __restrict__ wf, const float* __restrict__ bfv,
+                                                          const float* __restrict__ ws, const float* __restrict__ bsv,
+                                                          int C, int G, CgDims d, T* __restrict__ wpack,
+                                                          float* __restrict__ bpack) {
+    const int total = 2 * d.Cp * d.WS;
+    const int ldw = 2 * C + G;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+        const int row = q / d.WS, k = q - row * d.WS;
+        const int part = row / d.Cp, c = row - part * d.Cp;
+        const float* W = part ? ws : wf;
+        float v = 0.0f;
+        if (c < C) {
+            if (k < d.KE) {
+                if (k < G) v = W[c * ldw + 2 * C + k];
+            } else if (k < d.KE + d.Cp) {
+                const int kc = k - d.KE;
+                if (kc < C) v = W[c * ldw + kc];
+            } else if (k < d.KT) {
+                const int kc = k - d.KE - d.Cp;
+                if (kc < C) v = W[c * ldw + C + kc];
+            }
+        }
+        Elem<T>::st(wpack + q, v);
+    }
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < 2 * d.Cp; q += gridDim.x * blockDim.x) {
+        const int part = q / d.Cp, c = q - part * d.Cp;
+        const float* b = part ? bsv : bfv;
+        bpack[q] = (c < C && b) ? b[c] : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side dispatch
+// ------------------------------------------------------------------------------------------
+static constexpr int LDS_CAP = 160 * 1024;
+
+template <typename T>
+static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const char* name) {
+    const CgDims d = cg_dims(p.C, p.G, dtype);
+    p.Cp = d.Cp; p.KE = d.KE; p.KT = d.KT; p.WS = d.WS; p.EKS = d.EKS; p.NS = d.NS; p.GP = d.GP;
+    p.w_elems = 2 * d.Cp * d.WS;
+    p.n_groups = (int)cdiv(p.N, 32);
+    if (p.n_groups == 0) return MDL_OK;
+
+    // staging word: 4 bytes when the row length allows it
+    const bool word4 = (p.G * sizeof(T)) % 4 == 0 && (reinterpret_cast<uintptr_t>(p.ea) % 4) == 0;
+    const int EW = word4 ? (int)(4 / sizeof(T)) : 1;
+    p.GW = p.G / EW;
+    p.gw_inv = (unsigned)((0x100000000ull + p.GW - 1) / p.GW);
+
+    int vec = 1;
+    if (sizeof(T) == 2) {
+        const bool a16 = reinterpret_cast<uintptr_t>(p.x) % 16 == 0, a8 = reinterpret_cast<uintptr_t>(p.x) % 8 == 0;
+        if (p.C % 8 == 0 && a16) vec = 8; else if (p.C % 4 == 0 && a8) vec = 4;
+    }
+
+    const int et_bytes = (32 * d.EKS * (int)sizeof(T) + 15) & ~15;
+    p.wave_lds_bytes = et_bytes + 32 + 128;  // e tile + 32 slot bytes + 32 source ids
+    const int w_bytes = (p.w_elems * (int)sizeof(T) + 15) & ~15;
+    const int waves = 4;
+    bool w_lds = w_bytes + waves * p.wave_lds_bytes <= LDS_CAP;
+    const int lds = (w_lds ? w_bytes : 0) + waves * p.wave_lds_bytes;
+    const int wg_per_cu = lds * 2 <= LDS_CAP ? 2 : 1;
+
+    int64_t items = (int64_t)p.n_groups * d.NS;
+    int64_t grid = cdiv(items, waves);
+    const int64_t cap = 256 * wg_per_cu;
+    if (grid > cap) grid = cap;
+    // total waves must be a multiple of NS so that every wave keeps one channel slice
+    while ((grid * waves) % d.NS) ++grid;
+
+#define MDL_CG_LAUNCH(VEC_, EW_, WL_)                                                                        \
+    do {                                                                                                     \
+        auto kf = bwd ? cgconv_bwd_kernel<T, VEC_, EW_, WL_> : cgconv_fwd_kernel<T, VEC_, EW_, WL_>;         \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf),                                \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);                 \
+        if (e != hipSuccess) { set_error("%s: LDS attribute (%d B): %s", name, lds, hipGetErrorString(e)); return MDL_E_LAUNCH; } \
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);                           \
+    } while (0)
+#define MDL_CG_BY_WL(VEC_, EW_) do { if (w_lds) MDL_CG_LAUNCH(VEC_, EW_, true); else MDL_CG_LAUNCH(VEC_, EW_, false); } while (0)
+#define MDL_CG_BY_EW(VEC_) do { if (EW == 2) MDL_CG_BY_WL(VEC_, 2); else MDL_CG_BY_WL(VEC_, 1); } while (0)
+
+    if constexpr (sizeof(T) == 2) {
+        if (vec == 8) MDL_CG_BY_EW(8);
+        else if (vec == 4) MDL_CG_BY_EW(4);
+        else MDL_CG_BY_EW(1);
+    } else {
+        MDL_CG_BY_WL(1, 1);
+    }
+#undef MDL_CG_BY_EW
+#undef MDL_CG_BY_WL
+#undef MDL_CG_LAUNCH
+    return check_launch(name);
+}
+
+static int cg_check(const char* name, const void* x, const void* ea, const int32_t* rowptr, const int32_t* src,
+                    const int32_t* tgt, const void* wpack, const float* bpack, int64_t N, int64_t E, int C, int G,
+                    int aggr, int dtype) {
+    MDL_REQUIRE(N >= 0 && E >= 0 && N < (1ll << 31) - 64 && E < (1ll << 31) - 64, MDL_E_ARG, "%s: bad N=%lld E=%lld", name,
+                (long long)N, (long long)E);
+    MDL_REQUIRE(C >= 1 && C <= 256, MDL_E_UNSUPP, "%s: unsupported channels C=%d (1..256)", name, C);
+    MDL_REQUIRE(G >= 1 && G <= 64, MDL_E_UNSUPP, "%s: unsupported edge feature count G=%d (1..64)", name, G);
+    MDL_REQUIRE(dtype == MDL_F32 || dtype == MDL_BF16, MDL_E_UNSUPP, "%s: unsupported dtype %d", name, dtype);
+    MDL_REQUIRE(aggr == MDL_MEAN || aggr == MDL_SUM, MDL_E_UNSUPP, "%s: unsupported aggr %d", name, aggr);
+    MDL_REQUIRE(N == 0 || (x && rowptr && wpack && bpack), MDL_E_ARG, "%s: null pointer", name);
+    MDL_REQUIRE(E == 0 || (ea && src && tgt), MDL_E_ARG, "%s: null edge pointer", name);
+    MDL_REQUIRE(reinterpret_cast<uintptr_t>(wpack) % 16 == 0, MDL_E_ARG, "%s: wpack must be 16-byte aligned", name);
+    return MDL_OK;
+}
+
+}  // namespace mdl
+
+extern "C" size_t mdl_cgconv_wpack_bytes(int C, int G, int dtype) {
+    using namespace mdl;
+    if (C < 1 || G < 1 || (dtype != MDL_F32 && dtype != MDL_BF16)) return 0;
+    const CgDims d = cg_dims(C, G, dtype);
+    const size_t b = (size_t)2 * d.Cp * d.WS * (dtype == MDL_BF16 ? 2 : 4);
+    return (b + 15) & ~(size_t)15;
+}
+
+extern "C" int mdl_cgconv_pack_weights(const float* w_f, const float* b_f, const float* w_s, const float* b_s, int C,
+                                       int G, void* wpack, float* bpack, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(w_f && w_s && wpack && bpack, MDL_E_ARG, "mdl_cgconv_pack_weights: null pointer");
+    MDL_REQUIRE(C >= 1 && C <= 256 && G >= 1 && G <= 64, MDL_E_UNSUPP, "mdl_cgconv_pack_weights: unsupported C=%d G=%d", C, G);
+    const CgDims d = cg_dims(C, G, dtype);
+    const int total = 2 * d.Cp * d.WS;
+    dim3 grid((unsigned)cdiv(total, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MDL_BF16)
+        hipLaunchKernelGGL((cgconv_pack_kernel<bf16_t>), grid, block, 0, st, w_f, b_f, w_s, b_s, C, G, d, (bf16_t*)wpack, bpack);
+    else if (dtype == MDL_F32)
+        hipLaunchKernelGGL((cgconv_pack_kernel<float>), grid, block, 0, st, w_f, b_f, w_s, b_s, C, G, d, (float*)wpack, bpack);
+    else {
+        set_error("mdl_cgconv_pack_weights: unsupported dtype %d", dtype);
+        return MDL_E_UNSUPP;
+    }
+    return check_launch("mdl_cgconv_pack_weights");
+}
+
+extern "C" int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
+                              const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
+                              void* out, int64_t N, int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    int rc = cg_check("mdl_cgconv_fwd", x, edge_attr, rowptr, src, tgt, wpack, bpack, N, E, C, G, aggr, dtype);
+    if (rc) return rc;
+    MDL_REQUIRE(N == 0 || out, MDL_E_ARG, "mdl_cgconv_fwd: null out");
+    CgParams p = {};
+    p.x = x; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = eperm;
+    p.wpack = wpack; p.bpack = bpack; p.out = out; p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr;
+    if (dtype == MDL_BF16) return cg_launch<bf16_t>(false, p, dtype, (hipStream_t)stream, "mdl_cgconv_fwd");
+    return cg_launch<float>(false, p, dtype, (hipStream_t)stream, "mdl_cgconv_fwd");
+}
+
+extern "C" int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
+                              const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
+                              const void* grad_out, float* r_tgt, float* r_src, float* dwe, int64_t N, int64_t E,
+                              int C, int G, int aggr, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    int rc = cg_check("mdl_cgconv_bwd", x, edge_attr, rowptr, src, tgt, wpack, bpack, N, E, C, G, aggr, dtype);
+    if (rc) return rc;
+    MDL_REQUIRE(N == 0 || (grad_out && r_tgt && r_src && dwe), MDL_E_ARG, "mdl_cgconv_bwd: null pointer");
+    CgParams p = {};
+    p.x = x; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = eperm;
+    p.wpack = wpack; p.bpack = bpack; p.gout = grad_out; p.r_tgt = r_tgt; p.r_src = r_src; p.dwe = dwe;
+    p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr;
+    if (dtype == MDL_BF16) return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd");
+    return cg_launch<float>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd");
+}

@@ -1,0 +1,98 @@
+// rbf.hip — K1: Gaussian RBF edge expansion (write-bandwidth bound).
+// Restates GaussianSmearing.forward, /root/reference/matdeeplearn/process/process.py:588-590:
+//   dist = d[:,None] - offset[None,:];  out = exp(coeff * dist^2)       (all fp32)
+// Algorithmic bytes per edge: 4 (d) + G*sizeof(out)  ->  204 B fp32 / 104 B bf16 at G = 50.
+#include "mdl_common.h"
+
+namespace mdl {
+
+// One thread produces VEC consecutive elements of the flattened [E*G] output (dense case
+// ld_out == G) so every store is a full 16-byte (fp32 x4) / 8-byte (bf16 x4) vector and a
+// wave writes 1 KiB / 512 B contiguous.  exp() is the precise ocml expf: the kernel is bound by
+// the store stream (50 exps per 104..204 bytes), not by VALU.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void rbf_dense_kernel(const float* __restrict__ d,
+                                                        const float* __restrict__ offsets, float coeff,
+                                                        T* __restrict__ out, int64_t total, int G) {
+    __shared__ float s_off[256];
+    for (int i = threadIdx.x; i < G; i += blockDim.x) s_off[i] = offsets[i];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * VEC;
+    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; base < total; base += stride) {
+        int64_t e = base / G;
+        int k = (int)(base - e * G);
+        float de = d[e];
+        float v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float diff = de - s_off[k];
+            v[j] = expf(coeff * (diff * diff));
+            if (++k == G) {
+                k = 0;
+                ++e;
+                if (base + j + 1 < total) de = d[e];
+            }
+        }
+        if (base + VEC <= total) {
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<f32x4*>(out + base) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                bf16x4 p;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[j] = (short)f2bf(v[j]);
+                *reinterpret_cast<bf16x4*>(out + base) = p;
+            }
+        } else {
+            for (int j = 0; base + j < total; ++j) Elem<T>::st(out + base + j, v[j]);
+        }
+    }
+}
+
+// Strided rows (ld_out > G): one thread per element.
+template <typename T>
+__global__ __launch_bounds__(256) void rbf_strided_kernel(const float* __restrict__ d,
+                                                          const float* __restrict__ offsets, float coeff,
+                                                          T* __restrict__ out, int64_t E, int G, int64_t ld) {
+    const int64_t total = E * G;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int64_t e = i / G;
+        int k = (int)(i - e * G);
+        float diff = d[e] - offsets[k];
+        Elem<T>::st(out + e * ld + k, expf(coeff * (diff * diff)));
+    }
+}
+
+template <typename T>
+static int launch_rbf(const float* d, const float* offsets, float coeff, T* out, int64_t E, int G, int64_t ld,
+                      hipStream_t st) {
+    if (E == 0) return MDL_OK;
+    const int64_t total = E * G;
+    if (ld == G && (reinterpret_cast<uintptr_t>(out) % 16) == 0) {
+        int64_t blocks = cdiv(cdiv(total, 4), 256);
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL((rbf_dense_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), 0, st, d, offsets, coeff,
+                           out, total, G);
+    } else {
+        int64_t blocks = cdiv(total, 256);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL((rbf_strided_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, d, offsets, coeff,
+                           out, E, G, ld);
+    }
+    return check_launch("mdl_rbf_expand");
+}
+
+}  // namespace mdl
+
+extern "C" int mdl_rbf_expand(const float* d, const float* offsets, float coeff, void* out, int64_t E, int G,
+                              int64_t ld_out, int out_dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(E >= 0 && G > 0 && G <= 256, MDL_E_ARG, "mdl_rbf_expand: bad E=%lld G=%d", (long long)E, G);
+    MDL_REQUIRE(ld_out >= G, MDL_E_ARG, "mdl_rbf_expand: ld_out %lld < G %d", (long long)ld_out, G);
+    MDL_REQUIRE(E == 0 || (d && offsets && out), MDL_E_ARG, "mdl_rbf_expand: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dtype == MDL_F32) return launch_rbf<float>(d, offsets, coeff, (float*)out, E, G, ld_out, st);
+    if (out_dtype == MDL_BF16) return launch_rbf<bf16_t>(d, offsets, coeff, (bf16_t*)out, E, G, ld_out, st);
+    set_error("mdl_rbf_expand: unsupported dtype %d", out_dtype);
+    return MDL_E_UNSUPP;
+}

@@ -1,0 +1,166 @@
+// segment.hip — K5: CSR segmented reduce (sum / mean / max) forward + backward, and CSR rowptr build.
+// Restates torch_scatter.scatter(src, index, dim=0, reduce=...) for a SORTED index, as called at
+// /root/reference/matdeeplearn/models/megnet.py:86,130-132,342-348 and by PyG global_*_pool
+// (/root/reference/matdeeplearn/models/cgcnn.py:154).  Atomic-free and deterministic: one thread
+// owns VEC channels of one output row and walks the rows of its segment; consecutive lanes own
+// consecutive channel vectors, so every source row is read as one contiguous run.
+// Algorithmic bytes: E*C*s (read) + N*C*s (write) + 4*(N+1).
+#include "mdl_common.h"
+
+namespace mdl {
+
+__global__ __launch_bounds__(256) void csr_rowptr_kernel(const int32_t* __restrict__ idx, int64_t E, int64_t N,
+                                                         int32_t* __restrict__ rowptr) {
+    // rowptr[n] = number of entries with idx < n  (lower_bound), n in [0, N]
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n > N) return;
+    int64_t lo = 0, hi = E;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)idx[mid] < n) lo = mid + 1; else hi = mid;
+    }
+    rowptr[n] = (int32_t)lo;
+}
+
+template <typename T, int REDUCE>
+__global__ __launch_bounds__(256) void seg_fwd_kernel(const T* __restrict__ src, const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ perm, T* __restrict__ out,
+                                                      int32_t* __restrict__ argmax, int64_t N, int C) {
+    const int64_t total = N * C;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / C;
+        const int c = (int)(i - n * C);
+        const int b = rowptr[n], e = rowptr[n + 1];
+        float acc = (REDUCE == MDL_MAX) ? -INFINITY : 0.0f;
+        int best = -1;
+        for (int k = b; k < e; ++k) {
+            const int64_t r = perm ? perm[k] : k;
+            const float v = Elem<T>::ld(src + r * C + c);
+            if (REDUCE == MDL_MAX) {
+                if (v > acc || best < 0) { acc = v; best = (int)r; }
+            } else {
+                acc += v;
+            }
+        }
+        if (REDUCE == MDL_MEAN) acc = acc / (float)max(e - b, 1);
+        if (REDUCE == MDL_MAX) {
+            if (best < 0) acc = 0.0f;
+            argmax[i] = best;
+        }
+        Elem<T>::st(out + i, acc);
+    }
+}
+
+template <typename T, int REDUCE>
+__global__ __launch_bounds__(256) void seg_bwd_kernel(const T* __restrict__ go, const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ seg,
+                                                      const int32_t* __restrict__ perm, T* __restrict__ gs,
+                                                      int64_t E, int C) {
+    const int64_t total = E * C;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t k = i / C;
+        const int c = (int)(i - k * C);
+        const int n = seg[k];
+        float g = Elem<T>::ld(go + (int64_t)n * C + c);
+        if (REDUCE == MDL_MEAN) g = g / (float)max(rowptr[n + 1] - rowptr[n], 1);
+        const int64_t r = perm ? perm[k] : k;
+        Elem<T>::st(gs + r * C + c, g);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void seg_bwd_max_kernel(const T* __restrict__ go,
+                                                          const int32_t* __restrict__ argmax,
+                                                          T* __restrict__ gs, int64_t N, int C) {
+    const int64_t total = N * C;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int a = argmax[i];
+        if (a >= 0) gs[(int64_t)a * C + (i % C)] = go[i];
+    }
+}
+
+static unsigned grid_for(int64_t total) {
+    int64_t b = cdiv(total, 256);
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+template <typename T>
+static int seg_fwd(const T* src, const int32_t* rowptr, const int32_t* perm, T* out, int32_t* argmax, int64_t N,
+                   int64_t C, int reduce, hipStream_t st) {
+    if (N * C == 0) return MDL_OK;
+    dim3 g(grid_for(N * C)), b(256);
+    switch (reduce) {
+        case MDL_SUM: hipLaunchKernelGGL((seg_fwd_kernel<T, MDL_SUM>), g, b, 0, st, src, rowptr, perm, out, argmax, N, (int)C); break;
+        case MDL_MEAN: hipLaunchKernelGGL((seg_fwd_kernel<T, MDL_MEAN>), g, b, 0, st, src, rowptr, perm, out, argmax, N, (int)C); break;
+        case MDL_MAX: hipLaunchKernelGGL((seg_fwd_kernel<T, MDL_MAX>), g, b, 0, st, src, rowptr, perm, out, argmax, N, (int)C); break;
+        default: set_error("mdl_segment_reduce_fwd: bad reduce %d", reduce); return MDL_E_ARG;
+    }
+    return check_launch("mdl_segment_reduce_fwd");
+}
+
+template <typename T>
+static int seg_bwd(const T* go, const int32_t* rowptr, const int32_t* seg, const int32_t* perm,
+                   const int32_t* argmax, T* gs, int64_t N, int64_t E, int64_t C, int reduce, hipStream_t st) {
+    dim3 b(256);
+    switch (reduce) {
+        case MDL_SUM:
+            if (E * C == 0) return MDL_OK;
+            hipLaunchKernelGGL((seg_bwd_kernel<T, MDL_SUM>), dim3(grid_for(E * C)), b, 0, st, go, rowptr, seg, perm, gs, E, (int)C);
+            break;
+        case MDL_MEAN:
+            if (E * C == 0) return MDL_OK;
+            hipLaunchKernelGGL((seg_bwd_kernel<T, MDL_MEAN>), dim3(grid_for(E * C)), b, 0, st, go, rowptr, seg, perm, gs, E, (int)C);
+            break;
+        case MDL_MAX:
+            if (N * C == 0) return MDL_OK;
+            hipLaunchKernelGGL((seg_bwd_max_kernel<T>), dim3(grid_for(N * C)), b, 0, st, go, argmax, gs, N, (int)C);
+            break;
+        default: set_error("mdl_segment_reduce_bwd: bad reduce %d", reduce); return MDL_E_ARG;
+    }
+    return check_launch("mdl_segment_reduce_bwd");
+}
+
+}  // namespace mdl
+
+extern "C" int mdl_csr_rowptr(const int32_t* sorted_index, int64_t E, int64_t N, int32_t* rowptr,
+                              mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(E >= 0 && N >= 0 && rowptr && (E == 0 || sorted_index), MDL_E_ARG, "mdl_csr_rowptr: bad arguments");
+    MDL_REQUIRE(E < (1ll << 31) && N < (1ll << 31), MDL_E_UNSUPP, "mdl_csr_rowptr: int32 index overflow");
+    hipLaunchKernelGGL(csr_rowptr_kernel, dim3((unsigned)cdiv(N + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                       sorted_index, E, N, rowptr);
+    return check_launch("mdl_csr_rowptr");
+}
+
+extern "C" int mdl_segment_reduce_fwd(const void* src, const int32_t* rowptr, const int32_t* perm, void* out,
+                                      int32_t* argmax, int64_t N, int64_t C, int reduce, int dtype,
+                                      mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(N >= 0 && C > 0 && C < (1 << 20), MDL_E_ARG, "mdl_segment_reduce_fwd: bad N=%lld C=%lld", (long long)N, (long long)C);
+    MDL_REQUIRE(N == 0 || (rowptr && out), MDL_E_ARG, "mdl_segment_reduce_fwd: null pointer");
+    MDL_REQUIRE(reduce != MDL_MAX || argmax || N == 0, MDL_E_ARG, "mdl_segment_reduce_fwd: MDL_MAX needs argmax");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MDL_F32) return seg_fwd<float>((const float*)src, rowptr, perm, (float*)out, argmax, N, C, reduce, st);
+    if (dtype == MDL_BF16) return seg_fwd<bf16_t>((const bf16_t*)src, rowptr, perm, (bf16_t*)out, argmax, N, C, reduce, st);
+    set_error("mdl_segment_reduce_fwd: unsupported dtype %d", dtype);
+    return MDL_E_UNSUPP;
+}
+
+extern "C" int mdl_segment_reduce_bwd(const void* grad_out, const int32_t* rowptr, const int32_t* seg,
+                                      const int32_t* perm, const int32_t* argmax, void* grad_src, int64_t N,
+                                      int64_t E, int64_t C, int reduce, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(N >= 0 && E >= 0 && C > 0, MDL_E_ARG, "mdl_segment_reduce_bwd: bad sizes");
+    MDL_REQUIRE(reduce == MDL_MAX ? (argmax != nullptr || N == 0) : (seg != nullptr || E == 0), MDL_E_ARG,
+                "mdl_segment_reduce_bwd: missing seg/argmax");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MDL_F32) return seg_bwd<float>((const float*)grad_out, rowptr, seg, perm, argmax, (float*)grad_src, N, E, C, reduce, st);
+    if (dtype == MDL_BF16) return seg_bwd<bf16_t>((const bf16_t*)grad_out, rowptr, seg, perm, argmax, (bf16_t*)grad_src, N, E, C, reduce, st);
+    set_error("mdl_segment_reduce_bwd: unsupported dtype %d", dtype);
+    return MDL_E_UNSUPP;
+}

@@ -1,0 +1,276 @@
+"""Host-side operators over libmdl_hip.so: CSR graph index, RBF expansion, scatter / pooling, CGConv.
+
+These mirror the third-party operator API the reference calls (level b2):
+  scatter / scatter_mean / scatter_add  <- torch_scatter      (matdeeplearn/models/megnet.py:13,86,130-132,342-348)
+  global_{mean,add,max}_pool            <- torch_geometric.nn (matdeeplearn/models/cgcnn.py:154)
+  cgconv                                <- torch_geometric.nn.CGConv.forward (matdeeplearn/models/cgcnn.py:136-145)
+  rbf_expand                            <- GaussianSmearing.forward (matdeeplearn/process/process.py:588-590)
+Same argument meaning, differentiable through torch.autograd.Function, errors raised as Python
+exceptions.  Every op runs a hand-written HIP kernel; there is no eager/CPU fallback.
+"""
+import collections
+import math
+
+import torch
+
+from . import _lib
+from ._lib import MdlError, check, dtype_code, lib, ptr, require_hip, stream
+
+
+# ------------------------------------------------------------------------------------------------
+# CSR-by-target graph index
+# ------------------------------------------------------------------------------------------------
+class EdgeCSR:
+    """Edges sorted by target.  rowptr [N+1], src/tgt [E] int32, eperm [E] int32 or None when the
+    caller's per-edge tensors are already in CSR order (the product loader guarantees that)."""
+
+    __slots__ = ("rowptr", "src", "tgt", "eperm", "N", "E")
+
+    def __init__(self, rowptr, src, tgt, eperm, N, E):
+        self.rowptr, self.src, self.tgt, self.eperm, self.N, self.E = rowptr, src, tgt, eperm, int(N), int(E)
+
+
+def csr_rowptr(sorted_index_i32, num_segments):
+    require_hip(sorted_index_i32)
+    rowptr = torch.empty(num_segments + 1, dtype=torch.int32, device=sorted_index_i32.device)
+    check(lib().mdl_csr_rowptr(ptr(sorted_index_i32), sorted_index_i32.numel(), num_segments, ptr(rowptr), stream()),
+          "mdl_csr_rowptr")
+    return rowptr
+
+
+def build_csr(edge_index, num_nodes, assume_sorted=False):
+    """edge_index: [2, E] int64/int32 (row 0 = source j, row 1 = target i).  No host sync."""
+    require_hip(edge_index)
+    row, col = edge_index[0], edge_index[1]
+    if assume_sorted:
+        tgt = col.to(torch.int32).contiguous()
+        src = row.to(torch.int32).contiguous()
+        eperm = None
+    else:
+        perm = torch.argsort(col, stable=True)
+        tgt = col.index_select(0, perm).to(torch.int32)
+        src = row.index_select(0, perm).to(torch.int32)
+        eperm = perm.to(torch.int32)
+    return EdgeCSR(csr_rowptr(tgt, num_nodes), src, tgt, eperm, num_nodes, col.numel())
+
+
+_CSR_CACHE = collections.OrderedDict()
+_CSR_CACHE_MAX = 64
+
+
+def _key(edge_index, n):
+    return (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(n), edge_index.device.index)
+
+
+def register_csr(edge_index, csr):
+    """Attach a pre-built CSR to an edge_index tensor (used by the product loader)."""
+    k = _key(edge_index, csr.N)
+    _CSR_CACHE[k] = (csr, edge_index)  # keep the tensor alive so data_ptr cannot be recycled
+    while len(_CSR_CACHE) > _CSR_CACHE_MAX:
+        _CSR_CACHE.popitem(last=False)
+
+
+def csr_for(edge_index, num_nodes):
+    """CSR of a PyG-style edge_index; built on first use (device sort) and cached per tensor."""
+    k = _key(edge_index, num_nodes)
+    hit = _CSR_CACHE.get(k)
+    if hit is not None:
+        _CSR_CACHE.move_to_end(k)
+        return hit[0]
+    csr = build_csr(edge_index, num_nodes)
+    register_csr(edge_index, csr)
+    return csr
+
+
+# ------------------------------------------------------------------------------------------------
+# K1 — Gaussian RBF expansion
+# ------------------------------------------------------------------------------------------------
+def rbf_offsets(start=0.0, stop=1.0, resolution=50, device=None):
+    """process.py:583 — the fp32 torch.linspace centre buffer (computed on the host so the grid is
+    bit-identical to the reference's, then uploaded)."""
+    return torch.linspace(start, stop, resolution).to(device)
+
+
+def rbf_coeff(start=0.0, stop=1.0, width=0.2):
+    return -0.5 / ((stop - start) * width) ** 2  # process.py:585
+
+
+def rbf_expand(dist, start=0.0, stop=1.0, resolution=50, width=0.2, out_dtype=torch.float32, offsets=None,
+               out=None):
+    """GaussianSmearing(start, stop, resolution, width)(dist): [E] fp32 -> [E, resolution]."""
+    require_hip(dist)
+    if dist.dtype != torch.float32:
+        raise MdlError("rbf_expand: distances must be float32")
+    dist = dist.contiguous()
+    if offsets is None:
+        offsets = rbf_offsets(start, stop, resolution, dist.device)
+    E, G = dist.numel(), offsets.numel()
+    if out is None:
+        out = torch.empty((E, G), dtype=out_dtype, device=dist.device)
+    check(lib().mdl_rbf_expand(ptr(dist), ptr(offsets), float(rbf_coeff(start, stop, width)), ptr(out), E, G,
+                               out.stride(0) if E else G, dtype_code(out), stream()), "mdl_rbf_expand")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# K5 — scatter / pooling over a sorted (or sortable) index
+# ------------------------------------------------------------------------------------------------
+class _SegIndex:
+    __slots__ = ("rowptr", "seg", "perm", "N", "E")
+
+
+def _seg_index(index, dim_size, assume_sorted):
+    si = _SegIndex()
+    si.N, si.E = int(dim_size), index.numel()
+    if assume_sorted:
+        si.seg, si.perm = index.to(torch.int32).contiguous(), None
+    else:
+        perm = torch.argsort(index, stable=True)
+        si.seg, si.perm = index.index_select(0, perm).to(torch.int32), perm.to(torch.int32)
+    si.rowptr = csr_rowptr(si.seg, si.N)
+    return si
+
+
+class _SegmentReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, si, reduce):
+        require_hip(src)
+        src = src.contiguous()
+        C = src.numel() // max(src.shape[0], 1) if src.dim() > 1 else 1
+        out = torch.empty((si.N,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        argmax = torch.empty((si.N, C), dtype=torch.int32, device=src.device) if reduce == _lib.MDL_MAX else None
+        check(lib().mdl_segment_reduce_fwd(ptr(src), ptr(si.rowptr), ptr(si.perm), ptr(out), ptr(argmax), si.N, C,
+                                           reduce, dtype_code(src), stream()), "mdl_segment_reduce_fwd")
+        ctx.si, ctx.reduce, ctx.C, ctx.shape = si, reduce, C, tuple(src.shape)
+        ctx.save_for_backward(argmax) if argmax is not None else ctx.save_for_backward()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        si, C = ctx.si, ctx.C
+        g = g.contiguous()
+        argmax = ctx.saved_tensors[0] if ctx.reduce == _lib.MDL_MAX else None
+        alloc = torch.zeros if ctx.reduce == _lib.MDL_MAX else torch.empty
+        gs = alloc(ctx.shape, dtype=g.dtype, device=g.device)
+        check(lib().mdl_segment_reduce_bwd(ptr(g), ptr(si.rowptr), ptr(si.seg), ptr(si.perm), ptr(argmax), ptr(gs),
+                                           si.N, si.E, C, ctx.reduce, dtype_code(g), stream()),
+              "mdl_segment_reduce_bwd")
+        return gs, None, None
+
+
+def scatter(src, index, dim=0, dim_size=None, reduce="sum", assume_sorted=False):
+    """torch_scatter.scatter(src, index, dim=0, dim_size, reduce) semantics.  When
+    dim_size is None it is index.max()+1, which costs a host sync — pass dim_size on hot paths."""
+    if dim != 0:
+        raise MdlError("scatter: only dim=0 is on the hot path")
+    require_hip(src, index)
+    if reduce not in _lib.REDUCE:
+        raise MdlError("scatter: unsupported reduce %r" % (reduce,))
+    if dim_size is None:
+        dim_size = int(index.max()) + 1 if index.numel() else 0
+    si = _seg_index(index, dim_size, assume_sorted)
+    return _SegmentReduce.apply(src, si, _lib.REDUCE[reduce])
+
+
+def scatter_mean(src, index, dim=0, dim_size=None, assume_sorted=False):
+    return scatter(src, index, dim, dim_size, "mean", assume_sorted)
+
+
+def scatter_add(src, index, dim=0, dim_size=None, assume_sorted=False):
+    return scatter(src, index, dim, dim_size, "sum", assume_sorted)
+
+
+def global_mean_pool(x, batch, size=None):
+    """`batch` is non-decreasing by construction (PyG collate / the product loader)."""
+    return scatter(x, batch, 0, size, "mean", assume_sorted=True)
+
+
+def global_add_pool(x, batch, size=None):
+    return scatter(x, batch, 0, size, "sum", assume_sorted=True)
+
+
+def global_max_pool(x, batch, size=None):
+    return scatter(x, batch, 0, size, "max", assume_sorted=True)
+
+
+POOLS = {"global_mean_pool": global_mean_pool, "global_add_pool": global_add_pool,
+         "global_max_pool": global_max_pool}
+
+
+# ------------------------------------------------------------------------------------------------
+# K2/K3 — fused CGConv
+# ------------------------------------------------------------------------------------------------
+def _rup(a, b):
+    return (a + b - 1) // b * b
+
+
+class _CGConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, edge_attr, w_f, b_f, w_s, b_s, csr, aggr):
+        require_hip(x, edge_attr, w_f, w_s)
+        if edge_attr.dtype != x.dtype:
+            raise MdlError("cgconv: x (%s) and edge_attr (%s) must share a dtype" % (x.dtype, edge_attr.dtype))
+        x, edge_attr = x.contiguous(), edge_attr.contiguous()
+        N, C = x.shape
+        E, G = edge_attr.shape
+        if csr.N != N or csr.E != E:
+            raise MdlError("cgconv: CSR (%d nodes, %d edges) does not match x/edge_attr (%d, %d)" % (csr.N, csr.E, N, E))
+        dt = dtype_code(x)
+        L = lib()
+        wf32, ws32 = w_f.detach().float().contiguous(), w_s.detach().float().contiguous()
+        bf32 = None if b_f is None else b_f.detach().float().contiguous()
+        bs32 = None if b_s is None else b_s.detach().float().contiguous()
+        nbytes = L.mdl_cgconv_wpack_bytes(C, G, dt)
+        if nbytes == 0:
+            raise MdlError("cgconv: unsupported C=%d G=%d" % (C, G))
+        wpack = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        bpack = torch.empty(2 * _rup(C, 32), dtype=torch.float32, device=x.device)
+        check(L.mdl_cgconv_pack_weights(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpack), ptr(bpack), dt,
+                                        stream()), "mdl_cgconv_pack_weights")
+        out = torch.empty_like(x)
+        check(L.mdl_cgconv_fwd(ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(csr.eperm),
+                               ptr(wpack), ptr(bpack), ptr(out), N, E, C, G, aggr, dt, stream()), "mdl_cgconv_fwd")
+        ctx.save_for_backward(x, edge_attr, wf32, ws32, wpack, bpack)
+        ctx.csr, ctx.aggr, ctx.has_bias = csr, aggr, (b_f is not None, b_s is not None)
+        ctx.wdtypes = (w_f.dtype, w_s.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, edge_attr, wf32, ws32, wpack, bpack = ctx.saved_tensors
+        csr = ctx.csr
+        N, C = x.shape
+        E, G = edge_attr.shape
+        Cp, GP = _rup(C, 32), _rup(G, 64)
+        g = g.contiguous()
+        dt = dtype_code(x)
+        r_tgt = torch.empty((N, 2 * Cp), dtype=torch.float32, device=x.device)
+        r_src = torch.zeros((N, 2 * Cp), dtype=torch.float32, device=x.device)
+        dwe = torch.zeros((2 * Cp, GP), dtype=torch.float32, device=x.device)
+        check(lib().mdl_cgconv_bwd(ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt),
+                                   ptr(csr.eperm), ptr(wpack), ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe),
+                                   N, E, C, G, ctx.aggr, dt, stream()), "mdl_cgconv_bwd")
+        # node-level dense part (library GEMMs): [f-half | s-half] x {target, source}
+        rt = r_tgt.view(N, 2, Cp)[:, :, :C]
+        rs = r_src.view(N, 2, Cp)[:, :, :C]
+        cd = torch.float32 if dt == _lib.MDL_F32 else torch.bfloat16
+        R = torch.cat([rt[:, 0], rt[:, 1], rs[:, 0], rs[:, 1]], dim=1).to(cd)            # [N, 4C]
+        Wn = torch.cat([wf32[:, :C], ws32[:, :C], wf32[:, C:2 * C], ws32[:, C:2 * C]], dim=0).to(cd)  # [4C, C]
+        dx = torch.addmm(g, R, Wn) if ctx.needs_input_grad[0] else None
+        dWn = torch.mm(R.t(), x).float()                                                   # [4C, C]
+        dwe_f, dwe_s = dwe[:C, :G], dwe[Cp:Cp + C, :G]
+        dW_f = torch.cat([dWn[0:C], dWn[2 * C:3 * C], dwe_f], dim=1).to(ctx.wdtypes[0])
+        dW_s = torch.cat([dWn[C:2 * C], dWn[3 * C:4 * C], dwe_s], dim=1).to(ctx.wdtypes[1])
+        db = rt.sum(dim=0)                                                                  # [2, C] fp32
+        db_f = db[0] if ctx.has_bias[0] else None
+        db_s = db[1] if ctx.has_bias[1] else None
+        return dx, None, dW_f, db_f, dW_s, db_s, None, None
+
+
+def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None):
+    """CGConv forward.  x [N,C], edge_index [2,E], edge_attr [E,G]; returns [N,C]."""
+    if aggr not in ("mean", "add", "sum"):
+        raise MdlError("cgconv: aggr must be mean or add")
+    if csr is None:
+        csr = csr_for(edge_index, x.shape[0])
+    return _CGConvFn.apply(x, edge_attr, w_f, b_f, w_s, b_s, csr, _lib.REDUCE[aggr])

@@ -1,0 +1,72 @@
+"""Oracle graph construction (TEST INFRASTRUCTURE): restatement of the per-structure graph rule of
+matdeeplearn/process/process.py:258-388 for small cases, written as plain python/numpy loops so
+it shares no code with the vectorised product builder (matdeeplearn_amd/process/graph.py).
+
+Pinned by tests/golden/threshold_sort.npz, pt10_graphs.npz, onehot_degree.npz (all produced by
+the reference's own threshold_sort / OneHotDegree).
+"""
+import numpy as np
+
+
+def threshold_sort(matrix, threshold, neighbors):
+    """process.py:540-559 (adj=False branch).  Keep, per ROW, the entries whose ordinal rank among
+    the row (ascending, ties -> lower column first, scipy rankdata 'ordinal') is <= neighbors+1 and
+    whose value is <= threshold; everything else becomes 0.  The diagonal (distance 0) always has
+    rank 1, is kept, and stays 0 — so a row keeps at most `neighbors` non-zero entries."""
+    n = matrix.shape[0]
+    out = np.zeros_like(matrix, dtype=np.float64)
+    for i in range(n):
+        order = sorted(range(matrix.shape[1]), key=lambda j: (matrix[i, j], j))  # stable ordinal rank
+        for rank0, j in enumerate(order):
+            if rank0 + 1 <= neighbors + 1 and matrix[i, j] <= threshold:
+                out[i, j] = matrix[i, j]
+    return out
+
+
+def dense_to_edges(trimmed):
+    """process.py:294-305 — dense_to_sparse (row-major non-zeros, fp32) then add_self_loops(fill 0):
+    one [i, i] edge per node appended after all real edges."""
+    t = np.asarray(trimmed, dtype=np.float32)
+    rows, cols, w = [], [], []
+    for i in range(t.shape[0]):
+        for j in range(t.shape[1]):
+            if t[i, j] != 0:
+                rows.append(i)
+                cols.append(j)
+                w.append(t[i, j])
+    for i in range(t.shape[0]):
+        rows.append(i)
+        cols.append(i)
+        w.append(np.float32(0))
+    return np.array([rows, cols], dtype=np.int64), np.array(w, dtype=np.float32)
+
+
+def one_hot_degree(edge_index, num_nodes, max_degree):
+    """process.py:594-605 — one-hot of the OUT-degree (edge_index[0]) with max_degree+1 classes."""
+    deg = np.zeros(num_nodes, dtype=np.int64)
+    for s in edge_index[0]:
+        deg[s] += 1
+    out = np.zeros((num_nodes, max_degree + 1), dtype=np.float32)
+    out[np.arange(num_nodes), deg] = 1.0
+    return out
+
+
+def mic_distances(positions, cell, pbc):
+    """ase.Atoms.get_all_distances(mic=True) (process.py:284) for cells whose minimum image lies
+    within the 27 neighbouring images (true for the orthorhombic / mildly skewed cells used here)."""
+    p = np.asarray(positions, dtype=np.float64)
+    n = len(p)
+    shifts = [np.zeros(3)]
+    rng = [(-1, 0, 1) if b else (0,) for b in pbc]
+    shifts = [a * cell[0] + b * cell[1] + c * cell[2] for a in rng[0] for b in rng[1] for c in rng[2]]
+    d = np.zeros((n, n))
+    for i in range(n):
+        for j in range(n):
+            v = p[j] - p[i]
+            d[i, j] = min(np.linalg.norm(v + s) for s in shifts)
+    return d
+
+
+def build_graph(positions, cell, pbc, radius=8.0, max_neighbors=12):
+    d = mic_distances(positions, cell, pbc)
+    return dense_to_edges(threshold_sort(d, radius, max_neighbors))
