@@ -31,6 +31,10 @@
 
 #include "mdl_common.h"
 
+#ifndef MDL_BWD_WAVES
+#define MDL_BWD_WAVES 1   // waves per SIMD the backward kernel is register-allocated for
+#endif
+
 namespace mdl {
 
 struct CgParams {
@@ -54,6 +58,7 @@ struct CgParams {
     int n_groups;
     int w_elems;        // 2*Cp*WS
     int wave_lds_bytes; // per-wave LDS region
+    int bias_col;       // 1: bias lives in K column G of wpack (e tile column G holds 1.0)
 };
 
 struct CgDims {
@@ -111,7 +116,9 @@ template <int VEC>
 __device__ __forceinline__ bf16x8 ld_xfrag(const bf16_t* rowp, int c0, int h, int C) {
     const int c = c0 + 8 * h;
     bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (VEC == 8) {
+    if (VEC == 9) {            // 16-byte loads, channel count == padded count: no column mask
+        v = *reinterpret_cast<const bf16x8*>(rowp + c);
+    } else if (VEC == 8) {
         if (c < C) v = *reinterpret_cast<const bf16x8*>(rowp + c);
     } else if (VEC == 4) {
         bf16x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
@@ -128,19 +135,38 @@ __device__ __forceinline__ bf16x8 ld_xfrag(const bf16_t* rowp, int c0, int h, in
 template <int VEC>
 __device__ __forceinline__ float ld_xfrag(const float* rowp, int c0, int h, int C) {
     const int c = c0 + h;
+    if (VEC == 9) return rowp[c];
     return c < C ? rowp[c] : 0.0f;
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ bf16x8 pack_bf16x8(const float* v) {
-    bf16x8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(v[j]);
-    return r;
+    u32x4 r = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+    return __builtin_bit_cast(bf16x8, r);
 }
 
 // ------------------------------------------------------------------------------------------
 // Shared per-tile machinery
 // ------------------------------------------------------------------------------------------
+// Problem dimensions: compile-time when the kernel is instantiated for a fixed (CP_, G_) — loops
+// unroll fully, so all loads of a tile are issued before the first MFMA that needs them — or
+// run-time (CP_ = 0 / G_ = 0) for the generic fallback.
+template <typename T, int CP_, int G_, int EW>
+struct Dims {
+    static constexpr bool STATIC = (CP_ != 0) && (G_ != 0);
+    static constexpr int PADW = std::is_same<T, bf16_t>::value ? 8 : 1;
+    int C, Cp, G, KE, WS, EKS, GW;
+    __device__ __forceinline__ Dims(const CgParams& p) {
+        C = p.C;
+        Cp = CP_ ? CP_ : p.Cp;
+        G = G_ ? G_ : p.G;
+        KE = G_ ? ((G_ + 15) / 16 * 16) : p.KE;
+        WS = KE + 2 * Cp + PADW;
+        EKS = KE + PADW;
+        GW = G / EW;
+    }
+};
+
 template <typename T>
 struct WaveCtx {
     T* et;              // per-wave e tile  [32][EKS]
@@ -149,52 +175,132 @@ struct WaveCtx {
     const T* wbase;     // packed weights (LDS or global)
 };
 
-// Stage the 32 x G edge-feature tile of CSR slots [eb, eb+nv) into the wave's LDS tile.
-template <typename T, int EW>
-__device__ __forceinline__ void stage_e_tile(const CgParams& p, const WaveCtx<T>& w, int lane, int eb, int nv,
-                                             int my_ep) {
-    typedef typename std::conditional<EW * sizeof(T) == 4, unsigned, unsigned short>::type word_t;
-    const int total = 32 * p.GW;
+template <typename T, int EW> struct StageWord {
+    typedef typename std::conditional<EW * sizeof(T) == 4, unsigned, unsigned short>::type type;
+};
+
+// Generic (run-time G) staging of the 32 x G edge-feature tile: load -> LDS, word by word.
+template <typename T, int EW, typename D>
+__device__ __forceinline__ void stage_e_tile(const CgParams& p, const D& dm, const WaveCtx<T>& w, int lane, int eb,
+                                             int nv, int my_ep) {
+    typedef typename StageWord<T, EW>::type word_t;
+    const int total = 32 * dm.GW;
     const T* ea = static_cast<const T*>(p.ea);
     for (int q0 = 0; q0 < total; q0 += WAVE) {
         const int q = q0 + lane;
         const bool act = q < total;
         const int row = act ? (int)__umulhi((unsigned)q, p.gw_inv) : 0;
-        const int cw = q - row * p.GW;
+        const int cw = q - row * dm.GW;
         const int ep = p.eperm ? __shfl(my_ep, row) : eb + row;
         if (act && row < nv) {
-            const word_t v = *reinterpret_cast<const word_t*>(ea + (int64_t)ep * p.G + cw * EW);
-            *reinterpret_cast<word_t*>(w.et + row * p.EKS + cw * EW) = v;
+            const word_t v = *reinterpret_cast<const word_t*>(ea + (int64_t)ep * dm.G + cw * EW);
+            *reinterpret_cast<word_t*>(w.et + row * dm.EKS + cw * EW) = v;
         }
     }
 }
 
+// Static-G staging, split in two halves so the HBM latency of tile t+1 hides under the compute of
+// tile t: prefetch() issues the loads into registers, commit() writes them to the wave's LDS tile
+// at the top of the next iteration.
+template <typename T, int G_, int EW>
+struct EWords {
+    typedef typename StageWord<T, EW>::type word_t;
+    static constexpr int GW = G_ ? G_ / EW : 1;
+    static constexpr int NW = G_ ? (32 * GW + WAVE - 1) / WAVE : 1;
+    word_t w[NW];
+
+    __device__ __forceinline__ void prefetch(const CgParams& p, int lane, int eb, int nv, int my_ep) {
+        const T* ea = static_cast<const T*>(p.ea);
+        if (!p.eperm && (int64_t)eb + 32 <= p.E) {
+            // whole 32-row window is inside the array: one uniform 64-bit base + per-lane 32-bit
+            // offsets, no predication (rows >= nv belong to later edges; they are finite data and
+            // are multiplied by exact zeros downstream)
+            const char* tb = reinterpret_cast<const char*>(ea) + (int64_t)eb * (G_ * (int)sizeof(T));
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int q = j * WAVE + lane;
+                w[j] = 0;
+                if (j * WAVE + WAVE <= 32 * GW || q < 32 * GW)
+                    w[j] = *reinterpret_cast<const word_t*>(tb + (unsigned)q * (unsigned)(EW * sizeof(T)));
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int q = j * WAVE + lane;
+            const int row = q / GW, cw = q - row * GW;
+            const int ep = p.eperm ? __shfl(my_ep, row & 31) : eb + row;
+            w[j] = 0;
+            if (row < nv) w[j] = *reinterpret_cast<const word_t*>(ea + (int64_t)ep * G_ + cw * EW);
+        }
+    }
+    __device__ __forceinline__ void commit(T* et, int EKS, int lane) const {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int q = j * WAVE + lane;
+            const int row = q / GW, cw = q - row * GW;
+            if (row < 32) *reinterpret_cast<word_t*>(et + row * EKS + cw * EW) = w[j];
+        }
+    }
+};
+
+// x-row A fragments of one tile (target rows and source rows), all issued up front when the
+// channel count is static.
+template <typename T, int CP_, int VEC>
+struct XFrags {
+    typedef Mma<T> M;
+    static constexpr int NF = CP_ ? CP_ / M::KSTEP : 1;
+    typename M::frag_t t[NF], s[NF];
+    __device__ __forceinline__ void load(const T* x, int C, int my_tgt, int my_src, int h) {
+        const T* xt = x + (int64_t)my_tgt * C;
+        const T* xs = x + (int64_t)my_src * C;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) t[f] = ld_xfrag<VEC>(xt, f * M::KSTEP, h, C);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) s[f] = ld_xfrag<VEC>(xs, f * M::KSTEP, h, C);
+    }
+};
+
 // pre-activation tile: accf/accs (32 edge slots x 32 channels of slice s), bias pre-loaded.
-template <typename T, int VEC>
-__device__ __forceinline__ void pre_tile(const CgParams& p, const WaveCtx<T>& w, int lane, int s, int my_tgt,
-                                         int my_src, f32x16& accf, f32x16& accs) {
+template <typename T, int CP_, int VEC, typename D>
+__device__ __forceinline__ void pre_tile(const CgParams& p, const D& dm, const WaveCtx<T>& w, int lane, int s,
+                                         int my_tgt, int my_src, const XFrags<T, CP_, VEC>& xf, f32x16& accf,
+                                         f32x16& accs) {
     typedef Mma<T> M;
     const int i = lane & 31, h = lane >> 5;
-    const int rowf = s * 32 + i, rows = p.Cp + s * 32 + i;
-    const T* xt = static_cast<const T*>(p.x) + (int64_t)my_tgt * p.C;
-    const T* xs = static_cast<const T*>(p.x) + (int64_t)my_src * p.C;
-    // edge features
-    for (int k0 = 0; k0 < p.KE; k0 += M::KSTEP) {
-        typename M::frag_t a = ld_frag(w.et, i, p.EKS, k0, h);
-        accf = M::mma(a, ld_frag(w.wbase, rowf, p.WS, k0, h), accf);
-        accs = M::mma(a, ld_frag(w.wbase, rows, p.WS, k0, h), accs);
+    const int rowf = s * 32 + i, rows = dm.Cp + s * 32 + i;
+    // edge features (LDS tile)
+#pragma unroll
+    for (int k0 = 0; k0 < dm.KE; k0 += M::KSTEP) {
+        typename M::frag_t a = ld_frag(w.et, i, dm.EKS, k0, h);
+        accf = M::mma(a, ld_frag(w.wbase, rowf, dm.WS, k0, h), accf);
+        accs = M::mma(a, ld_frag(w.wbase, rows, dm.WS, k0, h), accs);
     }
-    // target-node features (x_i)
-    for (int k0 = 0; k0 < p.Cp; k0 += M::KSTEP) {
-        typename M::frag_t a = ld_xfrag<VEC>(xt, k0, h, p.C);
-        accf = M::mma(a, ld_frag(w.wbase, rowf, p.WS, p.KE + k0, h), accf);
-        accs = M::mma(a, ld_frag(w.wbase, rows, p.WS, p.KE + k0, h), accs);
-    }
-    // source-node features (x_j)
-    for (int k0 = 0; k0 < p.Cp; k0 += M::KSTEP) {
-        typename M::frag_t a = ld_xfrag<VEC>(xs, k0, h, p.C);
-        accf = M::mma(a, ld_frag(w.wbase, rowf, p.WS, p.KE + p.Cp + k0, h), accf);
-        accs = M::mma(a, ld_frag(w.wbase, rows, p.WS, p.KE + p.Cp + k0, h), accs);
+    if constexpr (CP_ != 0) {
+        constexpr int NF = XFrags<T, CP_, VEC>::NF;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {      // target-node features (x_i)
+            accf = M::mma(xf.t[f], ld_frag(w.wbase, rowf, dm.WS, dm.KE + f * M::KSTEP, h), accf);
+            accs = M::mma(xf.t[f], ld_frag(w.wbase, rows, dm.WS, dm.KE + f * M::KSTEP, h), accs);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {      // source-node features (x_j)
+            accf = M::mma(xf.s[f], ld_frag(w.wbase, rowf, dm.WS, dm.KE + dm.Cp + f * M::KSTEP, h), accf);
+            accs = M::mma(xf.s[f], ld_frag(w.wbase, rows, dm.WS, dm.KE + dm.Cp + f * M::KSTEP, h), accs);
+        }
+    } else {
+        const T* xt = static_cast<const T*>(p.x) + (int64_t)my_tgt * dm.C;
+        const T* xs = static_cast<const T*>(p.x) + (int64_t)my_src * dm.C;
+        for (int k0 = 0; k0 < dm.Cp; k0 += M::KSTEP) {
+            typename M::frag_t a = ld_xfrag<VEC>(xt, k0, h, dm.C);
+            accf = M::mma(a, ld_frag(w.wbase, rowf, dm.WS, dm.KE + k0, h), accf);
+            accs = M::mma(a, ld_frag(w.wbase, rows, dm.WS, dm.KE + k0, h), accs);
+        }
+        for (int k0 = 0; k0 < dm.Cp; k0 += M::KSTEP) {
+            typename M::frag_t a = ld_xfrag<VEC>(xs, k0, h, dm.C);
+            accf = M::mma(a, ld_frag(w.wbase, rowf, dm.WS, dm.KE + dm.Cp + k0, h), accf);
+            accs = M::mma(a, ld_frag(w.wbase, rows, dm.WS, dm.KE + dm.Cp + k0, h), accs);
+        }
     }
 }
 
@@ -206,15 +312,16 @@ __device__ __forceinline__ void seg_reduce_mma(const f32x16& v, const unsigned t
     if constexpr (std::is_same<T, bf16_t>::value) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a, b;
+            bf16x8 a;
+            float vv[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int r = 8 * ks + q;
                 const unsigned slot = (t4[r >> 2] >> (8 * (r & 3))) & 0xffu;
                 a[q] = (slot == (unsigned)ns) ? (short)0x3F80 : (short)0;
-                b[q] = (short)f2bf(v[r]);
+                vv[q] = v[r];
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pack_bf16x8(vv), acc, 0, 0, 0);
         }
     } else {
 #pragma unroll
@@ -225,13 +332,13 @@ __device__ __forceinline__ void seg_reduce_mma(const f32x16& v, const unsigned t
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void setup_wave(const CgParams& p, char* smem, bool w_lds, WaveCtx<T>& w) {
+template <typename T, typename D>
+__device__ __forceinline__ void setup_wave(const CgParams& p, const D& dm, char* smem, bool w_lds, WaveCtx<T>& w) {
     const int wave = threadIdx.x >> 6;
     const int w_bytes = w_lds ? ((p.w_elems * (int)sizeof(T) + 15) & ~15) : 0;
     char* base = smem + w_bytes + wave * p.wave_lds_bytes;
     w.et = reinterpret_cast<T*>(base);
-    const int et_bytes = (32 * p.EKS * (int)sizeof(T) + 15) & ~15;
+    const int et_bytes = (32 * dm.EKS * (int)sizeof(T) + 15) & ~15;
     w.tsl = reinterpret_cast<unsigned*>(base + et_bytes);
     w.srcl = reinterpret_cast<int*>(base + et_bytes + 32);
     w.wbase = w_lds ? reinterpret_cast<const T*>(smem) : static_cast<const T*>(p.wpack);
@@ -244,25 +351,47 @@ __device__ __forceinline__ void setup_wave(const CgParams& p, char* smem, bool w
     // zero the e tile once: padded columns [G, KE) stay 0 forever, rows never hold garbage bits
     unsigned* z = reinterpret_cast<unsigned*>(base);
     for (int q = threadIdx.x & 63; q < et_bytes / 4; q += WAVE) z[q] = 0u;
+    wave_lds_fence();
+    // bias column: e-tile column G is a constant 1 whose weight row holds the bias
+    if (p.bias_col && (threadIdx.x & 63) < 32) Elem<T>::st(w.et + (threadIdx.x & 63) * dm.EKS + dm.G, 1.0f);
     __syncthreads();
 }
+
+// per-lane indices of one edge tile (lane i and lane i+32 hold the same edge slot i)
+struct TileIdx {
+    int src, tgt, ep;
+    __device__ __forceinline__ void load(const CgParams& p, int eb, int e1, int i, int n0) {
+        const int eid = eb + i;
+        const bool ok = eid < e1;
+        src = ok ? p.src[eid] : n0;
+        tgt = ok ? p.tgt[eid] : n0;
+        ep = (p.eperm && ok) ? p.eperm[eid] : 0;
+    }
+};
 
 // ------------------------------------------------------------------------------------------
 // Forward
 // ------------------------------------------------------------------------------------------
-template <typename T, int VEC, int EW, bool W_LDS>
+template <typename T, int CP_, int G_, int VEC, int EW, bool W_LDS>
 __global__ __launch_bounds__(256, 2) void cgconv_fwd_kernel(CgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Mma<T> M;
+    typedef Gate<M::FAST> GT;
+    typedef Dims<T, CP_, G_, EW> D;
+    constexpr bool ST = D::STATIC;
+    const D dm(p);
     WaveCtx<T> w;
-    setup_wave<T>(p, smem, W_LDS, w);
+    setup_wave<T>(p, dm, smem, W_LDS, w);
 
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int total_waves = gridDim.x * (blockDim.x >> 6);
     const int s = gw % p.NS;
     const int gstride = total_waves / p.NS;
-    const float bf = p.bpack[s * 32 + i], bs = p.bpack[p.Cp + s * 32 + i];
+    // with a bias column the bias rides in the GEMM (K column G); otherwise it seeds the accumulators
+    constexpr bool BC = G_ != 0 && (G_ % 16) != 0;   // bias column known at compile time
+    const float bf = (BC || p.bias_col) ? 0.0f : p.bpack[s * 32 + i];
+    const float bs = (BC || p.bias_col) ? 0.0f : p.bpack[dm.Cp + s * 32 + i];
     const T* x = static_cast<const T*>(p.x);
     T* out = static_cast<T*>(p.out);
 
@@ -275,48 +404,59 @@ __global__ __launch_bounds__(256, 2) void cgconv_fwd_kernel(CgParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_out[r] = 0.0f;
 
+        TileIdx cur, nxt;
+        EWords<T, G_, EW> ew;
+        cur.load(p, e0, e1, i, n0);
+        nxt = cur;
+        if constexpr (ST) ew.prefetch(p, lane, e0, min(32, e1 - e0), cur.ep);
+
         for (int eb = e0; eb < e1; eb += 32) {
             const int nv = min(32, e1 - eb);
             const bool valid_i = i < nv;
-            const int eid = eb + i;
-            const int my_src = valid_i ? p.src[eid] : n0;
-            const int my_tgt = valid_i ? p.tgt[eid] : n0;
-            const int my_ep = (p.eperm && valid_i) ? p.eperm[eid] : 0;
             wave_lds_fence();
-            stage_e_tile<T, EW>(p, w, lane, eb, nv, my_ep);
-            if (h == 0) reinterpret_cast<unsigned char*>(w.tsl)[i] = valid_i ? (unsigned char)(my_tgt - n0) : 0xff;
+            if constexpr (ST) ew.commit(w.et, dm.EKS, lane); else stage_e_tile<T, EW>(p, dm, w, lane, eb, nv, cur.ep);
+            if (h == 0) reinterpret_cast<unsigned char*>(w.tsl)[i] = valid_i ? (unsigned char)(cur.tgt - n0) : 0xff;
             wave_lds_fence();
+
+            XFrags<T, CP_, VEC> xf;
+            if constexpr (CP_ != 0) xf.load(x, dm.C, cur.tgt, cur.src, h);
+            // software prefetch of the next tile (indices + edge-feature words) — issued AFTER the
+            // x gathers so that waiting for those does not drain the prefetch
+            if (eb + 32 < e1) {
+                nxt.load(p, eb + 32, e1, i, n0);
+                if constexpr (ST) ew.prefetch(p, lane, eb + 32, min(32, e1 - eb - 32), nxt.ep);
+            }
 
             f32x16 accf, accs;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
-            pre_tile<T, VEC>(p, w, lane, s, my_tgt, my_src, accf, accs);
+            pre_tile<T, CP_, VEC>(p, dm, w, lane, s, cur.tgt, cur.src, xf, accf, accs);
 
             unsigned t4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) t4[j] = w.tsl[2 * j + h];
+            // gate.  Edge slots >= nv hold finite garbage; their one-hot column is all zero, so they
+            // contribute exact zeros to the aggregation — no per-element masking needed.
             f32x16 m;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = sigmoidf_<M::FAST>(accf[r]) * softplusf_<M::FAST>(accs[r]);
-                m[r] = (d_row(r, h) < nv) ? v : 0.0f;
-            }
+            for (int r = 0; r < 16; ++r) m[r] = GT::sigmoid(accf[r]) * GT::softplus_u(accs[r]);
             seg_reduce_mma<T>(m, t4, i, acc_out);
+            cur = nxt;
         }
 
         // epilogue: out = x + acc / deg   (rows = node slots in D layout, col = channel)
         const int ch = s * 32 + i;
-        if (ch < p.C) {
+        if (ch < dm.C) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + d_row(r, h);
                 if (n < n1) {
-                    float a = acc_out[r];
+                    float a = acc_out[r] * GT::M_SCALE;
                     if (p.aggr == MDL_MEAN) {
-                        const int deg = p.rowptr[n + 1] - p.rowptr[n];
-                        a = a / (float)max(deg, 1);
+                        const float deg = (float)max(p.rowptr[n + 1] - p.rowptr[n], 1);
+                        a = M::FAST ? a * __builtin_amdgcn_rcpf(deg) : a / deg;
                     }
-                    const int64_t o = (int64_t)n * p.C + ch;
+                    const int64_t o = (int64_t)n * dm.C + ch;
                     Elem<T>::st(out + o, Elem<T>::ld(x + o) + a);
                 }
             }
@@ -327,13 +467,17 @@ __global__ __launch_bounds__(256, 2) void cgconv_fwd_kernel(CgParams p) {
 // ------------------------------------------------------------------------------------------
 // Backward edge pass
 // ------------------------------------------------------------------------------------------
-template <typename T, int VEC, int EW, bool W_LDS>
-__global__ __launch_bounds__(256, 2) void cgconv_bwd_kernel(CgParams p) {
+template <typename T, int CP_, int G_, int VEC, int EW, bool W_LDS>
+__global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Mma<T> M;
+    typedef Gate<M::FAST> GT;
+    typedef Dims<T, CP_, G_, EW> D;
+    constexpr bool ST = D::STATIC;
     constexpr bool BF = std::is_same<T, bf16_t>::value;
+    const D dm(p);
     WaveCtx<T> w;
-    setup_wave<T>(p, smem, W_LDS, w);
+    setup_wave<T>(p, dm, smem, W_LDS, w);
 
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -341,19 +485,21 @@ __global__ __launch_bounds__(256, 2) void cgconv_bwd_kernel(CgParams p) {
     const int s = gw % p.NS;
     const int gstride = total_waves / p.NS;
     const int ch = s * 32 + i;
-    const float bf = p.bpack[ch], bs = p.bpack[p.Cp + ch];
+    constexpr bool BC = G_ != 0 && (G_ % 16) != 0;
+    const float bf = (BC || p.bias_col) ? 0.0f : p.bpack[ch], bs = (BC || p.bias_col) ? 0.0f : p.bpack[dm.Cp + ch];
+    const T* x = static_cast<const T*>(p.x);
     const T* go = static_cast<const T*>(p.gout);
-    const int C2 = 2 * p.Cp;
+    const int C2 = 2 * dm.Cp;
 
     // dwe accumulators: [part f|s][n-tile of G]  (rows = channel slot, cols = edge feature)
-    f32x16 dwe_acc[2][2];
+    constexpr int GNT = G_ ? (G_ + 31) / 32 : 2;
+    f32x16 dwe_acc[2][GNT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < GNT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dwe_acc[a][b][r] = 0.0f;
-    const int gnt = (p.KE + 31) / 32;  // 1 or 2 column tiles of edge features
 
     for (int g = gw / p.NS; g < p.n_groups; g += gstride) {
         const int n0 = g * 32;
@@ -373,8 +519,8 @@ __global__ __launch_bounds__(256, 2) void cgconv_bwd_kernel(CgParams p) {
                     const int ns = BF ? (16 * f + 8 * h + q) : (2 * f + h);
                     const int n = n0 + ns;
                     float gv = 0.0f;
-                    if (n < n1 && ch < p.C) {
-                        gv = Elem<T>::ld(go + (int64_t)n * p.C + ch);
+                    if (n < n1 && ch < dm.C) {
+                        gv = Elem<T>::ld(go + (int64_t)n * dm.C + ch);
                         if (p.aggr == MDL_MEAN) gv = gv / (float)max(p.rowptr[n + 1] - p.rowptr[n], 1);
                     }
                     v[q] = gv;
@@ -387,55 +533,64 @@ __global__ __launch_bounds__(256, 2) void cgconv_bwd_kernel(CgParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Rf[r] = 0.0f; Rs[r] = 0.0f; }
 
+        TileIdx cur, nxt;
+        EWords<T, G_, EW> ew;
+        cur.load(p, e0, e1, i, n0);
+        nxt = cur;
+        if constexpr (ST) ew.prefetch(p, lane, e0, min(32, e1 - e0), cur.ep);
+
         for (int eb = e0; eb < e1; eb += 32) {
             const int nv = min(32, e1 - eb);
             const bool valid_i = i < nv;
-            const int eid = eb + i;
-            const int my_src = valid_i ? p.src[eid] : n0;
-            const int my_tgt = valid_i ? p.tgt[eid] : n0;
-            const int my_ep = (p.eperm && valid_i) ? p.eperm[eid] : 0;
-            const int my_ts = valid_i ? (my_tgt - n0) : 0xff;
+            const int my_ts = valid_i ? (cur.tgt - n0) : 0xff;
             wave_lds_fence();
-            stage_e_tile<T, EW>(p, w, lane, eb, nv, my_ep);
+            if constexpr (ST) ew.commit(w.et, dm.EKS, lane); else stage_e_tile<T, EW>(p, dm, w, lane, eb, nv, cur.ep);
             if (h == 0) {
                 reinterpret_cast<unsigned char*>(w.tsl)[i] = (unsigned char)my_ts;
-                w.srcl[i] = my_src;
+                w.srcl[i] = cur.src;
             }
             wave_lds_fence();
+
+            XFrags<T, CP_, VEC> xf;
+            if constexpr (CP_ != 0) xf.load(x, dm.C, cur.tgt, cur.src, h);
+            if (eb + 32 < e1) {
+                nxt.load(p, eb + 32, e1, i, n0);
+                if constexpr (ST) ew.prefetch(p, lane, eb + 32, min(32, e1 - eb - 32), nxt.ep);
+            }
 
             f32x16 accf, accs;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
-            pre_tile<T, VEC>(p, w, lane, s, my_tgt, my_src, accf, accs);
+            pre_tile<T, CP_, VEC>(p, dm, w, lane, s, cur.tgt, cur.src, xf, accf, accs);
 
-            // dm[edge slot][ch] = grad_out[tgt(edge)][ch] / deg : one-hot(edge -> node slot) x gB
-            f32x16 dm;
+            // dmv[edge slot][ch] = grad_out[tgt(edge)][ch] / deg : one-hot(edge -> node slot) x gB
+            f32x16 dmv;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dm[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) dmv[r] = 0.0f;
             if constexpr (BF) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     bf16x8 a;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) a[q] = (my_ts == 16 * ks + 8 * h + q) ? (short)0x3F80 : (short)0;
-                    dm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, gB[ks], dm, 0, 0, 0);
+                    dmv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, gB[ks], dmv, 0, 0, 0);
                 }
             } else {
 #pragma unroll
                 for (int f = 0; f < 16; ++f)
-                    dm = __builtin_amdgcn_mfma_f32_32x32x2f32((my_ts == 2 * f + h) ? 1.0f : 0.0f, gB[f], dm, 0, 0, 0);
+                    dmv = __builtin_amdgcn_mfma_f32_32x32x2f32((my_ts == 2 * f + h) ? 1.0f : 0.0f, gB[f], dmv, 0, 0, 0);
             }
 
             // gate derivative -> dpre (in place in accf/accs)
+            // (dmv is an exact 0 for edge slots >= nv — their one-hot row is empty — so dpre is 0 there)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float f = accf[r], sv = accs[r];
-                const float sf = sigmoidf_<M::FAST>(f);
-                const float sp = softplusf_<M::FAST>(sv);
-                const float ss = sigmoidf_<M::FAST>(sv);
-                const bool ok = d_row(r, h) < nv;
-                accf[r] = ok ? dm[r] * sp * sf * (1.0f - sf) : 0.0f;
-                accs[r] = ok ? dm[r] * sf * ss : 0.0f;
+                const float sf = GT::sigmoid(accf[r]);
+                float sp_u, ss;
+                GT::softplus_sigmoid(accs[r], sp_u, ss);
+                const float t = dmv[r] * sf;
+                accf[r] = (t * GT::M_SCALE) * (1.0f - sf) * sp_u;
+                accs[r] = t * ss;
             }
 
             unsigned t4[4];
@@ -445,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void cgconv_bwd_kernel(CgParams p) {
             seg_reduce_mma<T>(accs, t4, i, Rs);
 
             // r_src: scatter dpre to the SOURCE node of every edge slot (fp32 hardware atomics)
-            if (ch < p.C) {
+            if (ch < dm.C) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int slot = d_row(r, h);
@@ -453,63 +608,66 @@ __global__ __launch_bounds__(256, 2) void cgconv_bwd_kernel(CgParams p) {
                         const int sj = w.srcl[slot];
                         float* dst = p.r_src + (int64_t)sj * C2 + ch;
                         unsafeAtomicAdd(dst, accf[r]);
-                        unsafeAtomicAdd(dst + p.Cp, accs[r]);
+                        unsafeAtomicAdd(dst + dm.Cp, accs[r]);
                     }
                 }
             }
 
             // dwe[ch][gcol] += sum_slot dpre[slot][ch] * e[slot][gcol]
             //   A = dpre^T (lane = channel, k = edge slots: own registers), B = e tile column (LDS)
-            for (int nt = 0; nt < gnt; ++nt) {
+#pragma unroll
+            for (int nt = 0; nt < GNT; ++nt) {
                 const int gcol = nt * 32 + i;
-                if constexpr (BF) {
+                if (nt * 32 < dm.KE) {
+                    if constexpr (BF) {
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        bf16x8 af, as, b;
+                        for (int ks = 0; ks < 2; ++ks) {
+                            bf16x8 af, as, b;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int r = 8 * ks + q;
-                            af[q] = (short)f2bf(accf[r]);
-                            as[q] = (short)f2bf(accs[r]);
-                            b[q] = (gcol < p.KE) ? (short)w.et[d_row(r, h) * p.EKS + gcol] : (short)0;
+                            for (int q = 0; q < 8; ++q) {
+                                const int r = 8 * ks + q;
+                                af[q] = (short)f2bf(accf[r]);
+                                as[q] = (short)f2bf(accs[r]);
+                                b[q] = (gcol < dm.KE) ? (short)w.et[d_row(r, h) * dm.EKS + gcol] : (short)0;
+                            }
+                            dwe_acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, dwe_acc[0][nt], 0, 0, 0);
+                            dwe_acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as, b, dwe_acc[1][nt], 0, 0, 0);
                         }
-                        dwe_acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, dwe_acc[0][nt], 0, 0, 0);
-                        dwe_acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as, b, dwe_acc[1][nt], 0, 0, 0);
-                    }
-                } else {
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float b = (gcol < p.KE) ? w.et[d_row(r, h) * p.EKS + gcol] : 0.0f;
-                        dwe_acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(accf[r], b, dwe_acc[0][nt], 0, 0, 0);
-                        dwe_acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(accs[r], b, dwe_acc[1][nt], 0, 0, 0);
+                        for (int r = 0; r < 16; ++r) {
+                            const float b = (gcol < dm.KE) ? w.et[d_row(r, h) * dm.EKS + gcol] : 0.0f;
+                            dwe_acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(accf[r], b, dwe_acc[0][nt], 0, 0, 0);
+                            dwe_acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(accs[r], b, dwe_acc[1][nt], 0, 0, 0);
+                        }
                     }
                 }
             }
+            cur = nxt;
         }
 
         // r_tgt rows of this group (each written exactly once)
-        if (ch < p.Cp) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + d_row(r, h);
-                if (n < n1) {
-                    float* dst = p.r_tgt + (int64_t)n * C2 + ch;
-                    dst[0] = Rf[r];
-                    dst[p.Cp] = Rs[r];
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + d_row(r, h);
+            if (n < n1) {
+                float* dst = p.r_tgt + (int64_t)n * C2 + ch;
+                dst[0] = Rf[r];
+                dst[dm.Cp] = Rs[r];
             }
         }
     }
 
     // flush the wave's dwe partial sums: D rows = channel slot d_row(r,h) of slice s, cols = feature
-    for (int nt = 0; nt < gnt; ++nt) {
+#pragma unroll
+    for (int nt = 0; nt < GNT; ++nt) {
         const int gcol = nt * 32 + i;
-        if (gcol < p.G) {
+        if (gcol < dm.G) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = s * 32 + d_row(r, h);
                 unsafeAtomicAdd(p.dwe + (int64_t)c * p.GP + gcol, dwe_acc[0][nt][r]);
-                unsafeAtomicAdd(p.dwe + (int64_t)(p.Cp + c) * p.GP + gcol, dwe_acc[1][nt][r]);
+                unsafeAtomicAdd(p.dwe + (int64_t)(dm.Cp + c) * p.GP + gcol, dwe_acc[1][nt][r]);
             }
         }
     }
@@ -522,7 +680,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void cgconv_pack_kernel(const float* __restrict__ wf, const float* __restrict__ bfv,
                                                           const float* __restrict__ ws, const float* __restrict__ bsv,
                                                           int C, int G, CgDims d, T* __restrict__ wpack,
-                                                          float* __restrict__ bpack) {
+                                                          float* __restrict__ bpack, float scale, int bias_col) {
     const int total = 2 * d.Cp * d.WS;
     const int ldw = 2 * C + G;
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
@@ -533,6 +691,7 @@ __global__ __launch_bounds__(256) void cgconv_pack_kernel(const float* __restric
         if (c < C) {
             if (k < d.KE) {
                 if (k < G) v = W[c * ldw + 2 * C + k];
+                else if (k == G && bias_col) { const float* b = part ? bsv : bfv; v = b ? b[c] : 0.0f; }
             } else if (k < d.KE + d.Cp) {
                 const int kc = k - d.KE;
                 if (kc < C) v = W[c * ldw + kc];
@@ -541,12 +700,12 @@ __global__ __launch_bounds__(256) void cgconv_pack_kernel(const float* __restric
                 if (kc < C) v = W[c * ldw + C + kc];
             }
         }
-        Elem<T>::st(wpack + q, v);
+        Elem<T>::st(wpack + q, v * scale);
     }
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < 2 * d.Cp; q += gridDim.x * blockDim.x) {
         const int part = q / d.Cp, c = q - part * d.Cp;
         const float* b = part ? bsv : bfv;
-        bpack[q] = (c < C && b) ? b[c] : 0.0f;
+        bpack[q] = (c < C && b) ? b[c] * scale : 0.0f;
     }
 }
 
@@ -560,6 +719,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     const CgDims d = cg_dims(p.C, p.G, dtype);
     p.Cp = d.Cp; p.KE = d.KE; p.KT = d.KT; p.WS = d.WS; p.EKS = d.EKS; p.NS = d.NS; p.GP = d.GP;
     p.w_elems = 2 * d.Cp * d.WS;
+    p.bias_col = (p.G % 16) != 0;      // a zero-padding K column is free to carry the bias
     p.n_groups = (int)cdiv(p.N, 32);
     if (p.n_groups == 0) return MDL_OK;
 
@@ -585,29 +745,40 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
 
     int64_t items = (int64_t)p.n_groups * d.NS;
     int64_t grid = cdiv(items, waves);
-    const int64_t cap = 256 * wg_per_cu;
+    // backward is register-allocated for MDL_BWD_WAVES waves per SIMD: 1 -> one 4-wave workgroup per CU
+    const int64_t cap = 256 * ((bwd && MDL_BWD_WAVES == 1) ? 1 : wg_per_cu);
     if (grid > cap) grid = cap;
     // total waves must be a multiple of NS so that every wave keeps one channel slice
     while ((grid * waves) % d.NS) ++grid;
 
-#define MDL_CG_LAUNCH(VEC_, EW_, WL_)                                                                        \
+#define MDL_CG_LAUNCH(CP_, G_, VEC_, EW_, WL_)                                                               \
     do {                                                                                                     \
-        auto kf = bwd ? cgconv_bwd_kernel<T, VEC_, EW_, WL_> : cgconv_fwd_kernel<T, VEC_, EW_, WL_>;         \
+        auto kf = bwd ? cgconv_bwd_kernel<T, CP_, G_, VEC_, EW_, WL_> : cgconv_fwd_kernel<T, CP_, G_, VEC_, EW_, WL_>; \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf),                                \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);                 \
         if (e != hipSuccess) { set_error("%s: LDS attribute (%d B): %s", name, lds, hipGetErrorString(e)); return MDL_E_LAUNCH; } \
         hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);                           \
     } while (0)
-#define MDL_CG_BY_WL(VEC_, EW_) do { if (w_lds) MDL_CG_LAUNCH(VEC_, EW_, true); else MDL_CG_LAUNCH(VEC_, EW_, false); } while (0)
+#define MDL_CG_BY_WL(VEC_, EW_) do { if (w_lds) MDL_CG_LAUNCH(0, 0, VEC_, EW_, true); else MDL_CG_LAUNCH(0, 0, VEC_, EW_, false); } while (0)
 #define MDL_CG_BY_EW(VEC_) do { if (EW == 2) MDL_CG_BY_WL(VEC_, 2); else MDL_CG_BY_WL(VEC_, 1); } while (0)
 
+    // fully static instantiations for the reference's edge width G = 50 and common channel counts
+    const bool fast = p.G == 50 && p.C == d.Cp && w_lds;
+#ifdef MDL_CG_FAST_ONLY   // compile-time experiments: only the bf16 C=64 G=50 instantiation
+    if constexpr (sizeof(T) == 2) { if (fast && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 2, true); }
+#else
     if constexpr (sizeof(T) == 2) {
-        if (vec == 8) MDL_CG_BY_EW(8);
+        if (fast && vec == 8 && EW == 2 && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 2, true);
+        else if (fast && vec == 8 && EW == 2 && d.Cp == 32) MDL_CG_LAUNCH(32, 50, 9, 2, true);
+        else if (fast && vec == 8 && EW == 2 && d.Cp == 128) MDL_CG_LAUNCH(128, 50, 9, 2, true);
+        else if (vec == 8) MDL_CG_BY_EW(8);
         else if (vec == 4) MDL_CG_BY_EW(4);
         else MDL_CG_BY_EW(1);
     } else {
-        MDL_CG_BY_WL(1, 1);
+        if (fast && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 1, true);
+        else MDL_CG_BY_WL(1, 1);
     }
+#endif
 #undef MDL_CG_BY_EW
 #undef MDL_CG_BY_WL
 #undef MDL_CG_LAUNCH
@@ -648,10 +819,13 @@ extern "C" int mdl_cgconv_pack_weights(const float* w_f, const float* b_f, const
     const int total = 2 * d.Cp * d.WS;
     dim3 grid((unsigned)cdiv(total, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    const int bias_col = (G % 16) != 0;
     if (dtype == MDL_BF16)
-        hipLaunchKernelGGL((cgconv_pack_kernel<bf16_t>), grid, block, 0, st, w_f, b_f, w_s, b_s, C, G, d, (bf16_t*)wpack, bpack);
+        hipLaunchKernelGGL((cgconv_pack_kernel<bf16_t>), grid, block, 0, st, w_f, b_f, w_s, b_s, C, G, d, (bf16_t*)wpack, bpack,
+                           Gate<true>::W_SCALE, bias_col);
     else if (dtype == MDL_F32)
-        hipLaunchKernelGGL((cgconv_pack_kernel<float>), grid, block, 0, st, w_f, b_f, w_s, b_s, C, G, d, (float*)wpack, bpack);
+        hipLaunchKernelGGL((cgconv_pack_kernel<float>), grid, block, 0, st, w_f, b_f, w_s, b_s, C, G, d, (float*)wpack, bpack,
+                           Gate<false>::W_SCALE, bias_col);
     else {
         set_error("mdl_cgconv_pack_weights: unsupported dtype %d", dtype);
         return MDL_E_UNSUPP;

@@ -26,6 +26,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair (v_cvt_pk_bf16_f32 on gfx950, round-to-nearest-even)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    bf16x2_hw r = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_hw);
+    return *reinterpret_cast<unsigned*>(&r);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int dtype = MDL_F32;
@@ -51,18 +59,47 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // ---- gate math ---------------------------------------------------------------------------
-// FAST: v_exp/v_log/v_rcp based (bf16 mode).  PRECISE: ocml expf/log1pf (fp32 parity mode).
-template <bool FAST> __device__ __forceinline__ float sigmoidf_(float x) {
-    if (FAST) return __frcp_rn(1.0f + __expf(-x));
-    return 1.0f / (1.0f + expf(-x));
-}
-// softplus(x) = max(x,0) + log1p(exp(-|x|)); torch switches to identity above threshold 20,
-// where the two agree to < 2.1e-9 absolute, i.e. below fp32 resolution of x itself.
-template <bool FAST> __device__ __forceinline__ float softplusf_(float x) {
-    float a = fabsf(x);
-    if (FAST) return fmaxf(x, 0.0f) + __logf(1.0f + __expf(-a));
-    return fmaxf(x, 0.0f) + log1pf(expf(-a));
-}
+// PRECISE (fp32 parity mode): ocml expf/log1pf on the true pre-activations.
+// FAST (bf16 mode): the packed weights/biases are pre-scaled by log2(e), so the MFMA delivers
+// t = pre*log2(e) and everything runs on the hardware base-2 transcendentals (v_exp/v_log/v_rcp):
+//   sigmoid(pre)  = 1 / (1 + 2^-t)
+//   softplus(pre) = ln2 * sp2(t),  sp2(t) = max(t,0) + log2(1 + 2^-|t|)
+// The ln2 factor is folded into the per-node epilogue scale by the callers.
+// torch's softplus switches to identity above threshold 20, where both forms agree to < 2.1e-9.
+constexpr float LOG2E_F = 1.4426950408889634f;
+constexpr float LN2_F = 0.6931471805599453f;
+
+template <bool FAST> struct Gate;
+template <> struct Gate<false> {
+    static constexpr float W_SCALE = 1.0f;     // weight pre-scale
+    static constexpr float M_SCALE = 1.0f;     // message post-scale
+    __device__ static __forceinline__ float sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+    __device__ static __forceinline__ float softplus_u(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
+    // softplus (unscaled) and sigmoid of the same argument
+    __device__ static __forceinline__ void softplus_sigmoid(float x, float& sp_u, float& sg) {
+        const float ea = expf(-fabsf(x));
+        sp_u = fmaxf(x, 0.0f) + log1pf(ea);
+        const float r = 1.0f / (1.0f + ea);
+        sg = x >= 0.0f ? r : ea * r;
+    }
+};
+template <> struct Gate<true> {
+    static constexpr float W_SCALE = LOG2E_F;
+    static constexpr float M_SCALE = LN2_F;
+    __device__ static __forceinline__ float sigmoid(float t) {
+        return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
+    }
+    __device__ static __forceinline__ float softplus_u(float t) {
+        return fmaxf(t, 0.0f) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(t)));
+    }
+    __device__ static __forceinline__ void softplus_sigmoid(float t, float& sp_u, float& sg) {
+        const float ea = __builtin_amdgcn_exp2f(-fabsf(t));
+        const float l = 1.0f + ea;
+        sp_u = fmaxf(t, 0.0f) + __builtin_amdgcn_logf(l);
+        const float r = __builtin_amdgcn_rcpf(l);
+        sg = t >= 0.0f ? r : ea * r;
+    }
+};
 
 // ---- error plumbing ----------------------------------------------------------------------
 void set_error(const char* fmt, ...);

@@ -204,6 +204,23 @@ def _rup(a, b):
     return (a + b - 1) // b * b
 
 
+# bench.py sets this to {"fwd": [], "bwd": []} to collect (start, end) HIP events recorded on the
+# launch stream around the two conv kernels; None (default) = no events.
+KERNEL_EVENTS = None
+
+
+def _launch_timed(key, fn):
+    ev = KERNEL_EVENTS
+    if ev is None:
+        return fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    rc = fn()
+    b.record()
+    ev[key].append((a, b))
+    return rc
+
+
 class _CGConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, edge_attr, w_f, b_f, w_s, b_s, csr, aggr):
@@ -228,8 +245,9 @@ class _CGConvFn(torch.autograd.Function):
         check(L.mdl_cgconv_pack_weights(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpack), ptr(bpack), dt,
                                         stream()), "mdl_cgconv_pack_weights")
         out = torch.empty_like(x)
-        check(L.mdl_cgconv_fwd(ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(csr.eperm),
-                               ptr(wpack), ptr(bpack), ptr(out), N, E, C, G, aggr, dt, stream()), "mdl_cgconv_fwd")
+        check(_launch_timed("fwd", lambda: L.mdl_cgconv_fwd(
+            ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(csr.eperm), ptr(wpack),
+            ptr(bpack), ptr(out), N, E, C, G, aggr, dt, stream())), "mdl_cgconv_fwd")
         ctx.save_for_backward(x, edge_attr, wf32, ws32, wpack, bpack)
         ctx.csr, ctx.aggr, ctx.has_bias = csr, aggr, (b_f is not None, b_s is not None)
         ctx.wdtypes = (w_f.dtype, w_s.dtype)
@@ -247,9 +265,10 @@ class _CGConvFn(torch.autograd.Function):
         r_tgt = torch.empty((N, 2 * Cp), dtype=torch.float32, device=x.device)
         r_src = torch.zeros((N, 2 * Cp), dtype=torch.float32, device=x.device)
         dwe = torch.zeros((2 * Cp, GP), dtype=torch.float32, device=x.device)
-        check(lib().mdl_cgconv_bwd(ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt),
-                                   ptr(csr.eperm), ptr(wpack), ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe),
-                                   N, E, C, G, ctx.aggr, dt, stream()), "mdl_cgconv_bwd")
+        check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd(
+            ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(csr.eperm), ptr(wpack),
+            ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), N, E, C, G, ctx.aggr, dt, stream())),
+            "mdl_cgconv_bwd")
         # node-level dense part (library GEMMs): [f-half | s-half] x {target, source}
         rt = r_tgt.view(N, 2, Cp)[:, :, :C]
         rs = r_src.view(N, 2, Cp)[:, :, :C]

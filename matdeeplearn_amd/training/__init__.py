@@ -1,0 +1,5 @@
+"""Training harness around the hot path: the caller side of the drop-in boundary
+(/root/reference/matdeeplearn/training/training.py:34-207,227-270) restated for device-resident
+batches, plus the data-parallel engine (one flat gradient buffer, one RCCL all-reduce per step)."""
+from .loops import train, evaluate, trainer, make_optimizer, make_scheduler  # noqa: F401
+from .dp import ddp_setup, ddp_cleanup, FlatDataParallel  # noqa: F401

@@ -1,0 +1,88 @@
+"""Data parallelism over graphs: one process per GPU, ONE all-reduce of ONE flat fp32 gradient
+buffer per step (RCCL over xGMI; `gloo` on CPU for the test-suite).
+
+Replaces torch DistributedDataParallel as the reference uses it
+(/root/reference/matdeeplearn/training/training.py:227-237 ddp_setup, :263-266 DDP wrap with
+find_unused_parameters=True).  Gradient payloads here are 0.45-17.5 MB, i.e. latency
+bound on xGMI (7 links x ~153 GB/s): bucketing, the unused-parameter graph walk and the per-forward
+buffer broadcast of DDP only add launches, so:
+  * parameters are broadcast once from rank 0 (flat, coalesced);
+  * every parameter's .grad is a VIEW into one flat buffer -> backward accumulates in place;
+  * reduce_grads() issues a single all_reduce(SUM) and scales by 1/world_size (DDP averages);
+  * BatchNorm running statistics stay rank-local (as in the reference: no SyncBatchNorm) and
+    rank 0's are the ones saved/evaluated.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def ddp_setup(rank, world_size, backend=None, master_addr="127.0.0.1", master_port="12355"):
+    """training.py:227-237 — env rendezvous; backend nccl (= RCCL on ROCm) on GPUs, gloo on CPU."""
+    if rank in ("cpu", "cuda") or world_size <= 1:
+        return False
+    os.environ.setdefault("MASTER_ADDR", master_addr)
+    os.environ.setdefault("MASTER_PORT", str(master_port))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if not dist.is_initialized():
+        dist.init_process_group(backend, rank=int(rank), world_size=int(world_size))
+    return True
+
+
+def ddp_cleanup():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+class FlatDataParallel:
+    """Wraps a model in place: flat gradient storage + single all-reduce.  Not an nn.Module wrapper —
+    the model keeps its own class/attributes, so `model(data)`, `state_dict()` keys and hooks are
+    unchanged (the reference unwraps `model.module`; here there is nothing to unwrap)."""
+
+    def __init__(self, model, process_group=None, broadcast=True):
+        self.model = model
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatDataParallel: model has no trainable parameters")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise ValueError("FlatDataParallel expects fp32 master parameters")
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        if broadcast and self.world_size > 1:
+            self.broadcast_state()
+
+    def broadcast_state(self, src=0):
+        """Parameters and buffers from rank `src`, one flat message per dtype."""
+        with torch.no_grad():
+            tensors = [p.data for p in self.model.parameters()] + [b.data for b in self.model.buffers()]
+            by_dtype = {}
+            for t in tensors:
+                by_dtype.setdefault(t.dtype, []).append(t)
+            for dt, ts in by_dtype.items():
+                flat = torch.cat([t.reshape(-1) for t in ts])
+                dist.broadcast(flat, src=src, group=self.group)
+                off = 0
+                for t in ts:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def reduce_grads(self):
+        """Sum over ranks, then average (DDP semantics).  One collective per step."""
+        if self.world_size > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat_grad.mul_(1.0 / self.world_size)
+
+    def grad_bytes(self):
+        return self.flat_grad.numel() * 4

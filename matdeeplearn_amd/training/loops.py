@@ -1,0 +1,115 @@
+"""Train / evaluate / epoch driver — the callers of the hot path.
+
+Mirrors /root/reference/matdeeplearn/training/training.py: `train` (:34-54), `evaluate` (:58-92),
+`trainer` (:96-207) and the optimizer/scheduler lookup by name (:429-436):
+  * loss metric = sum(batch-mean loss x batch size) / sum(batch size)   (:45,51-53,67,84-86)
+  * the LR scheduler is stepped on the TRAINING error (:193)
+  * the best-validation weights are kept (:144-166); epoch time printed every `verbosity` epochs
+The loops are model-agnostic (any nn.Module whose forward takes a batch) and never force a
+host<->device sync inside an epoch: running sums stay on the device.
+"""
+import copy
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def make_optimizer(params, name="AdamW", lr=0.002, **optimizer_args):
+    """getattr(torch.optim, name)(params, lr, **optimizer_args) — training.py:429-432."""
+    kw = dict(optimizer_args)
+    plist = list(params)
+    if name in ("Adam", "AdamW") and plist and plist[0].is_cuda and "fused" not in kw and "foreach" not in kw:
+        kw["fused"] = True   # one kernel for all parameters instead of one per tensor
+    return getattr(torch.optim, name)(plist, lr=lr, **kw)
+
+
+def make_scheduler(optimizer, name="ReduceLROnPlateau", **scheduler_args):
+    return getattr(torch.optim.lr_scheduler, name)(optimizer, **scheduler_args)
+
+
+def train(model, optimizer, loader, loss_method, rank=None, dp=None, stats=None):
+    """One pass over `loader` in train mode.  Returns the sample-weighted mean loss (device scalar)."""
+    model.train()
+    loss_all, count = 0, 0
+    edges = 0
+    for data in loader:
+        data = data.to(rank)
+        if dp is not None:
+            dp.zero_grad()
+        else:
+            optimizer.zero_grad()
+        output = model(data)
+        loss = getattr(F, loss_method)(output, data.y)
+        loss.backward()
+        loss_all = loss_all + loss.detach() * output.size(0)
+        if dp is not None:
+            dp.reduce_grads()
+        optimizer.step()
+        count += output.size(0)
+        edges += int(getattr(data, "num_edges", 0))
+    if stats is not None:
+        stats["edges"] = stats.get("edges", 0) + edges
+        stats["graphs"] = stats.get("graphs", 0) + count
+    return loss_all / max(count, 1)
+
+
+def evaluate(loader, model, loss_method, rank=None, out=False):
+    """Eval-mode pass; with out=True also returns rows (id, target, prediction) like training.py:68-90."""
+    model.eval()
+    loss_all, count = 0, 0
+    ids, preds, targets = [], [], []
+    with torch.no_grad():
+        for data in loader:
+            data = data.to(rank)
+            output = model(data)
+            loss = getattr(F, loss_method)(output, data.y)
+            loss_all = loss_all + loss * output.size(0)
+            if out:
+                ids += list(data.structure_id)
+                preds.append(output.detach().cpu().numpy())
+                targets.append(data.y.detach().cpu().numpy())
+            count += output.size(0)
+    loss_all = loss_all / max(count, 1)
+    if out:
+        return loss_all, np.column_stack((np.array(ids, dtype=object), np.concatenate(targets), np.concatenate(preds)))
+    return loss_all
+
+
+def trainer(rank, world_size, model, optimizer, scheduler, loss, train_loader, val_loader, epochs, verbosity=5,
+            dp=None, log=print):
+    """Epoch driver (training.py:96-207).  Returns (model with the best-validation weights loaded,
+    history list of dicts)."""
+    import torch.distributed as dist
+
+    distributed = dp is not None and dp.world_size > 1
+    best_val, best_state = 1e10, None
+    history = []
+    t_mark = time.time()
+    for epoch in range(1, epochs + 1):
+        lr = optimizer.param_groups[0]["lr"]
+        if hasattr(train_loader, "set_epoch"):
+            train_loader.set_epoch(epoch)                       # training.py:120
+        stats = {}
+        train_error = train(model, optimizer, train_loader, loss, rank=rank, dp=dp, stats=stats)
+        if distributed:                                         # training.py:124-125, one tiny collective
+            dist.all_reduce(train_error, op=dist.ReduceOp.SUM)
+            train_error = train_error / world_size
+        val_error = None
+        if val_loader is not None and (not distributed or dist.get_rank() == 0):
+            val_error = float(evaluate(val_loader, model, loss, rank=rank))
+            if val_error < best_val:                            # training.py:144-166 (NaN never passes)
+                best_val = val_error
+                best_state = copy.deepcopy(model.state_dict())
+        train_error = float(train_error)
+        scheduler.step(train_error)                              # training.py:193 — on the TRAIN error
+        now = time.time()
+        history.append(dict(epoch=epoch, lr=lr, train=train_error, val=val_error, time=now - t_mark, **stats))
+        if verbosity and epoch % verbosity == 0 and (not distributed or dist.get_rank() == 0):
+            log("Epoch: {:04d}, Learning Rate: {:.6f}, Training Error: {:.5f}, Val Error: {}, Time per epoch (s): {:.5f}"
+                .format(epoch, lr, train_error, "n/a" if val_error is None else "%.5f" % val_error, now - t_mark))
+        t_mark = now
+    if best_state is not None:
+        model.load_state_dict(best_state)
+    return model, history

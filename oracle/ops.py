@@ -32,10 +32,20 @@ def scatter(src, index, dim=0, dim_size=None, reduce="sum"):
             out = out / cnt.clamp(min=1).view((n,) + (1,) * len(tail))
         return out
     if reduce == "max":
-        out = torch.full((n,) + tail, float("-inf"), dtype=src.dtype)
-        idx = index.view((-1,) + (1,) * len(tail)).expand_as(src)
-        out = out.scatter_reduce(0, idx, src, "amax", include_self=True)
-        return torch.where(torch.isinf(out) & (out < 0), torch.zeros_like(out), out)
+        # torch_scatter.scatter_max semantics: the value AND the gradient belong to ONE arg-max
+        # element per (segment, channel) — the first one in index order on ties (CPU kernel: strict >).
+        flat = src.reshape(src.shape[0], -1)
+        idx = index.view(-1, 1).expand_as(flat)
+        best = torch.full((n, flat.shape[1]), float("-inf"), dtype=src.dtype)
+        best = best.scatter_reduce(0, idx, flat.detach(), "amax", include_self=True)
+        pos = torch.arange(flat.shape[0]).view(-1, 1).expand_as(flat)
+        cand = torch.where(flat.detach() == best.index_select(0, index), pos, torch.full_like(pos, flat.shape[0]))
+        arg = torch.full((n, flat.shape[1]), flat.shape[0], dtype=torch.int64)
+        arg = arg.scatter_reduce(0, idx, cand, "amin", include_self=True)
+        has = arg < flat.shape[0]
+        picked = flat.gather(0, arg.clamp(max=max(flat.shape[0] - 1, 0))) if flat.shape[0] else best
+        out = torch.where(has, picked, torch.zeros_like(picked))
+        return out.reshape((n,) + tail)
     raise ValueError("unsupported reduce: %r" % (reduce,))
 
 

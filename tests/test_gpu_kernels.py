@@ -1,0 +1,171 @@
+"""GPU parity: every HIP kernel (through the C ABI / ctypes binding) against the CPU oracle on the
+same seeded inputs.  Tolerances: fp32 mode rtol 2e-5 / atol 2e-5 relative to the tensor scale
+(different summation order than the CPU GEMM, device exp/log within ~2 ulp);  bf16 mode is a
+performance mode — inputs are rounded to bf16 for BOTH sides and the result must agree to 3e-2 of
+the tensor scale (bf16 has 8 bits of mantissa; accumulation is fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as oops
+
+pytestmark = pytest.mark.gpu
+G_DIR = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rand_graph(n, seed, max_in=20, window=40, self_loops=True, empty_frac=0.1, sort=False):
+    g = torch.Generator().manual_seed(seed)
+    src, tgt = [], []
+    for i in range(n):
+        if torch.rand(1, generator=g).item() < empty_frac:
+            continue
+        k = int(torch.randint(1, max_in + 1, (1,), generator=g))
+        lo = max(0, i - window)
+        hi = min(n, i + window)
+        s = torch.randint(lo, hi, (k,), generator=g).tolist()
+        if self_loops:
+            s.append(i)
+        src += s
+        tgt += [i] * len(s)
+    ei = torch.tensor([src, tgt], dtype=torch.int64)
+    if not sort:
+        perm = torch.randperm(ei.shape[1], generator=g)
+        ei = ei[:, perm]
+    return ei
+
+
+def close(a, b, rtol, atol_scale):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    scale = float(b.abs().max()) + 1e-30
+    err = float((a - b).abs().max())
+    assert torch.allclose(a, b, rtol=rtol, atol=atol_scale * scale), "max abs err %.3e (scale %.3e)" % (err, scale)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_library_loads_and_reports_version():
+    from matdeeplearn_amd import _lib
+    assert _lib.lib().mdl_version() == 100
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rbf_matches_reference_golden(dtype):
+    from matdeeplearn_amd import ops
+    z = np.load(os.path.join(G_DIR, "rbf.npz"))
+    d = torch.from_numpy(z["d"]).to(dev())
+    out = ops.rbf_expand(d, 0.0, 1.0, 50, 0.2, out_dtype=dtype)
+    ref = torch.from_numpy(z["out"])
+    if dtype == torch.float32:
+        assert torch.allclose(out.cpu(), ref, rtol=1e-6, atol=1e-7)   # exp within ~2 ulp
+    else:
+        assert torch.allclose(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=1e-2, atol=1e-6)
+    # strided output (padded rows) and empty input
+    buf = torch.zeros(d.numel(), 64, dtype=dtype, device=dev())
+    ops.rbf_expand(d, out=buf[:, :50])
+    assert torch.equal(buf[:, :50], out) and float(buf[:, 50:].abs().max()) == 0.0
+    assert ops.rbf_expand(d[:0]).shape == (0, 50)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("sorted_idx", [True, False])
+def test_scatter_matches_oracle(reduce, dtype, sorted_idx):
+    from matdeeplearn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n_seg, E, C = 37, 500, 48
+    idx = torch.randint(0, n_seg, (E,), generator=g)
+    idx[idx == 5] = 6          # an empty segment
+    if sorted_idx:
+        idx, _ = torch.sort(idx)
+    src = torch.randn(E, C, generator=g).to(dtype).float()
+    src_o = src.clone().requires_grad_(True)
+    ref = oops.scatter(src_o, idx, 0, n_seg, reduce)
+    w = torch.randn(n_seg, C, generator=g).to(dtype).float()
+    (ref * w).sum().backward()
+    src_d = src.to(dev()).to(dtype).requires_grad_(True)
+    out = ops.scatter(src_d, idx.to(dev()), 0, n_seg, reduce, assume_sorted=sorted_idx)
+    (out.float() * w.to(dev())).sum().backward()
+    tol = (1e-5, 1e-6) if dtype == torch.float32 else (2e-2, 1e-2)
+    close(out, ref, *tol)
+    close(src_d.grad, src_o.grad, *tol)
+
+
+def _cgconv_case(n, C, G, dtype, sort, seed, aggr="mean", empty_frac=0.1):
+    from matdeeplearn_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    ei = rand_graph(n, seed, sort=sort, empty_frac=empty_frac)
+    E = ei.shape[1]
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x = rnd(n, C).to(dtype).float()
+    ea = torch.rand(E, G, generator=g).to(dtype).float()
+    k = 1.0 / (2 * C + G) ** 0.5
+    wf, ws = (rnd(C, 2 * C + G) * k * 3).to(dtype).float(), (rnd(C, 2 * C + G) * k * 3).to(dtype).float()
+    bf, bs = rnd(C) * 0.1, rnd(C) * 0.1
+    gout = rnd(n, C).to(dtype).float()
+
+    # oracle (fp32 CPU on the same, already-rounded inputs)
+    xo, wfo, wso, bfo, bso = [t.clone().requires_grad_(True) for t in (x, wf, ws, bf, bs)]
+    ref = oops.cgconv(xo, ei, ea, wfo, bfo, wso, bso, aggr)
+    (ref * gout).sum().backward()
+
+    d = dev()
+    xd = x.to(d).to(dtype).requires_grad_(True)
+    wfd, wsd, bfd, bsd = [t.to(d).clone().requires_grad_(True) for t in (wf, ws, bf, bs)]
+    csr = ops.build_csr(ei.to(d), n, assume_sorted=sort)
+    out = ops.cgconv(xd, ei.to(d), ea.to(d).to(dtype), wfd, bfd, wsd, bsd, aggr, csr=csr)
+    (out.float() * gout.to(d)).sum().backward()
+    tol = (2e-5, 2e-5) if dtype == torch.float32 else (3e-2, 3e-2)
+    close(out, ref, *tol)
+    close(xd.grad, xo.grad, *tol)
+    close(wfd.grad, wfo.grad, *tol)
+    close(wsd.grad, wso.grad, *tol)
+    close(bfd.grad, bfo.grad, *tol)
+    close(bsd.grad, bso.grad, *tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,C,G,sort", [(200, 64, 50, True), (200, 64, 50, False), (77, 32, 50, True),
+                                         (130, 100, 50, False), (65, 128, 50, True), (50, 64, 41, True),
+                                         (33, 20, 7, False), (1, 64, 50, True)])
+def test_cgconv_matches_oracle(dtype, n, C, G, sort):
+    _cgconv_case(n, C, G, dtype, sort, seed=n + C + G)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cgconv_sum_aggr_and_isolated_nodes(dtype):
+    _cgconv_case(150, 64, 50, dtype, True, seed=5, aggr="add", empty_frac=0.5)
+
+
+def test_cgconv_rejects_cpu_tensors_and_bad_shapes():
+    from matdeeplearn_amd import ops
+    x = torch.randn(4, 64)
+    ei = torch.tensor([[0, 1], [1, 0]])
+    with pytest.raises(ops.MdlError):
+        ops.cgconv(x, ei, torch.randn(2, 50), torch.randn(64, 178), None, torch.randn(64, 178), None)
+    d = dev()
+    with pytest.raises(ops.MdlError):   # G > 64 unsupported in this round
+        ops.cgconv(x.to(d), ei.to(d), torch.randn(2, 80, device=d), torch.randn(64, 208, device=d), None,
+                   torch.randn(64, 208, device=d), None)
+
+
+def test_cgconv_large_graph_permutation_invariance():
+    """Full-size property check (E ~ 1.3e5): shuffling the edge list must not change the result
+    beyond fp32 summation-order noise, and sum-aggregation is linear in the in-degree."""
+    from matdeeplearn_amd import ops
+    d = dev()
+    n, C, G = 10000, 64, 50
+    ei = rand_graph(n, 11, sort=True, empty_frac=0.0)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, C, generator=g).to(d)
+    ea = torch.rand(ei.shape[1], G, generator=g).to(d)
+    wf, ws = torch.randn(C, 178, generator=g).to(d) * 0.1, torch.randn(C, 178, generator=g).to(d) * 0.1
+    a = ops.cgconv(x, ei.to(d), ea, wf, None, ws, None, "mean", csr=ops.build_csr(ei.to(d), n, True))
+    perm = torch.randperm(ei.shape[1], generator=g)
+    eip = ei[:, perm].to(d)
+    b = ops.cgconv(x, eip, ea[perm.to(d)], wf, None, ws, None, "mean")
+    close(a, b, 1e-5, 1e-6)

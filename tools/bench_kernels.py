@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the conv kernels on one synthetic batch (used for rocprofv3 --pmc passes)."""
+import argparse, sys, os, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from matdeeplearn_amd import ops, _lib
+from matdeeplearn_amd.process import synthetic_bulk
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--graphs", type=int, default=8192)
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--dim", type=int, default=64)
+ap.add_argument("--which", default="fwd,bwd,rbf")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+ds = synthetic_bulk(a.graphs, seed=0).to(dev)
+dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+b = ds.collate(np.arange(a.graphs), edge_dtype=dt)
+C = a.dim
+x = torch.randn(b.num_nodes, C, device=dev).to(dt).requires_grad_(True)
+wf = (torch.randn(C, 2 * C + 50, device=dev) * 0.1).requires_grad_(True)
+ws = (torch.randn(C, 2 * C + 50, device=dev) * 0.1).requires_grad_(True)
+bf = torch.zeros(C, device=dev, requires_grad=True); bs = torch.zeros(C, device=dev, requires_grad=True)
+print("N=%d E=%d" % (b.num_nodes, b.num_edges))
+ev = {"fwd": [], "bwd": []}
+for it in range(a.iters + 2):
+    ops.KERNEL_EVENTS = ev if it >= 2 else None
+    out = ops.cgconv(x, None, b.edge_attr, wf, bf, ws, bs, "mean", csr=b.csr)
+    if "bwd" in a.which:
+        out.backward(torch.ones_like(out))
+    if "rbf" in a.which:
+        ops.rbf_expand(ds._dev["dist_norm"][: b.num_edges], out_dtype=dt)
+ops.KERNEL_EVENTS = None
+torch.cuda.synchronize()
+for k, v in ev.items():
+    if v:
+        t = [s.elapsed_time(e) * 1e3 for s, e in v]
+        print("%s: avg %.1f us  min %.1f us" % (k, sum(t) / len(t), min(t)))
