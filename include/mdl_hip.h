@@ -102,12 +102,22 @@ int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_t* rowptr, 
  *     r_tgt[i, :] = sum_{k: tgt_k = i} dpre_k      written once per node (no atomics)
  *     r_src[j, :] += sum_{k: src_k = j} dpre_k     fp32 atomics; caller zero-fills
  *     dwe[c, g]   += sum_k dpre_k[c] * edge_attr_k[g]   [2Cp, Gp] fp32, Gp = 64*ceil(G/64); caller zero-fills
- * from which the caller forms (dense GEMMs): dx = g + r_tgt W_tgt + r_src W_src, dW_tgt = r_tgt^T x,
- * dW_src = r_src^T x, db = colsum(r_tgt).  The gate pre-activations are recomputed, not stored. */
+ *     db[c]       += sum_i r_tgt[i, c]                  [2Cp] fp32 bias gradient; caller zero-fills; may be NULL
+ * from which the caller forms (dense, node level): dx = g + r_tgt W_tgt + r_src W_src, dW_tgt = r_tgt^T x,
+ * dW_src = r_src^T x — by library GEMMs or by mdl_cgconv_bwd_node.  The gate pre-activations are
+ * recomputed, not stored. */
 int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
                    const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
-                   const void* grad_out, float* r_tgt, float* r_src, float* dwe, int64_t N, int64_t E,
-                   int C, int G, int aggr, int dtype, mdlStream_t stream);
+                   const void* grad_out, float* r_tgt, float* r_src, float* dwe, float* db, int64_t N,
+                   int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream);
+
+/* Node-level dense half of the CGConv backward (same reference call site), one pass over r_tgt/r_src:
+ *     dx  [N, C]   = grad_out + [r_tgt | r_src] @ Wn          Wn = wn_t^T, wn_t: [C, 4Cp] in `dtype`
+ *     dwn [4Cp, C] += [r_tgt | r_src]^T @ x                   fp32, caller zero-fills
+ * Row blocks of Wn / dwn: (f_tgt, s_tgt, f_src, s_src), each Cp rows.  Supported: dtype MDL_BF16,
+ * C in {32, 64} (C == Cp); otherwise MDL_E_UNSUPP and the caller uses library GEMMs. */
+int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const float* r_tgt, const float* r_src,
+                        const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype, mdlStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,8 @@ PROTOTYPES = {
     "mdl_cgconv_wpack_bytes": (_sz, [_i32, _i32, _i32]),
     "mdl_cgconv_pack_weights": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mdl_cgconv_fwd": (_i32, [_vp] * 9 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
-    "mdl_cgconv_bwd": (_i32, [_vp] * 12 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mdl_cgconv_bwd": (_i32, [_vp] * 13 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mdl_cgconv_bwd_node": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _vp]),
 }
 
 _lib = None

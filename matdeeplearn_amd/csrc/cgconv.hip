@@ -51,6 +51,7 @@ struct CgParams {
     float* r_tgt;       // bwd [N, 2Cp]
     float* r_src;       // bwd [N, 2Cp]
     float* dwe;         // bwd [2Cp, GP]
+    float* db;          // bwd [2Cp] bias gradient = column sums of r_tgt (may be null)
     int64_t N, E;
     int C, G, Cp, KE, KT, WS, EKS, NS, GP, aggr;
     int GW;             // staging words per e row
@@ -172,6 +173,8 @@ struct WaveCtx {
     T* et;              // per-wave e tile  [32][EKS]
     unsigned* tsl;      // per-wave target-slot bytes (32 B) viewed as 8 dwords
     int* srcl;          // per-wave source ids (32 ints)   (backward only)
+    unsigned* ssl;      // per-wave source-window slot bytes (32 B) (backward only)
+    unsigned long long* touched;  // per-wave bitmap of window slots that received an edge
     const T* wbase;     // packed weights (LDS or global)
 };
 
@@ -332,6 +335,55 @@ __device__ __forceinline__ void seg_reduce_mma(const f32x16& v, const unsigned t
     }
 }
 
+// dpre fragments of one tile, packed once and used three times (B operand of the two segmented
+// reductions, A operand of the dwe product).  bf16: 2 K-steps of 8 values; f32: the 16 registers.
+template <typename T> struct DFrags;
+template <> struct DFrags<bf16_t> {
+    bf16x8 f[2], s[2];
+    __device__ __forceinline__ void pack(const f32x16& af, const f32x16& as) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float a[8], b[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { a[q] = af[8 * ks + q]; b[q] = as[8 * ks + q]; }
+            f[ks] = pack_bf16x8(a);
+            s[ks] = pack_bf16x8(b);
+        }
+    }
+};
+template <> struct DFrags<float> {
+    f32x16 f, s;
+    __device__ __forceinline__ void pack(const f32x16& af, const f32x16& as) { f = af; s = as; }
+};
+
+// accF/accS[slot row][ch] += onehot(byte(edge slot) == row_id) x dpre   (see seg_reduce_mma)
+template <typename T>
+__device__ __forceinline__ void seg_reduce2(const DFrags<T>& d, const unsigned b4[4], unsigned row_id, f32x16& accF,
+                                            f32x16& accS) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 8 * ks + q;
+                const unsigned slot = (b4[r >> 2] >> (8 * (r & 3))) & 0xffu;
+                a[q] = (slot == row_id) ? (short)0x3F80 : (short)0;
+            }
+            accF = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, d.f[ks], accF, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, d.s[ks], accS, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned slot = (b4[r >> 2] >> (8 * (r & 3))) & 0xffu;
+            const float a = (slot == row_id) ? 1.0f : 0.0f;
+            accF = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d.f[r], accF, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d.s[r], accS, 0, 0, 0);
+        }
+    }
+}
+
 template <typename T, typename D>
 __device__ __forceinline__ void setup_wave(const CgParams& p, const D& dm, char* smem, bool w_lds, WaveCtx<T>& w) {
     const int wave = threadIdx.x >> 6;
@@ -341,6 +393,8 @@ __device__ __forceinline__ void setup_wave(const CgParams& p, const D& dm, char*
     const int et_bytes = (32 * dm.EKS * (int)sizeof(T) + 15) & ~15;
     w.tsl = reinterpret_cast<unsigned*>(base + et_bytes);
     w.srcl = reinterpret_cast<int*>(base + et_bytes + 32);
+    w.ssl = reinterpret_cast<unsigned*>(base + et_bytes + 32 + 128);
+    w.touched = reinterpret_cast<unsigned long long*>(base + et_bytes + 32 + 128 + 32);
     w.wbase = w_lds ? reinterpret_cast<const T*>(smem) : static_cast<const T*>(p.wpack);
     if (w_lds) {
         const f32x4* g = reinterpret_cast<const f32x4*>(p.wpack);
@@ -501,6 +555,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) dwe_acc[a][b][r] = 0.0f;
 
+    float dbf_acc = 0.0f, dbs_acc = 0.0f;
     for (int g = gw / p.NS; g < p.n_groups; g += gstride) {
         const int n0 = g * 32;
         const int n1 = (int)min((int64_t)n0 + 32, p.N);
@@ -533,6 +588,28 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Rf[r] = 0.0f; Rs[r] = 0.0f; }
 
+        // Source window: the sources of a group's edges are its in-graph neighbours, i.e. a short
+        // node range.  Sums by SOURCE for the 64 nodes [wb, wb+64) are kept in registers (one-hot
+        // MFMA, like the target reduction) and flushed once per group; only sources outside the
+        // window (very large graphs) fall back to per-edge atomics.  wb = smallest source of the group.
+        int wb = 0x7fffffff;
+        for (int eb = e0; eb < e1; eb += 4 * WAVE) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int eid = eb + u * WAVE + lane;
+                wb = min(wb, eid < e1 ? p.src[eid] : 0x7fffffff);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wb = min(wb, __shfl_xor(wb, o));
+        wb = __builtin_amdgcn_readfirstlane(wb);
+        f32x16 Wf[2], Ws[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { Wf[mt][r] = 0.0f; Ws[mt][r] = 0.0f; }
+        if (lane == 0) *w.touched = 0ull;
+
         TileIdx cur, nxt;
         EWords<T, G_, EW> ew;
         cur.load(p, e0, e1, i, n0);
@@ -543,11 +620,16 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             const int nv = min(32, e1 - eb);
             const bool valid_i = i < nv;
             const int my_ts = valid_i ? (cur.tgt - n0) : 0xff;
+            const unsigned my_ss = (unsigned)(cur.src - wb);
+            const bool in_win = valid_i && my_ss < 64u;
+            const bool oob = valid_i && !in_win;
             wave_lds_fence();
             if constexpr (ST) ew.commit(w.et, dm.EKS, lane); else stage_e_tile<T, EW>(p, dm, w, lane, eb, nv, cur.ep);
             if (h == 0) {
                 reinterpret_cast<unsigned char*>(w.tsl)[i] = (unsigned char)my_ts;
-                w.srcl[i] = cur.src;
+                reinterpret_cast<unsigned char*>(w.ssl)[i] = in_win ? (unsigned char)my_ss : (unsigned char)0xff;
+                w.srcl[i] = oob ? cur.src : -1;
+                if (in_win) atomicOr(w.touched, 1ull << my_ss);
             }
             wave_lds_fence();
 
@@ -593,19 +675,21 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                 accs[r] = t * ss;
             }
 
-            unsigned t4[4];
+            DFrags<T> dp;
+            dp.pack(accf, accs);
+            unsigned t4[4], s4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t4[j] = w.tsl[2 * j + h];
-            seg_reduce_mma<T>(accf, t4, i, Rf);
-            seg_reduce_mma<T>(accs, t4, i, Rs);
+            for (int j = 0; j < 4; ++j) { t4[j] = w.tsl[2 * j + h]; s4[j] = w.ssl[2 * j + h]; }
+            seg_reduce2<T>(dp, t4, (unsigned)i, Rf, Rs);                 // by target  -> r_tgt
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) seg_reduce2<T>(dp, s4, (unsigned)(i + 32 * mt), Wf[mt], Ws[mt]);   // by source window
 
-            // r_src: scatter dpre to the SOURCE node of every edge slot (fp32 hardware atomics)
-            if (ch < dm.C) {
+            // sources outside the window: per-edge fp32 atomics (rare: graphs wider than the window)
+            if (__any(oob) && ch < dm.C) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int slot = d_row(r, h);
-                    if (slot < nv) {
-                        const int sj = w.srcl[slot];
+                    const int sj = w.srcl[d_row(r, h)];
+                    if (sj >= 0) {
                         float* dst = p.r_src + (int64_t)sj * C2 + ch;
                         unsafeAtomicAdd(dst, accf[r]);
                         unsafeAtomicAdd(dst + dm.Cp, accs[r]);
@@ -622,16 +706,12 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                     if constexpr (BF) {
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
-                            bf16x8 af, as, b;
+                            bf16x8 b;
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const int r = 8 * ks + q;
-                                af[q] = (short)f2bf(accf[r]);
-                                as[q] = (short)f2bf(accs[r]);
-                                b[q] = (gcol < dm.KE) ? (short)w.et[d_row(r, h) * dm.EKS + gcol] : (short)0;
-                            }
-                            dwe_acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, dwe_acc[0][nt], 0, 0, 0);
-                            dwe_acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as, b, dwe_acc[1][nt], 0, 0, 0);
+                            for (int q = 0; q < 8; ++q)
+                                b[q] = (gcol < dm.KE) ? (short)w.et[d_row(8 * ks + q, h) * dm.EKS + gcol] : (short)0;
+                            dwe_acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp.f[ks], b, dwe_acc[0][nt], 0, 0, 0);
+                            dwe_acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp.s[ks], b, dwe_acc[1][nt], 0, 0, 0);
                         }
                     } else {
 #pragma unroll
@@ -646,7 +726,27 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             cur = nxt;
         }
 
-        // r_tgt rows of this group (each written exactly once)
+        // flush the source window: one atomic row update per touched window node (instead of per edge)
+        wave_lds_fence();
+        {
+            const unsigned long long tm = *w.touched;
+            if (ch < dm.C) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int sl = 32 * mt + d_row(r, h);
+                        if ((tm >> sl) & 1ull) {
+                            float* dst = p.r_src + (int64_t)(wb + sl) * C2 + ch;
+                            unsafeAtomicAdd(dst, Wf[mt][r]);
+                            unsafeAtomicAdd(dst + dm.Cp, Ws[mt][r]);
+                        }
+                    }
+            }
+        }
+        // r_tgt rows of this group (each written exactly once); bias gradient = their column sums
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dbf_acc += Rf[r]; dbs_acc += Rs[r]; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = n0 + d_row(r, h);
@@ -658,6 +758,14 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
         }
     }
 
+    if (p.db) {
+        dbf_acc += __shfl_xor(dbf_acc, 32);
+        dbs_acc += __shfl_xor(dbs_acc, 32);
+        if (h == 0) {
+            unsafeAtomicAdd(p.db + ch, dbf_acc);
+            unsafeAtomicAdd(p.db + dm.Cp + ch, dbs_acc);
+        }
+    }
     // flush the wave's dwe partial sums: D rows = channel slot d_row(r,h) of slice s, cols = feature
 #pragma unroll
     for (int nt = 0; nt < GNT; ++nt) {
@@ -736,7 +844,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     }
 
     const int et_bytes = (32 * d.EKS * (int)sizeof(T) + 15) & ~15;
-    p.wave_lds_bytes = et_bytes + 32 + 128;  // e tile + 32 slot bytes + 32 source ids
+    p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16;  // e tile, tgt-slot bytes, source ids, src-slot bytes, bitmap
     const int w_bytes = (p.w_elems * (int)sizeof(T) + 15) & ~15;
     const int waves = 4;
     bool w_lds = w_bytes + waves * p.wave_lds_bytes <= LDS_CAP;
@@ -849,15 +957,15 @@ extern "C" int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_
 
 extern "C" int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
                               const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
-                              const void* grad_out, float* r_tgt, float* r_src, float* dwe, int64_t N, int64_t E,
-                              int C, int G, int aggr, int dtype, mdlStream_t stream) {
+                              const void* grad_out, float* r_tgt, float* r_src, float* dwe, float* db, int64_t N,
+                              int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream) {
     using namespace mdl;
     int rc = cg_check("mdl_cgconv_bwd", x, edge_attr, rowptr, src, tgt, wpack, bpack, N, E, C, G, aggr, dtype);
     if (rc) return rc;
     MDL_REQUIRE(N == 0 || (grad_out && r_tgt && r_src && dwe), MDL_E_ARG, "mdl_cgconv_bwd: null pointer");
     CgParams p = {};
     p.x = x; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = eperm;
-    p.wpack = wpack; p.bpack = bpack; p.gout = grad_out; p.r_tgt = r_tgt; p.r_src = r_src; p.dwe = dwe;
+    p.wpack = wpack; p.bpack = bpack; p.gout = grad_out; p.r_tgt = r_tgt; p.r_src = r_src; p.dwe = dwe; p.db = db;
     p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr;
     if (dtype == MDL_BF16) return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd");
     return cg_launch<float>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd");

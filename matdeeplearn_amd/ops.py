@@ -211,7 +211,7 @@ KERNEL_EVENTS = None
 
 def _launch_timed(key, fn):
     ev = KERNEL_EVENTS
-    if ev is None:
+    if ev is None or key not in ev:
         return fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -264,25 +264,35 @@ class _CGConvFn(torch.autograd.Function):
         dt = dtype_code(x)
         r_tgt = torch.empty((N, 2 * Cp), dtype=torch.float32, device=x.device)
         r_src = torch.zeros((N, 2 * Cp), dtype=torch.float32, device=x.device)
-        dwe = torch.zeros((2 * Cp, GP), dtype=torch.float32, device=x.device)
+        small = torch.zeros(2 * Cp * GP + 2 * Cp + 4 * Cp * C, dtype=torch.float32, device=x.device)
+        dwe = small[:2 * Cp * GP].view(2 * Cp, GP)
+        db = small[2 * Cp * GP:2 * Cp * GP + 2 * Cp]
+        dwn = small[2 * Cp * GP + 2 * Cp:].view(4 * Cp, C)
         check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd(
             ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(csr.eperm), ptr(wpack),
-            ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), N, E, C, G, ctx.aggr, dt, stream())),
+            ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, stream())),
             "mdl_cgconv_bwd")
-        # node-level dense part (library GEMMs): [f-half | s-half] x {target, source}
-        rt = r_tgt.view(N, 2, Cp)[:, :, :C]
-        rs = r_src.view(N, 2, Cp)[:, :, :C]
-        cd = torch.float32 if dt == _lib.MDL_F32 else torch.bfloat16
-        R = torch.cat([rt[:, 0], rt[:, 1], rs[:, 0], rs[:, 1]], dim=1).to(cd)            # [N, 4C]
-        Wn = torch.cat([wf32[:, :C], ws32[:, :C], wf32[:, C:2 * C], ws32[:, C:2 * C]], dim=0).to(cd)  # [4C, C]
-        dx = torch.addmm(g, R, Wn) if ctx.needs_input_grad[0] else None
-        dWn = torch.mm(R.t(), x).float()                                                   # [4C, C]
+        # node-level dense part: rows of Wn / dWn = (f_tgt, s_tgt, f_src, s_src)
+        Wn = torch.cat([wf32[:, :C], ws32[:, :C], wf32[:, C:2 * C], ws32[:, C:2 * C]], dim=0)      # [4C, C]
+        if dt == _lib.MDL_BF16 and C == Cp and C in (32, 64):
+            wn_t = Wn.t().contiguous().to(torch.bfloat16)                                          # [C, 4C]
+            dx = torch.empty_like(x)
+            check(_launch_timed("bwd_node", lambda: lib().mdl_cgconv_bwd_node(
+                ptr(x), ptr(g), ptr(r_tgt), ptr(r_src), ptr(wn_t), ptr(dx), ptr(dwn), N, C, dt, stream())),
+                "mdl_cgconv_bwd_node")
+            dWn = dwn
+        else:                                                                                      # library GEMMs
+            rt = r_tgt.view(N, 2, Cp)[:, :, :C]
+            rs = r_src.view(N, 2, Cp)[:, :, :C]
+            cd = torch.float32 if dt == _lib.MDL_F32 else torch.bfloat16
+            R = torch.cat([rt[:, 0], rt[:, 1], rs[:, 0], rs[:, 1]], dim=1).to(cd)                  # [N, 4C]
+            dx = torch.addmm(g, R, Wn.to(cd))
+            dWn = torch.mm(R.t(), x).float()                                                       # [4C, C]
         dwe_f, dwe_s = dwe[:C, :G], dwe[Cp:Cp + C, :G]
         dW_f = torch.cat([dWn[0:C], dWn[2 * C:3 * C], dwe_f], dim=1).to(ctx.wdtypes[0])
         dW_s = torch.cat([dWn[C:2 * C], dWn[3 * C:4 * C], dwe_s], dim=1).to(ctx.wdtypes[1])
-        db = rt.sum(dim=0)                                                                  # [2, C] fp32
-        db_f = db[0] if ctx.has_bias[0] else None
-        db_s = db[1] if ctx.has_bias[1] else None
+        db_f = db[:C].clone() if ctx.has_bias[0] else None
+        db_s = db[Cp:Cp + C].clone() if ctx.has_bias[1] else None
         return dx, None, dW_f, db_f, dW_s, db_s, None, None
 
 
