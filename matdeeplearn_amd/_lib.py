@@ -6,7 +6,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libmdl_hip.so")
+LIB_PATH = os.environ.get("MDL_HIP_LIB") or os.path.join(HERE, "lib", "libmdl_hip.so")  # env override: A/B builds
 
 MDL_F32, MDL_BF16 = 0, 1
 MDL_SUM, MDL_MEAN, MDL_MAX = 0, 1, 2

@@ -31,8 +31,31 @@
 
 #include "mdl_common.h"
 
+#ifndef MDL_CG_WM
+#define MDL_CG_WM 1       // where the static bf16 kernels keep W: 1 LDS, 2 registers, 3 x-part registers + e-part LDS
+#endif
+#ifndef MDL_FWD_XDB
+#define MDL_FWD_XDB 0     // 1: x-row gathers of tile t+1 in flight during tile t (costs 32 VGPRs)
+#endif
+#ifndef MDL_BWD_XDB
+#define MDL_BWD_XDB 1
+#endif
 #ifndef MDL_BWD_WAVES
 #define MDL_BWD_WAVES 1   // waves per SIMD the backward kernel is register-allocated for
+#endif
+
+#ifdef MDL_CG_TIMING   // experiment builds only: per-phase cycle counters of wave 0 / block 0
+__device__ long long g_cg_dbg[16];
+extern "C" int mdl_debug_read(long long* host16) {
+    return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_cg_dbg), 16 * sizeof(long long));
+}
+extern "C" int mdl_debug_reset() {
+    long long z[16] = {0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cg_dbg), z, sizeof(z));
+}
+#define TMARK(k) do { __builtin_amdgcn_sched_barrier(0); const long long _t = clock64(); if (gw == 0 && lane == 0) g_cg_dbg[k] += _t - tprev; tprev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TMARK(k) do { } while (0)
 #endif
 
 namespace mdl {
@@ -221,10 +244,8 @@ struct EWords {
             const char* tb = reinterpret_cast<const char*>(ea) + (int64_t)eb * (G_ * (int)sizeof(T));
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
-                const int q = j * WAVE + lane;
-                w[j] = 0;
-                if (j * WAVE + WAVE <= 32 * GW || q < 32 * GW)
-                    w[j] = *reinterpret_cast<const word_t*>(tb + (unsigned)q * (unsigned)(EW * sizeof(T)));
+                const int q = min(j * WAVE + lane, 32 * GW - 1);   // clamp, never guard (see TileIdx::load)
+                w[j] = *reinterpret_cast<const word_t*>(tb + (unsigned)q * (unsigned)(EW * sizeof(T)));
             }
             return;
         }
@@ -264,14 +285,64 @@ struct XFrags {
     }
 };
 
+// Packed weights of this wave's channel slice held in registers for the whole kernel (static
+// shapes): the B fragments of all K steps, f rows and s rows.  Removes every per-tile LDS read of W.
+template <typename T, int NK>
+struct WRegs {
+    typename Mma<T>::frag_t f[NK], s[NK];
+    __device__ __forceinline__ void load(const T* wpack, int rowf, int rows, int WS, int h, int k_first) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            f[k] = ld_frag(wpack, rowf, WS, k_first + k * Mma<T>::KSTEP, h);
+            s[k] = ld_frag(wpack, rows, WS, k_first + k * Mma<T>::KSTEP, h);
+        }
+    }
+};
+
 // pre-activation tile: accf/accs (32 edge slots x 32 channels of slice s), bias pre-loaded.
-template <typename T, int CP_, int VEC, typename D>
+template <typename T, int CP_, int VEC, int WM, int NKW, typename D>
 __device__ __forceinline__ void pre_tile(const CgParams& p, const D& dm, const WaveCtx<T>& w, int lane, int s,
-                                         int my_tgt, int my_src, const XFrags<T, CP_, VEC>& xf, f32x16& accf,
-                                         f32x16& accs) {
+                                         int my_tgt, int my_src, const XFrags<T, CP_, VEC>& xf,
+                                         const WRegs<T, NKW>& wr, f32x16& accf, f32x16& accs) {
     typedef Mma<T> M;
     const int i = lane & 31, h = lane >> 5;
     const int rowf = s * 32 + i, rows = dm.Cp + s * 32 + i;
+    if constexpr (CP_ != 0 && (WM == 2 || WM == 3)) {
+        // static shapes.  WM 2: all B fragments live in registers.  WM 3: the x-part of W lives in
+        // registers, the e-part is read from the LDS copy (those reads depend on nothing and are
+        // issued at the top of the tile).
+        constexpr int NF = XFrags<T, CP_, VEC>::NF;
+        constexpr int NE = (WM == 2) ? NKW - 2 * NF : 0;
+        if constexpr (WM == 2) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                typename M::frag_t a = ld_frag(w.et, i, dm.EKS, k * M::KSTEP, h);
+                accf = M::mma(a, wr.f[k], accf);
+                accs = M::mma(a, wr.s[k], accs);
+            }
+        } else {
+#pragma unroll
+            for (int k0 = 0; k0 < dm.KE; k0 += M::KSTEP) {
+                typename M::frag_t a = ld_frag(w.et, i, dm.EKS, k0, h);
+                accf = M::mma(a, ld_frag(w.wbase, rowf, dm.WS, k0, h), accf);
+                accs = M::mma(a, ld_frag(w.wbase, rows, dm.WS, k0, h), accs);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            accf = M::mma(xf.t[f], wr.f[NE + f], accf);
+            accs = M::mma(xf.t[f], wr.s[NE + f], accs);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            accf = M::mma(xf.s[f], wr.f[NE + NF + f], accf);
+            accs = M::mma(xf.s[f], wr.s[NE + NF + f], accs);
+        }
+        return;
+    }
+#ifdef MDL_CG_IGLP
+    if constexpr (CP_ != 0) __builtin_amdgcn_iglp_opt(MDL_CG_IGLP);
+#endif
     // edge features (LDS tile)
 #pragma unroll
     for (int k0 = 0; k0 < dm.KE; k0 += M::KSTEP) {
@@ -415,18 +486,69 @@ __device__ __forceinline__ void setup_wave(const CgParams& p, const D& dm, char*
 struct TileIdx {
     int src, tgt, ep;
     __device__ __forceinline__ void load(const CgParams& p, int eb, int e1, int i, int n0) {
+        // NOTE: loads are unconditional on a clamped index and the select happens on the VALUE.
+        // `cond ? load : x` makes hipcc branch around the load and wait for it at the join, which
+        // exposes one full memory latency per guarded load.
         const int eid = eb + i;
         const bool ok = eid < e1;
-        src = ok ? p.src[eid] : n0;
-        tgt = ok ? p.tgt[eid] : n0;
-        ep = (p.eperm && ok) ? p.eperm[eid] : 0;
+        if (p.E == 0) { src = tgt = n0; ep = 0; return; }            // uniform: graph without edges
+        const int ec = max(min(eid, e1 - 1), 0);
+        const int sv = p.src[ec], tv = p.tgt[ec];
+        src = ok ? sv : n0;
+        tgt = ok ? tv : n0;
+        ep = 0;
+        if (p.eperm) { const int pv = p.eperm[ec]; ep = ok ? pv : 0; }
     }
 };
 
 // ------------------------------------------------------------------------------------------
 // Forward
 // ------------------------------------------------------------------------------------------
-template <typename T, int CP_, int G_, int VEC, int EW, bool W_LDS>
+// seg_reduce_mma + in-degree count: cnt[node slot][*] += number of edge slots of the tile that map to
+// the node slot (one-hot x all-ones), so the epilogue needs no rowptr loads.
+template <typename T>
+__device__ __forceinline__ void seg_reduce_cnt(const f32x16& v, const unsigned t4[4], int ns, f32x16& acc,
+                                               f32x16& cnt) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a;
+            float vv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 8 * ks + q;
+                const unsigned slot = (t4[r >> 2] >> (8 * (r & 3))) & 0xffu;
+                a[q] = (slot == (unsigned)ns) ? (short)0x3F80 : (short)0;
+                vv[q] = v[r];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pack_bf16x8(vv), acc, 0, 0, 0);
+            cnt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, cnt, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned slot = (t4[r >> 2] >> (8 * (r & 3))) & 0xffu;
+            const float a = (slot == (unsigned)ns) ? 1.0f : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[r], acc, 0, 0, 0);
+            cnt = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.0f, cnt, 0, 0, 0);
+        }
+    }
+}
+
+// scalars of one 32-node group
+struct GroupInfo {
+    int g, n0, n1, e0, e1;
+    __device__ __forceinline__ void load(const CgParams& p, int g_) {
+        g = g_;
+        n0 = g * 32;
+        n1 = (int)min((int64_t)n0 + 32, p.N);
+        e0 = __builtin_amdgcn_readfirstlane(p.rowptr[n0]);
+        e1 = __builtin_amdgcn_readfirstlane(p.rowptr[n1]);
+    }
+};
+
+template <typename T, int CP_, int G_, int VEC, int EW, int WM>   // WM: 0 global, 1 LDS, 2 registers
 __global__ __launch_bounds__(256, 2) void cgconv_fwd_kernel(CgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Mma<T> M;
@@ -435,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void cgconv_fwd_kernel(CgParams p) {
     constexpr bool ST = D::STATIC;
     const D dm(p);
     WaveCtx<T> w;
-    setup_wave<T>(p, dm, smem, W_LDS, w);
+    setup_wave<T>(p, dm, smem, WM == 1 || WM == 3, w);
 
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -448,80 +570,168 @@ __global__ __launch_bounds__(256, 2) void cgconv_fwd_kernel(CgParams p) {
     const float bs = (BC || p.bias_col) ? 0.0f : p.bpack[dm.Cp + s * 32 + i];
     const T* x = static_cast<const T*>(p.x);
     T* out = static_cast<T*>(p.out);
+    constexpr int NKW = (WM == 2) ? (((G_ + 15) / 16 * 16) + 2 * CP_) / M::KSTEP : (WM == 3 ? 2 * CP_ / M::KSTEP : 1);
+    WRegs<T, NKW> wr;
+    if constexpr (WM == 2) wr.load(static_cast<const T*>(p.wpack), s * 32 + i, dm.Cp + s * 32 + i, dm.WS, h, 0);
+    if constexpr (WM == 3) wr.load(static_cast<const T*>(p.wpack), s * 32 + i, dm.Cp + s * 32 + i, dm.WS, h, dm.KE);
+    const int ch = s * 32 + i;
 
-    for (int g = gw / p.NS; g < p.n_groups; g += gstride) {
-        const int n0 = g * 32;
-        const int n1 = (int)min((int64_t)n0 + 32, p.N);
-        const int e0 = __builtin_amdgcn_readfirstlane(p.rowptr[n0]);
-        const int e1 = __builtin_amdgcn_readfirstlane(p.rowptr[n1]);
-        f32x16 acc_out;
+    // The wave walks its groups as ONE continuous stream of edge tiles: while tile t computes, the
+    // indices and edge-feature words of tile t+1 are in flight — across group boundaries too — so
+    // the load pipeline never drains.  A group's epilogue (residual add, mean, store) needs no
+    // dependent loads: the in-degree comes out of the one-hot MFMA (cnt) and the residual rows are
+    // requested at the top of the group's last tile.
+    int gcur = gw / p.NS;
+    if (gcur >= p.n_groups) return;
+    GroupInfo G, GN;
+    G.load(p, gcur);
+    bool hasN = gcur + gstride < p.n_groups;
+    if (hasN) GN.load(p, gcur + gstride);
+
+    f32x16 acc_out, cnt;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc_out[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) { acc_out[r] = 0.0f; cnt[r] = 0.0f; }
+    TileIdx cur, nxt;
+    EWords<T, G_, EW> ew;
+    XFrags<T, CP_, VEC> xf;
+    float xr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xr[r] = 0.0f;
 
-        TileIdx cur, nxt;
-        EWords<T, G_, EW> ew;
-        cur.load(p, e0, e1, i, n0);
-        nxt = cur;
-        if constexpr (ST) ew.prefetch(p, lane, e0, min(32, e1 - e0), cur.ep);
-
-        for (int eb = e0; eb < e1; eb += 32) {
-            const int nv = min(32, e1 - eb);
-            const bool valid_i = i < nv;
-            wave_lds_fence();
-            if constexpr (ST) ew.commit(w.et, dm.EKS, lane); else stage_e_tile<T, EW>(p, dm, w, lane, eb, nv, cur.ep);
-            if (h == 0) reinterpret_cast<unsigned char*>(w.tsl)[i] = valid_i ? (unsigned char)(cur.tgt - n0) : 0xff;
-            wave_lds_fence();
-
-            XFrags<T, CP_, VEC> xf;
-            if constexpr (CP_ != 0) xf.load(x, dm.C, cur.tgt, cur.src, h);
-            // software prefetch of the next tile (indices + edge-feature words) — issued AFTER the
-            // x gathers so that waiting for those does not drain the prefetch
-            if (eb + 32 < e1) {
-                nxt.load(p, eb + 32, e1, i, n0);
-                if constexpr (ST) ew.prefetch(p, lane, eb + 32, min(32, e1 - eb - 32), nxt.ep);
+    int eb = G.e0;
+    bool primed = false;          // cur / ew already hold the tile at eb (prefetched by the previous tile)
+#ifdef MDL_CG_TIMING
+    long long tprev = clock64();
+#endif
+    while (true) {
+        if (G.e0 == G.e1) {
+            // group without edges: out = x for its nodes (mean over nothing = 0)
+            if (ch < dm.C) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = G.n0 + d_row(r, h);
+                    if (n < G.n1) out[(int64_t)n * dm.C + ch] = x[(int64_t)n * dm.C + ch];
+                }
             }
-
-            f32x16 accf, accs;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
-            pre_tile<T, CP_, VEC>(p, dm, w, lane, s, cur.tgt, cur.src, xf, accf, accs);
-
-            unsigned t4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t4[j] = w.tsl[2 * j + h];
-            // gate.  Edge slots >= nv hold finite garbage; their one-hot column is all zero, so they
-            // contribute exact zeros to the aggregation — no per-element masking needed.
-            f32x16 m;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m[r] = GT::sigmoid(accf[r]) * GT::softplus_u(accs[r]);
-            seg_reduce_mma<T>(m, t4, i, acc_out);
-            cur = nxt;
+            if (!hasN) break;
+            G = GN;
+            hasN = G.g + gstride < p.n_groups;
+            if (hasN) GN.load(p, G.g + gstride);
+            eb = G.e0;
+            primed = false;
+            continue;
         }
+        if (!primed) {
+            cur.load(p, eb, G.e1, i, G.n0);
+            if constexpr (ST) ew.prefetch(p, lane, eb, min(32, G.e1 - eb), cur.ep);
+        }
+        const int nv = min(32, G.e1 - eb);
+        const bool valid_i = i < nv;
+        const bool last = eb + 32 >= G.e1;
+        TMARK(0);
+        wave_lds_fence();
+        if constexpr (ST) ew.commit(w.et, dm.EKS, lane); else stage_e_tile<T, EW>(p, dm, w, lane, eb, nv, cur.ep);
+        if (h == 0) reinterpret_cast<unsigned char*>(w.tsl)[i] = valid_i ? (unsigned char)(cur.tgt - G.n0) : 0xff;
+        wave_lds_fence();
+        TMARK(1);
 
-        // epilogue: out = x + acc / deg   (rows = node slots in D layout, col = channel)
-        const int ch = s * 32 + i;
-        if (ch < dm.C) {
+#ifndef MDL_ABL_NOX
+        if constexpr (CP_ != 0) xf.load(x, dm.C, cur.tgt, cur.src, h);
+#endif
+        // prefetch the next tile of the stream (same group, or the first tile of the next group)
+        primed = false;
+        if (!last) {
+            nxt.load(p, eb + 32, G.e1, i, G.n0);
+#ifndef MDL_ABL_NOE
+            if constexpr (ST) ew.prefetch(p, lane, eb + 32, min(32, G.e1 - eb - 32), nxt.ep);
+#endif
+            primed = true;
+        } else {
+            if (hasN && GN.e0 < GN.e1) {
+                nxt.load(p, GN.e0, GN.e1, i, GN.n0);
+#ifndef MDL_ABL_NOE
+                if constexpr (ST) ew.prefetch(p, lane, GN.e0, min(32, GN.e1 - GN.e0), nxt.ep);
+#endif
+                primed = true;
+            }
+            // residual rows of this group, needed by the epilogue right after this tile
+            if (ch < dm.C) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + d_row(r, h);
-                if (n < n1) {
-                    float a = acc_out[r] * GT::M_SCALE;
-                    if (p.aggr == MDL_MEAN) {
-                        const float deg = (float)max(p.rowptr[n + 1] - p.rowptr[n], 1);
-                        a = M::FAST ? a * __builtin_amdgcn_rcpf(deg) : a / deg;
-                    }
-                    const int64_t o = (int64_t)n * dm.C + ch;
-                    Elem<T>::st(out + o, Elem<T>::ld(x + o) + a);
+                for (int r = 0; r < 16; ++r) {
+                    const int n = min(G.n0 + d_row(r, h), G.n1 - 1);
+                    xr[r] = Elem<T>::ld(x + (int64_t)n * dm.C + ch);
                 }
             }
         }
+
+        TMARK(2);
+        f32x16 accf, accs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
+#ifndef MDL_ABL_NOPRE
+        pre_tile<T, CP_, VEC, WM, NKW>(p, dm, w, lane, s, cur.tgt, cur.src, xf, wr, accf, accs);
+#else
+        if constexpr (std::is_same<T, bf16_t>::value) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accf[r] += bf2f((bf16_t)xf.t[0][r & 7]); accs[r] += bf2f((bf16_t)xf.s[0][r & 7]) + bf2f(w.et[i * dm.EKS + r]); }
+        }
+#endif
+
+        TMARK(3);
+        unsigned t4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t4[j] = w.tsl[2 * j + h];
+        // gate.  Edge slots >= nv hold finite garbage; their one-hot column is all zero, so they
+        // contribute exact zeros to the aggregation — no per-element masking needed.
+        f32x16 m;
+#pragma unroll
+#ifndef MDL_ABL_NOGATE
+        for (int r = 0; r < 16; ++r) m[r] = GT::sigmoid(accf[r]) * GT::softplus_u(accs[r]);
+#else
+        for (int r = 0; r < 16; ++r) m[r] = accf[r] * accs[r];
+#endif
+        TMARK(4);
+        seg_reduce_cnt<T>(m, t4, i, acc_out, cnt);
+        TMARK(5);
+
+        if (last) {
+            // epilogue: out = x + acc / deg   (rows = node slots in D layout, col = channel)
+            if (ch < dm.C) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = G.n0 + d_row(r, h);
+                    if (n < G.n1) {
+                        float a = acc_out[r] * GT::M_SCALE;
+                        if (p.aggr == MDL_MEAN) {
+                            const float deg = fmaxf(cnt[r], 1.0f);
+                            a = M::FAST ? a * __builtin_amdgcn_rcpf(deg) : a / deg;
+                        }
+                        Elem<T>::st(out + (int64_t)n * dm.C + ch, xr[r] + a);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc_out[r] = 0.0f; cnt[r] = 0.0f; }
+            if (!hasN) break;
+            G = GN;
+            hasN = G.g + gstride < p.n_groups;
+            if (hasN) GN.load(p, G.g + gstride);
+            eb = G.e0;
+        } else {
+            eb += 32;
+        }
+        cur = nxt;
+        TMARK(6);
+#ifdef MDL_CG_TIMING
+        if (gw == 0 && lane == 0) g_cg_dbg[15] += 1;
+#endif
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // Backward edge pass
 // ------------------------------------------------------------------------------------------
-template <typename T, int CP_, int G_, int VEC, int EW, bool W_LDS>
+template <typename T, int CP_, int G_, int VEC, int EW, int WM>
 __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Mma<T> M;
@@ -531,7 +741,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
     constexpr bool BF = std::is_same<T, bf16_t>::value;
     const D dm(p);
     WaveCtx<T> w;
-    setup_wave<T>(p, dm, smem, W_LDS, w);
+    setup_wave<T>(p, dm, smem, WM == 1 || WM == 3, w);
 
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -544,6 +754,10 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
     const T* x = static_cast<const T*>(p.x);
     const T* go = static_cast<const T*>(p.gout);
     const int C2 = 2 * dm.Cp;
+    constexpr int NKW = (WM == 2) ? (((G_ + 15) / 16 * 16) + 2 * CP_) / M::KSTEP : (WM == 3 ? 2 * CP_ / M::KSTEP : 1);
+    WRegs<T, NKW> wr;
+    if constexpr (WM == 2) wr.load(static_cast<const T*>(p.wpack), s * 32 + i, dm.Cp + s * 32 + i, dm.WS, h, 0);
+    if constexpr (WM == 3) wr.load(static_cast<const T*>(p.wpack), s * 32 + i, dm.Cp + s * 32 + i, dm.WS, h, dm.KE);
 
     // dwe accumulators: [part f|s][n-tile of G]  (rows = channel slot, cols = edge feature)
     constexpr int GNT = G_ ? (G_ + 31) / 32 : 2;
@@ -597,7 +811,8 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int eid = eb + u * WAVE + lane;
-                wb = min(wb, eid < e1 ? p.src[eid] : 0x7fffffff);
+                const int sv = p.src[min(eid, e1 - 1)];                 // clamp, never guard
+                wb = min(wb, eid < e1 ? sv : 0x7fffffff);
             }
         }
 #pragma unroll
@@ -610,10 +825,15 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             for (int r = 0; r < 16; ++r) { Wf[mt][r] = 0.0f; Ws[mt][r] = 0.0f; }
         if (lane == 0) *w.touched = 0ull;
 
-        TileIdx cur, nxt;
+        TileIdx cur, nxt, nn;
         EWords<T, G_, EW> ew;
+        XFrags<T, CP_, VEC> xf, xn;
         cur.load(p, e0, e1, i, n0);
         nxt = cur;
+        if (e0 + 32 < e1) nxt.load(p, e0 + 32, e1, i, n0);
+        nn = nxt;
+        constexpr bool XDB = MDL_BWD_XDB != 0;
+        if constexpr (CP_ != 0 && XDB) xf.load(x, dm.C, cur.tgt, cur.src, h);
         if constexpr (ST) ew.prefetch(p, lane, e0, min(32, e1 - e0), cur.ep);
 
         for (int eb = e0; eb < e1; eb += 32) {
@@ -633,17 +853,17 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             }
             wave_lds_fence();
 
-            XFrags<T, CP_, VEC> xf;
-            if constexpr (CP_ != 0) xf.load(x, dm.C, cur.tgt, cur.src, h);
+            if constexpr (CP_ != 0 && !XDB) xf.load(x, dm.C, cur.tgt, cur.src, h);
             if (eb + 32 < e1) {
-                nxt.load(p, eb + 32, e1, i, n0);
+                if constexpr (CP_ != 0 && XDB) xn.load(x, dm.C, nxt.tgt, nxt.src, h);
+                if (eb + 64 < e1) nn.load(p, eb + 64, e1, i, n0);
                 if constexpr (ST) ew.prefetch(p, lane, eb + 32, min(32, e1 - eb - 32), nxt.ep);
             }
 
             f32x16 accf, accs;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
-            pre_tile<T, CP_, VEC>(p, dm, w, lane, s, cur.tgt, cur.src, xf, accf, accs);
+            pre_tile<T, CP_, VEC, WM, NKW>(p, dm, w, lane, s, cur.tgt, cur.src, xf, wr, accf, accs);
 
             // dmv[edge slot][ch] = grad_out[tgt(edge)][ch] / deg : one-hot(edge -> node slot) x gB
             f32x16 dmv;
@@ -724,6 +944,8 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                 }
             }
             cur = nxt;
+            nxt = nn;
+            if constexpr (XDB) xf = xn;
         }
 
         // flush the source window: one atomic row update per touched window node (instead of per edge)
@@ -847,7 +1069,10 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16;  // e tile, tgt-slot bytes, source ids, src-slot bytes, bitmap
     const int w_bytes = (p.w_elems * (int)sizeof(T) + 15) & ~15;
     const int waves = 4;
-    bool w_lds = w_bytes + waves * p.wave_lds_bytes <= LDS_CAP;
+    // static fast shapes keep W in registers (no LDS copy); otherwise LDS if it fits, else global
+    const bool fast = p.G == 50 && p.C == d.Cp && (d.Cp == 32 || d.Cp == 64) &&
+                      (sizeof(T) == 2 ? (vec == 8 && EW == 2) : d.Cp == 64);
+    const bool w_lds = (!fast || MDL_CG_WM != 2) && w_bytes + waves * p.wave_lds_bytes <= LDS_CAP;
     const int lds = (w_lds ? w_bytes : 0) + waves * p.wave_lds_bytes;
     const int wg_per_cu = lds * 2 <= LDS_CAP ? 2 : 1;
 
@@ -859,31 +1084,28 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     // total waves must be a multiple of NS so that every wave keeps one channel slice
     while ((grid * waves) % d.NS) ++grid;
 
-#define MDL_CG_LAUNCH(CP_, G_, VEC_, EW_, WL_)                                                               \
+#define MDL_CG_LAUNCH(CP_, G_, VEC_, EW_, WM_)                                                               \
     do {                                                                                                     \
-        auto kf = bwd ? cgconv_bwd_kernel<T, CP_, G_, VEC_, EW_, WL_> : cgconv_fwd_kernel<T, CP_, G_, VEC_, EW_, WL_>; \
+        auto kf = bwd ? cgconv_bwd_kernel<T, CP_, G_, VEC_, EW_, WM_> : cgconv_fwd_kernel<T, CP_, G_, VEC_, EW_, WM_>; \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf),                                \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);                 \
         if (e != hipSuccess) { set_error("%s: LDS attribute (%d B): %s", name, lds, hipGetErrorString(e)); return MDL_E_LAUNCH; } \
         hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);                           \
     } while (0)
-#define MDL_CG_BY_WL(VEC_, EW_) do { if (w_lds) MDL_CG_LAUNCH(0, 0, VEC_, EW_, true); else MDL_CG_LAUNCH(0, 0, VEC_, EW_, false); } while (0)
+#define MDL_CG_BY_WL(VEC_, EW_) do { if (w_lds) MDL_CG_LAUNCH(0, 0, VEC_, EW_, 1); else MDL_CG_LAUNCH(0, 0, VEC_, EW_, 0); } while (0)
 #define MDL_CG_BY_EW(VEC_) do { if (EW == 2) MDL_CG_BY_WL(VEC_, 2); else MDL_CG_BY_WL(VEC_, 1); } while (0)
 
-    // fully static instantiations for the reference's edge width G = 50 and common channel counts
-    const bool fast = p.G == 50 && p.C == d.Cp && w_lds;
 #ifdef MDL_CG_FAST_ONLY   // compile-time experiments: only the bf16 C=64 G=50 instantiation
-    if constexpr (sizeof(T) == 2) { if (fast && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 2, true); }
+    if constexpr (sizeof(T) == 2) { if (fast && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 2, MDL_CG_WM); }
 #else
     if constexpr (sizeof(T) == 2) {
-        if (fast && vec == 8 && EW == 2 && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 2, true);
-        else if (fast && vec == 8 && EW == 2 && d.Cp == 32) MDL_CG_LAUNCH(32, 50, 9, 2, true);
-        else if (fast && vec == 8 && EW == 2 && d.Cp == 128) MDL_CG_LAUNCH(128, 50, 9, 2, true);
+        if (fast && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 2, MDL_CG_WM);
+        else if (fast && d.Cp == 32) MDL_CG_LAUNCH(32, 50, 9, 2, MDL_CG_WM);
         else if (vec == 8) MDL_CG_BY_EW(8);
         else if (vec == 4) MDL_CG_BY_EW(4);
         else MDL_CG_BY_EW(1);
     } else {
-        if (fast && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 1, true);
+        if (fast) MDL_CG_LAUNCH(64, 50, 9, 1, 1);
         else MDL_CG_BY_WL(1, 1);
     }
 #endif

@@ -37,3 +37,15 @@ for k, v in ev.items():
     if v:
         t = [s.elapsed_time(e) * 1e3 for s, e in v]
         print("%s: avg %.1f us  min %.1f us" % (k, sum(t) / len(t), min(t)))
+try:
+    import ctypes
+    L = _lib.lib()
+    if hasattr(L, "mdl_debug_read"):
+        buf = (ctypes.c_longlong * 16)()
+        L.mdl_debug_read(buf)
+        v = list(buf)
+        n = max(v[15], 1)
+        names = ["loop-top/idx wait", "commit+tsl", "issue x/prefetch", "pre GEMM", "gate", "reduce", "epilogue/advance"]
+        print("per-tile cycles (wave 0, %d tiles):" % n, {names[k]: round(v[k] / n) for k in range(7)}, "sum", round(sum(v[:7]) / n))
+except Exception as e:
+    print("no timing:", e)

@@ -1,0 +1,15 @@
+#!/bin/bash
+# build_variant.sh <name> <extra hipcc flags...>  -> matdeeplearn_amd/lib/variants/<name>.so (for A/B runs via MDL_HIP_LIB)
+set -e
+name=$1; shift
+cd /root/repo/matdeeplearn_amd
+mkdir -p lib/variants lib/obj_$name
+for f in csrc/*.hip; do
+  b=$(basename $f .hip)
+  extra=""; [ "$b" = "cgconv" ] && extra="$@"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $extra -c $f -o lib/obj_$name/$b.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/variants/$name.so lib/obj_$name/*.o
+rm -rf lib/obj_$name
+echo built lib/variants/$name.so

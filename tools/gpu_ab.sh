@@ -1,0 +1,8 @@
+#!/bin/bash
+# A/B the kernel micro-benchmark over prebuilt library variants (fwd only unless BWD=1)
+OUT=gpurun_out/ab; mkdir -p $OUT
+W=${WHICH:-fwd}
+for v in "$@"; do
+  echo "== $v"
+  MDL_HIP_LIB=$PWD/matdeeplearn_amd/lib/variants/$v.so timeout 300 python tools/bench_kernels.py --which $W 2>&1 | grep -E "fwd|bwd|rror"
+done 2>&1 | tee $OUT/ab.log
