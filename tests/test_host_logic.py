@@ -1,0 +1,254 @@
+"""CPU suite for the host side: C-ABI surface, dataset/loader logic, training loops (with the oracle
+model — the product has no CPU compute path), and the data-parallel engine over gloo (world_size 2)."""
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+# ---------------------------------------------------------------------------------------------
+# C ABI
+# ---------------------------------------------------------------------------------------------
+def test_library_loads_and_exports_every_declared_symbol():
+    from matdeeplearn_amd import _lib
+    handle = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "mdl_hip.h")).read()
+    declared = set(re.findall(r"\b(mdl_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found in include/mdl_hip.h"
+    for name in declared:
+        assert hasattr(handle, name), "declared in mdl_hip.h but not exported: " + name
+    assert declared == set(_lib.PROTOTYPES), "ctypes prototype table out of sync with mdl_hip.h"
+    assert handle.mdl_version() == 100
+    assert handle.mdl_cgconv_wpack_bytes(64, 50, _lib.MDL_BF16) == 128 * 200 * 2
+    assert handle.mdl_cgconv_wpack_bytes(64, 50, 7) == 0
+
+
+def test_ops_fail_loudly_without_a_hip_device():
+    from matdeeplearn_amd import nn as mnn, ops
+    x = torch.randn(4, 64)
+    ei = torch.tensor([[0, 1, 2], [1, 2, 3]])
+    with pytest.raises(ops.MdlError):
+        ops.scatter(x, torch.tensor([0, 0, 1, 1]), 0, 2, "mean")
+    with pytest.raises(ops.MdlError):
+        ops.rbf_expand(torch.rand(5))
+    with pytest.raises(ops.MdlError):
+        mnn.CGConv(64, 50, aggr="mean")(x, ei, torch.randn(3, 50))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "matdeeplearn_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dirpath, f)
+
+
+# ---------------------------------------------------------------------------------------------
+# graph builder / dataset / loader
+# ---------------------------------------------------------------------------------------------
+def test_product_graph_builder_matches_reference_goldens():
+    from matdeeplearn_amd.process import graph as pg
+    z = np.load(os.path.join(G, "threshold_sort.npz"))
+    for t in "abcde":
+        assert np.array_equal(pg.threshold_sort(z["D_" + t], float(z["r_" + t]), int(z["k_" + t])), z["out_" + t])
+    ds, gg = np.load(os.path.join(G, "pt10_dataset.npz")), np.load(os.path.join(G, "pt10_graphs.npz"))
+    counts = []
+    for s in range(len(ds["ids"])):
+        r = pg.build_graph(ds["positions"][s], ds["numbers"][s], ds["cell"][s], ds["pbc"][s])
+        counts.append(r["edge_index"].shape[1])
+        if s < 8:
+            assert np.array_equal(r["edge_index"], gg["edge_index_%d" % s])
+            assert np.array_equal(r["edge_weight"], gg["edge_weight_%d" % s])
+            assert r["x"].shape == (10, 114)
+    assert np.array_equal(np.array(counts), gg["edges_per_graph"]) and sum(counts) == 99672
+    oh = np.load(os.path.join(G, "onehot_degree.npz"))
+    assert np.array_equal(pg.one_hot_degree(oh["edge_index"], 10, 13), oh["x"][:, 1:])
+
+
+def test_minimum_image_distances_against_bruteforce():
+    from matdeeplearn_amd.process import graph as pg
+    from oracle import graph as og
+    rng = np.random.default_rng(0)
+    cell = np.diag([7.0, 8.0, 9.0])
+    pos = rng.uniform(0, 9, size=(12, 3))
+    a = pg.distance_matrix(pos, cell, [True, True, False])
+    b = og.mic_distances(pos, cell, [True, True, False])
+    assert np.allclose(a, b, atol=1e-12)
+
+
+@pytest.fixture(scope="module")
+def small_ds():
+    from matdeeplearn_amd.process import synthetic_bulk
+    return synthetic_bulk(64, seed=3)
+
+
+def test_synthetic_bulk_graph_invariants(small_ds):
+    ds = small_ds
+    assert ds.x.shape[1] == 114 and len(ds) == 64
+    for g in range(len(ds)):
+        n0, n1, e0, e1 = ds.node_ptr[g], ds.node_ptr[g + 1], ds.edge_ptr[g], ds.edge_ptr[g + 1]
+        n = n1 - n0
+        src, tgt, d = ds.src[e0:e1], ds.tgt[e0:e1], ds.dist[e0:e1]
+        assert np.all(np.diff(tgt) >= 0), "edges must be sorted by target inside every graph"
+        assert src.min() >= 0 and src.max() < n and tgt.max() < n
+        loops = src == tgt
+        assert loops.sum() == n and np.all(d[loops] == 0)                 # exactly one self loop / node, weight 0
+        out_deg = np.bincount(src[~loops], minlength=n)
+        assert out_deg.max() <= 12                                           # <= 12 non-self out-edges per node
+        assert np.all(d[~loops] > 0) and d.max() <= 8.0
+        assert len(set(zip(src.tolist(), tgt.tolist()))) == e1 - e0         # no duplicate (i, j)
+        assert np.array_equal(ds.x[n0:n1, 100:].argmax(1), out_deg + 1)     # one-hot OUT-degree incl. the loop
+    assert ds.dist_norm.min() == 0.0 and abs(ds.dist_norm.max() - 1.0) < 1e-6
+
+
+def test_batch_assembly_matches_per_graph_concatenation(small_ds):
+    ds = small_ds
+    ds.to("cpu")
+    ids = np.array([5, 1, 7, 60, 5])
+    b, dn = ds.assemble(ids)
+    off = 0
+    for k, g in enumerate(ids):
+        n0, n1, e0, e1 = ds.node_ptr[g], ds.node_ptr[g + 1], ds.edge_ptr[g], ds.edge_ptr[g + 1]
+        sl = b.batch == k
+        assert torch.equal(b.x[sl], torch.from_numpy(ds.x[n0:n1]))
+        m = (b.csr.tgt >= off) & (b.csr.tgt < off + (n1 - n0))
+        assert torch.equal(b.csr.src[m] - off, torch.from_numpy(ds.src[e0:e1]))
+        assert torch.equal(b.csr.tgt[m] - off, torch.from_numpy(ds.tgt[e0:e1]))
+        assert torch.equal(dn[m], torch.from_numpy(ds.dist_norm[e0:e1]))
+        off += n1 - n0
+    assert (b.csr.tgt[1:] >= b.csr.tgt[:-1]).all()
+    cnt = torch.bincount(b.csr.tgt.long(), minlength=b.num_nodes)
+    assert torch.equal(torch.cumsum(cnt, 0).int(), b.csr.rowptr[1:]) and int(b.csr.rowptr[0]) == 0
+    assert torch.equal(b.y, torch.from_numpy(ds.y[ids, 0])) and b.u.shape == (5, 3) and b.num_graphs == 5
+    # lazily materialised PyG-style edge_index
+    assert b.edge_index.shape == (2, b.num_edges) and b.edge_index.dtype == torch.int64
+
+
+def test_device_loader_partitions_like_distributed_sampler(small_ds):
+    from matdeeplearn_amd.process import DeviceLoader
+    ds = small_ds
+    ds.to("cpu")
+    idx = np.arange(50)
+    seen = []
+    for r in range(4):
+        ld = DeviceLoader(ds, idx, batch_size=5, shuffle=True, seed=7, rank=r, world_size=4, rbf=lambda d: torch.zeros(len(d), 50))
+        ld.set_epoch(3)
+        order = ld._order()
+        assert len(order) == 13 and len(ld) == 3                        # ceil(50/4) padded, ceil(13/5) batches
+        seen.append(order)
+    flat = np.concatenate(seen)
+    assert set(flat.tolist()) == set(range(50)) and len(flat) == 52        # every index, 2 padded repeats
+    ld0 = DeviceLoader(ds, idx, batch_size=5, shuffle=True, seed=7, rbf=lambda d: torch.zeros(len(d), 50))
+    ld0.set_epoch(3)
+    a = ld0._order()
+    ld0.set_epoch(4)
+    assert not np.array_equal(a, ld0._order())
+
+
+# ---------------------------------------------------------------------------------------------
+# training loops on the reference's own test dataset (config 1: Pt10 CGCNN, CPU plumbing)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def pt10():
+    from matdeeplearn_amd.process import from_structures
+    z = np.load(os.path.join(G, "pt10_dataset.npz"))
+    n = 200
+    structs = [dict(positions=z["positions"][s], numbers=z["numbers"][s], cell=z["cell"][s], pbc=z["pbc"][s])
+               for s in range(n)]
+    ds = from_structures(structs, z["y"][:n], [str(v) for v in z["ids"][:n]])
+    return ds.to("cpu")
+
+
+def test_cfg1_pt10_cgcnn_trains_on_cpu_through_the_harness(pt10):
+    from matdeeplearn_amd.process import DeviceLoader, split_data
+    from matdeeplearn_amd.training import make_optimizer, make_scheduler, trainer, evaluate
+    from oracle import models as omodels, ops as oops
+    torch.manual_seed(42)
+    rbf = lambda d: oops.rbf_expand(d)
+    tr, va, te = split_data(len(pt10), 0.8, 0.05, 0.15, seed=42)
+    assert (len(tr), len(va), len(te)) == (160, 10, 30)
+    mk = lambda idx, sh: DeviceLoader(pt10, idx, batch_size=40, shuffle=sh, seed=1, rbf=rbf)
+    model = omodels.CGCNN(pt10, dim1=100, dim2=150, pre_fc_count=1, gc_count=4, post_fc_count=3)   # config.yml CGCNN_demo
+    opt = make_optimizer(model.parameters(), "AdamW", lr=0.002)
+    sch = make_scheduler(opt, "ReduceLROnPlateau", mode="min", factor=0.8, patience=10, min_lr=1e-5, threshold=2e-4)
+    model, hist = trainer("cpu", 1, model, opt, sch, "l1_loss", mk(tr, True), mk(va, False), epochs=4, verbosity=0)
+    assert len(hist) == 4 and all(np.isfinite(h["train"]) and np.isfinite(h["val"]) for h in hist)
+    assert hist[-1]["train"] < hist[0]["train"], hist                       # it learns
+    assert hist[0]["edges"] == int(sum(np.diff(pt10.edge_ptr)[tr]))         # edges/s bookkeeping
+    loss, rows = evaluate(mk(te, False), model, "l1_loss", out=True)
+    assert rows.shape == (30, 3) and np.isfinite(float(loss))
+
+
+def test_train_loss_is_sample_weighted_mean(pt10):
+    """training.py:45,51-53 — sum(batch-mean x batch-size) / sum(batch-size) == dataset MAE."""
+    from matdeeplearn_amd.process import DeviceLoader
+    from matdeeplearn_amd.training import evaluate
+    from oracle import models as omodels, ops as oops
+    torch.manual_seed(0)
+    rbf = lambda d: oops.rbf_expand(d)
+    model = omodels.CGCNN(pt10, dim1=32, dim2=32, gc_count=1, post_fc_count=1)
+    idx = np.arange(50)
+    a = float(evaluate(DeviceLoader(pt10, idx, batch_size=16, rbf=rbf), model, "l1_loss"))
+    b = float(evaluate(DeviceLoader(pt10, idx, batch_size=50, rbf=rbf), model, "l1_loss"))
+    assert abs(a - b) < 1e-5 * max(1.0, abs(b))
+
+
+# ---------------------------------------------------------------------------------------------
+# data parallel engine: world_size 2 over gloo
+# ---------------------------------------------------------------------------------------------
+def _dp_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from matdeeplearn_amd.process import DeviceLoader, synthetic_bulk
+    from matdeeplearn_amd.training import FlatDataParallel, ddp_setup, ddp_cleanup, make_optimizer
+    from oracle import models as omodels, ops as oops
+    assert ddp_setup(rank, world, backend="gloo", master_port=port)
+    torch.manual_seed(100 + rank)                     # different init per rank: broadcast must fix it
+    ds = synthetic_bulk(32, seed=5).to("cpu")
+    rbf = lambda d: oops.rbf_expand(d)
+    model = omodels.CGCNN(ds, dim1=16, dim2=16, gc_count=2, post_fc_count=1, batch_norm="False")
+    dp = FlatDataParallel(model)
+    p0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.zeros_like(p0) for _ in range(world)]
+    dist.all_gather(gathered, p0)
+    assert torch.equal(gathered[0], gathered[1]), "parameter broadcast failed"
+    # each rank: its shard of one global batch of 8 graphs
+    ids = np.arange(8)
+    batch = ds.collate(ids[rank::world], rbf=rbf)
+    dp.zero_grad()
+    loss = torch.nn.functional.l1_loss(model(batch), batch.y, reduction="sum") / 8.0
+    loss.backward()
+    dp.reduce_grads()
+    # reference: the full batch on one process; DDP averages, so compare with grad / world
+    ref = omodels.CGCNN(ds, dim1=16, dim2=16, gc_count=2, post_fc_count=1, batch_norm="False")
+    ref.load_state_dict(model.state_dict())
+    full = ds.collate(ids, rbf=rbf)
+    (torch.nn.functional.l1_loss(ref(full), full.y, reduction="sum") / 8.0).backward()
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p.grad, q.grad / world, rtol=1e-4, atol=1e-6), k
+        assert p.grad.data_ptr() >= dp.flat_grad.data_ptr()          # grads are views of the flat buffer
+    opt = make_optimizer(model.parameters(), "AdamW", lr=0.01)
+    opt.step()
+    p1 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    dist.all_gather(gathered, p1)
+    assert torch.equal(gathered[0], gathered[1]), "ranks diverged after the optimizer step"
+    if rank == 0:
+        open(tmp, "w").write("ok %d" % dp.grad_bytes())
+    ddp_cleanup()
+
+
+def test_flat_data_parallel_world_size_2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    out = str(tmp_path / "dp.txt")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    assert open(out).read().startswith("ok")
