@@ -119,6 +119,25 @@ int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, 
 int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const float* r_tgt, const float* r_src,
                         const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype, mdlStream_t stream);
 
+/* ---- generic gather / edge-weighted gather-reduce (SchNet CFConv, GCNConv, MEGNet, NNConv) ------
+ * Replace the index_select + elementwise + torch_scatter sequence of PyG MessagePassing.propagate at
+ * matdeeplearn/models/schnet.py:134-143, gcn.py:135-144, megnet.py:41-56,84-101,129-147, mpnn.py:148-157.
+ *
+ * out[k, :] = src[idx[k], :]                                        src: [*, C]; idx: [E] int32; out: [E, C] */
+int mdl_gather_rows(const void* src, const int32_t* idx, void* out, int64_t E, int64_t C, int dtype,
+                    mdlStream_t stream);
+/* out[i, :] = reduce_{k in [rowptr[i], rowptr[i+1])} h[col[k], :] * w[eid?eid[k]:k, :] * scale[eid?eid[k]:k]
+ * h: [*, F]; w: [E, F] or NULL; scale: [E] fp32 or NULL; col: [E] int32 (node gathered by CSR slot k);
+ * eid: [E] int32 original edge id of slot k or NULL; out: [N, F]; reduce in {MDL_SUM, MDL_MEAN}.
+ * CFConv: rows = targets, col = sources, w = filter, scale = cosine cutoff.  Gradient w.r.t. h: the
+ * same call on the transposed CSR (rows = sources, col = targets, h = grad_out). */
+int mdl_gather_mul_reduce(const void* h, const void* w, const float* scale, const int32_t* rowptr,
+                          const int32_t* col, const int32_t* eid, void* out, int64_t N, int64_t F, int reduce,
+                          int dtype, mdlStream_t stream);
+/* out[e, :] = a[ia[e], :] * b[ib[e], :] * scale[e]   (gradient w.r.t. the per-edge filter w) */
+int mdl_edge_mul(const void* a, const int32_t* ia, const void* b, const int32_t* ib, const float* scale, void* out,
+                 int64_t E, int64_t F, int dtype, mdlStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,121 @@
+// gather.hip — generic gather / edge-weighted gather-reduce kernels used by the SchNet (CFConv), GCN,
+// MEGNet and MPNN blocks.  They restate what PyG's MessagePassing.propagate does with ATen
+// index_select + elementwise + torch_scatter (call sites: /root/reference/matdeeplearn/models/
+// schnet.py:134-143, gcn.py:135-144, megnet.py:41-56,84-101,129-147, mpnn.py:148-157).
+//
+//   K4a  mdl_gather_mul_reduce:  out[i,:] = reduce_{k in row i} h[col[k],:] * w[eid(k),:] * scale[eid(k)]
+//        (CSR rows = aggregation nodes).  One thread owns VEC channels of one output row and walks the
+//        row's slots: atomic-free, deterministic; consecutive lanes = consecutive channels, so every
+//        h row / w row is read as one contiguous run.  The SAME kernel on the transposed CSR gives the
+//        gradient w.r.t. h; mdl_edge_mul gives the gradient w.r.t. w.
+//        Algorithmic bytes: E*(2*F*s + 8) + N*(F*s + 4).
+//   mdl_gather_rows: out[k,:] = src[idx[k],:]   (index_select along dim 0)
+#include "mdl_common.h"
+
+namespace mdl {
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          T* __restrict__ out, int64_t E, int C) {
+    const int64_t total = E * C;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t k = i / C;
+        const int c = (int)(i - k * C);
+        out[i] = src[(int64_t)idx[k] * C + c];
+    }
+}
+
+template <typename T, bool MEAN>
+__global__ __launch_bounds__(256) void gmr_kernel(const T* __restrict__ h, const T* __restrict__ w,
+                                                  const float* __restrict__ scale, const int32_t* __restrict__ rowptr,
+                                                  const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
+                                                  T* __restrict__ out, int64_t N, int F) {
+    const int64_t total = N * F;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / F;
+        const int c = (int)(i - n * F);
+        const int b = rowptr[n], e = rowptr[n + 1];
+        float acc = 0.0f;
+        for (int k = b; k < e; ++k) {
+            const int64_t id = eid ? eid[k] : k;
+            float v = Elem<T>::ld(h + (int64_t)col[k] * F + c);
+            if (w) v *= Elem<T>::ld(w + id * F + c);
+            if (scale) v *= scale[id];
+            acc += v;
+        }
+        if (MEAN) acc = acc / (float)max(e - b, 1);
+        Elem<T>::st(out + i, acc);
+    }
+}
+
+// dw[e,:] = a[ia[e],:] * b[ib[e],:] * scale[e]      (per-edge product of two gathered rows)
+template <typename T>
+__global__ __launch_bounds__(256) void edge_mul_kernel(const T* __restrict__ a, const int32_t* __restrict__ ia,
+                                                       const T* __restrict__ b, const int32_t* __restrict__ ib,
+                                                       const float* __restrict__ scale, T* __restrict__ out, int64_t E,
+                                                       int F) {
+    const int64_t total = E * F;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t e = i / F;
+        const int c = (int)(i - e * F);
+        float v = Elem<T>::ld(a + (int64_t)ia[e] * F + c) * Elem<T>::ld(b + (int64_t)ib[e] * F + c);
+        if (scale) v *= scale[e];
+        Elem<T>::st(out + i, v);
+    }
+}
+
+static unsigned g_grid(int64_t total) {
+    int64_t b = cdiv(total, 256);
+    if (b > 256 * 16) b = 256 * 16;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace mdl
+
+extern "C" int mdl_gather_rows(const void* src, const int32_t* idx, void* out, int64_t E, int64_t C, int dtype,
+                               mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(E >= 0 && C > 0 && (E == 0 || (src && idx && out)), MDL_E_ARG, "mdl_gather_rows: bad arguments");
+    if (E == 0) return MDL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MDL_F32)
+        hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(g_grid(E * C)), dim3(256), 0, st, (const float*)src, idx, (float*)out, E, (int)C);
+    else if (dtype == MDL_BF16)
+        hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(g_grid(E * C)), dim3(256), 0, st, (const bf16_t*)src, idx, (bf16_t*)out, E, (int)C);
+    else { set_error("mdl_gather_rows: unsupported dtype %d", dtype); return MDL_E_UNSUPP; }
+    return check_launch("mdl_gather_rows");
+}
+
+extern "C" int mdl_gather_mul_reduce(const void* h, const void* w, const float* scale, const int32_t* rowptr,
+                                     const int32_t* col, const int32_t* eid, void* out, int64_t N, int64_t F,
+                                     int reduce, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(N >= 0 && F > 0 && (N == 0 || (h && rowptr && out)), MDL_E_ARG, "mdl_gather_mul_reduce: bad arguments");
+    MDL_REQUIRE(reduce == MDL_SUM || reduce == MDL_MEAN, MDL_E_UNSUPP, "mdl_gather_mul_reduce: reduce must be sum or mean");
+    if (N == 0) return MDL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g(g_grid(N * F)), b(256);
+#define MDL_GMR(T_, M_) hipLaunchKernelGGL((gmr_kernel<T_, M_>), g, b, 0, st, (const T_*)h, (const T_*)w, scale, rowptr, col, eid, (T_*)out, N, (int)F)
+    if (dtype == MDL_F32) { if (reduce == MDL_MEAN) MDL_GMR(float, true); else MDL_GMR(float, false); }
+    else if (dtype == MDL_BF16) { if (reduce == MDL_MEAN) MDL_GMR(bf16_t, true); else MDL_GMR(bf16_t, false); }
+    else { set_error("mdl_gather_mul_reduce: unsupported dtype %d", dtype); return MDL_E_UNSUPP; }
+#undef MDL_GMR
+    return check_launch("mdl_gather_mul_reduce");
+}
+
+extern "C" int mdl_edge_mul(const void* a, const int32_t* ia, const void* b, const int32_t* ib, const float* scale,
+                            void* out, int64_t E, int64_t F, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(E >= 0 && F > 0 && (E == 0 || (a && ia && b && ib && out)), MDL_E_ARG, "mdl_edge_mul: bad arguments");
+    if (E == 0) return MDL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MDL_F32)
+        hipLaunchKernelGGL((edge_mul_kernel<float>), dim3(g_grid(E * F)), dim3(256), 0, st, (const float*)a, ia, (const float*)b, ib, scale, (float*)out, E, (int)F);
+    else if (dtype == MDL_BF16)
+        hipLaunchKernelGGL((edge_mul_kernel<bf16_t>), dim3(g_grid(E * F)), dim3(256), 0, st, (const bf16_t*)a, ia, (const bf16_t*)b, ib, scale, (bf16_t*)out, E, (int)F);
+    else { set_error("mdl_edge_mul: unsupported dtype %d", dtype); return MDL_E_UNSUPP; }
+    return check_launch("mdl_edge_mul");
+}

@@ -1,0 +1,103 @@
+"""Skeleton shared by the five reference model wrappers (each reference file repeats it:
+e.g. /root/reference/matdeeplearn/models/cgcnn.py:35-119,121-174):
+
+    pre_lin_list (+act) -> gc_count x [conv ... bn_list.i ... dropout] -> pool -> post_lin_list (+act) -> lin_out
+
+Constructor keywords (string booleans "True"/"False", unknown keys swallowed by **kwargs), the
+forward(batch) contract (`out.view(-1)` when the output dimension is 1) and the state_dict key names
+are the reference's.  Extra keyword: compute_dtype = "fp32" (parity mode) | "bf16".
+Dense layers are library GEMMs with fp32 master weights; everything indexed by edge_index / batch
+runs on the HIP kernels of libmdl_hip.so (matdeeplearn_amd.ops / matdeeplearn_amd.nn).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+from ..nn import Set2Set
+
+
+def dense(lin, h):
+    """nn.Linear in the dtype of h with fp32 master weights."""
+    if h.dtype == lin.weight.dtype:
+        return lin(h)
+    return F.linear(h, lin.weight.to(h.dtype), None if lin.bias is None else lin.bias.to(h.dtype))
+
+
+class GraphModel(nn.Module):
+    def _init_skeleton(self, data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order, batch_norm,
+                       batch_track_stats, act, dropout_rate, compute_dtype, post_fc_dim=None, early_mult=1,
+                       make_bn=True):
+        assert gc_count > 0, "Need at least 1 GC layer"
+        self.batch_track_stats = batch_track_stats != "False"
+        self.batch_norm, self.pool, self.act = batch_norm, pool, act
+        self.pool_order, self.dropout_rate = pool_order, dropout_rate
+        self.compute_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[compute_dtype]
+        self.gc_dim = data.num_features if pre_fc_count == 0 else dim1
+        post_in = self.gc_dim if post_fc_dim is None else post_fc_dim
+        y0 = data[0].y
+        self.output_dim = 1 if y0.ndim == 0 else len(y0[0])
+        s2s_early = pool == "set2set" and pool_order == "early"
+        if pool_order == "early":
+            first_in = post_in * ((2 * early_mult - 1) if (s2s_early and early_mult > 1) else (2 if s2s_early else early_mult))
+        else:
+            first_in = post_in
+        self.pre_lin_list = nn.ModuleList(
+            [nn.Linear(data.num_features if i == 0 else dim1, dim1) for i in range(pre_fc_count)])
+        self.bn_list = nn.ModuleList(
+            [nn.BatchNorm1d(self.gc_dim, track_running_stats=self.batch_track_stats) for _ in range(gc_count)]
+            if (batch_norm == "True" and make_bn) else [])
+        self.post_lin_list = nn.ModuleList(
+            [nn.Linear(first_in if i == 0 else dim2, dim2) for i in range(post_fc_count)])
+        self.lin_out = nn.Linear(dim2 if post_fc_count > 0 else first_in, self.output_dim)
+        return post_in
+
+    def _make_set2set(self, post_in):
+        if self.pool == "set2set" and self.pool_order == "early":
+            self.set2set = Set2Set(post_in, processing_steps=3)
+        elif self.pool == "set2set" and self.pool_order == "late":
+            self.set2set = Set2Set(self.output_dim, processing_steps=3, num_layers=1)
+            self.lin_out_2 = nn.Linear(self.output_dim * 2, self.output_dim)
+
+    # ---- shared forward pieces ----------------------------------------------------------------
+    def _inputs(self, data):
+        cd = self.compute_dtype
+        n = data.x.shape[0]
+        csr = getattr(data, "csr", None)
+        if csr is None:
+            csr = ops.csr_for(data.edge_index, n)
+        return data.x.to(cd), data.edge_attr.to(cd), csr
+
+    def _pre(self, out):
+        for lin in self.pre_lin_list:
+            out = getattr(F, self.act)(dense(lin, out))
+        return out
+
+    def _bn(self, i, out):
+        return self.bn_list[i](out) if self.batch_norm == "True" else out
+
+    def _drop(self, out):
+        return F.dropout(out, p=self.dropout_rate, training=self.training)
+
+    def _post(self, out):
+        for lin in self.post_lin_list:
+            out = getattr(F, self.act)(dense(lin, out))
+        return dense(self.lin_out, out)
+
+    def _pool(self, out, data):
+        num_graphs = getattr(data, "num_graphs", None)
+        if self.pool == "set2set":
+            return self.set2set(out, data.batch, num_graphs)
+        return ops.POOLS[self.pool](out, data.batch, num_graphs)
+
+    def _head(self, out, data):
+        if self.pool_order == "early":
+            out = self._post(self._pool(out, data).to(out.dtype))
+        else:
+            out = self._post(out)
+            if self.pool == "set2set":
+                out = dense(self.lin_out_2, self._pool(out, data).to(out.dtype))
+            else:
+                out = self._pool(out, data)
+        out = out.float()
+        return out.view(-1) if out.shape[1] == 1 else out

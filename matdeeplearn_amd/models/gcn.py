@@ -1,13 +1,13 @@
-"""CGCNN on the HIP message-passing engine — /root/reference/matdeeplearn/models/cgcnn.py:17-174.
-conv_list.i = CGConv(gc_dim, num_edge_features, aggr="mean", batch_norm=False) (:80-83); per layer
-conv -> bn_list.i -> dropout, NO activation between layers (:146 is commented out in the reference)."""
+"""GCN — /root/reference/matdeeplearn/models/gcn.py:17-173: GCNConv(gc_dim, gc_dim, improved=True,
+add_self_loops=False) called with edge_weight = raw distance (:80-82,135-144) -> BN -> act -> dropout."""
+import torch.nn.functional as F
 from torch import nn
 
-from ..nn import CGConv
+from ..nn import GCNConv
 from ._base import GraphModel
 
 
-class CGCNN(GraphModel):
+class GCN(GraphModel):
     def __init__(self, data, dim1=64, dim2=64, pre_fc_count=1, gc_count=3, post_fc_count=1,
                  pool="global_mean_pool", pool_order="early", batch_norm="True", batch_track_stats="True",
                  act="relu", dropout_rate=0.0, compute_dtype="fp32", **kwargs):
@@ -15,12 +15,13 @@ class CGCNN(GraphModel):
         post_in = self._init_skeleton(data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order,
                                       batch_norm, batch_track_stats, act, dropout_rate, compute_dtype)
         self.conv_list = nn.ModuleList(
-            [CGConv(self.gc_dim, data.num_edge_features, aggr="mean", batch_norm=False) for _ in range(gc_count)])
+            [GCNConv(self.gc_dim, self.gc_dim, improved=True, add_self_loops=False) for _ in range(gc_count)])
         self._make_set2set(post_in)
 
     def forward(self, data):
-        x, edge_attr, csr = self._inputs(data)
+        x, _, csr = self._inputs(data)
         out = self._pre(x)
         for i, conv in enumerate(self.conv_list):
-            out = self._drop(self._bn(i, conv(out, None, edge_attr, csr=csr)))
+            out = self._bn(i, conv(out, None, data.edge_weight, csr=csr))
+            out = self._drop(getattr(F, self.act)(out))
         return self._head(out, data)

@@ -1,26 +1,26 @@
-"""CGCNN on the HIP message-passing engine — /root/reference/matdeeplearn/models/cgcnn.py:17-174.
-conv_list.i = CGConv(gc_dim, num_edge_features, aggr="mean", batch_norm=False) (:80-83); per layer
-conv -> bn_list.i -> dropout, NO activation between layers (:146 is commented out in the reference)."""
+"""SchNet — /root/reference/matdeeplearn/models/schnet.py:16-172: conv_list.i = InteractionBlock(gc_dim,
+num_edge_features, dim3, cutoff) (:81); out = out + conv(out, edge_index, edge_weight, edge_attr) then
+BatchNorm (:134-143), no activation between layers."""
 from torch import nn
 
-from ..nn import CGConv
+from ..nn import InteractionBlock
 from ._base import GraphModel
 
 
-class CGCNN(GraphModel):
-    def __init__(self, data, dim1=64, dim2=64, pre_fc_count=1, gc_count=3, post_fc_count=1,
+class SchNet(GraphModel):
+    def __init__(self, data, dim1=64, dim2=64, dim3=64, cutoff=8, pre_fc_count=1, gc_count=3, post_fc_count=1,
                  pool="global_mean_pool", pool_order="early", batch_norm="True", batch_track_stats="True",
                  act="relu", dropout_rate=0.0, compute_dtype="fp32", **kwargs):
         super().__init__()
         post_in = self._init_skeleton(data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order,
                                       batch_norm, batch_track_stats, act, dropout_rate, compute_dtype)
         self.conv_list = nn.ModuleList(
-            [CGConv(self.gc_dim, data.num_edge_features, aggr="mean", batch_norm=False) for _ in range(gc_count)])
+            [InteractionBlock(self.gc_dim, data.num_edge_features, dim3, cutoff) for _ in range(gc_count)])
         self._make_set2set(post_in)
 
     def forward(self, data):
         x, edge_attr, csr = self._inputs(data)
         out = self._pre(x)
         for i, conv in enumerate(self.conv_list):
-            out = self._drop(self._bn(i, conv(out, None, edge_attr, csr=csr)))
+            out = self._drop(self._bn(i, out + conv(out, None, data.edge_weight, edge_attr, csr=csr)))
         return self._head(out, data)

@@ -38,3 +38,175 @@ class CGConv(nn.Module):
 
     def extra_repr(self):
         return "%d, dim=%d, aggr=%s" % (self.channels, self.dim, self.aggr)
+
+
+# ------------------------------------------------------------------------------------------------
+# SchNet: torch_geometric.nn.models.schnet.{ShiftedSoftplus, CFConv, InteractionBlock} (2.0.1) as
+# constructed at matdeeplearn/models/schnet.py:81 and called at schnet.py:134-143.
+# The filter MLP and the node Linears are library GEMMs; the gather * filter * cutoff -> segmented
+# sum is the K4a HIP kernel (forward, and its transpose for the gradient).
+# ------------------------------------------------------------------------------------------------
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+class ShiftedSoftplus(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.shift = math.log(2.0)
+
+    def forward(self, x):
+        return F.softplus(x) - self.shift
+
+
+class CFConv(nn.Module):
+    def __init__(self, in_channels, out_channels, num_filters, net, cutoff):
+        super().__init__()
+        self.lin1 = nn.Linear(in_channels, num_filters, bias=False)
+        self.lin2 = nn.Linear(num_filters, out_channels)
+        self.nn = net
+        self.cutoff = cutoff
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.lin1.weight)
+        nn.init.xavier_uniform_(self.lin2.weight)
+        self.lin2.bias.data.fill_(0)
+
+    def forward(self, x, edge_index, edge_weight, edge_attr, csr=None):
+        if csr is None:
+            csr = ops.csr_for(edge_index, x.shape[0])
+        c = 0.5 * (torch.cos(edge_weight.float() * (math.pi / self.cutoff)) + 1.0)   # [E] fp32
+        w = self.nn(edge_attr)                                                        # filter  [E, F]
+        h = self.lin1(x)
+        agg = ops.gather_mul_reduce(h, csr, w=w.to(h.dtype), scale=c, reduce="sum")
+        return self.lin2(agg)
+
+
+class InteractionBlock(nn.Module):
+    def __init__(self, hidden_channels, num_gaussians, num_filters, cutoff):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(num_gaussians, num_filters), ShiftedSoftplus(),
+                                 nn.Linear(num_filters, num_filters))
+        self.conv = CFConv(hidden_channels, hidden_channels, num_filters, self.mlp, cutoff)
+        self.act = ShiftedSoftplus()
+        self.lin = nn.Linear(hidden_channels, hidden_channels)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for m in (self.mlp[0], self.mlp[2], self.lin):
+            nn.init.xavier_uniform_(m.weight)
+            m.bias.data.fill_(0)
+        self.conv.reset_parameters()
+
+    def forward(self, x, edge_index, edge_weight, edge_attr, csr=None):
+        return self.lin(self.act(self.conv(x, edge_index, edge_weight, edge_attr, csr=csr)))
+
+
+# ------------------------------------------------------------------------------------------------
+# GCNConv(improved=True, add_self_loops=False) with edge_weight = raw distance — gcn.py:80-82,135-144 (A.5)
+# ------------------------------------------------------------------------------------------------
+class GCNConv(nn.Module):
+    def __init__(self, in_channels, out_channels, improved=False, add_self_loops=True, bias=True, **kwargs):
+        super().__init__()
+        if add_self_loops:
+            raise ops.MdlError("GCNConv(add_self_loops=True) is not on the reference path (gcn.py:81)")
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        nn.init.xavier_uniform_(self.lin.weight)
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+
+    def forward(self, x, edge_index, edge_weight=None, csr=None):
+        if csr is None:
+            csr = ops.csr_for(edge_index, x.shape[0])
+        n = x.shape[0]
+        if edge_weight is None:
+            edge_weight = torch.ones(csr.E, device=x.device)
+        ew = edge_weight.float()
+        deg = ops.scatter(ew.unsqueeze(1), csr.col, 0, n, "sum").squeeze(1)            # weighted in-degree
+        dis = deg.pow(-0.5)
+        dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
+        norm = ops.gather(dis.unsqueeze(1), csr.row).squeeze(1) * ew * ops.gather(dis.unsqueeze(1), csr.col).squeeze(1)
+        out = ops.gather_mul_reduce(self.lin(x), csr, w=None, scale=norm, reduce="sum")
+        return out + self.bias.to(out.dtype) if self.bias is not None else out
+
+
+# ------------------------------------------------------------------------------------------------
+# NNConv(aggr="mean") — mpnn.py:83-88,148-157 (A.4).  The per-edge C x C weight is produced and
+# consumed chunk by chunk (library GEMMs) so that the E x C^2 tensor of the reference never exists;
+# gather / mean-aggregation run on the HIP kernels.
+# ------------------------------------------------------------------------------------------------
+class NNConv(nn.Module):
+    def __init__(self, in_channels, out_channels, nn_module, aggr="add", root_weight=True, bias=True, chunk=32768):
+        super().__init__()
+        self.in_channels, self.out_channels, self.aggr, self.chunk = in_channels, out_channels, aggr, chunk
+        self.nn = nn_module
+        self.lin = nn.Linear(in_channels, out_channels, bias=False) if root_weight else None
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+
+    def _messages(self, xj, edge_attr):
+        w = self.nn(edge_attr).view(-1, self.in_channels, self.out_channels)
+        return torch.bmm(xj.unsqueeze(1), w).squeeze(1)
+
+    def forward(self, x, edge_index, edge_attr, csr=None):
+        from torch.utils.checkpoint import checkpoint
+        if csr is None:
+            csr = ops.csr_for(edge_index, x.shape[0])
+        xj = ops.gather(x, csr.row)                                   # caller's edge order
+        parts = []
+        for s in range(0, csr.E, self.chunk):
+            a, b = xj[s:s + self.chunk], edge_attr[s:s + self.chunk]
+            parts.append(checkpoint(self._messages, a, b, use_reentrant=False) if torch.is_grad_enabled()
+                         else self._messages(a, b))
+        m = torch.cat(parts) if parts else xj.new_zeros((0, self.out_channels))
+        out = ops.scatter(m, csr.col, 0, x.shape[0], self.aggr)
+        if self.lin is not None:
+            out = out + self.lin(x)
+        if self.bias is not None:
+            out = out + self.bias.to(out.dtype)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# MetaLayer — megnet.py:235-253 (A.6); Set2Set — cgcnn.py:112-119 (A.6)
+# ------------------------------------------------------------------------------------------------
+class MetaLayer(nn.Module):
+    def __init__(self, edge_model=None, node_model=None, global_model=None):
+        super().__init__()
+        self.edge_model, self.node_model, self.global_model = edge_model, node_model, global_model
+
+    def forward(self, x, edge_index, edge_attr=None, u=None, batch=None):
+        row, col = edge_index[0], edge_index[1]
+        if self.edge_model is not None:
+            edge_attr = self.edge_model(ops.gather(x, row), ops.gather(x, col), edge_attr, u,
+                                        batch if batch is None else batch.index_select(0, row))
+        if self.node_model is not None:
+            x = self.node_model(x, edge_index, edge_attr, u, batch)
+        if self.global_model is not None:
+            u = self.global_model(x, edge_index, edge_attr, u, batch)
+        return x, edge_attr, u
+
+
+class Set2Set(nn.Module):
+    def __init__(self, in_channels, processing_steps, num_layers=1):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, 2 * in_channels
+        self.processing_steps, self.num_layers = processing_steps, num_layers
+        self.lstm = nn.LSTM(self.out_channels, in_channels, num_layers)
+
+    def forward(self, x, batch, size=None):
+        b = int(batch.max()) + 1 if size is None else size
+        xf = x.float()
+        h = (xf.new_zeros((self.num_layers, b, self.in_channels)), xf.new_zeros((self.num_layers, b, self.in_channels)))
+        q_star = xf.new_zeros(b, self.out_channels)
+        for _ in range(self.processing_steps):
+            q, h = self.lstm(q_star.unsqueeze(0), h)
+            q = q.view(b, self.in_channels)
+            e = (xf * ops.gather(q, batch)).sum(dim=-1, keepdim=True)
+            emax = ops.gather(ops.scatter(e, batch, 0, b, "max", assume_sorted=True).detach(), batch)
+            a = torch.exp(e - emax)
+            a = a / (ops.gather(ops.scatter(a, batch, 0, b, "sum", assume_sorted=True), batch) + 1e-16)
+            r = ops.scatter(a * xf, batch, 0, b, "sum", assume_sorted=True)
+            q_star = torch.cat([q, r], dim=-1)
+        return q_star

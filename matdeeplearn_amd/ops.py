@@ -24,10 +24,44 @@ class EdgeCSR:
     """Edges sorted by target.  rowptr [N+1], src/tgt [E] int32, eperm [E] int32 or None when the
     caller's per-edge tensors are already in CSR order (the product loader guarantees that)."""
 
-    __slots__ = ("rowptr", "src", "tgt", "eperm", "N", "E")
+    __slots__ = ("rowptr", "src", "tgt", "eperm", "N", "E", "_row", "_col", "_t")
 
-    def __init__(self, rowptr, src, tgt, eperm, N, E):
+    def __init__(self, rowptr, src, tgt, eperm, N, E, row=None, col=None):
         self.rowptr, self.src, self.tgt, self.eperm, self.N, self.E = rowptr, src, tgt, eperm, int(N), int(E)
+        self._row, self._col, self._t = row, col, None
+
+    @property
+    def row(self):
+        """source of every edge in the CALLER's edge order (int32)"""
+        if self._row is None:
+            if self.eperm is None:
+                self._row = self.src
+            else:
+                self._row = torch.empty_like(self.src)
+                self._row[self.eperm.long()] = self.src
+        return self._row
+
+    @property
+    def col(self):
+        """target of every edge in the caller's edge order (int32)"""
+        if self._col is None:
+            if self.eperm is None:
+                self._col = self.tgt
+            else:
+                self._col = torch.empty_like(self.tgt)
+                self._col[self.eperm.long()] = self.tgt
+        return self._col
+
+    def transposed(self):
+        """CSR by SOURCE: (rowptr_s [N+1], col_s = target per slot, eid_s = caller's edge id per slot)."""
+        if self._t is None:
+            perm = torch.argsort(self.src, stable=True)
+            src_sorted = self.src.index_select(0, perm)
+            col_s = self.tgt.index_select(0, perm)
+            eid_s = (perm if self.eperm is None else self.eperm.long().index_select(0, perm)).to(torch.int32)
+            self._t = (csr_rowptr(src_sorted.contiguous(), self.N), col_s.contiguous(), eid_s.contiguous(),
+                       src_sorted.contiguous())
+        return self._t
 
 
 def csr_rowptr(sorted_index_i32, num_segments):
@@ -51,7 +85,9 @@ def build_csr(edge_index, num_nodes, assume_sorted=False):
         tgt = col.index_select(0, perm).to(torch.int32)
         src = row.index_select(0, perm).to(torch.int32)
         eperm = perm.to(torch.int32)
-    return EdgeCSR(csr_rowptr(tgt, num_nodes), src, tgt, eperm, num_nodes, col.numel())
+    return EdgeCSR(csr_rowptr(tgt, num_nodes), src, tgt, eperm, num_nodes, col.numel(),
+                   row=None if assume_sorted else row.to(torch.int32).contiguous(),
+                   col=None if assume_sorted else col.to(torch.int32).contiguous())
 
 
 _CSR_CACHE = collections.OrderedDict()
@@ -119,7 +155,22 @@ class _SegIndex:
     __slots__ = ("rowptr", "seg", "perm", "N", "E")
 
 
+_SEG_CACHE = collections.OrderedDict()
+
+
 def _seg_index(index, dim_size, assume_sorted):
+    key = (index.data_ptr(), index._version, index.numel(), int(dim_size), bool(assume_sorted), index.device.index)
+    hit = _SEG_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    si = _seg_index_build(index, dim_size, assume_sorted)
+    _SEG_CACHE[key] = (si, index)
+    while len(_SEG_CACHE) > 64:
+        _SEG_CACHE.popitem(last=False)
+    return si
+
+
+def _seg_index_build(index, dim_size, assume_sorted):
     si = _SegIndex()
     si.N, si.E = int(dim_size), index.numel()
     if assume_sorted:
@@ -303,3 +354,75 @@ def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None):
     if csr is None:
         csr = csr_for(edge_index, x.shape[0])
     return _CGConvFn.apply(x, edge_attr, w_f, b_f, w_s, b_s, csr, _lib.REDUCE[aggr])
+
+
+# ------------------------------------------------------------------------------------------------
+# generic gather / edge-weighted gather-reduce (SchNet CFConv, GCNConv, MEGNet, NNConv building blocks)
+# ------------------------------------------------------------------------------------------------
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, index):
+        require_hip(src, index)
+        src = src.contiguous()
+        idx = index.to(torch.int32).contiguous()
+        C = src.numel() // max(src.shape[0], 1)
+        out = torch.empty((idx.numel(),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        check(lib().mdl_gather_rows(ptr(src), ptr(idx), ptr(out), idx.numel(), C, dtype_code(src), stream()),
+              "mdl_gather_rows")
+        ctx.index, ctx.n = index, src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return scatter(g, ctx.index, 0, ctx.n, "sum"), None
+
+
+def gather(src, index):
+    """src.index_select(0, index) with a HIP forward and a segmented-reduce backward."""
+    return _Gather.apply(src, index)
+
+
+class _GatherMulReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, w, scale, csr, reduce):
+        require_hip(h)
+        h = h.contiguous()
+        N, F = csr.N, h.shape[1]
+        if w is not None:
+            w = w.contiguous()
+            if w.dtype != h.dtype:
+                raise MdlError("gather_mul_reduce: h and w must share a dtype")
+        if scale is not None:
+            scale = scale.float().contiguous()
+        out = torch.empty((N, F), dtype=h.dtype, device=h.device)
+        check(lib().mdl_gather_mul_reduce(ptr(h), ptr(w), ptr(scale), ptr(csr.rowptr), ptr(csr.src), ptr(csr.eperm),
+                                          ptr(out), N, F, reduce, dtype_code(h), stream()), "mdl_gather_mul_reduce")
+        ctx.csr, ctx.reduce = csr, reduce
+        ctx.save_for_backward(h, w, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w, scale = ctx.saved_tensors
+        csr = ctx.csr
+        g = g.contiguous()
+        if ctx.reduce == _lib.MDL_MEAN:
+            deg = (csr.rowptr[1:] - csr.rowptr[:-1]).clamp(min=1).to(g.dtype)
+            g = g / deg.unsqueeze(1)
+        dh = dw = None
+        if ctx.needs_input_grad[0]:
+            rowptr_s, col_s, eid_s, _ = csr.transposed()
+            dh = torch.empty_like(h)
+            check(lib().mdl_gather_mul_reduce(ptr(g), ptr(w), ptr(scale), ptr(rowptr_s), ptr(col_s), ptr(eid_s),
+                                              ptr(dh), csr.N, h.shape[1], _lib.MDL_SUM, dtype_code(h), stream()),
+                  "mdl_gather_mul_reduce(T)")
+        if w is not None and ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            check(lib().mdl_edge_mul(ptr(h), ptr(csr.row), ptr(g), ptr(csr.col), ptr(scale), ptr(dw), csr.E,
+                                     h.shape[1], dtype_code(h), stream()), "mdl_edge_mul")
+        return dh, dw, None, None, None
+
+
+def gather_mul_reduce(h, csr, w=None, scale=None, reduce="sum"):
+    """out[i] = reduce_{edges k -> i} h[src_k] * w[k] * scale[k]  (w: [E,F], scale: [E], caller's edge order)."""
+    return _GatherMulReduce.apply(h, w, scale, csr, _lib.REDUCE[reduce])

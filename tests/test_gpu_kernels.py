@@ -169,3 +169,57 @@ def test_cgconv_large_graph_permutation_invariance():
     eip = ei[:, perm].to(d)
     b = ops.cgconv(x, eip, ea[perm.to(d)], wf, None, ws, None, "mean")
     close(a, b, 1e-5, 1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# generic gather / gather-mul-reduce (SchNet / GCN / MEGNet building blocks)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("sort", [True, False])
+@pytest.mark.parametrize("reduce,use_w,use_scale", [("sum", True, True), ("mean", False, False), ("sum", False, True)])
+def test_gather_mul_reduce_matches_oracle(dtype, sort, reduce, use_w, use_scale):
+    from matdeeplearn_amd import ops
+    g = torch.Generator().manual_seed(9)
+    n, F_ = 90, 40
+    ei = rand_graph(n, 9, sort=sort)
+    E = ei.shape[1]
+    h = torch.randn(n, F_, generator=g).to(dtype).float()
+    w = torch.randn(E, F_, generator=g).to(dtype).float() if use_w else None
+    sc = torch.rand(E, generator=g) if use_scale else None
+    ho = h.clone().requires_grad_(True)
+    wo = w.clone().requires_grad_(True) if use_w else None
+    msg = ho.index_select(0, ei[0])
+    if use_w:
+        msg = msg * wo
+    if use_scale:
+        msg = msg * sc.view(-1, 1)
+    ref = oops.scatter(msg, ei[1], 0, n, reduce)
+    gout = torch.randn(n, F_, generator=g).to(dtype).float()
+    (ref * gout).sum().backward()
+    d = dev()
+    hd = h.to(d).to(dtype).requires_grad_(True)
+    wd = w.to(d).to(dtype).requires_grad_(True) if use_w else None
+    csr = ops.build_csr(ei.to(d), n, assume_sorted=sort)
+    out = ops.gather_mul_reduce(hd, csr, w=wd, scale=None if sc is None else sc.to(d), reduce=reduce)
+    (out.float() * gout.to(d)).sum().backward()
+    tol = (1e-5, 1e-6) if dtype == torch.float32 else (3e-2, 2e-2)
+    close(out, ref, *tol)
+    close(hd.grad, ho.grad, *tol)
+    if use_w:
+        close(wd.grad, wo.grad, *tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gather_rows_and_its_gradient(dtype):
+    from matdeeplearn_amd import ops
+    g = torch.Generator().manual_seed(4)
+    src = torch.randn(50, 24, generator=g).to(dtype)
+    idx = torch.randint(0, 50, (300,), generator=g)
+    d = dev()
+    sd = src.to(d).requires_grad_(True)
+    out = ops.gather(sd, idx.to(d))
+    assert torch.equal(out.cpu(), src.index_select(0, idx))
+    wgt = torch.randn(300, 24, generator=g).to(dtype)
+    (out * wgt.to(d)).sum().backward()
+    ref = torch.zeros(50, 24).index_add_(0, idx, wgt.float())
+    close(sd.grad, ref, 1e-5 if dtype == torch.float32 else 3e-2, 1e-6 if dtype == torch.float32 else 2e-2)
