@@ -119,6 +119,13 @@ int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, 
 int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const float* r_tgt, const float* r_src,
                         const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype, mdlStream_t stream);
 
+/* ---- tall-skinny TN GEMM: weight gradients of node-level Linear layers ---------------------------
+ * c[M, K] (fp32, row-major, caller zero-fills) += a[N, M]^T . b[N, K]   a, b bf16 with leading dims lda, ldb.
+ * Replaces the (out x N)(N x in) product autograd forms for dW of the reference's node-level Linears
+ * (e.g. pre_lin_list, matdeeplearn/models/cgcnn.py:64-74,124-130).  1 <= M <= 128, 1 <= K <= 256, bf16 only. */
+int mdl_gemm_tn(const void* a, int64_t lda, int M, const void* b, int64_t ldb, int K, float* c, int64_t N, int dtype,
+                mdlStream_t stream);
+
 /* ---- generic gather / edge-weighted gather-reduce (SchNet CFConv, GCNConv, MEGNet, NNConv) ------
  * Replace the index_select + elementwise + torch_scatter sequence of PyG MessagePassing.propagate at
  * matdeeplearn/models/schnet.py:134-143, gcn.py:135-144, megnet.py:41-56,84-101,129-147, mpnn.py:148-157.

@@ -548,8 +548,12 @@ struct GroupInfo {
     }
 };
 
+#ifndef MDL_FWD_THREADS
+#define MDL_FWD_THREADS 256     // workgroup size of the forward kernel (waves share one LDS copy of W)
+#define MDL_FWD_WAVES 2         // waves per SIMD it is register-allocated for
+#endif
 template <typename T, int CP_, int G_, int VEC, int EW, int WM>   // WM: 0 global, 1 LDS, 2 registers
-__global__ __launch_bounds__(256, 2) void cgconv_fwd_kernel(CgParams p) {
+__global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_kernel(CgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Mma<T> M;
     typedef Gate<M::FAST> GT;
@@ -1068,7 +1072,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     const int et_bytes = (32 * d.EKS * (int)sizeof(T) + 15) & ~15;
     p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16;  // e tile, tgt-slot bytes, source ids, src-slot bytes, bitmap
     const int w_bytes = (p.w_elems * (int)sizeof(T) + 15) & ~15;
-    const int waves = 4;
+    const int waves = bwd ? 4 : MDL_FWD_THREADS / 64;
     // static fast shapes keep W in registers (no LDS copy); otherwise LDS if it fits, else global
     const bool fast = p.G == 50 && p.C == d.Cp && (d.Cp == 32 || d.Cp == 64) &&
                       (sizeof(T) == 2 ? (vec == 8 && EW == 2) : d.Cp == 64);

@@ -17,16 +17,29 @@ __global__ __launch_bounds__(256) void rbf_dense_kernel(const float* __restrict_
     __shared__ float s_off[256];
     for (int i = threadIdx.x; i < G; i += blockDim.x) s_off[i] = offsets[i];
     __syncthreads();
+    // bf16 output keeps 8 mantissa bits: the hardware base-2 exponential (v_exp_f32, ~1 ulp fp32) is
+    // exact enough; the fp32 (parity) output uses the precise expf.
+    constexpr bool FAST = sizeof(T) == 2;
+    const float c2 = coeff * LOG2E_F;
+    const unsigned uG = (unsigned)G;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * VEC;
     for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; base < total; base += stride) {
-        int64_t e = base / G;
-        int k = (int)(base - e * G);
+        int64_t e;
+        int k;
+        if (total < (1ll << 32)) {                      // 32-bit division is several times cheaper than 64-bit
+            const unsigned ue = (unsigned)base / uG;
+            e = ue;
+            k = (int)((unsigned)base - ue * uG);
+        } else {
+            e = base / G;
+            k = (int)(base - e * G);
+        }
         float de = d[e];
         float v[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            float diff = de - s_off[k];
-            v[j] = expf(coeff * (diff * diff));
+            const float diff = de - s_off[k];
+            v[j] = FAST ? __builtin_amdgcn_exp2f(c2 * (diff * diff)) : expf(coeff * (diff * diff));
             if (++k == G) {
                 k = 0;
                 ++e;
@@ -37,10 +50,8 @@ __global__ __launch_bounds__(256) void rbf_dense_kernel(const float* __restrict_
             if constexpr (sizeof(T) == 4) {
                 *reinterpret_cast<f32x4*>(out + base) = f32x4{v[0], v[1], v[2], v[3]};
             } else {
-                bf16x4 p;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) p[j] = (short)f2bf(v[j]);
-                *reinterpret_cast<bf16x4*>(out + base) = p;
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                *reinterpret_cast<u32x2*>(out + base) = u32x2{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
             }
         } else {
             for (int j = 0; base + j < total; ++j) Elem<T>::st(out + base + j, v[j]);
@@ -58,8 +69,9 @@ __global__ __launch_bounds__(256) void rbf_strided_kernel(const float* __restric
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         int64_t e = i / G;
         int k = (int)(i - e * G);
-        float diff = d[e] - offsets[k];
-        Elem<T>::st(out + e * ld + k, expf(coeff * (diff * diff)));
+        const float diff = d[e] - offsets[k];
+        const float q = diff * diff;
+        Elem<T>::st(out + e * ld + k, sizeof(T) == 2 ? __builtin_amdgcn_exp2f((coeff * LOG2E_F) * q) : expf(coeff * q));
     }
 }
 

@@ -69,8 +69,11 @@ class GraphModel(nn.Module):
         return data.x.to(cd), data.edge_attr.to(cd), csr
 
     def _pre(self, out):
-        for lin in self.pre_lin_list:
-            out = getattr(F, self.act)(dense(lin, out))
+        for k, lin in enumerate(self.pre_lin_list):
+            if k == 0 and out.dtype == torch.bfloat16 and not out.requires_grad:
+                out = getattr(F, self.act)(ops.linear_input_leaf(out, lin.weight, lin.bias))   # HIP dW (K = #nodes)
+            else:
+                out = getattr(F, self.act)(dense(lin, out))
         return out
 
     def _bn(self, i, out):

@@ -426,3 +426,37 @@ class _GatherMulReduce(torch.autograd.Function):
 def gather_mul_reduce(h, csr, w=None, scale=None, reduce="sum"):
     """out[i] = reduce_{edges k -> i} h[src_k] * w[k] * scale[k]  (w: [E,F], scale: [E], caller's edge order)."""
     return _GatherMulReduce.apply(h, w, scale, csr, _lib.REDUCE[reduce])
+
+
+# ------------------------------------------------------------------------------------------------
+# node-level Linear whose INPUT needs no gradient (pre-FC on the dataset features): library GEMM
+# forward, tall-skinny TN HIP GEMM for the weight gradient (contraction over ~2e5 nodes)
+# ------------------------------------------------------------------------------------------------
+class _LinearInputLeaf(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w = weight.to(x.dtype)
+        out = torch.nn.functional.linear(x, w, None if bias is None else bias.to(x.dtype))
+        ctx.save_for_backward(x)
+        ctx.wdtype, ctx.has_bias, ctx.shape = weight.dtype, bias is not None, tuple(weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.contiguous()
+        M, K = ctx.shape
+        dw = torch.zeros((M, K), dtype=torch.float32, device=g.device)
+        check(lib().mdl_gemm_tn(ptr(g), g.stride(0), M, ptr(x), x.stride(0), K, ptr(dw), g.shape[0], dtype_code(g),
+                                stream()), "mdl_gemm_tn")
+        db = g.sum(dim=0, dtype=torch.float32).to(ctx.wdtype) if ctx.has_bias else None
+        return None, dw.to(ctx.wdtype), db
+
+
+def linear_input_leaf(x, weight, bias):
+    """F.linear for an input that needs no gradient; bf16 with out<=128, in<=256 uses the HIP TN GEMM
+    for dW, anything else falls back to the library autograd path."""
+    if (x.dtype == torch.bfloat16 and x.is_cuda and not x.requires_grad and x.dim() == 2 and x.stride(1) == 1
+            and weight.shape[0] <= 128 and weight.shape[1] <= 256):
+        return _LinearInputLeaf.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))

@@ -223,3 +223,18 @@ def test_gather_rows_and_its_gradient(dtype):
     (out * wgt.to(d)).sum().backward()
     ref = torch.zeros(50, 24).index_add_(0, idx, wgt.float())
     close(sd.grad, ref, 1e-5 if dtype == torch.float32 else 3e-2, 1e-6 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("N,M,K", [(1000, 64, 114), (129, 32, 50), (5000, 100, 200), (77, 128, 256), (1, 7, 3)])
+def test_gemm_tn_matches_torch(N, M, K):
+    """Tall-skinny weight-gradient GEMM (bf16 in, fp32 out) vs an fp32 matmul of the same rounded inputs."""
+    import ctypes
+    from matdeeplearn_amd import _lib
+    g = torch.Generator().manual_seed(N + M)
+    a = torch.randn(N, M, generator=g).to(torch.bfloat16).to(dev())
+    b = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev())
+    c = torch.zeros(M, K, device=dev())
+    _lib.check(_lib.lib().mdl_gemm_tn(_lib.ptr(a), a.stride(0), M, _lib.ptr(b), b.stride(0), K, _lib.ptr(c), N,
+                                      _lib.MDL_BF16, _lib.stream()), "mdl_gemm_tn")
+    ref = a.float().t() @ b.float()
+    close(c, ref, 1e-4, 1e-5)
