@@ -119,6 +119,25 @@ int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, 
 int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const float* r_tgt, const float* r_src,
                         const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype, mdlStream_t stream);
 
+/* ---- training-mode BatchNorm1d over rows, x: [N, C] row-major ------------------------------------
+ * Replaces torch.nn.BatchNorm1d as applied after every conv layer (matdeeplearn/models/cgcnn.py:85-87,143)
+ * and inside the MEGNet MLPs (megnet.py:47-48).  `sums` is a [2, C] fp32 scratch the caller zero-fills
+ * before each *_stats call; `save` is [2, C] fp32 (mean | invstd) written by mdl_bn_apply.
+ * Supported: C a multiple of 8 (bf16) / 4 (fp32) with 256 % (C/W) == 0, C <= 256.
+ *   stats:      sums[0] += sum(x - x[0,:]), sums[1] += sum((x - x[0,:])^2)   (shifted sums)
+ *   apply:      y = (x - mean) * rsqrt(var_biased + eps) * gamma + beta; running_mean/var (unbiased) updated
+ *               with `momentum` when non-NULL
+ *   bwd_stats:  sums[0] += sum(dy), sums[1] += sum(dy * xhat)       ( = dbeta, dgamma )
+ *   bwd_apply:  dx = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)) */
+int mdl_bn_stats(const void* x, float* sums, int64_t N, int C, int dtype, mdlStream_t stream);
+int mdl_bn_apply(const void* x, const float* sums, const float* gamma, const float* beta, float* save,
+                 float* running_mean, float* running_var, void* y, int64_t N, int C, float eps, float momentum,
+                 int dtype, mdlStream_t stream);
+int mdl_bn_bwd_stats(const void* dy, const void* x, const float* save, float* sums, int64_t N, int C, int dtype,
+                     mdlStream_t stream);
+int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save, const float* sums, const float* gamma, void* dx,
+                     int64_t N, int C, int dtype, mdlStream_t stream);
+
 /* ---- tall-skinny TN GEMM: weight gradients of node-level Linear layers ---------------------------
  * c[M, K] (fp32, row-major, caller zero-fills) += a[N, M]^T . b[N, K]   a, b bf16 with leading dims lda, ldb.
  * Replaces the (out x N)(N x in) product autograd forms for dW of the reference's node-level Linears

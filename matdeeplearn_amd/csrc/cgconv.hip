@@ -197,6 +197,9 @@ struct WaveCtx {
     unsigned* tsl;      // per-wave target-slot bytes (32 B) viewed as 8 dwords
     int* srcl;          // per-wave source ids (32 ints)   (backward only)
     unsigned* ssl;      // per-wave source-window slot bytes (32 B) (backward only)
+    bf16_t* oh_t;       // one-hot tables (bf16 kernels), see oh_update()
+    bf16_t* oh_e;
+    bf16_t* oh_w;
     unsigned long long* touched;  // per-wave bitmap of window slots that received an edge
     const T* wbase;     // packed weights (LDS or global)
 };
@@ -406,6 +409,29 @@ __device__ __forceinline__ void seg_reduce_mma(const f32x16& v, const unsigned t
     }
 }
 
+// One-hot operand tables in LDS (bf16 kernels).  Building a one-hot MFMA operand in registers costs
+// ~3 VALU per element (extract, compare, select, pack); instead every edge-slot lane keeps ONE 1.0 in
+// a small per-wave LDS table up to date (clear the old position, set the new one: 2 ds_write_b16) and
+// the consumers read their operand fragments with ds_read_b128.
+//   oh_t [32 node slots ][OHS]  column pos(edge slot): 1 where the edge's target is the row's node slot
+//   oh_e [32 edge slots ][OHS]  column node slot     : 1 at the edge's target slot   (grad_out expansion)
+//   oh_w [64 window slot][OHS]  column pos(edge slot): 1 where the edge's source is the row's window slot
+// pos() is the K order in which the D-layout registers of a lane map onto MFMA K slots.
+constexpr int OHS = 40;                                   // row stride in bf16 (80 B: odd number of 16-B slots)
+__device__ __forceinline__ int oh_pos(int slot) {         // inverse of slot = d_row(8*ks + q, h), pos = 16*ks + 8*h + q
+    const int hh = (slot >> 2) & 1, r = (slot & 3) + 4 * (slot >> 3);
+    return 16 * (r >> 3) + 8 * hh + (r & 7);
+}
+__device__ __forceinline__ void oh_update(bf16_t* tab, int old_row, int new_row, int colpos) {
+    if (old_row != new_row) {
+        if (old_row >= 0) tab[old_row * OHS + colpos] = 0;
+        if (new_row >= 0) tab[new_row * OHS + colpos] = 0x3F80;
+    }
+}
+__device__ __forceinline__ bf16x8 oh_frag(const bf16_t* tab, int row, int ks, int h) {
+    return *reinterpret_cast<const bf16x8*>(tab + row * OHS + 16 * ks + 8 * h);
+}
+
 // dpre fragments of one tile, packed once and used three times (B operand of the two segmented
 // reductions, A operand of the dwe product).  bf16: 2 K-steps of 8 values; f32: the 16 registers.
 template <typename T> struct DFrags;
@@ -455,6 +481,17 @@ __device__ __forceinline__ void seg_reduce2(const DFrags<T>& d, const unsigned b
     }
 }
 
+// bf16: one-hot A fragments come from an LDS table (oh_t / oh_w) instead of being built in registers
+__device__ __forceinline__ void seg_reduce2_tab(const DFrags<bf16_t>& d, const bf16_t* tab, int row, int h,
+                                                f32x16& accF, f32x16& accS) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 a = oh_frag(tab, row, ks, h);
+        accF = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, d.f[ks], accF, 0, 0, 0);
+        accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, d.s[ks], accS, 0, 0, 0);
+    }
+}
+
 template <typename T, typename D>
 __device__ __forceinline__ void setup_wave(const CgParams& p, const D& dm, char* smem, bool w_lds, WaveCtx<T>& w) {
     const int wave = threadIdx.x >> 6;
@@ -466,6 +503,9 @@ __device__ __forceinline__ void setup_wave(const CgParams& p, const D& dm, char*
     w.srcl = reinterpret_cast<int*>(base + et_bytes + 32);
     w.ssl = reinterpret_cast<unsigned*>(base + et_bytes + 32 + 128);
     w.touched = reinterpret_cast<unsigned long long*>(base + et_bytes + 32 + 128 + 32);
+    w.oh_t = reinterpret_cast<bf16_t*>(base + et_bytes + 32 + 128 + 32 + 16);
+    w.oh_e = w.oh_t + 32 * OHS;
+    w.oh_w = w.oh_e + 32 * OHS;
     w.wbase = w_lds ? reinterpret_cast<const T*>(smem) : static_cast<const T*>(p.wpack);
     if (w_lds) {
         const f32x4* g = reinterpret_cast<const f32x4*>(p.wpack);
@@ -475,7 +515,7 @@ __device__ __forceinline__ void setup_wave(const CgParams& p, const D& dm, char*
     }
     // zero the e tile once: padded columns [G, KE) stay 0 forever, rows never hold garbage bits
     unsigned* z = reinterpret_cast<unsigned*>(base);
-    for (int q = threadIdx.x & 63; q < et_bytes / 4; q += WAVE) z[q] = 0u;
+    for (int q = threadIdx.x & 63; q < p.wave_lds_bytes / 4; q += WAVE) z[q] = 0u;
     wave_lds_fence();
     // bias column: e-tile column G is a constant 1 whose weight row holds the bias
     if (p.bias_col && (threadIdx.x & 63) < 32) Elem<T>::st(w.et + (threadIdx.x & 63) * dm.EKS + dm.G, 1.0f);
@@ -774,6 +814,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             for (int r = 0; r < 16; ++r) dwe_acc[a][b][r] = 0.0f;
 
     float dbf_acc = 0.0f, dbs_acc = 0.0f;
+    int oh_ts = -1, oh_ss = -1;      // where this edge-slot lane currently has its 1.0 in the one-hot tables
     for (int g = gw / p.NS; g < p.n_groups; g += gstride) {
         const int n0 = g * 32;
         const int n1 = (int)min((int64_t)n0 + 32, p.N);
@@ -854,6 +895,17 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                 reinterpret_cast<unsigned char*>(w.ssl)[i] = in_win ? (unsigned char)my_ss : (unsigned char)0xff;
                 w.srcl[i] = oob ? cur.src : -1;
                 if (in_win) atomicOr(w.touched, 1ull << my_ss);
+                if constexpr (BF) {
+                    const int nts = valid_i ? my_ts : -1, nss = in_win ? (int)my_ss : -1;
+                    oh_update(w.oh_t, oh_ts, nts, oh_pos(i));
+                    oh_update(w.oh_w, oh_ss, nss, oh_pos(i));
+                    if (oh_ts != nts) {
+                        if (oh_ts >= 0) w.oh_e[i * OHS + oh_ts] = 0;
+                        if (nts >= 0) w.oh_e[i * OHS + nts] = 0x3F80;
+                    }
+                    oh_ts = nts;
+                    oh_ss = nss;
+                }
             }
             wave_lds_fence();
 
@@ -875,12 +927,8 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             for (int r = 0; r < 16; ++r) dmv[r] = 0.0f;
             if constexpr (BF) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 a;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) a[q] = (my_ts == 16 * ks + 8 * h + q) ? (short)0x3F80 : (short)0;
-                    dmv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, gB[ks], dmv, 0, 0, 0);
-                }
+                for (int ks = 0; ks < 2; ++ks)
+                    dmv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh_frag(w.oh_e, i, ks, h), gB[ks], dmv, 0, 0, 0);
             } else {
 #pragma unroll
                 for (int f = 0; f < 16; ++f)
@@ -901,12 +949,18 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 
             DFrags<T> dp;
             dp.pack(accf, accs);
-            unsigned t4[4], s4[4];
+            if constexpr (BF) {
+                seg_reduce2_tab(dp, w.oh_t, i, h, Rf, Rs);                  // by target  -> r_tgt
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { t4[j] = w.tsl[2 * j + h]; s4[j] = w.ssl[2 * j + h]; }
-            seg_reduce2<T>(dp, t4, (unsigned)i, Rf, Rs);                 // by target  -> r_tgt
+                for (int mt = 0; mt < 2; ++mt) seg_reduce2_tab(dp, w.oh_w, i + 32 * mt, h, Wf[mt], Ws[mt]);   // by source window
+            } else {
+                unsigned t4[4], s4[4];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) seg_reduce2<T>(dp, s4, (unsigned)(i + 32 * mt), Wf[mt], Ws[mt]);   // by source window
+                for (int j = 0; j < 4; ++j) { t4[j] = w.tsl[2 * j + h]; s4[j] = w.ssl[2 * j + h]; }
+                seg_reduce2<T>(dp, t4, (unsigned)i, Rf, Rs);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) seg_reduce2<T>(dp, s4, (unsigned)(i + 32 * mt), Wf[mt], Ws[mt]);
+            }
 
             // sources outside the window: per-edge fp32 atomics (rare: graphs wider than the window)
             if (__any(oob) && ch < dm.C) {
@@ -1070,7 +1124,8 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     }
 
     const int et_bytes = (32 * d.EKS * (int)sizeof(T) + 15) & ~15;
-    p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16;  // e tile, tgt-slot bytes, source ids, src-slot bytes, bitmap
+    // e tile, tgt-slot bytes, source ids, src-slot bytes, bitmap, one-hot tables (32 + 32 + 64 rows)
+    p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16 + ((bwd && sizeof(T) == 2) ? 128 * OHS * 2 : 0);
     const int w_bytes = (p.w_elems * (int)sizeof(T) + 15) & ~15;
     const int waves = bwd ? 4 : MDL_FWD_THREADS / 64;
     // static fast shapes keep W in registers (no LDS copy); otherwise LDS if it fits, else global
@@ -1109,7 +1164,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
         else if (vec == 4) MDL_CG_BY_EW(4);
         else MDL_CG_BY_EW(1);
     } else {
-        if (fast) MDL_CG_LAUNCH(64, 50, 9, 1, 1);
+        if (fast && w_lds) MDL_CG_LAUNCH(64, 50, 9, 1, 1);
         else MDL_CG_BY_WL(1, 1);
     }
 #endif

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
-from ..nn import Set2Set
+from ..nn import BatchNorm1d, Set2Set
 
 
 def dense(lin, h):
@@ -45,7 +45,7 @@ class GraphModel(nn.Module):
         self.pre_lin_list = nn.ModuleList(
             [nn.Linear(data.num_features if i == 0 else dim1, dim1) for i in range(pre_fc_count)])
         self.bn_list = nn.ModuleList(
-            [nn.BatchNorm1d(self.gc_dim, track_running_stats=self.batch_track_stats) for _ in range(gc_count)]
+            [BatchNorm1d(self.gc_dim, track_running_stats=self.batch_track_stats) for _ in range(gc_count)]
             if (batch_norm == "True" and make_bn) else [])
         self.post_lin_list = nn.ModuleList(
             [nn.Linear(first_in if i == 0 else dim2, dim2) for i in range(post_fc_count)])

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
-from ..nn import MetaLayer, Set2Set
+from ..nn import BatchNorm1d, MetaLayer, Set2Set
 from ._base import GraphModel, dense
 
 
@@ -20,7 +20,7 @@ class _Mlp(nn.Module):
         setattr(self, list_name, nn.ModuleList(
             [nn.Linear(in_dim if i == 0 else dim, dim) for i in range(fc_layers + 1)]))
         self.bn_list = nn.ModuleList(
-            [nn.BatchNorm1d(dim, track_running_stats=track) for _ in range(fc_layers + 1)] if batch_norm == "True" else [])
+            [BatchNorm1d(dim, track_running_stats=track) for _ in range(fc_layers + 1)] if batch_norm == "True" else [])
 
     def run(self, comb):
         out = comb

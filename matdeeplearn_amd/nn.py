@@ -210,3 +210,20 @@ class Set2Set(nn.Module):
             r = ops.scatter(a * xf, batch, 0, b, "sum", assume_sorted=True)
             q_star = torch.cat([q, r], dim=-1)
         return q_star
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm1d — same parameters / buffers / state_dict keys as torch.nn.BatchNorm1d (the reference
+# constructs BatchNorm1d(gc_dim, track_running_stats=...) at cgcnn.py:85-87); training-mode forward
+# and backward run on the HIP stream kernels when the shape allows, otherwise the library path.
+# ------------------------------------------------------------------------------------------------
+class BatchNorm1d(nn.BatchNorm1d):
+    def forward(self, x):
+        use_batch_stats = self.training or not self.track_running_stats
+        if use_batch_stats and x.dim() == 2 and ops.bn_supported(x) and self.momentum is not None:
+            rm = rv = None
+            if self.training and self.track_running_stats:
+                rm, rv = self.running_mean, self.running_var
+                self.num_batches_tracked.add_(1)
+            return ops.batch_norm_train(x, self.weight, self.bias, rm, rv, self.eps, self.momentum)
+        return super().forward(x)

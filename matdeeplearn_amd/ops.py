@@ -460,3 +460,52 @@ def linear_input_leaf(x, weight, bias):
             and weight.shape[0] <= 128 and weight.shape[1] <= 256):
         return _LinearInputLeaf.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
+
+
+# ------------------------------------------------------------------------------------------------
+# training-mode BatchNorm1d over rows (HIP streams instead of four slow library passes)
+# ------------------------------------------------------------------------------------------------
+def bn_supported(x):
+    if not (x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    w = 8 if x.dtype == torch.bfloat16 else 4
+    c = x.shape[1]
+    return x.shape[0] >= 1 and c % w == 0 and c <= 256 and 256 % (c // w) == 0
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+        N, C = x.shape
+        dt = dtype_code(x)
+        buf = torch.zeros((4, C), dtype=torch.float32, device=x.device)      # rows 0-1: sums, rows 2-3: save
+        sums, save = buf[:2], buf[2:]
+        gw = None if weight is None else weight.detach().float().contiguous()
+        gb = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty_like(x)
+        check(lib().mdl_bn_stats(ptr(x), ptr(sums), N, C, dt, stream()), "mdl_bn_stats")
+        check(lib().mdl_bn_apply(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
+                                 ptr(y), N, C, float(eps), float(momentum), dt, stream()), "mdl_bn_apply")
+        ctx.save_for_backward(x, save, gw)
+        ctx.has = (weight is not None, bias is not None)
+        ctx.wdt = None if weight is None else weight.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, save, gw = ctx.saved_tensors
+        N, C = x.shape
+        dy = dy.contiguous()
+        dt = dtype_code(x)
+        sums = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        check(lib().mdl_bn_bwd_stats(ptr(dy), ptr(x), ptr(save), ptr(sums), N, C, dt, stream()), "mdl_bn_bwd_stats")
+        check(lib().mdl_bn_bwd_apply(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, dt, stream()),
+              "mdl_bn_bwd_apply")
+        dgamma = sums[1].to(ctx.wdt) if ctx.has[0] else None
+        dbeta = sums[0].to(ctx.wdt) if ctx.has[1] else None
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def batch_norm_train(x, weight, bias, running_mean, running_var, eps=1e-5, momentum=0.1):
+    return _BatchNormTrain.apply(x, weight, bias, running_mean, running_var, eps, momentum)

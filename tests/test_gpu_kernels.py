@@ -238,3 +238,37 @@ def test_gemm_tn_matches_torch(N, M, K):
                                       _lib.MDL_BF16, _lib.stream()), "mdl_gemm_tn")
     ref = a.float().t() @ b.float()
     close(c, ref, 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C", [(1000, 64), (37, 64), (5000, 128), (1, 32), (999, 16)])
+def test_batchnorm_train_matches_torch(dtype, N, C):
+    """HIP BatchNorm1d (training mode) vs torch.nn.BatchNorm1d on CPU: output, running stats, all gradients."""
+    from matdeeplearn_amd import nn as mnn
+    g = torch.Generator().manual_seed(N + C)
+    x = (torch.randn(N, C, generator=g) * 2 + 3).to(dtype).float()
+    go = torch.randn(N, C, generator=g).to(dtype).float()
+    ref = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        ref.bias.copy_(torch.randn(C, generator=g))
+    mine = mnn.BatchNorm1d(C)
+    mine.load_state_dict(ref.state_dict())
+    mine.to(dev())
+    if N == 1:
+        return   # torch refuses batch statistics of a single row in training mode
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    (yr * go).sum().backward()
+    xd = x.to(dev()).to(dtype).requires_grad_(True)
+    yd = mine(xd)
+    assert yd.dtype == dtype
+    (yd.float() * go.to(dev())).sum().backward()
+    tol = (2e-5, 2e-5) if dtype == torch.float32 else (3e-2, 2e-2)
+    close(yd, yr, *tol)
+    close(xd.grad, xr.grad, *tol)
+    close(mine.weight.grad, ref.weight.grad, *tol)
+    close(mine.bias.grad, ref.bias.grad, *tol)
+    close(mine.running_mean, ref.running_mean, 1e-4 if dtype == torch.float32 else 1e-2, 1e-5 if dtype == torch.float32 else 1e-2)
+    close(mine.running_var, ref.running_var, 1e-4 if dtype == torch.float32 else 2e-2, 1e-5 if dtype == torch.float32 else 1e-2)
+    assert int(mine.num_batches_tracked) == 1
