@@ -939,9 +939,8 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             // (dmv is an exact 0 for edge slots >= nv — their one-hot row is empty — so dpre is 0 there)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float sf = GT::sigmoid(accf[r]);
-                float sp_u, ss;
-                GT::softplus_sigmoid(accs[r], sp_u, ss);
+                float sf, sp_u, ss;
+                GT::deriv(accf[r], accs[r], sf, sp_u, ss);
                 const float t = dmv[r] * sf;
                 accf[r] = (t * GT::M_SCALE) * (1.0f - sf) * sp_u;
                 accs[r] = t * ss;

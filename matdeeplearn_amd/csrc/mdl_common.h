@@ -82,6 +82,11 @@ template <> struct Gate<false> {
         const float r = 1.0f / (1.0f + ea);
         sg = x >= 0.0f ? r : ea * r;
     }
+    // everything the backward needs: sigmoid(f), softplus_u(s), sigmoid(s)
+    __device__ static __forceinline__ void deriv(float f, float sv, float& sf, float& sp_u, float& ss) {
+        sf = sigmoid(f);
+        softplus_sigmoid(sv, sp_u, ss);
+    }
 };
 template <> struct Gate<true> {
     static constexpr float W_SCALE = LOG2E_F;
@@ -98,6 +103,18 @@ template <> struct Gate<true> {
         sp_u = fmaxf(t, 0.0f) + __builtin_amdgcn_logf(l);
         const float r = __builtin_amdgcn_rcpf(l);
         sg = t >= 0.0f ? r : ea * r;
+    }
+    // Transcendentals are the scarce resource (a wave64 v_exp/v_log/v_rcp occupies the SIMD ~8x longer
+    // than an FMA): the two reciprocals 1/(1+2^-f) and 1/(1+2^-|s|) share ONE v_rcp of the product.
+    __device__ static __forceinline__ void deriv(float f, float sv, float& sf, float& sp_u, float& ss) {
+        const float a1 = 1.0f + __builtin_amdgcn_exp2f(fminf(-f, 126.0f));   // clamp: a1 * l must stay finite
+        const float ea = __builtin_amdgcn_exp2f(-fabsf(sv));
+        const float l = 1.0f + ea;
+        const float r = __builtin_amdgcn_rcpf(a1 * l);
+        sf = r * l;
+        const float rl = r * a1;
+        sp_u = fmaxf(sv, 0.0f) + __builtin_amdgcn_logf(l);
+        ss = sv >= 0.0f ? rl : ea * rl;
     }
 };
 
