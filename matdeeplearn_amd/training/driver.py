@@ -1,0 +1,166 @@
+"""Job drivers — the outer loops of /root/reference/matdeeplearn/training/training.py restated around the
+device-resident dataset:  train_regular (:377-539), train_CV (:587-715), train_repeat (:719-843),
+train_ensemble (:1069-1196), predict (:543-583, from a state_dict instead of a pickled full model).
+They read the same YAML keys as the reference's config.yml (sections Job / Processing / Training /
+Models, string booleans) and write the same CSV artefacts (`*_outputs.csv`, `_errorvalues.csv`).
+The drivers are model-agnostic: `model_factory(name)` returns the class; default = the HIP models.
+"""
+import csv
+import os
+import time
+
+import numpy as np
+import torch
+import yaml
+
+from ..process import DeviceLoader, split_data, split_data_CV
+from .dp import FlatDataParallel, ddp_cleanup, ddp_setup
+from .loops import evaluate, make_optimizer, make_scheduler, trainer
+
+
+def load_config(path, run_mode="Training", model=None):
+    """config.yml -> (job, processing, training, model_params) like main.py:145-211."""
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    job = dict(cfg["Job"][run_mode])
+    job["run_mode"] = run_mode
+    name = model or job.get("model", "CGCNN_demo")
+    models = cfg["Models"]
+    key = name if name in models else next((k for k in models if models[k].get("model") == name), None)
+    if key is None:
+        raise KeyError("model %r not in config" % name)
+    return job, dict(cfg["Processing"]), dict(cfg["Training"]), dict(models[key])
+
+
+def default_model_factory(name):
+    from .. import models
+    return getattr(models, name)
+
+
+def write_results(rows, path):
+    """ids, target, prediction — training.py:211-223 (all rows are written; the reference drops the last)."""
+    with open(path, "w", newline="") as f:
+        wr = csv.writer(f)
+        ncol = (rows.shape[1] - 1) // 2 if len(rows) else 1
+        wr.writerow(["ids"] + ["target"] * ncol + ["prediction"] * ncol)
+        wr.writerows(rows.tolist())
+
+
+def _loaders(dataset, splits, batch_size, seed, rank, world_size, edge_dtype, rbf):
+    tr, va, te = splits
+    r = rank if isinstance(rank, int) else 0
+    mk = lambda idx, sh, ws=1, rk=0: DeviceLoader(dataset, idx, batch_size, shuffle=sh, seed=seed, rank=rk,
+                                                     world_size=ws, edge_dtype=edge_dtype, rbf=rbf) if len(idx) else None
+    # training.py:291-325 — DistributedSampler on train only; val/test on rank 0
+    return mk(tr, True, world_size, r), (mk(va, False) if r == 0 else None), (mk(te, False) if r == 0 else None)
+
+
+def train_regular(rank, world_size, dataset, job, training, model_params, splits=None, model_factory=None,
+                  rbf=None, edge_dtype=torch.float32, log=print):
+    """One training job.  Returns dict(train_error, val_error, test_error, history, model)."""
+    model_factory = model_factory or default_model_factory
+    distributed = ddp_setup(rank, world_size)
+    params = dict(model_params)
+    lr = params.get("lr", 0.001) * (world_size if distributed else 1)        # training.py:388-389
+    dataset.target_index = training.get("target_index", 0)
+    seed = job.get("seed", 0) or int(np.random.randint(1, 1e6))
+    if splits is None:
+        splits = split_data(len(dataset), training["train_ratio"], training["val_ratio"], training["test_ratio"], seed)
+    train_loader, val_loader, test_loader = _loaders(dataset, splits, params.get("batch_size", 100), seed, rank,
+                                                     world_size if distributed else 1, edge_dtype, rbf)
+    torch.manual_seed(seed)
+    model = model_factory(params["model"])(data=dataset, **params)
+    dev = dataset.device if dataset.device is not None else torch.device("cpu")
+    model = model.to(dev)
+    if job.get("load_model") == "True" and os.path.exists(job.get("model_path", "")):
+        model.load_state_dict(torch.load(job["model_path"], map_location=dev)["model_state_dict"])   # training.py:259
+    dp = FlatDataParallel(model) if distributed else None
+    opt = make_optimizer(model.parameters(), params.get("optimizer", "AdamW"), lr=lr, **params.get("optimizer_args", {}))
+    sch = make_scheduler(opt, params.get("scheduler", "ReduceLROnPlateau"), **params.get("scheduler_args", {}))
+    t0 = time.time()
+    model, history = trainer(rank, world_size, model, opt, sch, training["loss"], train_loader, val_loader,
+                             params.get("epochs", 1), training.get("verbosity", 5), dp=dp, log=log)
+    out = dict(history=history, model=model, seed=seed, train_time=time.time() - t0)
+    is_root = (not distributed) or rank == 0
+    if is_root:
+        name = job.get("job_name", "my_train_job")
+        for tag, idx in zip(("train", "val", "test"), splits):
+            if len(idx) == 0:
+                out[tag + "_error"] = float("nan")
+                continue
+            ld = DeviceLoader(dataset, idx, params.get("batch_size", 100), edge_dtype=edge_dtype, rbf=rbf)
+            err, rows = evaluate(ld, model, training["loss"], rank=rank, out=True)   # training.py:460-486
+            out[tag + "_error"] = float(err)
+            out[tag + "_rows"] = rows
+            if job.get("write_output") == "True":
+                write_results(rows, "%s_%s_outputs.csv" % (name, tag))
+        if job.get("save_model") == "True":                                       # training.py:489-510
+            torch.save({"model_state_dict": model.state_dict(), "optimizer_state_dict": opt.state_dict(),
+                        "scheduler_state_dict": sch.state_dict()}, job.get("model_path", "my_model.pth"))
+        log("Train Error: {:.5f}, Val Error: {:.5f}, Test Error: {:.5f}".format(
+            out["train_error"], out["val_error"], out["test_error"]))
+    if distributed:
+        ddp_cleanup()
+    return out
+
+
+def predict(dataset, model_name, model_params, state_path, loss="l1_loss", model_factory=None, rbf=None,
+            edge_dtype=torch.float32, batch_size=128, out_csv=None):
+    """training.py:543-583 with a state_dict checkpoint (pickled PyG full models cannot be honoured)."""
+    model_factory = model_factory or default_model_factory
+    dev = dataset.device or torch.device("cpu")
+    model = model_factory(model_name)(data=dataset, **model_params).to(dev)
+    model.load_state_dict(torch.load(state_path, map_location=dev)["model_state_dict"])
+    ld = DeviceLoader(dataset, np.arange(len(dataset)), batch_size, edge_dtype=edge_dtype, rbf=rbf)
+    err, rows = evaluate(ld, model, loss, out=True)
+    if out_csv:
+        write_results(rows, out_csv)
+    return float(err), rows
+
+
+def train_repeat(rank, world_size, dataset, job, training, model_params, **kw):
+    """training.py:719-843 — `repeat_trials` trainings with fresh seeds; mean/std of the errors."""
+    trials = int(job.get("repeat_trials", 5))
+    errs = []
+    for i in range(trials):
+        j = dict(job, seed=int(np.random.randint(1, 1e6)), job_name="%s%d" % (job.get("job_name", "repeat"), i))
+        r = train_regular(rank, world_size, dataset, j, training, model_params, **kw)
+        errs.append([r.get("train_error", np.nan), r.get("val_error", np.nan), r.get("test_error", np.nan)])
+    errs = np.array(errs)
+    return dict(errors=errs, mean=errs.mean(0), std=errs.std(0))
+
+
+def train_CV(rank, world_size, dataset, job, training, model_params, **kw):
+    """training.py:587-715 — k-fold: fold i is the test set, the rest is training (no validation)."""
+    folds = split_data_CV(len(dataset), int(job.get("cv_folds", 5)), job.get("seed", 0) or int(np.random.randint(1, 1e6)))
+    errs, rows = [], []
+    for i in range(len(folds)):
+        tr = np.concatenate([f for k, f in enumerate(folds) if k != i])
+        r = train_regular(rank, world_size, dataset, dict(job, job_name="%s_fold%d" % (job.get("job_name", "cv"), i)),
+                          training, model_params, splits=(tr, np.array([], dtype=np.int64), folds[i]), **kw)
+        errs.append(r.get("test_error", np.nan))
+        if "test_rows" in r:
+            rows.append(r["test_rows"])
+    return dict(fold_errors=np.array(errs), cv_error=float(np.mean(errs)), rows=np.concatenate(rows) if rows else None)
+
+
+def train_ensemble(rank, world_size, dataset, job, training, models_params, **kw):
+    """training.py:1069-1196 — one training per listed model on the SAME split; ensemble = mean prediction."""
+    seed = job.get("seed", 0) or int(np.random.randint(1, 1e6))
+    splits = split_data(len(dataset), training["train_ratio"], training["val_ratio"], training["test_ratio"], seed)
+    per_model, preds, target = [], [], None
+    for k, mp in enumerate(models_params):
+        r = train_regular(rank, world_size, dataset, dict(job, seed=seed, job_name="%s_%d" % (job.get("job_name", "ens"), k)),
+                          training, mp, splits=splits, **kw)
+        per_model.append(r.get("test_error", np.nan))
+        if "test_rows" in r:
+            rows = r["test_rows"]
+            ncol = (rows.shape[1] - 1) // 2
+            preds.append(rows[:, 1 + ncol:].astype(np.float64))
+            target = rows[:, 1:1 + ncol].astype(np.float64)
+    out = dict(model_errors=np.array(per_model))
+    if preds:
+        ens = np.mean(preds, axis=0)                                              # training.py:1153
+        out["ensemble_error"] = float(np.abs(ens - target).mean())
+        out["ensemble_prediction"] = ens
+    return out

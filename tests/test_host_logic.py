@@ -252,3 +252,72 @@ def test_flat_data_parallel_world_size_2_gloo(tmp_path):
     os.environ["MASTER_PORT"] = str(port)
     mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
     assert open(out).read().startswith("ok")
+
+
+# ---------------------------------------------------------------------------------------------
+# job drivers (Training / Repeat / CV / Ensemble / Predict) on CPU with the oracle models
+# ---------------------------------------------------------------------------------------------
+def _oracle_factory(name):
+    from oracle import models as omodels
+    return omodels.REGISTRY[name]
+
+
+def test_drivers_regular_cv_ensemble_predict(pt10, tmp_path, monkeypatch):
+    from matdeeplearn_amd.training import train_regular, train_CV, train_ensemble, train_repeat, predict
+    from oracle import ops as oops
+    monkeypatch.chdir(tmp_path)
+    rbf = lambda d: oops.rbf_expand(d)
+    training = dict(target_index=0, loss="l1_loss", train_ratio=0.8, val_ratio=0.05, test_ratio=0.15, verbosity=0)
+    mp = dict(model="CGCNN", dim1=16, dim2=16, gc_count=1, post_fc_count=1, epochs=2, lr=0.005, batch_size=50,
+              optimizer="AdamW", optimizer_args={}, scheduler="ReduceLROnPlateau",
+              scheduler_args={"mode": "min", "factor": 0.8, "patience": 10})
+    job = dict(job_name="t", seed=11, save_model="True", model_path="m.pth", write_output="True")
+    kw = dict(model_factory=_oracle_factory, rbf=rbf, log=lambda *a: None)
+    r = train_regular("cpu", 1, pt10, job, training, mp, **kw)
+    assert np.isfinite([r["train_error"], r["val_error"], r["test_error"]]).all()
+    assert os.path.exists("m.pth") and os.path.exists("t_test_outputs.csv")
+    rows = open("t_test_outputs.csv").read().strip().splitlines()
+    assert rows[0] == "ids,target,prediction" and len(rows) == 1 + 30
+    err, prows = predict(pt10, "CGCNN", mp, "m.pth", model_factory=_oracle_factory, rbf=rbf)
+    assert prows.shape == (200, 3) and np.isfinite(err)
+    cv = train_CV("cpu", 1, pt10, dict(job, cv_folds=4, save_model="False", write_output="False"), training, mp, **kw)
+    assert cv["fold_errors"].shape == (4,) and cv["rows"].shape[0] == 200
+    ens = train_ensemble("cpu", 1, pt10, dict(job, save_model="False", write_output="False"), training,
+                         [mp, dict(mp, model="GCN"), dict(mp, model="SchNet", dim3=8)], **kw)
+    assert ens["model_errors"].shape == (3,) and np.isfinite(ens["ensemble_error"])
+    rep = train_repeat("cpu", 1, pt10, dict(job, repeat_trials=2, save_model="False", write_output="False"), training, mp, **kw)
+    assert rep["errors"].shape == (2, 3)
+
+
+def test_load_reference_style_config(tmp_path):
+    from matdeeplearn_amd.training import load_config
+    cfg = tmp_path / "config.yml"
+    cfg.write_text("""
+Job:
+    Training:
+        job_name: "my_train_job"
+        model: CGCNN_demo
+        seed: 0
+        save_model: "True"
+Processing:
+    graph_max_radius: 8.0
+    graph_max_neighbors: 12
+Training:
+    target_index: 0
+    loss: "l1_loss"
+    train_ratio: 0.8
+    val_ratio: 0.05
+    test_ratio: 0.15
+    verbosity: 5
+Models:
+    CGCNN_demo:
+        model: CGCNN
+        dim1: 100
+        gc_count: 4
+        batch_norm: "True"
+        lr: 0.002
+        batch_size: 100
+""")
+    job, proc, tr, mp = load_config(str(cfg), "Training")
+    assert job["model"] == "CGCNN_demo" and mp["model"] == "CGCNN" and mp["batch_norm"] == "True"
+    assert proc["graph_max_neighbors"] == 12 and tr["loss"] == "l1_loss"
