@@ -39,8 +39,8 @@ def parse():
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--gc", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-graphs", type=int, default=256, help="graphs per CPU-baseline step")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-graphs", type=int, default=1024, help="graphs per CPU-baseline step")
+    ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -146,10 +146,22 @@ def main():
     dom = "bwd" if tot["bwd"] >= tot["fwd"] else "fwd"
     ab = {"fwd": ab_fwd, "bwd": ab_bwd}
 
+    # HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes over tools/bench_kernels.py,
+    # tools/gpu_pmc.sh -> profiles/hbm_traffic.json), scaled to this batch's edge count
+    traffic = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        if C == 64 and args.dtype == "bf16":
+            for k in ("fwd", "bwd"):
+                if "mdl_cgconv_" + k in tj:
+                    traffic[k] = int(tj["mdl_cgconv_" + k]["bytes"] * e_step / tj["E"])
+    except (OSError, ValueError, KeyError):
+        pass
+
     def roof(k):
         ach = ab[k] / avg[k] / 1e9
         return {"kernel": "mdl_cgconv_%s" % k, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(k),
                 "avg_launch_us": round(avg[k] * 1e6, 2), "launches": len(dur[k]),
                 "algorithmic_bytes_per_launch": int(ab[k])}
 
@@ -168,6 +180,22 @@ def main():
         "roofline": roof(dom),
         "roofline_other": roof("fwd" if dom == "bwd" else "bwd"),
     }
+
+    # ---- the same training step at the reference's batch size (config.yml:136 batch_size 100): launch bound
+    if world == 1:
+        rb = 100
+        ids_small = [rng.choice(len(ds), size=rb, replace=False) for _ in range(60)]
+        for i in range(10):
+            step(ids_small[i], False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        e_small = 0
+        for i in range(10, 60):
+            e_small += step(ids_small[i], False)[0]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        res["ref_batch_100"] = {"value": round(e_small / dt, 1), "unit": "edges/s", "ms_per_step": round(dt / 50 * 1e3, 4),
+                                "edges_per_step": int(e_small / 50)}
 
     # ---- CPU baseline: the oracle (pure-torch restatement of the reference path) on host cores ----
     if world == 1 and not args.no_cpu_baseline:
