@@ -69,8 +69,10 @@ def main():
     from matdeeplearn_amd.process import synthetic_bulk
     from matdeeplearn_amd.training import FlatDataParallel, make_optimizer
 
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MDL_FORCE_DIST") == "1"   # the env var exercises the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- data: identical synthetic dataset on every rank, resident in HBM -----------------------
@@ -102,12 +104,12 @@ def main():
         loss = torch.nn.functional.l1_loss(out, batch.y)
         loss.backward()
         ops.KERNEL_EVENTS = None
-        dp.reduce_grads()
+        dp.reduce_grads(force=use_dist)
         opt.step()
         return batch.num_edges, batch.num_nodes
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -126,13 +128,13 @@ def main():
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     etot = torch.tensor([float(edges)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(etot, op=dist.ReduceOp.SUM)
     elapsed_max, edges_all = float(tmax), float(etot)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -200,7 +202,7 @@ def main():
     # ---- CPU baseline: the oracle (pure-torch restatement of the reference path) on host cores ----
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args, ds, model)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     print(json.dumps(res))
 

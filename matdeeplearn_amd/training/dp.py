@@ -78,9 +78,9 @@ class FlatDataParallel:
     def zero_grad(self):
         self.flat_grad.zero_()
 
-    def reduce_grads(self):
+    def reduce_grads(self, force=False):
         """Sum over ranks, then average (DDP semantics).  One collective per step."""
-        if self.world_size > 1:
+        if self.world_size > 1 or (force and dist.is_initialized()):
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_grad.mul_(1.0 / self.world_size)
 
