@@ -97,7 +97,7 @@ def main():
     ktimes = {"fwd": [], "bwd": []}
 
     def step(ids, timed):
-        batch = ds.collate(ids, edge_dtype=cdt)
+        batch = ds.collate(ids, edge_dtype=cdt, x_dtype=cdt)
         dp.zero_grad()
         ops.KERNEL_EVENTS = ktimes if timed else None
         out = model(batch)

@@ -119,6 +119,22 @@ int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, 
 int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const float* r_tgt, const float* r_src,
                         const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype, mdlStream_t stream);
 
+/* ---- K8: device-side batch assembly ---------------------------------------------------------------
+ * Builds one mini-batch from the device-resident flat dataset in a single launch (one workgroup per
+ * graph).  Replaces the Python collate + H2D of the PyG DataLoader built at
+ * matdeeplearn/training/training.py:300-325 / :39 (Batch.from_data_list semantics: per-key concatenation,
+ * edge indices offset by the graph's first node, `batch` vector).
+ * ids/noff/eoff: [B], [B+1], [B+1] int64 on the device (noff/eoff = exclusive prefix sums of the batch's node
+ * and edge counts; noff[B] = N, eoff[B] = E).  Dataset arrays: node_ptr/edge_ptr [G+1] int64, x_all [Nt,F] fp32,
+ * src_l/tgt_l [Et] graph-local int32 (sorted by target inside every graph), dist/dist_norm [Et] fp32,
+ * lrowptr [Nt] int32 (exclusive in-degree prefix inside the node's graph), y_all [G,T] fp32.
+ * Outputs: x [N,F] in `dtype`, batch [N] int64, rowptr [N+1], src/tgt [E] int32, ew/dn [E] fp32, y [B] fp32. */
+int mdl_assemble_batch(const int64_t* ids, const int64_t* noff, const int64_t* eoff, const int64_t* node_ptr,
+                       const int64_t* edge_ptr, const float* x_all, const int32_t* src_l, const int32_t* tgt_l,
+                       const float* dist, const float* dist_norm, const int32_t* lrowptr, const float* y_all,
+                       void* x, int64_t* batch, int32_t* rowptr, int32_t* src, int32_t* tgt, float* ew, float* dn,
+                       float* y, int B, int F, int T, int target_index, int dtype, mdlStream_t stream);
+
 /* ---- training-mode BatchNorm1d over rows, x: [N, C] row-major ------------------------------------
  * Replaces torch.nn.BatchNorm1d as applied after every conv layer (matdeeplearn/models/cgcnn.py:85-87,143)
  * and inside the MEGNet MLPs (megnet.py:47-48).  `sums` is a [2, C] fp32 scratch the caller zero-fills

@@ -1,0 +1,82 @@
+// assemble.hip — K8: device-side batch assembly.  One launch builds a whole mini-batch from the
+// device-resident flat dataset (matdeeplearn_amd/process/dataset.py): node features (converted to the
+// compute dtype), the `batch` vector, the CSR-by-target index (rowptr / src / tgt with batch-global
+// node ids), raw and normalised distances and the targets.  It replaces, on the hot path, the Python
+// collate of the PyG DataLoader the reference builds at /root/reference/matdeeplearn/training/training.py:300-325
+// (Batch.from_data_list: per-key concatenation, edge_index offset by the graph's first node, `batch`
+// vector) and the host->device copy at training.py:39.
+// One workgroup per graph: every copy is a contiguous run.  Algorithmic bytes: N*(F*4 + F*s + 12) + E*(4*4 + 4*4).
+#include "mdl_common.h"
+
+namespace mdl {
+
+struct AsmParams {
+    const int64_t* ids;        // [B] graph ids of the batch (device)
+    const int64_t* noff;       // [B+1] first batch node of every graph
+    const int64_t* eoff;       // [B+1] first batch edge of every graph
+    const int64_t* node_ptr;   // dataset [G+1]
+    const int64_t* edge_ptr;   // dataset [G+1]
+    const float* x_all;        // dataset [Nt, F] fp32
+    const int32_t* src_l;      // dataset [Et] graph-local source
+    const int32_t* tgt_l;      // dataset [Et] graph-local target (sorted inside every graph)
+    const float* dist;         // dataset [Et]
+    const float* dist_norm;    // dataset [Et]
+    const int32_t* lrowptr;    // dataset [Nt] exclusive in-degree prefix inside the node's graph
+    const float* y_all;        // dataset [G, T]
+    void* x;                   // out [N, F] in dtype
+    int64_t* batch;            // out [N]
+    int32_t* rowptr;           // out [N+1]
+    int32_t* src;              // out [E]
+    int32_t* tgt;              // out [E]
+    float* ew;                 // out [E] raw distance (edge_weight)
+    float* dn;                 // out [E] normalised distance
+    float* y;                  // out [B]
+    int F, T, target_index, B;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_kernel(AsmParams p) {
+    const int g = blockIdx.x;
+    const int64_t gid = p.ids[g];
+    const int64_t n0s = p.node_ptr[gid], nn = p.node_ptr[gid + 1] - n0s;
+    const int64_t e0s = p.edge_ptr[gid], ne = p.edge_ptr[gid + 1] - e0s;
+    const int64_t no = p.noff[g], eo = p.eoff[g];
+    T* xo = static_cast<T*>(p.x) + no * p.F;
+    const float* xi = p.x_all + n0s * p.F;
+    for (int64_t q = threadIdx.x; q < nn * p.F; q += blockDim.x) Elem<T>::st(xo + q, xi[q]);
+    for (int64_t j = threadIdx.x; j < nn; j += blockDim.x) {
+        p.batch[no + j] = g;
+        p.rowptr[no + j] = (int32_t)(eo + p.lrowptr[n0s + j]);
+    }
+    const int32_t shift = (int32_t)no;
+    for (int64_t k = threadIdx.x; k < ne; k += blockDim.x) {
+        p.src[eo + k] = p.src_l[e0s + k] + shift;
+        p.tgt[eo + k] = p.tgt_l[e0s + k] + shift;
+        p.ew[eo + k] = p.dist[e0s + k];
+        p.dn[eo + k] = p.dist_norm[e0s + k];
+    }
+    if (threadIdx.x == 0) {
+        p.y[g] = p.y_all[gid * p.T + p.target_index];
+        if (g == p.B - 1) p.rowptr[no + nn] = (int32_t)(eo + ne);
+    }
+}
+
+}  // namespace mdl
+
+extern "C" int mdl_assemble_batch(const int64_t* ids, const int64_t* noff, const int64_t* eoff, const int64_t* node_ptr,
+                                  const int64_t* edge_ptr, const float* x_all, const int32_t* src_l, const int32_t* tgt_l,
+                                  const float* dist, const float* dist_norm, const int32_t* lrowptr, const float* y_all,
+                                  void* x, int64_t* batch, int32_t* rowptr, int32_t* src, int32_t* tgt, float* ew, float* dn,
+                                  float* y, int B, int F, int T, int target_index, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(B >= 1 && F >= 1 && T >= 1 && target_index >= 0 && target_index < T, MDL_E_ARG, "mdl_assemble_batch: bad sizes");
+    MDL_REQUIRE(ids && noff && eoff && node_ptr && edge_ptr && x_all && lrowptr && y_all && x && batch && rowptr && y,
+                MDL_E_ARG, "mdl_assemble_batch: null pointer");
+    AsmParams p = {ids, noff, eoff, node_ptr, edge_ptr, x_all, src_l, tgt_l, dist, dist_norm, lrowptr, y_all,
+                   x, batch, rowptr, src, tgt, ew, dn, y, F, T, target_index, B};
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MDL_F32) hipLaunchKernelGGL((assemble_kernel<float>), dim3((unsigned)B), dim3(256), 0, st, p);
+    else if (dtype == MDL_BF16) hipLaunchKernelGGL((assemble_kernel<bf16_t>), dim3((unsigned)B), dim3(256), 0, st, p);
+    else { set_error("mdl_assemble_batch: unsupported dtype %d", dtype); return MDL_E_UNSUPP; }
+    return check_launch("mdl_assemble_batch");
+}

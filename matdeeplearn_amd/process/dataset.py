@@ -65,6 +65,10 @@ class GraphDataset:
                           / (np.float32(hi) - np.float32(lo))).numpy()
         gl_tgt = np.asarray(tgt, dtype=np.int64) + np.repeat(self.node_ptr[:-1], np.diff(self.edge_ptr))
         self.in_deg = np.bincount(gl_tgt, minlength=len(z)).astype(np.int32)
+        # exclusive in-degree prefix inside every graph: batch rowptr[n] = (first batch edge of the graph) + lrowptr
+        csum = np.concatenate([[0], np.cumsum(self.in_deg, dtype=np.int64)])
+        nodes_per_graph = np.diff(self.node_ptr)
+        self.lrowptr = (csum[:-1] - np.repeat(csum[self.node_ptr[:-1]], nodes_per_graph)).astype(np.int32)
         self.device = None
         self._dev = {}
 
@@ -96,16 +100,56 @@ class GraphDataset:
         self._dev = dict(node_ptr=f(self.node_ptr), edge_ptr=f(self.edge_ptr), x=f(self.x, torch.float32),
                          src=f(self.src, torch.int32), tgt=f(self.tgt, torch.int32),
                          dist=f(self.dist, torch.float32), dist_norm=f(self.dist_norm, torch.float32),
-                         in_deg=f(self.in_deg, torch.int32), y=f(self.y, torch.float32),
+                         in_deg=f(self.in_deg, torch.int32), lrowptr=f(self.lrowptr, torch.int32),
+                         y=f(self.y, torch.float32),
                          offsets=ops.rbf_offsets(0.0, 1.0, self.num_edge_features, device))
         self.device = device
         return self
 
-    def collate(self, ids, edge_dtype=torch.float32, rbf=None):
+    def assemble_hip(self, ids, x_dtype=torch.float32):
+        """K8: the whole batch assembly in ONE HIP launch (one workgroup per graph).  Prefix offsets are
+        computed on the host from node_ptr/edge_ptr (B numbers) and uploaded with the ids in one copy."""
+        from .. import _lib
+        d = self._dev
+        ids = np.asarray(ids, dtype=np.int64)
+        B = len(ids)
+        ncnt = self.node_ptr[ids + 1] - self.node_ptr[ids]
+        ecnt = self.edge_ptr[ids + 1] - self.edge_ptr[ids]
+        noff = np.concatenate([[0], np.cumsum(ncnt)])
+        eoff = np.concatenate([[0], np.cumsum(ecnt)])
+        N, E = int(noff[-1]), int(eoff[-1])
+        dev = self.device
+        host = torch.from_numpy(np.concatenate([ids, noff, eoff]).astype(np.int64))
+        pack = host.to(dev, non_blocking=True)
+        ids_d, noff_d, eoff_d = pack[:B], pack[B:2 * B + 1], pack[2 * B + 1:]
+        F = self.num_features
+        x = torch.empty((N, F), dtype=x_dtype, device=dev)
+        batch = torch.empty(N, dtype=torch.int64, device=dev)
+        rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        src = torch.empty(E, dtype=torch.int32, device=dev)
+        tgt = torch.empty(E, dtype=torch.int32, device=dev)
+        ew = torch.empty(E, dtype=torch.float32, device=dev)
+        dn = torch.empty(E, dtype=torch.float32, device=dev)
+        y = torch.empty(B, dtype=torch.float32, device=dev)
+        p = _lib.ptr
+        _lib.check(_lib.lib().mdl_assemble_batch(
+            p(ids_d), p(noff_d), p(eoff_d), p(d["node_ptr"]), p(d["edge_ptr"]), p(d["x"]), p(d["src"]), p(d["tgt"]),
+            p(d["dist"]), p(d["dist_norm"]), p(d["lrowptr"]), p(d["y"]), p(x), p(batch), p(rowptr), p(src), p(tgt),
+            p(ew), p(dn), p(y), B, F, self.y.shape[1], int(self.target_index), _lib.dtype_code(x), _lib.stream()),
+            "mdl_assemble_batch")
+        csr = ops.EdgeCSR(rowptr, src, tgt, None, N, E)
+        return Batch(x=x, edge_attr=None, edge_weight=ew, batch=batch, y=y, u=torch.zeros(B, 3, device=dev),
+                     num_graphs=B, csr=csr, num_nodes=N, num_edges=E,
+                     structure_id=[self.ids[i] for i in ids]), dn
+
+    def collate(self, ids, edge_dtype=torch.float32, rbf=None, x_dtype=None):
         """Assemble the batch for graph ids (host int array) on the device and expand the edge
         features with the K1 HIP kernel.  No host sync: sizes come from the host node/edge_ptr.
         `rbf` lets the CPU test-suite inject the oracle expansion; the product default is the kernel."""
-        b, dist_norm = self.assemble(ids)
+        if rbf is None and self.device is not None and self.device.type == "cuda" and self.target_index != -1:
+            b, dist_norm = self.assemble_hip(ids, x_dtype if x_dtype is not None else torch.float32)
+        else:
+            b, dist_norm = self.assemble(ids)
         if rbf is None:
             b.edge_attr = ops.rbf_expand(dist_norm, 0.0, 1.0, self.num_edge_features, 0.2, out_dtype=edge_dtype,
                                          offsets=self._dev["offsets"])
@@ -239,4 +283,4 @@ class DeviceLoader:
     def __iter__(self):
         idx = self._order()
         for i in range(0, len(idx), self.batch_size):
-            yield self.ds.collate(idx[i:i + self.batch_size], self.edge_dtype, self.rbf)
+            yield self.ds.collate(idx[i:i + self.batch_size], self.edge_dtype, self.rbf, x_dtype=self.edge_dtype)

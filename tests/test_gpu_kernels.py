@@ -272,3 +272,19 @@ def test_batchnorm_train_matches_torch(dtype, N, C):
     close(mine.running_mean, ref.running_mean, 1e-4 if dtype == torch.float32 else 1e-2, 1e-5 if dtype == torch.float32 else 1e-2)
     close(mine.running_var, ref.running_var, 1e-4 if dtype == torch.float32 else 2e-2, 1e-5 if dtype == torch.float32 else 1e-2)
     assert int(mine.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16])
+def test_hip_batch_assembly_matches_tensor_op_assembly(x_dtype):
+    """K8 (one launch per batch) vs the index-arithmetic assembly checked on CPU against per-graph concatenation."""
+    from matdeeplearn_amd.process import synthetic_bulk
+    ds = synthetic_bulk(200, seed=11).to(dev())
+    ids = np.random.default_rng(0).choice(200, size=57, replace=False)
+    a, dna = ds.assemble(ids)
+    b, dnb = ds.assemble_hip(ids, x_dtype)
+    assert torch.equal(a.x.to(x_dtype), b.x) and torch.equal(a.batch, b.batch) and torch.equal(a.y, b.y)
+    assert torch.equal(a.csr.rowptr, b.csr.rowptr) and torch.equal(a.csr.src, b.csr.src) and torch.equal(a.csr.tgt, b.csr.tgt)
+    assert torch.equal(a.edge_weight, b.edge_weight) and torch.equal(dna, dnb)
+    assert (a.num_nodes, a.num_edges) == (b.num_nodes, b.num_edges)
+    full = ds.collate(ids, edge_dtype=torch.float32)
+    assert full.edge_attr.shape == (b.num_edges, 50)
