@@ -40,6 +40,9 @@
 #ifndef MDL_BWD_XDB
 #define MDL_BWD_XDB 1
 #endif
+#ifndef MDL_FWD_ALLSLICES
+#define MDL_FWD_ALLSLICES 1   // static shapes: one forward wave handles all channel slices of its group
+#endif
 #ifndef MDL_BWD_WAVES
 #define MDL_BWD_WAVES 1   // waves per SIMD the backward kernel is register-allocated for
 #endif
@@ -620,6 +623,91 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
     if constexpr (WM == 3) wr.load(static_cast<const T*>(p.wpack), s * 32 + i, dm.Cp + s * 32 + i, dm.WS, h, dm.KE);
     const int ch = s * 32 + i;
 
+#if MDL_FWD_ALLSLICES
+    if constexpr (ST && WM == 1) {
+        // One wave handles ALL channel slices of its group.  Staging the tile (edge-feature stream, index
+        // loads, x gathers, one-hot table) is slice independent: doing it once per tile instead of once per
+        // (tile, slice) removes the duplicated per-tile overhead; the pre-GEMM / gate / aggregation then
+        // run per 32-channel slice on the same staged operands.
+        constexpr int NSL = CP_ / 32;
+        const int nw_total = gridDim.x * (blockDim.x >> 6);
+        for (int g = gw; g < p.n_groups; g += nw_total) {
+            GroupInfo G;
+            G.load(p, g);
+            f32x16 acc_out[NSL], cnt;
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_out[sl][r] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cnt[r] = 0.0f;
+            if (G.e0 == G.e1) {                                  // group without edges: out = x
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = G.n0 + d_row(r, h);
+                        if (n < G.n1) out[(int64_t)n * dm.C + sl * 32 + i] = x[(int64_t)n * dm.C + sl * 32 + i];
+                    }
+                continue;
+            }
+            TileIdx cur, nxt;
+            EWords<T, G_, EW> ew;
+            cur.load(p, G.e0, G.e1, i, G.n0);
+            nxt = cur;
+            ew.prefetch(p, lane, G.e0, min(32, G.e1 - G.e0), cur.ep);
+            for (int eb = G.e0; eb < G.e1; eb += 32) {
+                const int nv = min(32, G.e1 - eb);
+                const bool last = eb + 32 >= G.e1;
+                wave_lds_fence();
+                ew.commit(w.et, dm.EKS, lane);
+                if (h == 0) reinterpret_cast<unsigned char*>(w.tsl)[i] = (i < nv) ? (unsigned char)(cur.tgt - G.n0) : 0xff;
+                wave_lds_fence();
+                XFrags<T, CP_, VEC> xf;
+                xf.load(x, dm.C, cur.tgt, cur.src, h);
+                if (!last) {
+                    nxt.load(p, eb + 32, G.e1, i, G.n0);
+                    ew.prefetch(p, lane, eb + 32, min(32, G.e1 - eb - 32), nxt.ep);
+                }
+                unsigned t4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t4[j] = w.tsl[2 * j + h];
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl) {
+                    f32x16 accf, accs;
+                    const float b0 = (BC || p.bias_col) ? 0.0f : p.bpack[sl * 32 + i];
+                    const float b1 = (BC || p.bias_col) ? 0.0f : p.bpack[dm.Cp + sl * 32 + i];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { accf[r] = b0; accs[r] = b1; }
+                    pre_tile<T, CP_, VEC, WM, NKW>(p, dm, w, lane, sl, cur.tgt, cur.src, xf, wr, accf, accs);
+                    f32x16 m;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[r] = GT::sigmoid(accf[r]) * GT::softplus_u(accs[r]);
+                    if (sl == 0) seg_reduce_cnt<T>(m, t4, i, acc_out[sl], cnt);
+                    else seg_reduce_mma<T>(m, t4, i, acc_out[sl]);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the slices' register footprints apart
+                }
+                cur = nxt;
+            }
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = G.n0 + d_row(r, h);
+                    if (n < G.n1) {
+                        float a = acc_out[sl][r] * GT::M_SCALE;
+                        if (p.aggr == MDL_MEAN) {
+                            const float deg = fmaxf(cnt[r], 1.0f);
+                            a = M::FAST ? a * __builtin_amdgcn_rcpf(deg) : a / deg;
+                        }
+                        const int64_t o = (int64_t)n * dm.C + sl * 32 + i;
+                        Elem<T>::st(out + o, Elem<T>::ld(x + o) + a);
+                    }
+                }
+        }
+        return;
+    }
+#endif
     // The wave walks its groups as ONE continuous stream of edge tiles: while tile t computes, the
     // indices and edge-feature words of tile t+1 are in flight — across group boundaries too — so
     // the load pipeline never drains.  A group's epilogue (residual add, mean, store) needs no
@@ -1134,7 +1222,8 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     const int lds = (w_lds ? w_bytes : 0) + waves * p.wave_lds_bytes;
     const int wg_per_cu = lds * 2 <= LDS_CAP ? 2 : 1;
 
-    int64_t items = (int64_t)p.n_groups * d.NS;
+    const bool all_slices = !bwd && fast && MDL_FWD_ALLSLICES && MDL_CG_WM == 1 && (sizeof(T) == 2 || w_lds);
+    int64_t items = (int64_t)p.n_groups * (all_slices ? 1 : d.NS);
     int64_t grid = cdiv(items, waves);
     // backward is register-allocated for MDL_BWD_WAVES waves per SIMD: 1 -> one 4-wave workgroup per CU
     const int64_t cap = 256 * ((bwd && MDL_BWD_WAVES == 1) ? 1 : wg_per_cu);
