@@ -52,6 +52,19 @@ import torch
 import torch.nn.functional as F
 
 
+def _lin(lin, h):
+    """nn.Linear applied in the dtype of h (fp32 master weights, bf16 activations)."""
+    if h.dtype == lin.weight.dtype:
+        return lin(h)
+    return F.linear(h, lin.weight.to(h.dtype), None if lin.bias is None else lin.bias.to(h.dtype))
+
+
+def _seq(seq, h):
+    for m in seq:
+        h = _lin(m, h) if isinstance(m, nn.Linear) else m(h)
+    return h
+
+
 class ShiftedSoftplus(nn.Module):
     def __init__(self):
         super().__init__()
@@ -79,10 +92,10 @@ class CFConv(nn.Module):
         if csr is None:
             csr = ops.csr_for(edge_index, x.shape[0])
         c = 0.5 * (torch.cos(edge_weight.float() * (math.pi / self.cutoff)) + 1.0)   # [E] fp32
-        w = self.nn(edge_attr)                                                        # filter  [E, F]
-        h = self.lin1(x)
+        w = _seq(self.nn, edge_attr)                                                  # filter  [E, F]
+        h = _lin(self.lin1, x)
         agg = ops.gather_mul_reduce(h, csr, w=w.to(h.dtype), scale=c, reduce="sum")
-        return self.lin2(agg)
+        return _lin(self.lin2, agg)
 
 
 class InteractionBlock(nn.Module):
@@ -102,7 +115,7 @@ class InteractionBlock(nn.Module):
         self.conv.reset_parameters()
 
     def forward(self, x, edge_index, edge_weight, edge_attr, csr=None):
-        return self.lin(self.act(self.conv(x, edge_index, edge_weight, edge_attr, csr=csr)))
+        return _lin(self.lin, self.act(self.conv(x, edge_index, edge_weight, edge_attr, csr=csr)))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -128,7 +141,7 @@ class GCNConv(nn.Module):
         dis = deg.pow(-0.5)
         dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
         norm = ops.gather(dis.unsqueeze(1), csr.row).squeeze(1) * ew * ops.gather(dis.unsqueeze(1), csr.col).squeeze(1)
-        out = ops.gather_mul_reduce(self.lin(x), csr, w=None, scale=norm, reduce="sum")
+        out = ops.gather_mul_reduce(_lin(self.lin, x), csr, w=None, scale=norm, reduce="sum")
         return out + self.bias.to(out.dtype) if self.bias is not None else out
 
 
