@@ -27,6 +27,7 @@
 //
 // Algorithmic bytes: fwd E*(G*s + C*s + 4) + N*(2*C*s + 4);
 //                                   bwd E*(G*s + 2*C*s + 4) + N*(3*C*s + 4).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "mdl_common.h"
@@ -43,23 +44,45 @@
 #ifndef MDL_FWD_ALLSLICES
 #define MDL_FWD_ALLSLICES 1   // static shapes: one forward wave handles all channel slices of its group
 #endif
+#ifndef MDL_FWD_XEARLY
+#define MDL_FWD_XEARLY 1   // all-slices forward: gather the next tile's x rows right after the last slice's MFMAs
+#endif
+#ifndef MDL_CG_PHASE_BARRIERS
+#define MDL_CG_PHASE_BARRIERS 0
+#endif
 #ifndef MDL_BWD_WAVES
 #define MDL_BWD_WAVES 1   // waves per SIMD the backward kernel is register-allocated for
 #endif
 
-#ifdef MDL_CG_TIMING   // experiment builds only: per-phase cycle counters of wave 0 / block 0
-__device__ long long g_cg_dbg[16];
-extern "C" int mdl_debug_read(long long* host16) {
-    return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_cg_dbg), 16 * sizeof(long long));
+#ifdef MDL_CG_TIMING   // experiment builds only: per-phase cycle counters of wave 0 (kept in SGPRs, flushed at the end)
+__device__ long long g_cg_dbg[48];
+extern "C" int mdl_debug_read(long long* host48) {
+    return (int)hipMemcpyFromSymbol(host48, HIP_SYMBOL(g_cg_dbg), 48 * sizeof(long long));
 }
 extern "C" int mdl_debug_reset() {
-    long long z[16] = {0};
+    long long z[48] = {0};
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cg_dbg), z, sizeof(z));
 }
-#define TMARK(k) do { __builtin_amdgcn_sched_barrier(0); const long long _t = clock64(); if (gw == 0 && lane == 0) g_cg_dbg[k] += _t - tprev; tprev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TDECL const long long tstart = clock64(); long long tprev = tstart; long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tcount = 0
+#define TMARK(k) do { __builtin_amdgcn_sched_barrier(0); const long long _t = clock64(); tacc[k] += _t - tprev; tprev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TPIN16(v) do { _Pragma("unroll") for (int _r = 0; _r < 16; ++_r) asm volatile("" : "+v"(v[_r])); } while (0)
+#define TTILE() (tcount += 1)
+#define TRESET() TMARK(10)
+#define TFLUSH(base) do { if (gw == 0 && lane == 0) { for (int _k = 0; _k < 12; ++_k) g_cg_dbg[(base) + _k] += tacc[_k]; g_cg_dbg[(base) + 15] += tcount; g_cg_dbg[(base) + 14] += clock64() - tstart; } } while (0)
+#else
+#define TDECL do { } while (0)
+#if MDL_CG_PHASE_BARRIERS   // keep the phases of a tile apart in the instruction schedule (no timing)
+#define TMARK(k) __builtin_amdgcn_sched_barrier(0)
+#define TPIN16(v) do { _Pragma("unroll") for (int _r = 0; _r < 16; ++_r) asm volatile("" : "+v"(v[_r])); } while (0)
 #else
 #define TMARK(k) do { } while (0)
+#define TPIN16(v) do { } while (0)
 #endif
+#define TTILE() do { } while (0)
+#define TRESET() do { } while (0)
+#define TFLUSH(base) do { } while (0)
+#endif
+
 
 namespace mdl {
 
@@ -241,27 +264,28 @@ struct EWords {
     static constexpr int NW = G_ ? (32 * GW + WAVE - 1) / WAVE : 1;
     word_t w[NW];
 
-    __device__ __forceinline__ void prefetch(const CgParams& p, int lane, int eb, int nv, int my_ep) {
-        const T* ea = static_cast<const T*>(p.ea);
-        if (!p.eperm && (int64_t)eb + 32 <= p.E) {
-            // whole 32-row window is inside the array: one uniform 64-bit base + per-lane 32-bit
-            // offsets, no predication (rows >= nv belong to later edges; they are finite data and
-            // are multiplied by exact zeros downstream)
-            const char* tb = reinterpret_cast<const char*>(ea) + (int64_t)eb * (G_ * (int)sizeof(T));
+    // The static kernels are only launched for target-sorted edge features (no eperm; the host permutes
+    // once).  One uniform 64-bit tile base + per-lane 32-bit offsets, no predication: rows past the end of
+    // the group belong to later edges (finite data, multiplied by exact zeros downstream); only the last
+    // tile of the whole array clamps its offsets so that nothing is read past the end of the buffer.
+    __device__ __forceinline__ void prefetch(const CgParams& p, int lane, int eb, int /*nv*/, int /*my_ep*/) {
+        constexpr unsigned WB = EW * sizeof(T);
+        const char* tb = reinterpret_cast<const char*>(p.ea) + (int64_t)eb * (G_ * (int)sizeof(T));
+        if ((int64_t)(p.E - eb) * GW >= NW * WAVE) {
+            // all NW*64 words lie inside the array (the tail of the last word belongs to the next rows and is
+            // dropped by commit): one per-lane pointer + compile-time offsets
+            const char* lp = tb + lane * WB;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) w[j] = *reinterpret_cast<const word_t*>(lp + j * (WAVE * WB));
+        } else {
+            const unsigned lim = (unsigned)((p.E - eb) * GW - 1);          // last word of the array, tile relative
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
-                const int q = min(j * WAVE + lane, 32 * GW - 1);   // clamp, never guard (see TileIdx::load)
-                w[j] = *reinterpret_cast<const word_t*>(tb + (unsigned)q * (unsigned)(EW * sizeof(T)));
+                const unsigned q = min((unsigned)(j * WAVE + lane), lim);
+                // (volatile on purpose: a different instruction flavour, so hipcc cannot tail-merge these
+                // loads with the fast path's and burn 13 address register pairs on the merged block)
+                w[j] = *reinterpret_cast<const volatile word_t*>(tb + q * WB);
             }
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const int q = j * WAVE + lane;
-            const int row = q / GW, cw = q - row * GW;
-            const int ep = p.eperm ? __shfl(my_ep, row & 31) : eb + row;
-            w[j] = 0;
-            if (row < nv) w[j] = *reinterpret_cast<const word_t*>(ea + (int64_t)ep * G_ + cw * EW);
         }
     }
     __device__ __forceinline__ void commit(T* et, int EKS, int lane) const {
@@ -528,19 +552,20 @@ __device__ __forceinline__ void setup_wave(const CgParams& p, const D& dm, char*
 // per-lane indices of one edge tile (lane i and lane i+32 hold the same edge slot i)
 struct TileIdx {
     int src, tgt, ep;
+    template <bool WITH_EP = true>
     __device__ __forceinline__ void load(const CgParams& p, int eb, int e1, int i, int n0) {
-        // NOTE: loads are unconditional on a clamped index and the select happens on the VALUE.
-        // `cond ? load : x` makes hipcc branch around the load and wait for it at the join, which
-        // exposes one full memory latency per guarded load.
-        const int eid = eb + i;
-        const bool ok = eid < e1;
+        // RAW loads on a clamped index, nothing else.  Slots past the end of the group (eb + i >= e1) get
+        // the indices of the group's last edge: valid rows whose contribution every consumer masks by
+        // slot validity (i < nv).  No select / arithmetic on the loaded values here: this is called
+        // inside `if (more tiles)` blocks, and any use of a loaded value inside the block makes hipcc
+        // wait for it (and for every older load, i.e. the x gathers issued just before) at that point.
+        // Likewise never `cond ? load : x`: hipcc branches around the load and waits at the join.
         if (p.E == 0) { src = tgt = n0; ep = 0; return; }            // uniform: graph without edges
-        const int ec = max(min(eid, e1 - 1), 0);
-        const int sv = p.src[ec], tv = p.tgt[ec];
-        src = ok ? sv : n0;
-        tgt = ok ? tv : n0;
+        const int ec = max(min(eb + i, e1 - 1), 0);
+        src = p.src[ec];
+        tgt = p.tgt[ec];
         ep = 0;
-        if (p.eperm) { const int pv = p.eperm[ec]; ep = ok ? pv : 0; }
+        if (WITH_EP && p.eperm) ep = p.eperm[ec];
     }
 };
 
@@ -583,11 +608,11 @@ __device__ __forceinline__ void seg_reduce_cnt(const f32x16& v, const unsigned t
 struct GroupInfo {
     int g, n0, n1, e0, e1;
     __device__ __forceinline__ void load(const CgParams& p, int g_) {
-        g = g_;
+        g = g_;                                   // pass a wave-uniform value: the two loads become s_load
         n0 = g * 32;
         n1 = (int)min((int64_t)n0 + 32, p.N);
-        e0 = __builtin_amdgcn_readfirstlane(p.rowptr[n0]);
-        e1 = __builtin_amdgcn_readfirstlane(p.rowptr[n1]);
+        e0 = p.rowptr[n0];
+        e1 = p.rowptr[n1];
     }
 };
 
@@ -605,6 +630,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
     const D dm(p);
     WaveCtx<T> w;
     setup_wave<T>(p, dm, smem, WM == 1 || WM == 3, w);
+    TDECL;
 
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -631,16 +657,19 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
         // run per 32-channel slice on the same staged operands.
         constexpr int NSL = CP_ / 32;
         const int nw_total = gridDim.x * (blockDim.x >> 6);
-        for (int g = gw; g < p.n_groups; g += nw_total) {
-            GroupInfo G;
-            G.load(p, g);
-            f32x16 acc_out[NSL], cnt;
-#pragma unroll
-            for (int sl = 0; sl < NSL; ++sl)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc_out[sl][r] = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cnt[r] = 0.0f;
+        if (gw >= p.n_groups) return;
+        // The wave walks its groups as one continuous stream: the next group's row pointers are requested
+        // at the top of the current group, and the indices / edge-feature words of the next group's first
+        // tile during the current group's last tile, so a group boundary costs no dependent round trips.
+        GroupInfo G, GN;
+        G.load(p, __builtin_amdgcn_readfirstlane(gw));
+        TileIdx cur, nxt;
+        EWords<T, G_, EW> ew;
+        XFrags<T, CP_, VEC> xf;
+        bool primed = false;                                  // cur / ew / xf already hold the group's first tile
+        while (true) {
+            const bool hasN = G.g + nw_total < p.n_groups;
+            if (hasN) GN.load(p, G.g + nw_total);
             if (G.e0 == G.e1) {                                  // group without edges: out = x
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl)
@@ -649,26 +678,44 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                         const int n = G.n0 + d_row(r, h);
                         if (n < G.n1) out[(int64_t)n * dm.C + sl * 32 + i] = x[(int64_t)n * dm.C + sl * 32 + i];
                     }
+                if (!hasN) break;
+                G = GN;
+                primed = false;
                 continue;
             }
-            TileIdx cur, nxt;
-            EWords<T, G_, EW> ew;
-            cur.load(p, G.e0, G.e1, i, G.n0);
+            f32x16 acc_out[NSL], cnt;
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_out[sl][r] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cnt[r] = 0.0f;
+            if (!primed) {
+                cur.template load<false>(p, G.e0, G.e1, i, G.n0);
+                ew.prefetch(p, lane, G.e0, min(32, G.e1 - G.e0), cur.ep);
+                xf.load(x, dm.C, cur.tgt, cur.src, h);
+            }
             nxt = cur;
-            ew.prefetch(p, lane, G.e0, min(32, G.e1 - G.e0), cur.ep);
+            bool nextHasEdges = false;                        // evaluated at the last tile (GN arrives by then)
+            TRESET();
             for (int eb = G.e0; eb < G.e1; eb += 32) {
                 const int nv = min(32, G.e1 - eb);
                 const bool last = eb + 32 >= G.e1;
+                TMARK(0);
                 wave_lds_fence();
                 ew.commit(w.et, dm.EKS, lane);
                 if (h == 0) reinterpret_cast<unsigned char*>(w.tsl)[i] = (i < nv) ? (unsigned char)(cur.tgt - G.n0) : 0xff;
                 wave_lds_fence();
-                XFrags<T, CP_, VEC> xf;
-                xf.load(x, dm.C, cur.tgt, cur.src, h);
+                TMARK(1);
                 if (!last) {
-                    nxt.load(p, eb + 32, G.e1, i, G.n0);
+                    nxt.template load<false>(p, eb + 32, G.e1, i, G.n0);
                     ew.prefetch(p, lane, eb + 32, min(32, G.e1 - eb - 32), nxt.ep);
+                } else if (hasN && GN.e0 < GN.e1) {
+                    nextHasEdges = true;
+                    nxt.template load<false>(p, GN.e0, GN.e1, i, GN.n0);
+                    ew.prefetch(p, lane, GN.e0, min(32, GN.e1 - GN.e0), nxt.ep);
                 }
+                TMARK(2);
                 unsigned t4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) t4[j] = w.tsl[2 * j + h];
@@ -680,31 +727,60 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { accf[r] = b0; accs[r] = b1; }
                     pre_tile<T, CP_, VEC, WM, NKW>(p, dm, w, lane, sl, cur.tgt, cur.src, xf, wr, accf, accs);
+                    TPIN16(accf); TPIN16(accs);
+                    TMARK(3 + 3 * sl);
+#if MDL_FWD_XEARLY
+                    // the x rows of the NEXT tile: requested as soon as the last slice's MFMAs have consumed this
+                    // tile's fragments (same registers), so their latency hides under the gate / aggregation
+                    if (sl == NSL - 1 && (!last || nextHasEdges)) xf.load(x, dm.C, nxt.tgt, nxt.src, h);
+#endif
                     f32x16 m;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) m[r] = GT::sigmoid(accf[r]) * GT::softplus_u(accs[r]);
+                    TPIN16(m);
+                    TMARK(4 + 3 * sl);
                     if (sl == 0) seg_reduce_cnt<T>(m, t4, i, acc_out[sl], cnt);
                     else seg_reduce_mma<T>(m, t4, i, acc_out[sl]);
+                    TPIN16(acc_out[sl]);
+                    TMARK(5 + 3 * sl);
                     __builtin_amdgcn_sched_barrier(0);      // keep the slices' register footprints apart
                 }
+#if !MDL_FWD_XEARLY
+                if (!last || nextHasEdges) xf.load(x, dm.C, nxt.tgt, nxt.src, h);
+#endif
                 cur = nxt;
+                TTILE();
             }
+            // epilogue: out = x + acc / deg.  All residual rows are requested first (clamped row index, no
+            // guards), so the group pays one memory round trip instead of one per row.
+            {
+                float xr[NSL][16];
 #pragma unroll
-            for (int sl = 0; sl < NSL; ++sl)
+                for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = G.n0 + d_row(r, h);
-                    if (n < G.n1) {
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = min(G.n0 + d_row(r, h), G.n1 - 1);
+                        xr[sl][r] = Elem<T>::ld(x + (int64_t)n * dm.C + sl * 32 + i);
+                    }
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = G.n0 + d_row(r, h);
                         float a = acc_out[sl][r] * GT::M_SCALE;
                         if (p.aggr == MDL_MEAN) {
                             const float deg = fmaxf(cnt[r], 1.0f);
                             a = M::FAST ? a * __builtin_amdgcn_rcpf(deg) : a / deg;
                         }
-                        const int64_t o = (int64_t)n * dm.C + sl * 32 + i;
-                        Elem<T>::st(out + o, Elem<T>::ld(x + o) + a);
+                        if (n < G.n1) Elem<T>::st(out + (int64_t)n * dm.C + sl * 32 + i, xr[sl][r] + a);
                     }
-                }
+            }
+            TMARK(11);
+            if (!hasN) break;
+            G = GN;
+            primed = nextHasEdges;
         }
+        TFLUSH(0);
         return;
     }
 #endif
@@ -713,7 +789,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
     // the load pipeline never drains.  A group's epilogue (residual add, mean, store) needs no
     // dependent loads: the in-degree comes out of the one-hot MFMA (cnt) and the residual rows are
     // requested at the top of the group's last tile.
-    int gcur = gw / p.NS;
+    int gcur = __builtin_amdgcn_readfirstlane(gw / p.NS);
     if (gcur >= p.n_groups) return;
     GroupInfo G, GN;
     G.load(p, gcur);
@@ -732,9 +808,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
 
     int eb = G.e0;
     bool primed = false;          // cur / ew already hold the tile at eb (prefetched by the previous tile)
-#ifdef MDL_CG_TIMING
-    long long tprev = clock64();
-#endif
+            TRESET();
     while (true) {
         if (G.e0 == G.e1) {
             // group without edges: out = x for its nodes (mean over nothing = 0)
@@ -754,7 +828,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
             continue;
         }
         if (!primed) {
-            cur.load(p, eb, G.e1, i, G.n0);
+            cur.template load<!ST>(p, eb, G.e1, i, G.n0);
             if constexpr (ST) ew.prefetch(p, lane, eb, min(32, G.e1 - eb), cur.ep);
         }
         const int nv = min(32, G.e1 - eb);
@@ -773,14 +847,14 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
         // prefetch the next tile of the stream (same group, or the first tile of the next group)
         primed = false;
         if (!last) {
-            nxt.load(p, eb + 32, G.e1, i, G.n0);
+            nxt.template load<!ST>(p, eb + 32, G.e1, i, G.n0);
 #ifndef MDL_ABL_NOE
             if constexpr (ST) ew.prefetch(p, lane, eb + 32, min(32, G.e1 - eb - 32), nxt.ep);
 #endif
             primed = true;
         } else {
             if (hasN && GN.e0 < GN.e1) {
-                nxt.load(p, GN.e0, GN.e1, i, GN.n0);
+                nxt.template load<!ST>(p, GN.e0, GN.e1, i, GN.n0);
 #ifndef MDL_ABL_NOE
                 if constexpr (ST) ew.prefetch(p, lane, GN.e0, min(32, GN.e1 - GN.e0), nxt.ep);
 #endif
@@ -854,9 +928,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
         }
         cur = nxt;
         TMARK(6);
-#ifdef MDL_CG_TIMING
-        if (gw == 0 && lane == 0) g_cg_dbg[15] += 1;
-#endif
+            TTILE();
     }
 }
 
@@ -874,6 +946,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
     const D dm(p);
     WaveCtx<T> w;
     setup_wave<T>(p, dm, smem, WM == 1 || WM == 3, w);
+    TDECL;
 
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -903,51 +976,71 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 
     float dbf_acc = 0.0f, dbs_acc = 0.0f;
     int oh_ts = -1, oh_ss = -1;      // where this edge-slot lane currently has its 1.0 in the one-hot tables
-    for (int g = gw / p.NS; g < p.n_groups; g += gstride) {
+    for (int g = __builtin_amdgcn_readfirstlane(gw / p.NS); g < p.n_groups; g += gstride) {
         const int n0 = g * 32;
         const int n1 = (int)min((int64_t)n0 + 32, p.N);
-        const int e0 = __builtin_amdgcn_readfirstlane(p.rowptr[n0]);
-        const int e1 = __builtin_amdgcn_readfirstlane(p.rowptr[n1]);
+        const int e0 = p.rowptr[n0];          // g is wave-uniform: scalar loads
+        const int e1 = p.rowptr[n1];
 
-        // B fragments of the (1/deg-scaled) grad_out tile for the one-hot expansion to edges
-        typename M::frag_t gB[BF ? 2 : 16];
+        // ---- group prologue.  Every load below is unconditional on a clamped index and all of them are
+        // issued before the first use, so the group pays ~one memory round trip (a guarded load costs one each).
+        // (1) in-degrees of the group's nodes: lane i keeps 1/deg of node slot i
+        const int nd = min(n0 + i, n1 - 1);
+        const int dg0 = p.rowptr[nd], dg1 = p.rowptr[nd + 1];
+        // (2) grad_out columns of this lane's channel for the B fragments of the one-hot expansion to edges
+        constexpr int NFg = BF ? 2 : 16, PERg = BF ? 8 : 1;
+        float graw[NFg][PERg];
         {
-            constexpr int NF = BF ? 2 : 16, PER = BF ? 8 : 1;
+            const int chc = min(ch, dm.C - 1);
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                float v[PER];
+            for (int f = 0; f < NFg; ++f)
 #pragma unroll
-                for (int q = 0; q < PER; ++q) {
+                for (int q = 0; q < PERg; ++q) {
                     const int ns = BF ? (16 * f + 8 * h + q) : (2 * f + h);
-                    const int n = n0 + ns;
-                    float gv = 0.0f;
-                    if (n < n1 && ch < dm.C) {
-                        gv = Elem<T>::ld(go + (int64_t)n * dm.C + ch);
-                        if (p.aggr == MDL_MEAN) gv = gv / (float)max(p.rowptr[n + 1] - p.rowptr[n], 1);
-                    }
-                    v[q] = gv;
+                    graw[f][q] = Elem<T>::ld(go + (int64_t)min(n0 + ns, n1 - 1) * dm.C + chc);
                 }
-                if constexpr (BF) gB[f] = pack_bf16x8(v); else gB[f] = v[0];
+        }
+        // (3) source window base.  The sources of a group's edges are its in-graph neighbours, i.e. a short
+        // node range: sums by SOURCE for the 64 nodes [wb, wb+64) are kept in registers (one-hot MFMA, like the
+        // target reduction) and flushed once per group; only sources outside the window (very large graphs)
+        // fall back to per-edge atomics.  wb = smallest source of the group.
+        int wb = 0x7fffffff;
+        for (int eb = e0; eb < e1; eb += 8 * WAVE) {
+            int sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv[u] = p.src[min(eb + u * WAVE + lane, e1 - 1)];     // clamp, never guard
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wb = min(wb, sv[u]);                                    // (clamped slots repeat a real edge)
+        }
+        // (4) first tiles of the edge stream
+        TileIdx cur, nxt, nn;
+        EWords<T, G_, EW> ew;
+        XFrags<T, CP_, VEC> xf, xn;
+        cur.template load<!ST>(p, e0, e1, i, n0);
+        nxt = cur;
+        if (e0 + 32 < e1) nxt.template load<!ST>(p, e0 + 32, e1, i, n0);
+        nn = nxt;
+        constexpr bool XDB = MDL_BWD_XDB != 0;
+        if constexpr (ST) ew.prefetch(p, lane, e0, min(32, e1 - e0), cur.ep);
+        if constexpr (CP_ != 0 && XDB) xf.load(x, dm.C, cur.tgt, cur.src, h);
+
+        const float invd = (p.aggr == MDL_MEAN) ? 1.0f / (float)max(dg1 - dg0, 1) : 1.0f;
+        typename M::frag_t gB[NFg];
+#pragma unroll
+        for (int f = 0; f < NFg; ++f) {
+            float v[PERg];
+#pragma unroll
+            for (int q = 0; q < PERg; ++q) {
+                const int ns = BF ? (16 * f + 8 * h + q) : (2 * f + h);
+                const float sc = __shfl(invd, ns);
+                v[q] = (n0 + ns < n1 && ch < dm.C) ? graw[f][q] * sc : 0.0f;
             }
+            if constexpr (BF) gB[f] = pack_bf16x8(v); else gB[f] = v[0];
         }
 
         f32x16 Rf, Rs;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Rf[r] = 0.0f; Rs[r] = 0.0f; }
-
-        // Source window: the sources of a group's edges are its in-graph neighbours, i.e. a short
-        // node range.  Sums by SOURCE for the 64 nodes [wb, wb+64) are kept in registers (one-hot
-        // MFMA, like the target reduction) and flushed once per group; only sources outside the
-        // window (very large graphs) fall back to per-edge atomics.  wb = smallest source of the group.
-        int wb = 0x7fffffff;
-        for (int eb = e0; eb < e1; eb += 4 * WAVE) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int eid = eb + u * WAVE + lane;
-                const int sv = p.src[min(eid, e1 - 1)];                 // clamp, never guard
-                wb = min(wb, eid < e1 ? sv : 0x7fffffff);
-            }
-        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) wb = min(wb, __shfl_xor(wb, o));
         wb = __builtin_amdgcn_readfirstlane(wb);
@@ -958,18 +1051,9 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             for (int r = 0; r < 16; ++r) { Wf[mt][r] = 0.0f; Ws[mt][r] = 0.0f; }
         if (lane == 0) *w.touched = 0ull;
 
-        TileIdx cur, nxt, nn;
-        EWords<T, G_, EW> ew;
-        XFrags<T, CP_, VEC> xf, xn;
-        cur.load(p, e0, e1, i, n0);
-        nxt = cur;
-        if (e0 + 32 < e1) nxt.load(p, e0 + 32, e1, i, n0);
-        nn = nxt;
-        constexpr bool XDB = MDL_BWD_XDB != 0;
-        if constexpr (CP_ != 0 && XDB) xf.load(x, dm.C, cur.tgt, cur.src, h);
-        if constexpr (ST) ew.prefetch(p, lane, e0, min(32, e1 - e0), cur.ep);
-
+            TRESET();
         for (int eb = e0; eb < e1; eb += 32) {
+            TMARK(0);
             const int nv = min(32, e1 - eb);
             const bool valid_i = i < nv;
             const int my_ts = valid_i ? (cur.tgt - n0) : 0xff;
@@ -996,18 +1080,22 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                 }
             }
             wave_lds_fence();
+            TMARK(1);
 
             if constexpr (CP_ != 0 && !XDB) xf.load(x, dm.C, cur.tgt, cur.src, h);
             if (eb + 32 < e1) {
                 if constexpr (CP_ != 0 && XDB) xn.load(x, dm.C, nxt.tgt, nxt.src, h);
-                if (eb + 64 < e1) nn.load(p, eb + 64, e1, i, n0);
+                if (eb + 64 < e1) nn.template load<!ST>(p, eb + 64, e1, i, n0);
                 if constexpr (ST) ew.prefetch(p, lane, eb + 32, min(32, e1 - eb - 32), nxt.ep);
             }
 
+            TMARK(2);
             f32x16 accf, accs;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
             pre_tile<T, CP_, VEC, WM, NKW>(p, dm, w, lane, s, cur.tgt, cur.src, xf, wr, accf, accs);
+            TPIN16(accf); TPIN16(accs);
+            TMARK(3);
 
             // dmv[edge slot][ch] = grad_out[tgt(edge)][ch] / deg : one-hot(edge -> node slot) x gB
             f32x16 dmv;
@@ -1023,6 +1111,8 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                     dmv = __builtin_amdgcn_mfma_f32_32x32x2f32((my_ts == 2 * f + h) ? 1.0f : 0.0f, gB[f], dmv, 0, 0, 0);
             }
 
+            TPIN16(dmv);
+            TMARK(4);
             // gate derivative -> dpre (in place in accf/accs)
             // (dmv is an exact 0 for edge slots >= nv — their one-hot row is empty — so dpre is 0 there)
 #pragma unroll
@@ -1034,12 +1124,19 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                 accs[r] = t * ss;
             }
 
+            TPIN16(accf); TPIN16(accs);
+            TMARK(5);
             DFrags<T> dp;
             dp.pack(accf, accs);
+            TMARK(6);
             if constexpr (BF) {
                 seg_reduce2_tab(dp, w.oh_t, i, h, Rf, Rs);                  // by target  -> r_tgt
+                TPIN16(Rf); TPIN16(Rs);
+                TMARK(7);
+#ifndef MDL_ABL_NOWIN
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) seg_reduce2_tab(dp, w.oh_w, i + 32 * mt, h, Wf[mt], Ws[mt]);   // by source window
+#endif
             } else {
                 unsigned t4[4], s4[4];
 #pragma unroll
@@ -1049,6 +1146,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                 for (int mt = 0; mt < 2; ++mt) seg_reduce2<T>(dp, s4, (unsigned)(i + 32 * mt), Wf[mt], Ws[mt]);
             }
 
+            TMARK(8);
             // sources outside the window: per-edge fp32 atomics (rare: graphs wider than the window)
             if (__any(oob) && ch < dm.C) {
 #pragma unroll
@@ -1064,6 +1162,9 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 
             // dwe[ch][gcol] += sum_slot dpre[slot][ch] * e[slot][gcol]
             //   A = dpre^T (lane = channel, k = edge slots: own registers), B = e tile column (LDS)
+#ifdef MDL_ABL_NODWE
+            if (false)
+#endif
 #pragma unroll
             for (int nt = 0; nt < GNT; ++nt) {
                 const int gcol = nt * 32 + i;
@@ -1091,6 +1192,8 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             cur = nxt;
             nxt = nn;
             if constexpr (XDB) xf = xn;
+            TMARK(9);
+            TTILE();
         }
 
         // flush the source window: one atomic row update per touched window node (instead of per edge)
@@ -1123,8 +1226,10 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                 dst[dm.Cp] = Rs[r];
             }
         }
+        TMARK(11);
     }
 
+    TFLUSH(16);
     if (p.db) {
         dbf_acc += __shfl_xor(dbf_acc, 32);
         dbs_acc += __shfl_xor(dbs_acc, 32);
@@ -1216,7 +1321,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     const int w_bytes = (p.w_elems * (int)sizeof(T) + 15) & ~15;
     const int waves = bwd ? 4 : MDL_FWD_THREADS / 64;
     // static fast shapes keep W in registers (no LDS copy); otherwise LDS if it fits, else global
-    const bool fast = p.G == 50 && p.C == d.Cp && (d.Cp == 32 || d.Cp == 64) &&
+    const bool fast = !p.eperm && p.G == 50 && p.C == d.Cp && (d.Cp == 32 || d.Cp == 64) &&
                       (sizeof(T) == 2 ? (vec == 8 && EW == 2) : d.Cp == 64);
     const bool w_lds = (!fast || MDL_CG_WM != 2) && w_bytes + waves * p.wave_lds_bytes <= LDS_CAP;
     const int lds = (w_lds ? w_bytes : 0) + waves * p.wave_lds_bytes;
@@ -1228,6 +1333,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     // backward is register-allocated for MDL_BWD_WAVES waves per SIMD: 1 -> one 4-wave workgroup per CU
     const int64_t cap = 256 * ((bwd && MDL_BWD_WAVES == 1) ? 1 : wg_per_cu);
     if (grid > cap) grid = cap;
+    if (const char* gc = getenv("MDL_GRID_CAP")) { const int64_t c = atoll(gc); if (c > 0 && grid > c) grid = c; }   // experiments
     // total waves must be a multiple of NS so that every wave keeps one channel slice
     while ((grid * waves) % d.NS) ++grid;
 

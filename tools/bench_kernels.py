@@ -41,11 +41,14 @@ try:
     import ctypes
     L = _lib.lib()
     if hasattr(L, "mdl_debug_read"):
-        buf = (ctypes.c_longlong * 16)()
+        buf = (ctypes.c_longlong * 48)()
         L.mdl_debug_read(buf)
         v = list(buf)
         n = max(v[15], 1)
-        names = ["loop-top/idx wait", "commit+tsl", "issue x/prefetch", "pre GEMM", "gate", "reduce", "epilogue/advance"]
-        print("per-tile cycles (wave 0, %d tiles):" % n, {names[k]: round(v[k] / n) for k in range(7)}, "sum", round(sum(v[:7]) / n))
+        names = ["loop top (wait prefetch)", "commit+tsl", "issue x/prefetch", "pre0", "gate0", "reduce0", "pre1", "gate1", "reduce1", "-", "group prologue", "group epilogue"]
+        print("fwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[14] / n), {names[k]: round(v[k] / n) for k in range(12)}, "sum", round(sum(v[:12]) / n))
+        n = max(v[31], 1)
+        names = ["loop top", "commit+tables", "issue loads", "pre", "dmv", "gate deriv", "pack", "reduce tgt", "reduce win", "dwe+rest", "group prologue", "group epilogue"]
+        print("bwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[30] / n), {names[k]: round(v[16 + k] / n) for k in range(12)}, "sum", round(sum(v[16:28]) / n))
 except Exception as e:
     print("no timing:", e)
