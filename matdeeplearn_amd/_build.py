@@ -29,7 +29,7 @@ def sources():
 
 
 def _deps_mtime():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "mdl_hip.h"))
     return max(os.path.getmtime(h) for h in hdrs)
 

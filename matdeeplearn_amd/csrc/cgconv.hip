@@ -50,12 +50,22 @@
 #ifndef MDL_CG_PHASE_BARRIERS
 #define MDL_CG_PHASE_BARRIERS 0
 #endif
+#ifndef MDL_CG_CB_DEFAULT
+#define MDL_CG_CB_DEFAULT 0   // 1: cooperative column-block kernels for the static bf16 shapes
+#endif
+#ifndef MDL_CB_FWD_WG_PER_CU
+#define MDL_CB_FWD_WG_PER_CU 2
+#endif
 #ifndef MDL_BWD_WAVES
 #define MDL_BWD_WAVES 1   // waves per SIMD the backward kernel is register-allocated for
 #endif
 
 #ifdef MDL_CG_TIMING   // experiment builds only: per-phase cycle counters of wave 0 (kept in SGPRs, flushed at the end)
 __device__ long long g_cg_dbg[48];
+__device__ long long g_cg_life[2][4096][3];     // [fwd|bwd][wave] = wall start, wall end, tiles (last launch)
+extern "C" int mdl_debug_life(long long* host, int which) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cg_life), sizeof(long long) * 4096 * 3, sizeof(long long) * 4096 * 3 * which);
+}
 extern "C" int mdl_debug_read(long long* host48) {
     return (int)hipMemcpyFromSymbol(host48, HIP_SYMBOL(g_cg_dbg), 48 * sizeof(long long));
 }
@@ -63,12 +73,12 @@ extern "C" int mdl_debug_reset() {
     long long z[48] = {0};
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cg_dbg), z, sizeof(z));
 }
-#define TDECL const long long tstart = clock64(); long long tprev = tstart; long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tcount = 0
+#define TDECL const long long tstart = clock64(), wstart = wall_clock64(); long long tprev = tstart; long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tcount = 0
 #define TMARK(k) do { __builtin_amdgcn_sched_barrier(0); const long long _t = clock64(); tacc[k] += _t - tprev; tprev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define TPIN16(v) do { _Pragma("unroll") for (int _r = 0; _r < 16; ++_r) asm volatile("" : "+v"(v[_r])); } while (0)
 #define TTILE() (tcount += 1)
 #define TRESET() TMARK(10)
-#define TFLUSH(base) do { if (gw == 0 && lane == 0) { for (int _k = 0; _k < 12; ++_k) g_cg_dbg[(base) + _k] += tacc[_k]; g_cg_dbg[(base) + 15] += tcount; g_cg_dbg[(base) + 14] += clock64() - tstart; } } while (0)
+#define TFLUSH(base) do { if (gw == 0 && lane == 0) { for (int _k = 0; _k < 12; ++_k) g_cg_dbg[(base) + _k] += tacc[_k]; g_cg_dbg[(base) + 15] += tcount; g_cg_dbg[(base) + 14] += clock64() - tstart; g_cg_dbg[(base) + 13] += wall_clock64() - wstart; } if (lane == 0 && gw < 4096) { g_cg_life[(base) / 16][gw][0] = wstart; g_cg_life[(base) / 16][gw][1] = wall_clock64(); g_cg_life[(base) / 16][gw][2] = tcount; } } while (0)
 #else
 #define TDECL do { } while (0)
 #if MDL_CG_PHASE_BARRIERS   // keep the phases of a tile apart in the instruction schedule (no timing)
@@ -604,13 +614,39 @@ __device__ __forceinline__ void seg_reduce_cnt(const f32x16& v, const unsigned t
     }
 }
 
-// scalars of one 32-node group
+// Work partition: wave `wi` of `W` owns the contiguous NODE range [na, nb) whose incoming edges are the
+// wi-th of W equal shares of the edge array (boundaries rounded to node boundaries), found with a wave-wide
+// 64-ary search on rowptr.  Ranges partition [0, N); a node's edges are never split, so no cross-wave
+// combination is needed, every wave carries the same number of edge tiles (+-1) whatever N is, and small
+// batches still spread over the whole chip.  Inside its range a wave walks groups of up to 32 nodes.
+__device__ __forceinline__ int wave_lower_bound(const int32_t* __restrict__ rowptr, int N, int64_t b, int lane) {
+    int lo = 0, hi = N;                        // answer = first n in [lo, hi] with rowptr[n] >= b  (rowptr[N] = E >= b)
+    while (lo < hi) {
+        const int step = (hi - lo + 63) >> 6;  // >= 1
+        const int n = min(lo + lane * step, hi);
+        const unsigned long long ge = __ballot((int64_t)rowptr[n] >= b);   // monotone in lane
+        if (ge == 0ull) { lo = min(lo + 63 * step, hi) + 1; continue; }   // all probes below b
+        const int fl = __builtin_ctzll(ge);
+        if (fl == 0) { hi = lo; break; }
+        hi = min(lo + fl * step, hi);
+        lo = lo + (fl - 1) * step + 1;
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
+}
+struct NodeRange {
+    int na, nb;
+    __device__ __forceinline__ NodeRange(const CgParams& p, int wi, int W, int lane) {
+        const int64_t b0 = p.E * (int64_t)wi / W, b1 = p.E * (int64_t)(wi + 1) / W;
+        na = (wi == 0) ? 0 : wave_lower_bound(p.rowptr, (int)p.N, b0, lane);
+        nb = (wi == W - 1) ? (int)p.N : wave_lower_bound(p.rowptr, (int)p.N, b1, lane);
+    }
+};
+// scalars of one group of <= 32 nodes [n0, n1) inside a wave's node range
 struct GroupInfo {
-    int g, n0, n1, e0, e1;
-    __device__ __forceinline__ void load(const CgParams& p, int g_) {
-        g = g_;                                   // pass a wave-uniform value: the two loads become s_load
-        n0 = g * 32;
-        n1 = (int)min((int64_t)n0 + 32, p.N);
+    int n0, n1, e0, e1;
+    __device__ __forceinline__ void load(const CgParams& p, int n0_, int nb) {
+        n0 = n0_;                                 // wave-uniform: the two loads become s_load
+        n1 = min(n0 + 32, nb);
         e0 = p.rowptr[n0];
         e1 = p.rowptr[n1];
     }
@@ -657,19 +693,20 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
         // run per 32-channel slice on the same staged operands.
         constexpr int NSL = CP_ / 32;
         const int nw_total = gridDim.x * (blockDim.x >> 6);
-        if (gw >= p.n_groups) return;
+        const NodeRange R(p, __builtin_amdgcn_readfirstlane(gw), nw_total, lane);
+        if (R.na >= R.nb) return;
         // The wave walks its groups as one continuous stream: the next group's row pointers are requested
         // at the top of the current group, and the indices / edge-feature words of the next group's first
         // tile during the current group's last tile, so a group boundary costs no dependent round trips.
         GroupInfo G, GN;
-        G.load(p, __builtin_amdgcn_readfirstlane(gw));
+        G.load(p, R.na, R.nb);
         TileIdx cur, nxt;
         EWords<T, G_, EW> ew;
         XFrags<T, CP_, VEC> xf;
         bool primed = false;                                  // cur / ew / xf already hold the group's first tile
         while (true) {
-            const bool hasN = G.g + nw_total < p.n_groups;
-            if (hasN) GN.load(p, G.g + nw_total);
+            const bool hasN = G.n1 < R.nb;
+            if (hasN) GN.load(p, G.n1, R.nb);
             if (G.e0 == G.e1) {                                  // group without edges: out = x
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl)
@@ -789,12 +826,12 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
     // the load pipeline never drains.  A group's epilogue (residual add, mean, store) needs no
     // dependent loads: the in-degree comes out of the one-hot MFMA (cnt) and the residual rows are
     // requested at the top of the group's last tile.
-    int gcur = __builtin_amdgcn_readfirstlane(gw / p.NS);
-    if (gcur >= p.n_groups) return;
+    const NodeRange R(p, __builtin_amdgcn_readfirstlane(gw / p.NS), gstride, lane);
+    if (R.na >= R.nb) return;
     GroupInfo G, GN;
-    G.load(p, gcur);
-    bool hasN = gcur + gstride < p.n_groups;
-    if (hasN) GN.load(p, gcur + gstride);
+    G.load(p, R.na, R.nb);
+    bool hasN = G.n1 < R.nb;
+    if (hasN) GN.load(p, G.n1, R.nb);
 
     f32x16 acc_out, cnt;
 #pragma unroll
@@ -821,8 +858,8 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
             }
             if (!hasN) break;
             G = GN;
-            hasN = G.g + gstride < p.n_groups;
-            if (hasN) GN.load(p, G.g + gstride);
+            hasN = G.n1 < R.nb;
+            if (hasN) GN.load(p, G.n1, R.nb);
             eb = G.e0;
             primed = false;
             continue;
@@ -920,8 +957,8 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
             for (int r = 0; r < 16; ++r) { acc_out[r] = 0.0f; cnt[r] = 0.0f; }
             if (!hasN) break;
             G = GN;
-            hasN = G.g + gstride < p.n_groups;
-            if (hasN) GN.load(p, G.g + gstride);
+            hasN = G.n1 < R.nb;
+            if (hasN) GN.load(p, G.n1, R.nb);
             eb = G.e0;
         } else {
             eb += 32;
@@ -976,10 +1013,10 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 
     float dbf_acc = 0.0f, dbs_acc = 0.0f;
     int oh_ts = -1, oh_ss = -1;      // where this edge-slot lane currently has its 1.0 in the one-hot tables
-    for (int g = __builtin_amdgcn_readfirstlane(gw / p.NS); g < p.n_groups; g += gstride) {
-        const int n0 = g * 32;
-        const int n1 = (int)min((int64_t)n0 + 32, p.N);
-        const int e0 = p.rowptr[n0];          // g is wave-uniform: scalar loads
+    const NodeRange R(p, __builtin_amdgcn_readfirstlane(gw / p.NS), gstride, lane);
+    for (int n0 = R.na; n0 < R.nb; n0 += 32) {
+        const int n1 = min(n0 + 32, R.nb);
+        const int e0 = p.rowptr[n0];          // n0 is wave-uniform: scalar loads
         const int e1 = p.rowptr[n1];
 
         // ---- group prologue.  Every load below is unconditional on a clamped index and all of them are
@@ -1253,6 +1290,8 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
     }
 }
 
+#include "cgconv_cb.inc"   // namespace mdl::cb
+
 // ------------------------------------------------------------------------------------------
 // Weight packing: nn.Linear [C, 2C+G] (target|source|edge) -> [2Cp][WS] with K order [e|x_tgt|x_src]
 // ------------------------------------------------------------------------------------------
@@ -1328,7 +1367,9 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     const int wg_per_cu = lds * 2 <= LDS_CAP ? 2 : 1;
 
     const bool all_slices = !bwd && fast && MDL_FWD_ALLSLICES && MDL_CG_WM == 1 && (sizeof(T) == 2 || w_lds);
-    int64_t items = (int64_t)p.n_groups * (all_slices ? 1 : d.NS);
+    // one node range per wave (per slice), at least ~2 edge tiles each; see NodeRange
+    const int64_t ranges = std::max<int64_t>(1, std::min<int64_t>(cdiv(p.E, 64), p.N));
+    int64_t items = ranges * (all_slices ? 1 : d.NS);
     int64_t grid = cdiv(items, waves);
     // backward is register-allocated for MDL_BWD_WAVES waves per SIMD: 1 -> one 4-wave workgroup per CU
     const int64_t cap = 256 * ((bwd && MDL_BWD_WAVES == 1) ? 1 : wg_per_cu);
@@ -1336,6 +1377,26 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     if (const char* gc = getenv("MDL_GRID_CAP")) { const int64_t c = atoll(gc); if (c > 0 && grid > c) grid = c; }   // experiments
     // total waves must be a multiple of NS so that every wave keeps one channel slice
     while ((grid * waves) % d.NS) ++grid;
+
+    // cooperative column-block kernels (cgconv_cb.inc): bf16 static shapes
+    if constexpr (sizeof(T) == 2) {
+        const char* cbe = getenv("MDL_CG_CB");
+        const bool use_cb = cbe ? atoi(cbe) != 0 : (MDL_CG_CB_DEFAULT != 0);
+        if (use_cb && fast && !bwd && p.E > 0 && p.bias_col) {
+            int cb_wgs = MDL_CB_FWD_WG_PER_CU;
+            if (const char* e2 = getenv("MDL_CB_WGS")) cb_wgs = atoi(e2);   // experiments
+            int64_t cb_grid = std::min<int64_t>(256 * cb_wgs, ranges);
+            if (const char* gc = getenv("MDL_GRID_CAP")) { const int64_t c = atoll(gc); if (c > 0 && cb_grid > c) cb_grid = c; }   // experiments
+            if (d.Cp == 64) {
+                const int cb_lds = 2 * cb::Cfg<64>::BUF_FWD;
+                hipLaunchKernelGGL(cb::fwd_kernel<64>, dim3((unsigned)cb_grid), dim3(cb::Cfg<64>::NT), cb_lds, st, p);
+            } else {
+                const int cb_lds = 2 * cb::Cfg<32>::BUF_FWD;
+                hipLaunchKernelGGL(cb::fwd_kernel<32>, dim3((unsigned)cb_grid), dim3(cb::Cfg<32>::NT), cb_lds, st, p);
+            }
+            return check_launch(name);
+        }
+    }
 
 #define MDL_CG_LAUNCH(CP_, G_, VEC_, EW_, WM_)                                                               \
     do {                                                                                                     \

@@ -24,11 +24,23 @@ class EdgeCSR:
     """Edges sorted by target.  rowptr [N+1], src/tgt [E] int32, eperm [E] int32 or None when the
     caller's per-edge tensors are already in CSR order (the product loader guarantees that)."""
 
-    __slots__ = ("rowptr", "src", "tgt", "eperm", "N", "E", "_row", "_col", "_t")
+    __slots__ = ("rowptr", "src", "tgt", "eperm", "N", "E", "_row", "_col", "_t", "_attr")
 
     def __init__(self, rowptr, src, tgt, eperm, N, E, row=None, col=None):
         self.rowptr, self.src, self.tgt, self.eperm, self.N, self.E = rowptr, src, tgt, eperm, int(N), int(E)
+        self._attr = None
         self._row, self._col, self._t = row, col, None
+
+    def sorted_attr(self, edge_attr):
+        """edge_attr rows in CSR (target-sorted) order.  The static CGConv kernels stream the edge features
+        sequentially, so an unsorted edge list is permuted ONCE per (edge_attr, CSR) here (cached; edge_attr
+        is constant across the layers of a model) instead of being gathered through eperm in every launch."""
+        if self.eperm is None:
+            return edge_attr
+        k = (edge_attr.data_ptr(), edge_attr._version, edge_attr.dtype, tuple(edge_attr.shape))
+        if self._attr is None or self._attr[0] != k:
+            self._attr = (k, edge_attr.index_select(0, self.eperm.long()).contiguous(), edge_attr)
+        return self._attr[1]
 
     @property
     def row(self):
@@ -296,8 +308,9 @@ class _CGConvFn(torch.autograd.Function):
         check(L.mdl_cgconv_pack_weights(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpack), ptr(bpack), dt,
                                         stream()), "mdl_cgconv_pack_weights")
         out = torch.empty_like(x)
+        edge_attr = csr.sorted_attr(edge_attr)          # CSR order: the kernels never go through eperm
         check(_launch_timed("fwd", lambda: L.mdl_cgconv_fwd(
-            ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(csr.eperm), ptr(wpack),
+            ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
             ptr(bpack), ptr(out), N, E, C, G, aggr, dt, stream())), "mdl_cgconv_fwd")
         ctx.save_for_backward(x, edge_attr, wf32, ws32, wpack, bpack)
         ctx.csr, ctx.aggr, ctx.has_bias = csr, aggr, (b_f is not None, b_s is not None)
@@ -320,7 +333,7 @@ class _CGConvFn(torch.autograd.Function):
         db = small[2 * Cp * GP:2 * Cp * GP + 2 * Cp]
         dwn = small[2 * Cp * GP + 2 * Cp:].view(4 * Cp, C)
         check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd(
-            ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(csr.eperm), ptr(wpack),
+            ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
             ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, stream())),
             "mdl_cgconv_bwd")
         # node-level dense part: rows of Wn / dWn = (f_tgt, s_tgt, f_src, s_src)

@@ -46,9 +46,25 @@ try:
         v = list(buf)
         n = max(v[15], 1)
         names = ["loop top (wait prefetch)", "commit+tsl", "issue x/prefetch", "pre0", "gate0", "reduce0", "pre1", "gate1", "reduce1", "-", "group prologue", "group epilogue"]
-        print("fwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[14] / n), {names[k]: round(v[k] / n) for k in range(12)}, "sum", round(sum(v[:12]) / n))
+        print("fwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[14] / n), {names[k]: round(v[k] / n) for k in range(12)}, "sum", round(sum(v[:12]) / n), "| shader clock %.2f GHz, wave-0 lifetime %.1f us/launch" % (v[14] / max(v[13], 1) * 0.1, v[13] / 100.0 / max(1, a.iters + 2)))
         n = max(v[31], 1)
         names = ["loop top", "commit+tables", "issue loads", "pre", "dmv", "gate deriv", "pack", "reduce tgt", "reduce win", "dwe+rest", "group prologue", "group epilogue"]
-        print("bwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[30] / n), {names[k]: round(v[16 + k] / n) for k in range(12)}, "sum", round(sum(v[16:28]) / n))
+        print("bwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[30] / n), {names[k]: round(v[16 + k] / n) for k in range(12)}, "sum", round(sum(v[16:28]) / n), "| shader clock %.2f GHz, wave-0 lifetime %.1f us/launch" % (v[30] / max(v[29], 1) * 0.1, v[29] / 100.0 / max(1, a.iters + 2)))
+    if hasattr(L, "mdl_debug_life"):
+        import numpy as np
+        for which, nm in ((0, "fwd"), (1, "bwd")):
+            buf = (ctypes.c_longlong * (4096 * 3))()
+            L.mdl_debug_life(buf, which)
+            arr = np.array(list(buf), dtype=np.int64).reshape(4096, 3)
+            arr = arr[arr[:, 1] > 0]
+            if len(arr):
+                t0 = arr[:, 0].min()
+                st, en = (arr[:, 0] - t0) / 100.0, (arr[:, 1] - t0) / 100.0
+                life = en - st
+                print("%s waves %d: start us min/med/max %.1f %.1f %.1f | end us min/med/max %.1f %.1f %.1f | life us min/med/max %.1f %.1f %.1f | tiles min/med/max %d %d %d" % (
+                    nm, len(arr), st.min(), np.median(st), st.max(), en.min(), np.median(en), en.max(), life.min(), np.median(life), life.max(),
+                    arr[:, 2].min(), np.median(arr[:, 2]), arr[:, 2].max()))
+                q = np.argsort(en)[-8:]
+                print("   slowest waves:", [(int(k), round(float(st[k]), 1), round(float(en[k]), 1), int(arr[k, 2])) for k in q])
 except Exception as e:
     print("no timing:", e)
