@@ -1382,7 +1382,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     if constexpr (sizeof(T) == 2) {
         const char* cbe = getenv("MDL_CG_CB");
         const bool use_cb = cbe ? atoi(cbe) != 0 : (MDL_CG_CB_DEFAULT != 0);
-        if (use_cb && fast && !bwd && p.E > 0 && p.bias_col) {
+        if (use_cb && fast && !bwd && p.E >= 64 && p.bias_col) {   // (E >= 64: the kernels' edge-feature window is 1024 dwords)
             int cb_wgs = MDL_CB_FWD_WG_PER_CU;
             if (const char* e2 = getenv("MDL_CB_WGS")) cb_wgs = atoi(e2);   // experiments
             int64_t cb_grid = std::min<int64_t>(256 * cb_wgs, ranges);

@@ -1,3 +1,4 @@
+import os
 #!/usr/bin/env python3
 """Micro-benchmark of the conv kernels on one synthetic batch (used for rocprofv3 --pmc passes)."""
 import argparse, sys, os, time
@@ -45,6 +46,9 @@ try:
         L.mdl_debug_read(buf)
         v = list(buf)
         n = max(v[15], 1)
+        if os.environ.get("MDL_CG_CB") == "1":
+            cbn = ["data loads issue", "mfma chain", "gate+swaps", "reduce", "epilogue", "barrier", "commit (waits)", "idx issue"]
+            print("cb fwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[14] / n), {cbn[k]: round(v[k] / n) for k in range(8)})
         names = ["loop top (wait prefetch)", "commit+tsl", "issue x/prefetch", "pre0", "gate0", "reduce0", "pre1", "gate1", "reduce1", "-", "group prologue", "group epilogue"]
         print("fwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[14] / n), {names[k]: round(v[k] / n) for k in range(12)}, "sum", round(sum(v[:12]) / n), "| shader clock %.2f GHz, wave-0 lifetime %.1f us/launch" % (v[14] / max(v[13], 1) * 0.1, v[13] / 100.0 / max(1, a.iters + 2)))
         n = max(v[31], 1)
