@@ -56,6 +56,9 @@
 #ifndef MDL_CB_FWD_WG_PER_CU
 #define MDL_CB_FWD_WG_PER_CU 2
 #endif
+#ifndef MDL_FWD_PRE_DEPTH
+#define MDL_FWD_PRE_DEPTH 3   // all-slices forward: pinned LDS-read / MFMA interleave in pre_tile, reads issued ahead (-6 %)
+#endif
 #ifndef MDL_BWD_WAVES
 #define MDL_BWD_WAVES 1   // waves per SIMD the backward kernel is register-allocated for
 #endif
@@ -340,7 +343,7 @@ struct WRegs {
 };
 
 // pre-activation tile: accf/accs (32 edge slots x 32 channels of slice s), bias pre-loaded.
-template <typename T, int CP_, int VEC, int WM, int NKW, typename D>
+template <typename T, int CP_, int VEC, int WM, int NKW, int DEPTH = 0, typename D>
 __device__ __forceinline__ void pre_tile(const CgParams& p, const D& dm, const WaveCtx<T>& w, int lane, int s,
                                          int my_tgt, int my_src, const XFrags<T, CP_, VEC>& xf,
                                          const WRegs<T, NKW>& wr, f32x16& accf, f32x16& accs) {
@@ -401,6 +404,18 @@ __device__ __forceinline__ void pre_tile(const CgParams& p, const D& dm, const W
         for (int f = 0; f < NF; ++f) {      // source-node features (x_j)
             accf = M::mma(xf.s[f], ld_frag(w.wbase, rowf, dm.WS, dm.KE + dm.Cp + f * M::KSTEP, h), accf);
             accs = M::mma(xf.s[f], ld_frag(w.wbase, rows, dm.WS, dm.KE + dm.Cp + f * M::KSTEP, h), accs);
+        }
+        // Pin the schedule of the chain: DEPTH fragment reads up front, then one read behind every MFMA, so
+        // that the LDS latency of a weight fragment hides under the MFMAs issued before it.  (Left alone, hipcc keeps
+        // one or two reads in flight and every MFMA waits out a full LDS round trip.)
+        if constexpr (DEPTH > 0 && std::is_same<T, bf16_t>::value) {
+            constexpr int NMMA = 2 * (D::STATIC ? ((50 + 15) / 16 + 2 * NF) : 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, DEPTH, 0);
+#pragma unroll
+            for (int q = 0; q < NMMA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
         }
     } else {
         const T* xt = static_cast<const T*>(p.x) + (int64_t)my_tgt * dm.C;
@@ -720,13 +735,11 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                 primed = false;
                 continue;
             }
-            f32x16 acc_out[NSL], cnt;
+            f32x16 acc_out[NSL];
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_out[sl][r] = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cnt[r] = 0.0f;
             if (!primed) {
                 cur.template load<false>(p, G.e0, G.e1, i, G.n0);
                 ew.prefetch(p, lane, G.e0, min(32, G.e1 - G.e0), cur.ep);
@@ -763,7 +776,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                     const float b1 = (BC || p.bias_col) ? 0.0f : p.bpack[dm.Cp + sl * 32 + i];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { accf[r] = b0; accs[r] = b1; }
-                    pre_tile<T, CP_, VEC, WM, NKW>(p, dm, w, lane, sl, cur.tgt, cur.src, xf, wr, accf, accs);
+                    pre_tile<T, CP_, VEC, WM, NKW, MDL_FWD_PRE_DEPTH>(p, dm, w, lane, sl, cur.tgt, cur.src, xf, wr, accf, accs);
                     TPIN16(accf); TPIN16(accs);
                     TMARK(3 + 3 * sl);
 #if MDL_FWD_XEARLY
@@ -776,8 +789,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                     for (int r = 0; r < 16; ++r) m[r] = GT::sigmoid(accf[r]) * GT::softplus_u(accs[r]);
                     TPIN16(m);
                     TMARK(4 + 3 * sl);
-                    if (sl == 0) seg_reduce_cnt<T>(m, t4, i, acc_out[sl], cnt);
-                    else seg_reduce_mma<T>(m, t4, i, acc_out[sl]);
+                    seg_reduce_mma<T>(m, t4, i, acc_out[sl]);
                     TPIN16(acc_out[sl]);
                     TMARK(5 + 3 * sl);
                     __builtin_amdgcn_sched_barrier(0);      // keep the slices' register footprints apart
@@ -791,6 +803,10 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
             // epilogue: out = x + acc / deg.  All residual rows are requested first (clamped row index, no
             // guards), so the group pays one memory round trip instead of one per row.
             {
+                // in-degrees straight from rowptr (lane i keeps the degree of node slot i; no count accumulator and
+                // no count MFMAs in the tile loop), fetched together with the residual rows
+                const int ndg = min(G.n0 + i, G.n1 - 1);
+                const int dg0 = p.rowptr[ndg], dg1 = p.rowptr[ndg + 1];
                 float xr[NSL][16];
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl)
@@ -799,16 +815,17 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                         const int n = min(G.n0 + d_row(r, h), G.n1 - 1);
                         xr[sl][r] = Elem<T>::ld(x + (int64_t)n * dm.C + sl * 32 + i);
                     }
+                const float invd = M::FAST ? __builtin_amdgcn_rcpf((float)max(dg1 - dg0, 1)) : 1.0f / (float)max(dg1 - dg0, 1);
+                float invr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) invr[r] = __shfl(invd, d_row(r, h));
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int n = G.n0 + d_row(r, h);
                         float a = acc_out[sl][r] * GT::M_SCALE;
-                        if (p.aggr == MDL_MEAN) {
-                            const float deg = fmaxf(cnt[r], 1.0f);
-                            a = M::FAST ? a * __builtin_amdgcn_rcpf(deg) : a / deg;
-                        }
+                        if (p.aggr == MDL_MEAN) a *= invr[r];
                         if (n < G.n1) Elem<T>::st(out + (int64_t)n * dm.C + sl * 32 + i, xr[sl][r] + a);
                     }
             }
