@@ -1227,9 +1227,22 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
                             bf16x8 b;
+                            if constexpr (ST) {
+                                // column fragment of the row-major e tile with the LDS transpose read: each 16-lane group
+                                // reads a [4 rows][16 cols] block (lane t supplies row t>>2, cols 4*(t&3)..) and lane t gets
+                                // column t of the 4 rows.  K slots 8ks+q = rows 16ks+4h+q (q<4) and 16ks+8+4h+(q-4).
+                                typedef __attribute__((ext_vector_type(4))) short s16x4;
+                                typedef __attribute__((address_space(3))) s16x4* lds4_t;
+                                const int t = i & 15;
+                                const bf16_t* base = w.et + (16 * ks + 4 * h + (t >> 2)) * dm.EKS + nt * 32 + (i & 16) + 4 * (t & 3);
+                                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(base));
+                                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(base + 8 * dm.EKS));
+                                b = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            } else {
 #pragma unroll
-                            for (int q = 0; q < 8; ++q)
-                                b[q] = (gcol < dm.KE) ? (short)w.et[d_row(8 * ks + q, h) * dm.EKS + gcol] : (short)0;
+                                for (int q = 0; q < 8; ++q)
+                                    b[q] = (gcol < dm.KE) ? (short)w.et[d_row(8 * ks + q, h) * dm.EKS + gcol] : (short)0;
+                            }
                             dwe_acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp.f[ks], b, dwe_acc[0][nt], 0, 0, 0);
                             dwe_acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp.s[ks], b, dwe_acc[1][nt], 0, 0, 0);
                         }
