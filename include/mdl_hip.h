@@ -109,7 +109,13 @@ int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_t* rowptr, 
 int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
                    const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
                    const void* grad_out, float* r_tgt, float* r_src, float* dwe, float* db, int64_t N,
-                   int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream);
+                   int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes, mdlStream_t stream);
+
+/* Optional scratch for mdl_cgconv_bwd (caller-owned device memory, contents ignored; the library zeroes what it
+ * uses, on the stream).  With it the backward hands 32-node groups to its waves dynamically (large problems);
+ * without it (NULL / 0) every wave gets a fixed edge-balanced node range.  Same results up to the order of the
+ * fp32 atomic adds into r_src / dwe / db. */
+size_t mdl_cgconv_workspace_bytes(int64_t N, int64_t E, int C, int G, int dtype);
 
 /* Node-level dense half of the CGConv backward (same reference call site), one pass over r_tgt/r_src:
  *     dx  [N, C]   = grad_out + [r_tgt | r_src] @ Wn          Wn = wn_t^T, wn_t: [C, 4Cp] in `dtype`

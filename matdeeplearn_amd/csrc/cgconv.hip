@@ -114,6 +114,7 @@ struct CgParams {
     float* r_src;       // bwd [N, 2Cp]
     float* dwe;         // bwd [2Cp, GP]
     float* db;          // bwd [2Cp] bias gradient = column sums of r_tgt (may be null)
+    unsigned* ctr;      // bwd, optional: NS zeroed work counters (caller workspace) -> dynamic group scheduling
     int64_t N, E;
     int C, G, Cp, KE, KT, WS, EKS, NS, GP, aggr;
     int GW;             // staging words per e row
@@ -650,6 +651,7 @@ __device__ __forceinline__ int wave_lower_bound(const int32_t* __restrict__ rowp
 }
 struct NodeRange {
     int na, nb;
+    __device__ __forceinline__ NodeRange(int a, int b) : na(a), nb(b) {}
     __device__ __forceinline__ NodeRange(const CgParams& p, int wi, int W, int lane) {
         const int64_t b0 = p.E * (int64_t)wi / W, b1 = p.E * (int64_t)(wi + 1) / W;
         na = (wi == 0) ? 0 : wave_lower_bound(p.rowptr, (int)p.N, b0, lane);
@@ -1030,9 +1032,20 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 
     float dbf_acc = 0.0f, dbs_acc = 0.0f;
     int oh_ts = -1, oh_ss = -1;      // where this edge-slot lane currently has its 1.0 in the one-hot tables
-    const NodeRange R(p, __builtin_amdgcn_readfirstlane(gw / p.NS), gstride, lane);
-    for (int n0 = R.na; n0 < R.nb; n0 += 32) {
-        const int n1 = min(n0 + 32, R.nb);
+    // Work distribution.  Static: one edge-balanced node range per wave (NodeRange).  Dynamic (p.ctr, large
+    // problems): the waves of a slice take 32-node groups from a shared counter — equal tile counts do not mean equal
+    // time (graphs wider than the source window fall back to atomics, CUs differ in memory latency), and the
+    // kernel ends with its slowest wave.  The next group id is requested at the top of the current group.
+    const bool dyn = p.ctr != nullptr;
+    NodeRange R{0, 0};
+    if (!dyn) R = NodeRange(p, __builtin_amdgcn_readfirstlane(gw / p.NS), gstride, lane);
+    const int nend = dyn ? (int)p.N : R.nb;
+    int gpend = 0;                                   // lane 0: group id returned by the counter (in flight)
+    if (dyn && lane == 0) gpend = (int)atomicAdd(p.ctr + s, 1u);
+    int n0 = dyn ? 32 * __builtin_amdgcn_readfirstlane(gpend) : R.na;
+    while (n0 < nend) {
+        const int n1 = min(n0 + 32, nend);
+        if (dyn && lane == 0) gpend = (int)atomicAdd(p.ctr + s, 1u);   // next group: issued now, read at the end of this one
         const int e0 = p.rowptr[n0];          // n0 is wave-uniform: scalar loads
         const int e1 = p.rowptr[n1];
 
@@ -1294,6 +1307,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             }
         }
         TMARK(11);
+        n0 = dyn ? 32 * __builtin_amdgcn_readfirstlane(gpend) : n1;
     }
 
     TFLUSH(16);
@@ -1407,6 +1421,14 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     if (const char* gc = getenv("MDL_GRID_CAP")) { const int64_t c = atoll(gc); if (c > 0 && grid > c) grid = c; }   // experiments
     // total waves must be a multiple of NS so that every wave keeps one channel slice
     while ((grid * waves) % d.NS) ++grid;
+    // dynamic group scheduling only pays when every wave gets several 32-node groups
+    if (bwd && p.ctr) {
+        if ((int64_t)p.n_groups * d.NS >= 4 * grid * waves && d.NS <= 16) {
+            if (hipMemsetAsync(p.ctr, 0, 64, st) != hipSuccess) { set_error("%s: workspace memset failed", name); return MDL_E_LAUNCH; }
+        } else {
+            p.ctr = nullptr;
+        }
+    }
 
     // cooperative column-block kernels (cgconv_cb.inc): bf16 static shapes
     if constexpr (sizeof(T) == 2) {
@@ -1521,10 +1543,13 @@ extern "C" int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_
     return cg_launch<float>(false, p, dtype, (hipStream_t)stream, "mdl_cgconv_fwd");
 }
 
+extern "C" size_t mdl_cgconv_workspace_bytes(int64_t, int64_t, int, int, int) { return 64; }
+
 extern "C" int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
                               const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
                               const void* grad_out, float* r_tgt, float* r_src, float* dwe, float* db, int64_t N,
-                              int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream) {
+                              int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
+                              mdlStream_t stream) {
     using namespace mdl;
     int rc = cg_check("mdl_cgconv_bwd", x, edge_attr, rowptr, src, tgt, wpack, bpack, N, E, C, G, aggr, dtype);
     if (rc) return rc;
@@ -1533,6 +1558,8 @@ extern "C" int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_
     p.x = x; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = eperm;
     p.wpack = wpack; p.bpack = bpack; p.gout = grad_out; p.r_tgt = r_tgt; p.r_src = r_src; p.dwe = dwe; p.db = db;
     p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr;
+    // optional caller workspace: work counters for dynamic group scheduling (zeroed here, on the stream)
+    p.ctr = (workspace && ws_bytes >= mdl_cgconv_workspace_bytes(N, E, C, G, dtype)) ? static_cast<unsigned*>(workspace) : nullptr;
     if (dtype == MDL_BF16) return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd");
     return cg_launch<float>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd");
 }

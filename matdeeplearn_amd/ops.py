@@ -284,6 +284,19 @@ def _launch_timed(key, fn):
     return rc
 
 
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    """Per-device scratch for the kernels' work counters (the library zeroes what it uses on the stream; launches on one
+    stream are ordered, so the layers of a model share it)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = _WS[key] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    return t
+
+
 class _CGConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, edge_attr, w_f, b_f, w_s, b_s, csr, aggr):
@@ -332,10 +345,11 @@ class _CGConvFn(torch.autograd.Function):
         dwe = small[:2 * Cp * GP].view(2 * Cp, GP)
         db = small[2 * Cp * GP:2 * Cp * GP + 2 * Cp]
         dwn = small[2 * Cp * GP + 2 * Cp:].view(4 * Cp, C)
+        ws = _workspace(x.device, lib().mdl_cgconv_workspace_bytes(N, E, C, G, dt))
         check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd(
             ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
-            ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, stream())),
-            "mdl_cgconv_bwd")
+            ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt,
+            ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd")
         # node-level dense part: rows of Wn / dWn = (f_tgt, s_tgt, f_src, s_src)
         Wn = torch.cat([wf32[:, :C], ws32[:, :C], wf32[:, C:2 * C], ws32[:, C:2 * C]], dim=0)      # [4C, C]
         if dt == _lib.MDL_BF16 and C == Cp and C in (32, 64):
