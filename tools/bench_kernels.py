@@ -24,7 +24,7 @@ wf = (torch.randn(C, 2 * C + 50, device=dev) * 0.1).requires_grad_(True)
 ws = (torch.randn(C, 2 * C + 50, device=dev) * 0.1).requires_grad_(True)
 bf = torch.zeros(C, device=dev, requires_grad=True); bs = torch.zeros(C, device=dev, requires_grad=True)
 print("N=%d E=%d" % (b.num_nodes, b.num_edges))
-ev = {"fwd": [], "bwd": []}
+ev = {"fwd": [], "bwd": [], "bwd_node": []}
 for it in range(a.iters + 2):
     ops.KERNEL_EVENTS = ev if it >= 2 else None
     out = ops.cgconv(x, None, b.edge_attr, wf, bf, ws, bs, "mean", csr=b.csr)
