@@ -14,6 +14,10 @@
 // in registers across the grid-stride loop and are flushed once per wave with fp32 atomics.
 #include "mdl_common.h"
 
+#ifndef MDL_NODE_STREAM
+#define MDL_NODE_STREAM 1   // LDS-staged streaming kernel (0: the first, strided-load kernel below)
+#endif
+
 namespace mdl {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -136,6 +140,144 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_kernel(const bf16_t* __res
             }
 }
 
+// ------------------------------------------------------------------------------------------
+// Streaming version (default): 64-node tiles staged through LDS.
+//   * [r_tgt | r_src] rows of the tile are read ONCE from HBM with 16-byte coalesced loads (registers, one tile
+//     ahead), converted to bf16 and written to an LDS tile; x rows likewise;
+//   * dx uses the tile row-wise (A fragments = ds_read_b128), dWn needs both operands k-major over the NODES
+//     (R^T and x as [k = node] fragments): those come out of the same row-major tiles with the LDS transpose
+//     read ds_read_b64_tr_b16 — no strided global loads, no second pass over r_tgt/r_src.
+// Wave w: one (32-node, 32-feature) block of dx and MT*NT/4... of the (4Cp x C) dWn blocks (kept in registers over
+// the grid-stride loop, flushed once with fp32 atomics).
+template <int CP>
+__global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gout,
+                                                                    const float* __restrict__ r_tgt,
+                                                                    const float* __restrict__ r_src,
+                                                                    const bf16_t* __restrict__ wn_t, bf16_t* __restrict__ dx,
+                                                                    float* __restrict__ dwn, int64_t N) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds4_t;
+    constexpr int TN = 64;               // nodes per tile
+    constexpr int K4 = 4 * CP;           // columns of [r_tgt | r_src]
+    constexpr int LD = K4 + 8;           // LDS row stride of Wn^T and of the R tile (odd number of 16-byte slots)
+    constexpr int LX = CP + 8;           // LDS row stride of the x tile
+    constexpr int NT = CP / 32;          // 32-wide feature tiles
+    constexpr int RCH = K4 / 4;          // 16-byte chunks (4 floats) per R row
+    constexpr int NRL = TN * RCH / 256;  // R chunks per thread: 16 (CP 64) / 8 (CP 32)
+    constexpr int XCH = CP / 8;          // 16-byte chunks per x row
+    constexpr int NXL = TN * XCH / 256;  // x chunks per thread: 2 / 1
+    constexpr int MJ = (K4 / 32) * NT / 4;   // (32-row, 32-col) dWn blocks per wave: 4 / 1
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* wl = reinterpret_cast<bf16_t*>(smem);                    // Wn^T  [CP][LD]
+    bf16_t* rl = wl + CP * LD;                                       // R tile [TN][LD]
+    bf16_t* xl = rl + TN * LD;                                       // x tile [TN][LX]
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, wv = tid >> 6;
+    for (int q = tid; q < CP * (K4 / 8); q += 256) {
+        const int row = q / (K4 / 8), c8 = q - row * (K4 / 8);
+        *reinterpret_cast<bf16x8*>(wl + row * LD + c8 * 8) = *reinterpret_cast<const bf16x8*>(wn_t + row * K4 + c8 * 8);
+    }
+    f32x16 dw[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw[j][r] = 0.0f;
+
+    const int64_t n_tiles = (N + TN - 1) / TN;
+    f32x4 rreg[NRL];
+    u32x4_t xreg[NXL];
+    // thread -> chunk mapping: chunk c = l*256 + tid; with RCH | 256 or 256 | RCH*k the row advances by a constant per l,
+    // so full tiles use one per-thread pointer + compile-time offsets
+    static_assert(256 % RCH == 0 && 256 % XCH == 0, "chunk mapping");
+    constexpr int RROWS = 256 / RCH, XROWS = 256 / XCH;      // rows covered by one load of the whole workgroup
+    const int rrow0 = tid / RCH, rcc = tid % RCH, xrow0 = tid / XCH, xcc = tid % XCH;
+    const float* rsel = (rcc < RCH / 2) ? r_tgt + 4 * rcc : r_src + 4 * (rcc - RCH / 2);
+    auto load_tile = [&](int64_t tile) {
+        const int64_t nb = tile * TN;
+        if (nb + TN <= N) {
+            const float* rp = rsel + (nb + rrow0) * (2 * CP);
+            const bf16_t* xp = x + (nb + xrow0) * CP + 8 * xcc;
+#pragma unroll
+            for (int l = 0; l < NRL; ++l) rreg[l] = *reinterpret_cast<const f32x4*>(rp + l * (RROWS * 2 * CP));
+#pragma unroll
+            for (int l = 0; l < NXL; ++l) xreg[l] = *reinterpret_cast<const u32x4_t*>(xp + l * (XROWS * CP));
+        } else {                                                                          // last tile: clamp the rows
+#pragma unroll
+            for (int l = 0; l < NRL; ++l)
+                rreg[l] = *reinterpret_cast<const volatile f32x4*>(rsel + min(nb + rrow0 + l * RROWS, N - 1) * (2 * CP));
+#pragma unroll
+            for (int l = 0; l < NXL; ++l)
+                xreg[l] = *reinterpret_cast<const volatile u32x4_t*>(x + min(nb + xrow0 + l * XROWS, N - 1) * CP + 8 * xcc);
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < n_tiles) load_tile(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int64_t nb = tile * TN;
+        __syncthreads();                                   // everyone is done reading the previous tile (and Wn is in)
+#pragma unroll
+        for (int l = 0; l < NRL; ++l) {
+            const int row = rrow0 + l * RROWS, cc = rcc;
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+            const u32x2_t v = {pk_bf16(rreg[l][0], rreg[l][1]), pk_bf16(rreg[l][2], rreg[l][3])};
+            *reinterpret_cast<u32x2_t*>(rl + row * LD + 4 * cc) = v;
+        }
+#pragma unroll
+        for (int l = 0; l < NXL; ++l) {
+            const int row = xrow0 + l * XROWS, cc = xcc;
+            u32x4_t v = xreg[l];
+            if (nb + row >= N) v = u32x4_t{0u, 0u, 0u, 0u};         // rows past the end drop out of dWn
+            *reinterpret_cast<u32x4_t*>(xl + row * LX + 8 * cc) = v;
+        }
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) load_tile(tile + gridDim.x);   // next tile's loads fly during this tile's MFMAs
+
+        // ---- dx block (mt, nt) of this wave: rows = 32 nodes, K = 4Cp, cols = 32 features
+        if (wv < 2 * NT) {
+            const int mt = wv / NT, nt = wv - mt * NT;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < K4 / 16; ++kk) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(rl + (mt * 32 + i) * LD + 16 * kk + 8 * h);
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + (nt * 32 + i) * LD + 16 * kk + 8 * h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            }
+            bf16_t gv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gv[r] = gout[min(nb + mt * 32 + d_row(r, h), N - 1) * CP + nt * 32 + i];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t n = nb + mt * 32 + d_row(r, h);
+                if (n < N) dx[n * CP + nt * 32 + i] = f2bf(bf2f(gv[r]) + acc[r]);
+            }
+        }
+        // ---- dWn blocks of this wave: rows = 32 columns of R, cols = 32 features, K = the tile's 64 nodes
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int blk = wv * MJ + j, mt = blk / NT, nt = blk - mt * NT;
+            const int t = i & 15;
+#pragma unroll
+            for (int ks = 0; ks < TN / 16; ++ks) {
+                // k-major fragments over the nodes 16ks + 8h + {0..7}: two transpose reads of [4 nodes][16 cols] blocks
+                const bf16_t* pa = rl + (16 * ks + 8 * h + (t >> 2)) * LD + mt * 32 + (i & 16) + 4 * (t & 3);
+                const bf16_t* pb = xl + (16 * ks + 8 * h + (t >> 2)) * LX + nt * 32 + (i & 16) + 4 * (t & 3);
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)pa), a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(pa + 4 * LD));
+                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)pb), b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(pb + 4 * LX));
+                const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                const bf16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                dw[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, dw[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+        const int blk = wv * MJ + j, mt = blk / NT, nt = blk - mt * NT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) unsafeAtomicAdd(dwn + (int64_t)(mt * 32 + d_row(r, h)) * CP + nt * 32 + i, dw[j][r]);
+    }
+}
+
 }  // namespace mdl
 
 extern "C" int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const float* r_tgt, const float* r_src,
@@ -149,9 +291,28 @@ extern "C" int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const fl
     MDL_REQUIRE(reinterpret_cast<uintptr_t>(wn_t) % 16 == 0 && reinterpret_cast<uintptr_t>(r_tgt) % 16 == 0 &&
                     reinterpret_cast<uintptr_t>(r_src) % 16 == 0, MDL_E_ARG, "mdl_cgconv_bwd_node: 16-byte alignment required");
     if (N == 0) return MDL_OK;
+    hipStream_t st = (hipStream_t)stream;
+#if MDL_NODE_STREAM
+    {
+        int64_t sgrid = cdiv(N, 64);
+        if (sgrid > 512) sgrid = 512;
+        if (C == 64) {
+            const int lds = (64 * (256 + 8) + 64 * (256 + 8) + 64 * (64 + 8)) * 2;
+            auto kf = cgconv_node_stream_kernel<64>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
+                               r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N);
+        } else {
+            const int lds = (32 * (128 + 8) + 64 * (128 + 8) + 64 * (32 + 8)) * 2;
+            auto kf = cgconv_node_stream_kernel<32>;
+            hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
+                               r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N);
+        }
+        return check_launch("mdl_cgconv_bwd_node");
+    }
+#endif
     int64_t grid = cdiv(N, 128);
     if (grid > 512) grid = 512;
-    hipStream_t st = (hipStream_t)stream;
     if (C == 64) {
         const int lds = 64 * (256 + 8) * 2;
         hipLaunchKernelGGL((cgconv_node_kernel<64>), dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x,
