@@ -62,17 +62,28 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ a,
         for (int j = 0; j < W; ++j) { p0[j] = save[cg * W + j]; p1[j] = save[C + cg * W + j]; }   // mean, invstd
     }
     if (active) {
-        for (int64_t n = (int64_t)blockIdx.x * rows_per_block + rl; n < N; n += (int64_t)gridDim.x * rows_per_block) {
-            float va[W];
-            Vec<T>::ld(a + n * C + cg * W, va);
-            if (MODE == 0) {
+        // four rows per trip, all loads issued before the first use (clamped row, masked contribution): a thread
+        // makes only a handful of trips, so with one load in flight the kernel is bound by memory latency
+        constexpr int U = 4;
+        const int64_t stride = (int64_t)gridDim.x * rows_per_block;
+        for (int64_t n0 = (int64_t)blockIdx.x * rows_per_block + rl; n0 < N; n0 += U * stride) {
+            float va[U][W], vb[U][W];
 #pragma unroll
-                for (int j = 0; j < W; ++j) { const float d = va[j] - p0[j]; s0[j] += d; s1[j] += d * d; }
-            } else {
-                float vb[W];
-                Vec<T>::ld(b + n * C + cg * W, vb);
+            for (int u = 0; u < U; ++u) {
+                const int64_t n = min(n0 + u * stride, N - 1);
+                Vec<T>::ld(a + n * C + cg * W, va[u]);
+                if (MODE != 0) Vec<T>::ld(b + n * C + cg * W, vb[u]);
+            }
 #pragma unroll
-                for (int j = 0; j < W; ++j) { s0[j] += va[j]; s1[j] += va[j] * ((vb[j] - p0[j]) * p1[j]); }
+            for (int u = 0; u < U; ++u) {
+                const float m = (n0 + u * stride < N) ? 1.0f : 0.0f;
+                if (MODE == 0) {
+#pragma unroll
+                    for (int j = 0; j < W; ++j) { const float d = (va[u][j] - p0[j]) * m; s0[j] += d; s1[j] += d * d; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < W; ++j) { const float v = va[u][j] * m; s0[j] += v; s1[j] += v * ((vb[u][j] - p0[j]) * p1[j]); }
+                }
             }
         }
     }
@@ -123,13 +134,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         }
     }
     // grid-stride over (row, channel group); blockDim is a multiple of CG so cg is loop invariant
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = q / CG;
-        float v[W];
-        Vec<T>::ld(x + n * C + cg * W, v);
+    constexpr int U = 4;                                     // four independent 16-byte loads in flight per thread
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < total; q0 += U * stride) {
+        float v[U][W];
 #pragma unroll
-        for (int j = 0; j < W; ++j) v[j] = v[j] * scale[j] + shiftv[j];
-        Vec<T>::st(y + n * C + cg * W, v);
+        for (int u = 0; u < U; ++u) Vec<T>::ld(x + (min(q0 + u * stride, total - 1) / CG) * C + cg * W, v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t q = q0 + u * stride;
+#pragma unroll
+            for (int j = 0; j < W; ++j) v[u][j] = v[u][j] * scale[j] + shiftv[j];
+            if (q < total) Vec<T>::st(y + (q / CG) * C + cg * W, v[u]);
+        }
     }
 }
 
@@ -153,14 +170,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         k0[j] = sums[c] * invn;            // mean(dy)
         k1[j] = sums[C + c] * invn;        // mean(dy * xhat)
     }
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = q / CG;
-        float vd[W], vx[W];
-        Vec<T>::ld(dy + n * C + cg * W, vd);
-        Vec<T>::ld(x + n * C + cg * W, vx);
+    constexpr int U = 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < total; q0 += U * stride) {
+        float vd[U][W], vx[U][W];
 #pragma unroll
-        for (int j = 0; j < W; ++j) vd[j] = gs[j] * (vd[j] - k0[j] - (vx[j] - mean[j]) * istd[j] * k1[j]);
-        Vec<T>::st(dx + n * C + cg * W, vd);
+        for (int u = 0; u < U; ++u) {
+            const int64_t n = min(q0 + u * stride, total - 1) / CG;
+            Vec<T>::ld(dy + n * C + cg * W, vd[u]);
+            Vec<T>::ld(x + n * C + cg * W, vx[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t q = q0 + u * stride;
+#pragma unroll
+            for (int j = 0; j < W; ++j) vd[u][j] = gs[j] * (vd[u][j] - k0[j] - (vx[u][j] - mean[j]) * istd[j] * k1[j]);
+            if (q < total) Vec<T>::st(dx + (q / CG) * C + cg * W, vd[u]);
+        }
     }
 }
 
@@ -176,7 +202,7 @@ static int bn_check(const char* name, int64_t N, int C, int dtype, const void* p
 static unsigned bn_grid(int64_t N, int C, int W) {
     const int rows = 256 / (C / W);
     int64_t g = cdiv(N, (int64_t)rows * 8);
-    if (g > 1024) g = 1024;
+    if (g > 512) g = 512;         // every block ends with 2C atomics on the same addresses: few, fat blocks
     return (unsigned)(g < 1 ? 1 : g);
 }
 
