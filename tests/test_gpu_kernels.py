@@ -201,8 +201,13 @@ def test_cgconv_c_abi_eperm_and_workspace_paths():
                                     P(r_tgt), P(r_src), P(dwe), P(db), n, E, C, G, 1, dt, P(wsb), ws_bytes if use_ws else 0,
                                     st()), "bwd")
         res.append((r_tgt, r_src, dwe, db))
-    for a, b in zip(*res):
-        close(a, b, 1e-4, 1e-5)
+    (rt0, rs0, dwe0, db0), (rt1, rs1, dwe1, db1) = res
+    close(rt0, rt1, 1e-6, 1e-7)          # by-target sums: same tiles' worth of bf16 terms, fp32 accumulation
+    close(dwe0, dwe1, 1e-4, 1e-5)        # fp32 partial sums per wave, atomics in a different order
+    close(db0, db1, 1e-4, 1e-5)
+    # by-source sums: an edge whose source falls outside its group's 64-node window is added in fp32 instead of as a
+    # bf16-rounded MFMA operand, and the two schedules cut the groups (hence the windows) differently
+    close(rs0, rs1, 1e-2, 1e-2)
 
 
 def test_cgconv_rejects_cpu_tensors_and_bad_shapes():
