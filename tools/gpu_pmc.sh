@@ -17,8 +17,9 @@ import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    if "cgconv" in k or "rbf" in k:
-        short = "bwd" if "bwd" in k else ("fwd" if "fwd" in k else "rbf")
+    short = "bwd" if "cgconv_bwd_kernel" in k else "fwd" if ("cgconv_fwd_kernel" in k or "cb::fwd_kernel" in k) else \
+        "node" if "cgconv_node" in k else "rbf" if "rbf_" in k else None
+    if short:
         agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k, {c: round(sum(v) / len(v), 1) for c, v in d.items()})
@@ -32,14 +33,14 @@ python - $OUT/summary.txt $OUT/plain.log > $OUT/hbm_traffic.json <<'PY'
 import ast, json, re, sys
 vals = {}
 for line in open(sys.argv[1]):
-    m = re.match(r"^(fwd|bwd|rbf) (\{.*\})\s*$", line)
+    m = re.match(r"^(fwd|bwd|rbf|node) (\{.*\})\s*$", line)
     if m:
         vals.setdefault(m.group(1), {}).update(ast.literal_eval(m.group(2)))
 ne = re.search(r"N=(\d+) E=(\d+)", open(sys.argv[2]).read())
 out = {"N": int(ne.group(1)), "E": int(ne.group(2)), "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024; separate --pmc passes"}
 for k, d in vals.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        out["mdl_cgconv_" + k if k != "rbf" else "mdl_rbf_expand"] = {
+        out[{"rbf": "mdl_rbf_expand", "node": "mdl_cgconv_bwd_node"}.get(k, "mdl_cgconv_" + k)] = {
             "fetch_kib": d["FETCH_SIZE"], "write_kib": d["WRITE_SIZE"], "bytes": int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)}
 print(json.dumps(out, indent=1))
 PY
