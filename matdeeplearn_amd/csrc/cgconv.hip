@@ -53,6 +53,9 @@
 #ifndef MDL_CG_CB_DEFAULT
 #define MDL_CG_CB_DEFAULT 0   // 1: cooperative column-block kernels for the static bf16 shapes
 #endif
+#ifndef MDL_CG_CB_BWD_DEFAULT
+#define MDL_CG_CB_BWD_DEFAULT 0   // 1: cooperative column-block backward edge pass for the static bf16 shapes
+#endif
 #ifndef MDL_CB_FWD_WG_PER_CU
 #define MDL_CB_FWD_WG_PER_CU 2
 #endif
@@ -1215,7 +1218,11 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 
             TMARK(8);
             // sources outside the window: per-edge fp32 atomics (rare: graphs wider than the window)
+#ifdef MDL_ABL_NOOOB
+            if (false) {
+#else
             if (__any(oob) && ch < dm.C) {
+#endif
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int sj = w.srcl[d_row(r, h)];
@@ -1445,6 +1452,25 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
             } else {
                 const int cb_lds = 2 * cb::Cfg<32>::BUF_FWD;
                 hipLaunchKernelGGL(cb::fwd_kernel<32>, dim3((unsigned)cb_grid), dim3(cb::Cfg<32>::NT), cb_lds, st, p);
+            }
+            return check_launch(name);
+        }
+        const char* cbb = getenv("MDL_CG_CB_BWD");
+        const bool use_cbb = cbb ? atoi(cbb) != 0 : (MDL_CG_CB_BWD_DEFAULT != 0);
+        if (use_cbb && fast && bwd && p.E >= 64 && p.bias_col) {
+            int cb_wgs = MDL_CB_BWD_OCC;
+            if (const char* e2 = getenv("MDL_CB_WGS")) cb_wgs = atoi(e2);   // experiments
+            const int64_t cb_grid = std::min<int64_t>(256 * cb_wgs, ranges);
+            if (d.Cp == 64) {
+                const int cb_lds = 2 * cb::BwdLds<64>::BUF + cb::Cfg<64>::NCB * 32 * (cb::Cfg<64>::KE + 8) * 2;
+                auto kf = cb::bwd_kernel<64>;
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds);
+                hipLaunchKernelGGL(kf, dim3((unsigned)cb_grid), dim3(cb::Cfg<64>::NT), cb_lds, st, p);
+            } else {
+                const int cb_lds = 2 * cb::BwdLds<32>::BUF + cb::Cfg<32>::NCB * 32 * (cb::Cfg<32>::KE + 8) * 2;
+                auto kf = cb::bwd_kernel<32>;
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds);
+                hipLaunchKernelGGL(kf, dim3((unsigned)cb_grid), dim3(cb::Cfg<32>::NT), cb_lds, st, p);
             }
             return check_launch(name);
         }

@@ -142,10 +142,12 @@ def test_cgconv_sum_aggr_and_isolated_nodes(dtype):
 
 
 @pytest.mark.parametrize("C", [64, 32])
-def test_cgconv_cooperative_forward_kernel_matches_oracle(C, monkeypatch):
-    """The opt-in weight-stationary forward kernel (MDL_CG_CB=1, cgconv_cb.inc) against the oracle, on a graph large
-    enough for several workgroups, multi-tile groups and partial last tiles."""
+def test_cgconv_cooperative_kernels_match_oracle(C, monkeypatch):
+    """The opt-in weight-stationary kernels (cgconv_cb.inc: forward MDL_CG_CB=1, backward edge pass MDL_CG_CB_BWD=1)
+    against the oracle, on graphs large enough for several workgroups, multi-tile groups, partial last tiles and
+    sources outside the 64-node window."""
     monkeypatch.setenv("MDL_CG_CB", "1")
+    monkeypatch.setenv("MDL_CG_CB_BWD", "1")
     _cgconv_case(700, C, 50, torch.bfloat16, True, seed=21, empty_frac=0.05)
     _cgconv_case(90, C, 50, torch.bfloat16, True, seed=22, aggr="add")
 

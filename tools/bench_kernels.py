@@ -52,6 +52,9 @@ try:
         names = ["loop top (wait prefetch)", "commit+tsl", "issue x/prefetch", "pre0", "gate0", "reduce0", "pre1", "gate1", "reduce1", "-", "group prologue", "group epilogue"]
         print("fwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[14] / n), {names[k]: round(v[k] / n) for k in range(12)}, "sum", round(sum(v[:12]) / n), "| shader clock %.2f GHz, wave-0 lifetime %.1f us/launch" % (v[14] / max(v[13], 1) * 0.1, v[13] / 100.0 / max(1, a.iters + 2)))
         n = max(v[31], 1)
+        if os.environ.get("MDL_CG_CB_BWD") == "1":
+            cbn = ["mfma chain", "dmv", "deriv+swaps", "reductions+dwe", "oob", "group flush", "commit+tables", "loads issue", "barrier"]
+            print("cb bwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[30] / n), {cbn[k]: round(v[16 + k] / n) for k in range(9)})
         names = ["loop top", "commit+tables", "issue loads", "pre", "dmv", "gate deriv", "pack", "reduce tgt", "reduce win", "dwe+rest", "group prologue", "group epilogue"]
         print("bwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[30] / n), {names[k]: round(v[16 + k] / n) for k in range(12)}, "sum", round(sum(v[16:28]) / n), "| shader clock %.2f GHz, wave-0 lifetime %.1f us/launch" % (v[30] / max(v[29], 1) * 0.1, v[29] / 100.0 / max(1, a.iters + 2)))
     if hasattr(L, "mdl_debug_life"):
