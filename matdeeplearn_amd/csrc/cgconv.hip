@@ -1194,6 +1194,25 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                 accs[r] = t * ss;
             }
 
+            // sources outside the window: per-edge fp32 atomics (graphs wider than the window).  Issued as early as the
+            // values exist: a pending atomic turns every later wait for a load into vmcnt(0) (loads and stores complete out of
+            // order with respect to each other), so the more of this tile's MFMA work lies behind them the better
+#ifdef MDL_ABL_NOOOB
+            if (false) {
+#else
+            if (__any(oob) && ch < dm.C) {
+#endif
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sj = w.srcl[d_row(r, h)];
+                    if (sj >= 0) {
+                        float* dst = p.r_src + (int64_t)sj * C2 + ch;
+                        unsafeAtomicAdd(dst, accf[r]);
+                        unsafeAtomicAdd(dst + dm.Cp, accs[r]);
+                    }
+                }
+            }
+
             TPIN16(accf); TPIN16(accs);
             TMARK(5);
             DFrags<T> dp;
@@ -1217,23 +1236,6 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             }
 
             TMARK(8);
-            // sources outside the window: per-edge fp32 atomics (rare: graphs wider than the window)
-#ifdef MDL_ABL_NOOOB
-            if (false) {
-#else
-            if (__any(oob) && ch < dm.C) {
-#endif
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int sj = w.srcl[d_row(r, h)];
-                    if (sj >= 0) {
-                        float* dst = p.r_src + (int64_t)sj * C2 + ch;
-                        unsafeAtomicAdd(dst, accf[r]);
-                        unsafeAtomicAdd(dst + dm.Cp, accs[r]);
-                    }
-                }
-            }
-
             // dwe[ch][gcol] += sum_slot dpre[slot][ch] * e[slot][gcol]
             //   A = dpre^T (lane = channel, k = edge slots: own registers), B = e tile column (LDS)
 #ifdef MDL_ABL_NODWE
