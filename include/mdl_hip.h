@@ -125,6 +125,13 @@ size_t mdl_cgconv_workspace_bytes(int64_t N, int64_t E, int C, int G, int dtype)
 int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const float* r_tgt, const float* r_src,
                         const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype, mdlStream_t stream);
 
+/* Small layout helpers around the backward (replace the cat / transpose / cast / clone chain autograd would run):
+ *   wn_t [C, 4Cp] (bf16) = Wn^T for mdl_cgconv_bwd_node from the two nn.Linear weights [C, 2C+G] (fp32);
+ *   dw_f, dw_s [C, 2C+G], db_f, db_s [C] (fp32; db_* may be NULL) from dwn [4Cp, C], dwe [2Cp, GP], db [2Cp]. */
+int mdl_cgconv_pack_node_weights(const float* w_f, const float* w_s, int C, int G, void* wn_t, int dtype, mdlStream_t stream);
+int mdl_cgconv_assemble_grads(const float* dwn, const float* dwe, const float* db, int C, int G, float* dw_f, float* dw_s,
+                              float* db_f, float* db_s, mdlStream_t stream);
+
 /* ---- K8: device-side batch assembly ---------------------------------------------------------------
  * Builds one mini-batch from the device-resident flat dataset in a single launch (one workgroup per
  * graph).  Replaces the Python collate + H2D of the PyG DataLoader built at

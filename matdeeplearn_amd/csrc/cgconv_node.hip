@@ -280,6 +280,63 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
 
 }  // namespace mdl
 
+namespace mdl {
+// wn_t [C][4Cp] (dtype bf16) = transpose of Wn = rows (f_tgt, s_tgt, f_src, s_src) of the two Linears' node columns
+__global__ __launch_bounds__(256) void cgconv_pack_node_kernel(const float* __restrict__ wf, const float* __restrict__ ws, int C,
+                                                               int Cp, int ldw, bf16_t* __restrict__ wn_t) {
+    const int total = C * 4 * Cp;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+        const int k = q / (4 * Cp), r = q - k * (4 * Cp);          // wn_t[k][r] = Wn[r][k]
+        const int blk = r / Cp, c = r - blk * Cp;                  // blk: 0 f_tgt, 1 s_tgt, 2 f_src, 3 s_src
+        float v = 0.0f;
+        if (c < C) v = ((blk & 1) ? ws : wf)[c * ldw + (blk >> 1) * C + k];
+        wn_t[q] = f2bf(v);
+    }
+}
+// dW_f / dW_s [C][2C+G] and db_f / db_s [C] from the kernels' partial layouts (dwn [4Cp][C], dwe [2Cp][GP], db [2Cp])
+__global__ __launch_bounds__(256) void cgconv_grads_kernel(const float* __restrict__ dwn, const float* __restrict__ dwe,
+                                                           const float* __restrict__ db, int C, int Cp, int G, int GP,
+                                                           float* __restrict__ dwf, float* __restrict__ dws,
+                                                           float* __restrict__ dbf, float* __restrict__ dbs) {
+    const int ldw = 2 * C + G, total = 2 * C * ldw;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+        const int part = q / (C * ldw), rem = q - part * (C * ldw);
+        const int c = rem / ldw, k = rem - c * ldw;
+        float v;
+        if (k < C) v = dwn[(part * Cp + c) * C + k];                              // target columns
+        else if (k < 2 * C) v = dwn[((2 + part) * Cp + c) * C + (k - C)];         // source columns
+        else v = dwe[(part * Cp + c) * GP + (k - 2 * C)];                         // edge-feature columns
+        (part ? dws : dwf)[rem] = v;
+    }
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < 2 * C; q += gridDim.x * blockDim.x) {
+        const int part = q / C, c = q - part * C;
+        float* dst = part ? dbs : dbf;
+        if (dst) dst[c] = db[part * Cp + c];
+    }
+}
+}  // namespace mdl
+
+extern "C" int mdl_cgconv_pack_node_weights(const float* w_f, const float* w_s, int C, int G, void* wn_t, int dtype,
+                                            mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_cgconv_pack_node_weights: bf16 only");
+    MDL_REQUIRE(w_f && w_s && wn_t && C >= 1 && G >= 0, MDL_E_ARG, "mdl_cgconv_pack_node_weights: bad arguments");
+    const int Cp = (C + 31) / 32 * 32;
+    hipLaunchKernelGGL(cgconv_pack_node_kernel, dim3((unsigned)cdiv((int64_t)C * 4 * Cp, 256)), dim3(256), 0, (hipStream_t)stream, w_f,
+                       w_s, C, Cp, 2 * C + G, (bf16_t*)wn_t);
+    return check_launch("mdl_cgconv_pack_node_weights");
+}
+
+extern "C" int mdl_cgconv_assemble_grads(const float* dwn, const float* dwe, const float* db, int C, int G, float* dw_f,
+                                         float* dw_s, float* db_f, float* db_s, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(dwn && dwe && db && dw_f && dw_s && C >= 1 && G >= 0, MDL_E_ARG, "mdl_cgconv_assemble_grads: bad arguments");
+    const int Cp = (C + 31) / 32 * 32, GP = (G + 63) / 64 * 64;
+    hipLaunchKernelGGL(cgconv_grads_kernel, dim3((unsigned)cdiv((int64_t)2 * C * (2 * C + G), 256)), dim3(256), 0, (hipStream_t)stream,
+                       dwn, dwe, db, C, Cp, G, GP, dw_f, dw_s, db_f, db_s);
+    return check_launch("mdl_cgconv_assemble_grads");
+}
+
 extern "C" int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const float* r_tgt, const float* r_src,
                                    const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype,
                                    mdlStream_t stream) {

@@ -351,21 +351,28 @@ class _CGConvFn(torch.autograd.Function):
             ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt,
             ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd")
         # node-level dense part: rows of Wn / dWn = (f_tgt, s_tgt, f_src, s_src)
-        Wn = torch.cat([wf32[:, :C], ws32[:, :C], wf32[:, C:2 * C], ws32[:, C:2 * C]], dim=0)      # [4C, C]
         if dt == _lib.MDL_BF16 and C == Cp and C in (32, 64):
-            wn_t = Wn.t().contiguous().to(torch.bfloat16)                                          # [C, 4C]
+            wn_t = torch.empty((C, 4 * Cp), dtype=torch.bfloat16, device=x.device)                 # Wn^T
+            check(lib().mdl_cgconv_pack_node_weights(ptr(wf32), ptr(ws32), C, G, ptr(wn_t), dt, stream()),
+                  "mdl_cgconv_pack_node_weights")
             dx = torch.empty_like(x)
             check(_launch_timed("bwd_node", lambda: lib().mdl_cgconv_bwd_node(
                 ptr(x), ptr(g), ptr(r_tgt), ptr(r_src), ptr(wn_t), ptr(dx), ptr(dwn), N, C, dt, stream())),
                 "mdl_cgconv_bwd_node")
-            dWn = dwn
-        else:                                                                                      # library GEMMs
-            rt = r_tgt.view(N, 2, Cp)[:, :, :C]
-            rs = r_src.view(N, 2, Cp)[:, :, :C]
-            cd = torch.float32 if dt == _lib.MDL_F32 else torch.bfloat16
-            R = torch.cat([rt[:, 0], rt[:, 1], rs[:, 0], rs[:, 1]], dim=1).to(cd)                  # [N, 4C]
-            dx = torch.addmm(g, R, Wn.to(cd))
-            dWn = torch.mm(R.t(), x).float()                                                       # [4C, C]
+            dW_f = torch.empty((C, 2 * C + G), dtype=torch.float32, device=x.device)
+            dW_s = torch.empty_like(dW_f)
+            db_f = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[0] else None
+            db_s = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[1] else None
+            check(lib().mdl_cgconv_assemble_grads(ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s),
+                                                  stream()), "mdl_cgconv_assemble_grads")
+            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None
+        Wn = torch.cat([wf32[:, :C], ws32[:, :C], wf32[:, C:2 * C], ws32[:, C:2 * C]], dim=0)      # [4C, C]
+        rt = r_tgt.view(N, 2, Cp)[:, :, :C]                                                        # library GEMMs
+        rs = r_src.view(N, 2, Cp)[:, :, :C]
+        cd = torch.float32 if dt == _lib.MDL_F32 else torch.bfloat16
+        R = torch.cat([rt[:, 0], rt[:, 1], rs[:, 0], rs[:, 1]], dim=1).to(cd)                      # [N, 4C]
+        dx = torch.addmm(g, R, Wn.to(cd))
+        dWn = torch.mm(R.t(), x).float()                                                           # [4C, C]
         dwe_f, dwe_s = dwe[:C, :G], dwe[Cp:Cp + C, :G]
         dW_f = torch.cat([dWn[0:C], dWn[2 * C:3 * C], dwe_f], dim=1).to(ctx.wdtypes[0])
         dW_s = torch.cat([dWn[C:2 * C], dWn[3 * C:4 * C], dwe_s], dim=1).to(ctx.wdtypes[1])
