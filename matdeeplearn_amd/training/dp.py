@@ -7,8 +7,11 @@ find_unused_parameters=True).  Gradient payloads here are 0.45-17.5 MB (SURVEY 5
 bound on xGMI (7 links x ~153 GB/s): bucketing, the unused-parameter graph walk and the per-forward
 buffer broadcast of DDP only add launches, so:
   * parameters are broadcast once from rank 0 (flat, coalesced);
-  * every parameter's .grad is a VIEW into one flat buffer -> backward accumulates in place;
-  * reduce_grads() issues a single all_reduce(SUM) and scales by 1/world_size (DDP averages);
+  * zero_grad() drops the gradients (grad = None): backward then hands each parameter its gradient tensor
+    without one accumulate-kernel per parameter (35 launches per step for CGCNN);
+  * reduce_grads() packs them into ONE flat buffer with a single multi-tensor copy, issues a single
+    all_reduce(SUM), scales by 1/world_size (DDP averages) and leaves every .grad a VIEW into that buffer;
+    on one GPU it does nothing at all;
   * BatchNorm running statistics stay rank-local (as in the reference: no SyncBatchNorm) and
     rank 0's are the ones saved/evaluated.
 """
@@ -51,12 +54,14 @@ class FlatDataParallel:
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views = []
         off = 0
         for p in self.params:
             if p.dtype != torch.float32:
                 raise ValueError("FlatDataParallel expects fp32 master parameters")
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat_grad[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self.zero_grad()
         if broadcast and self.world_size > 1:
             self.broadcast_state()
 
@@ -76,13 +81,26 @@ class FlatDataParallel:
                     off += t.numel()
 
     def zero_grad(self):
-        self.flat_grad.zero_()
+        for p in self.params:
+            p.grad = None
 
     def reduce_grads(self, force=False):
-        """Sum over ranks, then average (DDP semantics).  One collective per step."""
-        if self.world_size > 1 or (force and dist.is_initialized()):
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat_grad.mul_(1.0 / self.world_size)
+        """Sum over ranks, then average (DDP semantics).  One pack + one collective per step."""
+        if not (self.world_size > 1 or (force and dist.is_initialized())):
+            return
+        srcs, dsts = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()                                   # parameter unused in this step
+            elif p.grad.data_ptr() != v.data_ptr():
+                srcs.append(p.grad)
+                dsts.append(v)
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
+        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat_grad.mul_(1.0 / self.world_size)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def grad_bytes(self):
         return self.flat_grad.numel() * 4

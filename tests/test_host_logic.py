@@ -233,7 +233,7 @@ def _dp_worker(rank, world, port, tmp):
     (torch.nn.functional.l1_loss(ref(full), full.y, reduction="sum") / 8.0).backward()
     for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
         assert torch.allclose(p.grad, q.grad / world, rtol=1e-4, atol=1e-6), k
-        assert p.grad.data_ptr() >= dp.flat_grad.data_ptr()          # grads are views of the flat buffer
+        assert p.grad.data_ptr() >= dp.flat_grad.data_ptr()          # after the reduce, grads are views of the flat buffer
     opt = make_optimizer(model.parameters(), "AdamW", lr=0.01)
     opt.step()
     p1 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
