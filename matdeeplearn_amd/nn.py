@@ -56,7 +56,7 @@ def _lin(lin, h):
     """nn.Linear applied in the dtype of h (fp32 master weights, bf16 activations)."""
     if h.dtype == lin.weight.dtype:
         return lin(h)
-    return F.linear(h, lin.weight.to(h.dtype), None if lin.bias is None else lin.bias.to(h.dtype))
+    return ops.linear(h, lin.weight, lin.bias)
 
 
 def _seq(seq, h):

@@ -463,37 +463,44 @@ def gather_mul_reduce(h, csr, w=None, scale=None, reduce="sum"):
 
 
 # ------------------------------------------------------------------------------------------------
-# node-level Linear whose INPUT needs no gradient (pre-FC on the dataset features): library GEMM
-# forward, tall-skinny TN HIP GEMM for the weight gradient (contraction over ~2e5 nodes)
+# dense Linear on many rows (nodes / graphs): library GEMMs for the forward and dX, the tall-skinny TN HIP
+# GEMM for the weight gradient — dW = g^T x contracts over the ROWS (2e5 nodes, 8192 graphs), a shape the
+# library handles badly (47 us for a 64 x 64 x 8192 product, 0.7 ms for 64 x 114 x 2e5)
 # ------------------------------------------------------------------------------------------------
-class _LinearInputLeaf(torch.autograd.Function):
+class _LinearTN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         w = weight.to(x.dtype)
         out = torch.nn.functional.linear(x, w, None if bias is None else bias.to(x.dtype))
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x, w)
         ctx.wdtype, ctx.has_bias, ctx.shape = weight.dtype, bias is not None, tuple(weight.shape)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
+        x, w = ctx.saved_tensors
         g = g.contiguous()
         M, K = ctx.shape
+        dx = g @ w if ctx.needs_input_grad[0] else None
         dw = torch.zeros((M, K), dtype=torch.float32, device=g.device)
         check(lib().mdl_gemm_tn(ptr(g), g.stride(0), M, ptr(x), x.stride(0), K, ptr(dw), g.shape[0], dtype_code(g),
                                 stream()), "mdl_gemm_tn")
         db = g.sum(dim=0, dtype=torch.float32).to(ctx.wdtype) if ctx.has_bias else None
-        return None, dw.to(ctx.wdtype), db
+        return dx, dw.to(ctx.wdtype), db
+
+
+def linear(x, weight, bias):
+    """F.linear in the dtype of x (fp32 master weights); bf16 inputs with many rows, out <= 128, in <= 256 take the
+    HIP TN GEMM for dW, anything else the library autograd path."""
+    if (x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] >= 1024
+            and weight.shape[0] <= 128 and weight.shape[1] <= 256 and weight.requires_grad):
+        return _LinearTN.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
 
 
 def linear_input_leaf(x, weight, bias):
-    """F.linear for an input that needs no gradient; bf16 with out<=128, in<=256 uses the HIP TN GEMM
-    for dW, anything else falls back to the library autograd path."""
-    if (x.dtype == torch.bfloat16 and x.is_cuda and not x.requires_grad and x.dim() == 2 and x.stride(1) == 1
-            and weight.shape[0] <= 128 and weight.shape[1] <= 256):
-        return _LinearInputLeaf.apply(x, weight, bias)
-    return torch.nn.functional.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
+    """Linear for an input that needs no gradient (pre-FC on the dataset features)."""
+    return linear(x, weight, bias)
 
 
 # ------------------------------------------------------------------------------------------------
