@@ -6,7 +6,10 @@
 // pre-activations (E x C each) and the message (E x C) in HBM and aggregates with atomics.  Here
 // nothing per-edge is ever written:
 //
-//   work item  = (group of 32 consecutive TARGET nodes, 32-channel slice)  -> one wave, no barriers
+//   partition  = one contiguous, edge-balanced NODE range per wave (NodeRange; the backward can instead take 32-node
+//                groups from a counter in the caller's workspace), walked in groups of <= 32 target nodes
+//   work item  = (group, 32-channel slice) -> one wave, no barriers; the static-shape forward handles all slices
+//                of a group in one wave ("all-slices": the tile staging is shared)
 //   edge tile  = 32 consecutive CSR slots of the group (edges are sorted by target)
 //   pre        = z_tile (32 x KT) * Wpack^T (KT x 64)      MFMA 32x32, K order [e | x_tgt | x_src]
 //                  e_tile: streamed coalesced HBM -> per-wave LDS (the dominant HBM stream)
@@ -19,8 +22,10 @@
 //
 // Backward recomputes pre (no E x 2C activations are stored), expands grad_out to edges with a
 // one-hot MFMA, forms dpre = d/d(pre) on registers and reduces it three ways:
-//   r_tgt (by target: MFMA, registers), r_src (by source: fp32 atomics), dwe = dpre^T e (MFMA).
-// The node-level dense GEMMs (dx, dW_tgt, dW_src) are left to the caller (see include/mdl_hip.h).
+//   r_tgt (by target: MFMA, registers), r_src (by source: one-hot MFMA into a 64-node register window, fp32 atomics
+//   outside it), dwe = dpre^T e (MFMA).  The node-level dense products (dx, dW_tgt, dW_src) are cgconv_node.hip.
+// cgconv_cb.inc (included below) holds a second, cooperative weight-stationary design of both kernels (opt-in).
+// DESIGN.md section 4 has the measured phase breakdown and the list of variants behind the MDL_* switches below.
 //
 // dtype MDL_BF16: v_mfma_f32_32x32x16_bf16, fast gate math.  MDL_F32 (parity mode):
 // v_mfma_f32_32x32x2_f32 (bit-exact fp32 fma chain), precise gate math.
