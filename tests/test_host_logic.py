@@ -321,3 +321,40 @@ Models:
     job, proc, tr, mp = load_config(str(cfg), "Training")
     assert job["model"] == "CGCNN_demo" and mp["model"] == "CGCNN" and mp["batch_norm"] == "True"
     assert proc["graph_max_neighbors"] == 12 and tr["loss"] == "l1_loss"
+
+
+# ---------------------------------------------------------------------------------------------
+# static check of the compiled conv kernels (no GPU needed: hipcc cross-compiles gfx950)
+# ---------------------------------------------------------------------------------------------
+def test_conv_kernels_register_budget():
+    """Spills are a performance bug in these kernels, not a detail: a scratch reload is a VMEM load whose wait drains
+    the whole prefetch queue.  The backward edge kernels must not spill at all; the all-slices
+    forward is allowed its known, cold-path spills."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "matdeeplearn_amd", "csrc", "cgconv.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "cgconv.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+                        "-Wno-unused-result", "-DMDL_CG_FAST_ONLY", "-S", "--cuda-device-only", "-o", out, src],
+                       check=True, capture_output=True, timeout=600)
+        text = open(out).read()
+    stats = {}
+    for m in re.finditer(r"^(_ZN3mdl[0-9A-Za-z_]+):.*?; ScratchSize: (\d+).*?; Occupancy: (\d+)", text, re.S | re.M):
+        stats[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    def find(frag):
+        hits = [v for k, v in stats.items() if frag in k]
+        assert hits, "kernel %s not found in the assembly" % frag
+        return hits[0]
+    scratch, occ = find("cgconv_bwd_kernelItLi64ELi50")          # per-wave backward, bf16 C=64 G=50
+    assert scratch == 0 and occ == 1
+    scratch, occ = find("cgconv_fwd_kernelItLi64ELi50")          # all-slices forward
+    assert scratch <= 128 and occ == 2
+    for frag in ("2cb10fwd_kernelILi64", "2cb10bwd_kernelILi64"):  # cooperative kernels
+        scratch, occ = find(frag)
+        assert scratch == 0 and occ >= 2
