@@ -99,7 +99,7 @@ int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_t* rowptr, 
                    void* out, int64_t N, int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream);
 
 /* Backward edge pass.  With dpre_k = d loss / d (W z_k + b) in R^{2Cp} (f half | s half):
- *     r_tgt[i, :] = sum_{k: tgt_k = i} dpre_k      written once per node (no atomics)
+ *     r_tgt[i, :] = sum_{k: tgt_k = i} dpre_k      [N, 2Cp] in `dtype`, written once per node (no atomics)
  *     r_src[j, :] += sum_{k: src_k = j} dpre_k     fp32 atomics; caller zero-fills
  *     dwe[c, g]   += sum_k dpre_k[c] * edge_attr_k[g]   [2Cp, Gp] fp32, Gp = 64*ceil(G/64); caller zero-fills
  *     db[c]       += sum_i r_tgt[i, c]                  [2Cp] fp32 bias gradient; caller zero-fills; may be NULL
@@ -108,7 +108,7 @@ int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_t* rowptr, 
  * recomputed, not stored. */
 int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
                    const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
-                   const void* grad_out, float* r_tgt, float* r_src, float* dwe, float* db, int64_t N,
+                   const void* grad_out, void* r_tgt, float* r_src, float* dwe, float* db, int64_t N,
                    int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes, mdlStream_t stream);
 
 /* Optional scratch for mdl_cgconv_bwd (caller-owned device memory, contents ignored; the library zeroes what it
@@ -122,7 +122,7 @@ size_t mdl_cgconv_workspace_bytes(int64_t N, int64_t E, int C, int G, int dtype)
  *     dwn [4Cp, C] += [r_tgt | r_src]^T @ x                   fp32, caller zero-fills
  * Row blocks of Wn / dwn: (f_tgt, s_tgt, f_src, s_src), each Cp rows.  Supported: dtype MDL_BF16,
  * C in {32, 64} (C == Cp); otherwise MDL_E_UNSUPP and the caller uses library GEMMs. */
-int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const float* r_tgt, const float* r_src,
+int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const void* r_tgt, const float* r_src,
                         const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype, mdlStream_t stream);
 
 /* Small layout helpers around the backward (replace the cat / transpose / cast / clone chain autograd would run):

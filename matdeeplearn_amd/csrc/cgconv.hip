@@ -118,7 +118,7 @@ struct CgParams {
     const float* bpack;
     void* out;          // fwd
     const void* gout;   // bwd
-    float* r_tgt;       // bwd [N, 2Cp]
+    void* r_tgt;        // bwd [N, 2Cp] in the compute dtype (written once per node)
     float* r_src;       // bwd [N, 2Cp]
     float* dwe;         // bwd [2Cp, GP]
     float* db;          // bwd [2Cp] bias gradient = column sums of r_tgt (may be null)
@@ -1315,9 +1315,9 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
         for (int r = 0; r < 16; ++r) {
             const int n = n0 + d_row(r, h);
             if (n < n1) {
-                float* dst = p.r_tgt + (int64_t)n * C2 + ch;
-                dst[0] = Rf[r];
-                dst[dm.Cp] = Rs[r];
+                T* dst = static_cast<T*>(p.r_tgt) + (int64_t)n * C2 + ch;
+                Elem<T>::st(dst, Rf[r]);
+                Elem<T>::st(dst + dm.Cp, Rs[r]);
             }
         }
         TMARK(11);
@@ -1580,7 +1580,7 @@ extern "C" size_t mdl_cgconv_workspace_bytes(int64_t, int64_t, int, int, int) { 
 
 extern "C" int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
                               const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
-                              const void* grad_out, float* r_tgt, float* r_src, float* dwe, float* db, int64_t N,
+                              const void* grad_out, void* r_tgt, float* r_src, float* dwe, float* db, int64_t N,
                               int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
                               mdlStream_t stream) {
     using namespace mdl;

@@ -7,16 +7,13 @@
 // The reference gets these from autograd through eager cat/addmm ops
 // (/root/reference/matdeeplearn/models/cgcnn.py:136-145 via PyG CGConv); a library GEMM handles the
 // (4Cp x N)(N x C) product badly (K = N ~ 2e5, 256 x 64 output), so both products are done here in one
-// pass over r_tgt/r_src: HBM-bound, algorithmic bytes N*(2*2Cp*4 + 3*C*2).
+// pass over r_tgt/r_src: HBM-bound, algorithmic bytes N*(2Cp*2 + 2Cp*4 + 3*C*2).
 //
-// Workgroup = 4 waves = 128 consecutive nodes.  Wave w: dx rows of its own 32 nodes (MFMA, K = 4Cp),
-// and the dWn row block [w*Cp, (w+1)*Cp) over all 128 nodes (MFMA, K = nodes).  dWn partials stay
-// in registers across the grid-stride loop and are flushed once per wave with fp32 atomics.
+// r_tgt arrives in bf16 (the edge kernel writes it once per node in the compute dtype), r_src in fp32 (it is
+// accumulated with atomics).  dWn partials stay in registers across the grid-stride loop and are flushed once per
+// wave with fp32 atomics.
 #include "mdl_common.h"
 
-#ifndef MDL_NODE_STREAM
-#define MDL_NODE_STREAM 1   // LDS-staged streaming kernel (0: the first, strided-load kernel below)
-#endif
 
 namespace mdl {
 
@@ -27,121 +24,8 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int CP>   // CP = padded channels = C (32 or 64)
-__global__ __launch_bounds__(256, 2) void cgconv_node_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gout,
-                                                             const float* __restrict__ r_tgt,
-                                                             const float* __restrict__ r_src,
-                                                             const bf16_t* __restrict__ wn_t, bf16_t* __restrict__ dx,
-                                                             float* __restrict__ dwn, int64_t N) {
-    constexpr int K4 = 4 * CP;          // columns of [r_tgt | r_src]
-    constexpr int LD = K4 + 8;          // LDS row stride of Wn^T (odd number of 16-byte slots)
-    constexpr int NT = CP / 32;         // 32-wide feature tiles
-    constexpr int MT = CP / 32;         // 32-row tiles of this wave's dWn row block
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* wl = reinterpret_cast<bf16_t*>(smem);
-    for (int q = threadIdx.x; q < CP * (K4 / 8); q += blockDim.x) {
-        const int row = q / (K4 / 8), c8 = q - row * (K4 / 8);
-        *reinterpret_cast<bf16x8*>(wl + row * LD + c8 * 8) = *reinterpret_cast<const bf16x8*>(wn_t + row * K4 + c8 * 8);
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-    f32x16 dw[MT][NT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dw[a][b][r] = 0.0f;
-
-    const int64_t n_super = (N + 127) / 128;
-    for (int64_t sc = blockIdx.x; sc < n_super; sc += gridDim.x) {
-        const int64_t nb = sc * 128;
-        // ---- dx for this wave's 32 nodes -------------------------------------------------------
-        {
-            const int64_t node = nb + wv * 32 + i;
-            const bool ok = node < N;
-            const float* rt = r_tgt + node * (2 * CP);
-            const float* rs = r_src + node * (2 * CP);
-            f32x16 acc[NT];
-#pragma unroll
-            for (int b = 0; b < NT; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
-#pragma unroll
-            for (int kk = 0; kk < K4 / 16; ++kk) {
-                const int c0 = 16 * kk + 8 * h;
-                const float* src = (c0 < 2 * CP) ? rt + c0 : rs + (c0 - 2 * CP);
-                float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ok) {
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
-                    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-                    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-                }
-                const bf16x8 a = pack8(v);
-#pragma unroll
-                for (int b = 0; b < NT; ++b) {
-                    const bf16x8 bb = *reinterpret_cast<const bf16x8*>(wl + (b * 32 + i) * LD + 16 * kk + 8 * h);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[b], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < NT; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t n = nb + wv * 32 + d_row(r, h);
-                    if (n < N) {
-                        const int64_t o = n * CP + b * 32 + i;
-                        dx[o] = f2bf(bf2f(gout[o]) + acc[b][r]);
-                    }
-                }
-        }
-        // ---- dWn rows [wv*CP, (wv+1)*CP) over the 128 nodes ---------------------------------------
-        {
-            const float* rbase = (wv < 2) ? r_tgt : r_src;
-            const int coff = (wv & 1) * CP;                 // f-half / s-half inside the 2CP row
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                bf16x8 bfr[NT];
-#pragma unroll
-                for (int b = 0; b < NT; ++b) {
-                    bf16x8 t;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int64_t n = nb + 16 * ks + 8 * h + q;
-                        t[q] = (n < N) ? (short)x[n * CP + b * 32 + i] : (short)0;
-                    }
-                    bfr[b] = t;
-                }
-#pragma unroll
-                for (int a = 0; a < MT; ++a) {
-                    float v[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int64_t n = nb + 16 * ks + 8 * h + q;
-                        v[q] = (n < N) ? rbase[n * (2 * CP) + coff + a * 32 + i] : 0.0f;
-                    }
-                    const bf16x8 af = pack8(v);
-#pragma unroll
-                    for (int b = 0; b < NT; ++b) dw[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[b], dw[a][b], 0, 0, 0);
-                }
-            }
-        }
-    }
-    // flush dWn partials: D rows = channel slot, cols = feature
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wv * CP + a * 32 + d_row(r, h);
-                unsafeAtomicAdd(dwn + (int64_t)row * CP + b * 32 + i, dw[a][b][r]);
-            }
-}
-
 // ------------------------------------------------------------------------------------------
-// Streaming version (default): 64-node tiles staged through LDS.
+// 64-node tiles staged through LDS.
 //   * [r_tgt | r_src] rows of the tile are read ONCE from HBM with 16-byte coalesced loads (registers, one tile
 //     ahead), converted to bf16 and written to an LDS tile; x rows likewise;
 //   * dx uses the tile row-wise (A fragments = ds_read_b128), dWn needs both operands k-major over the NODES
@@ -151,7 +35,7 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_kernel(const bf16_t* __res
 // the grid-stride loop, flushed once with fp32 atomics).
 template <int CP>
 __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gout,
-                                                                    const float* __restrict__ r_tgt,
+                                                                    const bf16_t* __restrict__ r_tgt,
                                                                     const float* __restrict__ r_src,
                                                                     const bf16_t* __restrict__ wn_t, bf16_t* __restrict__ dx,
                                                                     float* __restrict__ dwn, int64_t N) {
@@ -162,16 +46,18 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
     constexpr int LD = K4 + 8;           // LDS row stride of Wn^T and of the R tile (odd number of 16-byte slots)
     constexpr int LX = CP + 8;           // LDS row stride of the x tile
     constexpr int NT = CP / 32;          // 32-wide feature tiles
-    constexpr int RCH = K4 / 4;          // 16-byte chunks (4 floats) per R row
-    constexpr int NRL = TN * RCH / 256;  // R chunks per thread: 16 (CP 64) / 8 (CP 32)
+    constexpr int TCH = 2 * CP / 8;      // 16-byte chunks per r_tgt row (8 bf16)
+    constexpr int SCH = 2 * CP / 4;      // 16-byte chunks per r_src row (4 floats)
+    constexpr int NTL = TN * TCH / 256;  // r_tgt chunks per thread: 4 (CP 64) / 2 (CP 32)
+    constexpr int NSL = TN * SCH / 256;  // r_src chunks per thread: 8 / 4
     constexpr int XCH = CP / 8;          // 16-byte chunks per x row
     constexpr int NXL = TN * XCH / 256;  // x chunks per thread: 2 / 1
     constexpr int MJ = (K4 / 32) * NT / 4;   // (32-row, 32-col) dWn blocks per wave: 4 / 1
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* wl = reinterpret_cast<bf16_t*>(smem);                    // Wn^T  [CP][LD]
-    bf16_t* rl = wl + CP * LD;                                       // R tile [TN][LD]
+    bf16_t* rl = wl + CP * LD;                                       // R tile [TN][LD]  (columns: r_tgt | r_src)
     bf16_t* xl = rl + TN * LD;                                       // x tile [TN][LX]
-    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int q = tid; q < CP * (K4 / 8); q += 256) {
         const int row = q / (K4 / 8), c8 = q - row * (K4 / 8);
         *reinterpret_cast<bf16x8*>(wl + row * LD + c8 * 8) = *reinterpret_cast<const bf16x8*>(wn_t + row * K4 + c8 * 8);
@@ -183,31 +69,33 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
         for (int r = 0; r < 16; ++r) dw[j][r] = 0.0f;
 
     const int64_t n_tiles = (N + TN - 1) / TN;
-    f32x4 rreg[NRL];
+    u32x4_t treg[NTL];
+    f32x4 sreg[NSL];
     u32x4_t xreg[NXL];
-    // thread -> chunk mapping: chunk c = l*256 + tid; with RCH | 256 or 256 | RCH*k the row advances by a constant per l,
-    // so full tiles use one per-thread pointer + compile-time offsets
-    static_assert(256 % RCH == 0 && 256 % XCH == 0, "chunk mapping");
-    constexpr int RROWS = 256 / RCH, XROWS = 256 / XCH;      // rows covered by one load of the whole workgroup
-    const int rrow0 = tid / RCH, rcc = tid % RCH, xrow0 = tid / XCH, xcc = tid % XCH;
-    const float* rsel = (rcc < RCH / 2) ? r_tgt + 4 * rcc : r_src + 4 * (rcc - RCH / 2);
+    // thread -> chunk mapping: chunk c = l*256 + tid; the chunk counts per row divide 256, so the row advances by a
+    // constant per l
+    static_assert(256 % TCH == 0 && 256 % SCH == 0 && 256 % XCH == 0, "chunk mapping");
+    constexpr int TROWS = 256 / TCH, SROWS = 256 / SCH, XROWS = 256 / XCH;     // rows covered by one load of the workgroup
+    const int trow0 = tid / TCH, tcc = tid % TCH, srow0 = tid / SCH, scc = tid % SCH, xrow0 = tid / XCH, xcc = tid % XCH;
+    // Buffer loads: the tile base is uniform (a fresh resource per tile, so any N works), each thread keeps ONE 32-bit
+    // byte offset per array, the per-l row strides go into the scalar offset, and rows past N read as zeros (range
+    // check against the bytes that remain) — no clamps, no separate last-tile path.
+    const int to = (trow0 * (2 * CP) + 8 * tcc) * 2, so = (srow0 * (2 * CP) + 4 * scc) * 4, xo = (xrow0 * CP + 8 * xcc) * 2;
+    auto rsrc = [](const void* base, int64_t bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7fffffffLL ? bytes : 0x7fffffffLL), 0x00020000);
+    };
     auto load_tile = [&](int64_t tile) {
-        const int64_t nb = tile * TN;
-        if (nb + TN <= N) {
-            const float* rp = rsel + (nb + rrow0) * (2 * CP);
-            const bf16_t* xp = x + (nb + xrow0) * CP + 8 * xcc;
+        const int64_t nb = tile * TN, rem = N - nb;
+        const __amdgpu_buffer_rsrc_t tr = rsrc(r_tgt + nb * (2 * CP), rem * (2 * CP * 2));
+        const __amdgpu_buffer_rsrc_t sr = rsrc(r_src + nb * (2 * CP), rem * (2 * CP * 4));
+        const __amdgpu_buffer_rsrc_t xr = rsrc(x + nb * CP, rem * (CP * 2));
 #pragma unroll
-            for (int l = 0; l < NRL; ++l) rreg[l] = *reinterpret_cast<const f32x4*>(rp + l * (RROWS * 2 * CP));
+        for (int l = 0; l < NTL; ++l) treg[l] = __builtin_amdgcn_raw_buffer_load_b128(tr, to, l * (TROWS * 2 * CP * 2), 0);
 #pragma unroll
-            for (int l = 0; l < NXL; ++l) xreg[l] = *reinterpret_cast<const u32x4_t*>(xp + l * (XROWS * CP));
-        } else {                                                                          // last tile: clamp the rows
+        for (int l = 0; l < NSL; ++l)
+            sreg[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sr, so, l * (SROWS * 2 * CP * 4), 0));
 #pragma unroll
-            for (int l = 0; l < NRL; ++l)
-                rreg[l] = *reinterpret_cast<const volatile f32x4*>(rsel + min(nb + rrow0 + l * RROWS, N - 1) * (2 * CP));
-#pragma unroll
-            for (int l = 0; l < NXL; ++l)
-                xreg[l] = *reinterpret_cast<const volatile u32x4_t*>(x + min(nb + xrow0 + l * XROWS, N - 1) * CP + 8 * xcc);
-        }
+        for (int l = 0; l < NXL; ++l) xreg[l] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo, l * (XROWS * CP * 2), 0);
     };
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) load_tile(tile);
@@ -215,42 +103,46 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
         const int64_t nb = tile * TN;
         __syncthreads();                                   // everyone is done reading the previous tile (and Wn is in)
 #pragma unroll
-        for (int l = 0; l < NRL; ++l) {
-            const int row = rrow0 + l * RROWS, cc = rcc;
+        for (int l = 0; l < NTL; ++l) *reinterpret_cast<u32x4_t*>(rl + (trow0 + l * TROWS) * LD + 8 * tcc) = treg[l];
+#pragma unroll
+        for (int l = 0; l < NSL; ++l) {
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-            const u32x2_t v = {pk_bf16(rreg[l][0], rreg[l][1]), pk_bf16(rreg[l][2], rreg[l][3])};
-            *reinterpret_cast<u32x2_t*>(rl + row * LD + 4 * cc) = v;
+            const u32x2_t v = {pk_bf16(sreg[l][0], sreg[l][1]), pk_bf16(sreg[l][2], sreg[l][3])};
+            *reinterpret_cast<u32x2_t*>(rl + (srow0 + l * SROWS) * LD + 2 * CP + 4 * scc) = v;
         }
 #pragma unroll
         for (int l = 0; l < NXL; ++l) {
-            const int row = xrow0 + l * XROWS, cc = xcc;
-            u32x4_t v = xreg[l];
-            if (nb + row >= N) v = u32x4_t{0u, 0u, 0u, 0u};         // rows past the end drop out of dWn
-            *reinterpret_cast<u32x4_t*>(xl + row * LX + 8 * cc) = v;
+            *reinterpret_cast<u32x4_t*>(xl + (xrow0 + l * XROWS) * LX + 8 * xcc) = xreg[l];   // rows past N are zeros
         }
         __syncthreads();
-        if (tile + gridDim.x < n_tiles) load_tile(tile + gridDim.x);   // next tile's loads fly during this tile's MFMAs
-
-        // ---- dx block (mt, nt) of this wave: rows = 32 nodes, K = 4Cp, cols = 32 features
-        if (wv < 2 * NT) {
-            const int mt = wv / NT, nt = wv - mt * NT;
+        // ---- dx block (mt, nt) of this wave: rows = 32 nodes, K = 4Cp, cols = 32 features.  The grad_out loads go
+        // out BEFORE the next tile's prefetch (loads complete in order: behind it they would wait for the whole tile)
+        const bool dxw = wv < 2 * NT;
+        const int mt0 = wv / NT, nt0 = wv - mt0 * NT;
+        const int64_t remg = N - nb - mt0 * 32;
+        const int go = (4 * h * CP + nt0 * 32 + i) * 2;
+        const bool more = tile + gridDim.x < n_tiles;
+        if (!dxw) {
+            if (more) load_tile(tile + gridDim.x);                     // next tile's loads fly during this tile's MFMAs
+        } else {
+            short gv[16];
+            const __amdgpu_buffer_rsrc_t gr = rsrc(gout + (nb + mt0 * 32) * CP, (remg > 0 ? remg : 0) * (CP * 2));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gv[r] = __builtin_amdgcn_raw_buffer_load_b16(gr, go, ((r & 3) + 8 * (r >> 2)) * CP * 2, 0);
+            if (more) load_tile(tile + gridDim.x);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
             for (int kk = 0; kk < K4 / 16; ++kk) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(rl + (mt * 32 + i) * LD + 16 * kk + 8 * h);
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + (nt * 32 + i) * LD + 16 * kk + 8 * h);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(rl + (mt0 * 32 + i) * LD + 16 * kk + 8 * h);
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + (nt0 * 32 + i) * LD + 16 * kk + 8 * h);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
             }
-            bf16_t gv[16];
+            const __amdgpu_buffer_rsrc_t dr = rsrc(dx + (nb + mt0 * 32) * CP, (remg > 0 ? remg : 0) * (CP * 2));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gv[r] = gout[min(nb + mt * 32 + d_row(r, h), N - 1) * CP + nt * 32 + i];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t n = nb + mt * 32 + d_row(r, h);
-                if (n < N) dx[n * CP + nt * 32 + i] = f2bf(bf2f(gv[r]) + acc[r]);
-            }
+            for (int r = 0; r < 16; ++r)                                 // rows past N fall outside the resource: dropped
+                __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(bf2f((bf16_t)gv[r]) + acc[r]), dr, go, ((r & 3) + 8 * (r >> 2)) * CP * 2, 0);
         }
         // ---- dWn blocks of this wave: rows = 32 columns of R, cols = 32 features, K = the tile's 64 nodes
 #pragma unroll
@@ -337,7 +229,7 @@ extern "C" int mdl_cgconv_assemble_grads(const float* dwn, const float* dwe, con
     return check_launch("mdl_cgconv_assemble_grads");
 }
 
-extern "C" int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const float* r_tgt, const float* r_src,
+extern "C" int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const void* r_tgt, const float* r_src,
                                    const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype,
                                    mdlStream_t stream) {
     using namespace mdl;
@@ -349,35 +241,19 @@ extern "C" int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const fl
                     reinterpret_cast<uintptr_t>(r_src) % 16 == 0, MDL_E_ARG, "mdl_cgconv_bwd_node: 16-byte alignment required");
     if (N == 0) return MDL_OK;
     hipStream_t st = (hipStream_t)stream;
-#if MDL_NODE_STREAM
-    {
-        int64_t sgrid = cdiv(N, 64);
-        if (sgrid > 512) sgrid = 512;
-        if (C == 64) {
-            const int lds = (64 * (256 + 8) + 64 * (256 + 8) + 64 * (64 + 8)) * 2;
-            auto kf = cgconv_node_stream_kernel<64>;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
-                               r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N);
-        } else {
-            const int lds = (32 * (128 + 8) + 64 * (128 + 8) + 64 * (32 + 8)) * 2;
-            auto kf = cgconv_node_stream_kernel<32>;
-            hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
-                               r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N);
-        }
-        return check_launch("mdl_cgconv_bwd_node");
-    }
-#endif
-    int64_t grid = cdiv(N, 128);
-    if (grid > 512) grid = 512;
+    int64_t sgrid = cdiv(N, 64);
+    if (sgrid > 512) sgrid = 512;
     if (C == 64) {
-        const int lds = 64 * (256 + 8) * 2;
-        hipLaunchKernelGGL((cgconv_node_kernel<64>), dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x,
-                           (const bf16_t*)grad_out, r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N);
+        const int lds = (64 * (256 + 8) + 64 * (256 + 8) + 64 * (64 + 8)) * 2;
+        auto kf = cgconv_node_stream_kernel<64>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
+                           (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N);
     } else {
-        const int lds = 32 * (128 + 8) * 2;
-        hipLaunchKernelGGL((cgconv_node_kernel<32>), dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x,
-                           (const bf16_t*)grad_out, r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N);
+        const int lds = (32 * (128 + 8) + 64 * (128 + 8) + 64 * (32 + 8)) * 2;
+        auto kf = cgconv_node_stream_kernel<32>;
+        hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
+                           (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N);
     }
     return check_launch("mdl_cgconv_bwd_node");
 }

@@ -19,11 +19,9 @@ typedef unsigned short bf16_t;                               // raw bf16 bits
 
 // ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) ---------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+__device__ __forceinline__ bf16_t f2bf(float f) {               // v_cvt_pk_bf16_f32 (gfx950): RNE, NaN quieted
+    const __bf16 r = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, r);
 }
 
 // two floats -> packed bf16 pair (v_cvt_pk_bf16_f32 on gfx950, round-to-nearest-even)

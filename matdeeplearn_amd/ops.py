@@ -339,7 +339,7 @@ class _CGConvFn(torch.autograd.Function):
         Cp, GP = _rup(C, 32), _rup(G, 64)
         g = g.contiguous()
         dt = dtype_code(x)
-        r_tgt = torch.empty((N, 2 * Cp), dtype=torch.float32, device=x.device)
+        r_tgt = torch.empty((N, 2 * Cp), dtype=x.dtype, device=x.device)          # by-target sums, compute dtype
         r_src = torch.zeros((N, 2 * Cp), dtype=torch.float32, device=x.device)
         small = torch.zeros(2 * Cp * GP + 2 * Cp + 4 * Cp * C, dtype=torch.float32, device=x.device)
         dwe = small[:2 * Cp * GP].view(2 * Cp, GP)

@@ -194,7 +194,7 @@ def test_cgconv_c_abi_eperm_and_workspace_paths():
     ws_bytes = L.mdl_cgconv_workspace_bytes(n, E, C, G, dt)
     assert ws_bytes > 0
     for use_ws in (False, True):
-        r_tgt = torch.empty(n, 2 * C, device=d)
+        r_tgt = torch.empty(n, 2 * C, device=d, dtype=torch.bfloat16)        # compute dtype
         r_src = torch.zeros(n, 2 * C, device=d)
         dwe = torch.zeros(2 * C, 64, device=d)
         db = torch.zeros(2 * C, device=d)
@@ -204,7 +204,7 @@ def test_cgconv_c_abi_eperm_and_workspace_paths():
                                     st()), "bwd")
         res.append((r_tgt, r_src, dwe, db))
     (rt0, rs0, dwe0, db0), (rt1, rs1, dwe1, db1) = res
-    close(rt0, rt1, 1e-6, 1e-7)          # by-target sums: same tiles' worth of bf16 terms, fp32 accumulation
+    close(rt0, rt1, 8e-3, 1e-3)          # by-target sums: fp32 accumulation, stored in bf16 (one ulp of slack)
     close(dwe0, dwe1, 1e-4, 1e-5)        # fp32 partial sums per wave, atomics in a different order
     close(db0, db1, 1e-4, 1e-5)
     # by-source sums: an edge whose source falls outside its group's 64-node window is added in fp32 instead of as a

@@ -337,13 +337,15 @@ def test_conv_kernels_register_budget():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(ROOT, "matdeeplearn_amd", "csrc", "cgconv.hip")
+    text = ""
     with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "cgconv.s")
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-                        "-Wno-unused-result", "-DMDL_CG_FAST_ONLY", "-S", "--cuda-device-only", "-o", out, src],
-                       check=True, capture_output=True, timeout=600)
-        text = open(out).read()
+        for name in ("cgconv.hip", "cgconv_node.hip"):
+            src = os.path.join(ROOT, "matdeeplearn_amd", "csrc", name)
+            out = os.path.join(td, name + ".s")
+            subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+                            "-Wno-unused-result", "-DMDL_CG_FAST_ONLY", "-S", "--cuda-device-only", "-o", out, src],
+                           check=True, capture_output=True, timeout=600)
+            text += open(out).read()
     stats = {}
     for m in re.finditer(r"^(_ZN3mdl[0-9A-Za-z_]+):.*?; ScratchSize: (\d+).*?; Occupancy: (\d+)", text, re.S | re.M):
         stats[m.group(1)] = (int(m.group(2)), int(m.group(3)))
@@ -355,6 +357,7 @@ def test_conv_kernels_register_budget():
     assert scratch == 0 and occ == 1
     scratch, occ = find("cgconv_fwd_kernelItLi64ELi50")          # all-slices forward
     assert scratch <= 128 and occ == 2
-    for frag in ("2cb10fwd_kernelILi64", "2cb10bwd_kernelILi64"):  # cooperative kernels
+    for frag in ("2cb10fwd_kernelILi64", "2cb10bwd_kernelILi64",    # cooperative kernels
+                 "cgconv_node_stream_kernelILi64", "cgconv_node_stream_kernelILi32"):    # node-level dense half
         scratch, occ = find(frag)
         assert scratch == 0 and occ >= 2
