@@ -43,6 +43,12 @@
 #ifndef MDL_FWD_XDB
 #define MDL_FWD_XDB 0     // 1: x-row gathers of tile t+1 in flight during tile t (costs 32 VGPRs)
 #endif
+#ifndef MDL_EW_BUFFER
+#define MDL_EW_BUFFER 1    // edge-feature tile prefetch with buffer loads (0: global loads, clamped second path for the array tail)
+#endif
+#ifndef MDL_BWD_UNCOND
+#define MDL_BWD_UNCOND 1   // backward tile loop: next-tile loads issued unconditionally (clamped)
+#endif
 #ifndef MDL_BWD_XDB
 #define MDL_BWD_XDB 1
 #endif
@@ -287,28 +293,41 @@ struct EWords {
     word_t w[NW];
 
     // The static kernels are only launched for target-sorted edge features (no eperm; the host permutes
-    // once).  One uniform 64-bit tile base + per-lane 32-bit offsets, no predication: rows past the end of
-    // the group belong to later edges (finite data, multiplied by exact zeros downstream); only the last
-    // tile of the whole array clamps its offsets so that nothing is read past the end of the buffer.
+    // once).  Buffer loads: a fresh resource per tile (uniform base in SGPRs, range = the bytes that remain in
+    // the array), ONE per-lane 32-bit offset, the word index j in the immediate.  No predication and no second
+    // code path: rows past the end of the group belong to later edges (finite data, multiplied by exact zeros
+    // downstream), words past the end of the array fail the range check and read as zeros.  (A clamped second
+    // path for the last tile costs more than its instructions: every control-flow join in the tile loop makes
+    // hipcc's wait-count bookkeeping assume the worse of the two paths.)
     __device__ __forceinline__ void prefetch(const CgParams& p, int lane, int eb, int /*nv*/, int /*my_ep*/) {
+#if MDL_EW_BUFFER
+        constexpr int WB = EW * (int)sizeof(T);
+        static_assert(WB == 4 || WB == 2, "staging word");
+        const char* tb = reinterpret_cast<const char*>(p.ea) + (int64_t)eb * (G_ * (int)sizeof(T));
+        const int64_t rem = (p.E - (int64_t)eb) * (G_ * (int)sizeof(T));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(tb), 0, (int)(rem < 0 ? 0 : (rem < 0x7fffffffLL ? rem : 0x7fffffffLL)), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            if constexpr (WB == 4) w[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane * WB, j * (WAVE * WB), 0);
+            else w[j] = __builtin_amdgcn_raw_buffer_load_b16(rs, lane * WB, j * (WAVE * WB), 0);
+        }
+#else
         constexpr unsigned WB = EW * sizeof(T);
         const char* tb = reinterpret_cast<const char*>(p.ea) + (int64_t)eb * (G_ * (int)sizeof(T));
         if ((int64_t)(p.E - eb) * GW >= NW * WAVE) {
-            // all NW*64 words lie inside the array (the tail of the last word belongs to the next rows and is
-            // dropped by commit): one per-lane pointer + compile-time offsets
             const char* lp = tb + lane * WB;
 #pragma unroll
             for (int j = 0; j < NW; ++j) w[j] = *reinterpret_cast<const word_t*>(lp + j * (WAVE * WB));
         } else {
-            const unsigned lim = (unsigned)((p.E - eb) * GW - 1);          // last word of the array, tile relative
+            const unsigned lim = (unsigned)((p.E - eb) * GW - 1);
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const unsigned q = min((unsigned)(j * WAVE + lane), lim);
-                // (volatile on purpose: a different instruction flavour, so hipcc cannot tail-merge these
-                // loads with the fast path's and burn 13 address register pairs on the merged block)
                 w[j] = *reinterpret_cast<const volatile word_t*>(tb + q * WB);
             }
         }
+#endif
     }
     __device__ __forceinline__ void commit(T* et, int EKS, int lane) const {
 #pragma unroll
@@ -586,7 +605,7 @@ __device__ __forceinline__ void setup_wave(const CgParams& p, const D& dm, char*
 // per-lane indices of one edge tile (lane i and lane i+32 hold the same edge slot i)
 struct TileIdx {
     int src, tgt, ep;
-    template <bool WITH_EP = true>
+    template <bool WITH_EP = true, bool GUARD_EMPTY = true>
     __device__ __forceinline__ void load(const CgParams& p, int eb, int e1, int i, int n0) {
         // RAW loads on a clamped index, nothing else.  Slots past the end of the group (eb + i >= e1) get
         // the indices of the group's last edge: valid rows whose contribution every consumer masks by
@@ -594,7 +613,8 @@ struct TileIdx {
         // inside `if (more tiles)` blocks, and any use of a loaded value inside the block makes hipcc
         // wait for it (and for every older load, i.e. the x gathers issued just before) at that point.
         // Likewise never `cond ? load : x`: hipcc branches around the load and waits at the join.
-        if (p.E == 0) { src = tgt = n0; ep = 0; return; }            // uniform: graph without edges
+        if (GUARD_EMPTY && p.E == 0) { src = tgt = n0; ep = 0; return; }   // uniform: graph without edges (callers inside
+                                                                           // a tile loop know e1 > 0 and drop the branch)
         const int ec = max(min(eb + i, e1 - 1), 0);
         src = p.src[ec];
         tgt = p.tgt[ec];
@@ -1158,11 +1178,20 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             TMARK(1);
 
             if constexpr (CP_ != 0 && !XDB) xf.load(x, dm.C, cur.tgt, cur.src, h);
+#if MDL_BWD_UNCOND
+            // Unconditional on purpose (indices are clamped, so the last tile of a group re-reads valid rows): a path
+            // that skips these loads merges into the loop with "the x fragments are the newest loads in flight", and
+            // the waits hipcc then puts in front of the MFMAs drain this tile's prefetches as well.
+            if constexpr (CP_ != 0 && XDB) xn.load(x, dm.C, nxt.tgt, nxt.src, h);
+            nn.template load<!ST, false>(p, eb + 64, e1, i, n0);
+            if constexpr (ST) ew.prefetch(p, lane, MDL_EW_BUFFER ? eb + 32 : min(eb + 32, (int)p.E - 1), 32, nxt.ep);
+#else
             if (eb + 32 < e1) {
                 if constexpr (CP_ != 0 && XDB) xn.load(x, dm.C, nxt.tgt, nxt.src, h);
                 if (eb + 64 < e1) nn.template load<!ST>(p, eb + 64, e1, i, n0);
                 if constexpr (ST) ew.prefetch(p, lane, eb + 32, min(32, e1 - eb - 32), nxt.ep);
             }
+#endif
 
             TMARK(2);
             f32x16 accf, accs;
