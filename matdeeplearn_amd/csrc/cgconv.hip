@@ -43,6 +43,9 @@
 #ifndef MDL_FWD_XDB
 #define MDL_FWD_XDB 0     // 1: x-row gathers of tile t+1 in flight during tile t (costs 32 VGPRs)
 #endif
+#ifndef MDL_FWD_UNCOND
+#define MDL_FWD_UNCOND 1   // all-slices forward: next-tile loads issued on every path (uniform selects, no branches)
+#endif
 #ifndef MDL_EW_BUFFER
 #define MDL_EW_BUFFER 1    // edge-feature tile prefetch with buffer loads (0: global loads, clamped second path for the array tail)
 #endif
@@ -745,6 +748,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
         // tile during the current group's last tile, so a group boundary costs no dependent round trips.
         GroupInfo G, GN;
         G.load(p, R.na, R.nb);
+        GN = G;
         TileIdx cur, nxt;
         EWords<T, G_, EW> ew;
         XFrags<T, CP_, VEC> xf;
@@ -787,6 +791,21 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                 if (h == 0) reinterpret_cast<unsigned char*>(w.tsl)[i] = (i < nv) ? (unsigned char)(cur.tgt - G.n0) : 0xff;
                 wave_lds_fence();
                 TMARK(1);
+#if MDL_FWD_UNCOND
+                // The next tile's loads are issued on EVERY path, from uniform selects of the tile base (next tile of
+                // this group / first tile of the next group / this tile again when the stream ends): a path that skips
+                // them joins the loop with "the x fragments are the newest loads in flight", and the waits hipcc then
+                // places in front of the x MFMAs also drain the prefetches issued a few instructions earlier.
+                {
+                    const bool nh = hasN && GN.e0 < GN.e1;
+                    nextHasEdges = last && nh;
+                    const int pe = last ? (nh ? GN.e0 : eb) : eb + 32;
+                    const int pe1 = nextHasEdges ? GN.e1 : G.e1;
+                    const int pn0 = nextHasEdges ? GN.n0 : G.n0;
+                    nxt.template load<false, false>(p, pe, pe1, i, pn0);
+                    ew.prefetch(p, lane, pe, 32, 0);
+                }
+#else
                 if (!last) {
                     nxt.template load<false>(p, eb + 32, G.e1, i, G.n0);
                     ew.prefetch(p, lane, eb + 32, min(32, G.e1 - eb - 32), nxt.ep);
@@ -795,6 +814,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                     nxt.template load<false>(p, GN.e0, GN.e1, i, GN.n0);
                     ew.prefetch(p, lane, GN.e0, min(32, GN.e1 - GN.e0), nxt.ep);
                 }
+#endif
                 TMARK(2);
                 unsigned t4[4];
 #pragma unroll
@@ -812,7 +832,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
 #if MDL_FWD_XEARLY
                     // the x rows of the NEXT tile: requested as soon as the last slice's MFMAs have consumed this
                     // tile's fragments (same registers), so their latency hides under the gate / aggregation
-                    if (sl == NSL - 1 && (!last || nextHasEdges)) xf.load(x, dm.C, nxt.tgt, nxt.src, h);
+                    if (sl == NSL - 1 && (MDL_FWD_UNCOND || !last || nextHasEdges)) xf.load(x, dm.C, nxt.tgt, nxt.src, h);
 #endif
                     f32x16 m;
 #pragma unroll
