@@ -1239,13 +1239,15 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             TMARK(4);
             // gate derivative -> dpre (in place in accf/accs)
             // (dmv is an exact 0 for edge slots >= nv — their one-hot row is empty — so dpre is 0 there)
+            {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float sf, sp_u, ss;
-                GT::deriv(accf[r], accs[r], sf, sp_u, ss);
-                const float t = dmv[r] * sf;
-                accf[r] = (t * GT::M_SCALE) * (1.0f - sf) * sp_u;
-                accs[r] = t * ss;
+                for (int r = 0; r < 16; ++r) {
+                    float sf, sp_u, ss;
+                    GT::deriv(accf[r], accs[r], sf, sp_u, ss);
+                    const float t = dmv[r] * sf;
+                    accf[r] = (t * GT::M_SCALE) * (1.0f - sf) * sp_u;
+                    accs[r] = t * ss;
+                }
             }
 
             // sources outside the window: per-edge fp32 atomics (graphs wider than the window).  Issued as early as the
@@ -1256,11 +1258,20 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 #else
             if (__any(oob) && ch < dm.C) {
 #endif
+                // the 16 source ids of this lane's rows (d_row(4q+k, h) = 8q + 4h + k) in four 16-byte LDS reads up front:
+                // read one by one between the atomics, each costs an LDS round trip the compiler will not hoist
+                typedef __attribute__((ext_vector_type(4))) int i32x4;
+                int sj[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const i32x4 v = *reinterpret_cast<const i32x4*>(w.srcl + 8 * q + 4 * h);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sj[4 * q + k] = v[k];
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int sj = w.srcl[d_row(r, h)];
-                    if (sj >= 0) {
-                        float* dst = p.r_src + (int64_t)sj * C2 + ch;
+                    if (sj[r] >= 0) {
+                        float* dst = p.r_src + (int64_t)sj[r] * C2 + ch;
                         unsafeAtomicAdd(dst, accf[r]);
                         unsafeAtomicAdd(dst + dm.Cp, accs[r]);
                     }

@@ -89,29 +89,42 @@ template <> struct Gate<false> {
 template <> struct Gate<true> {
     static constexpr float W_SCALE = LOG2E_F;
     static constexpr float M_SCALE = LN2_F;
+    // max(t, c) as ONE instruction: fmaxf() costs an extra canonicalising v_max (IEEE mode quiets signalling NaNs
+    // first), which these kernels do not need.  Plain VALU ops on compiler-managed registers: no hazards to mind.
+    __device__ static __forceinline__ float relu(float t) {
+        float r;
+        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(t));
+        return r;
+    }
+    // 2^-max(f, -126): the clamp keeps (1 + 2^-f)(1 + 2^-|s|) finite
+    __device__ static __forceinline__ float exp2_neg_capped(float f) {
+        float r;
+        asm("v_max_f32 %0, 0xc2fc0000, %1" : "=v"(r) : "v"(f));
+        return __builtin_amdgcn_exp2f(-r);
+    }
     __device__ static __forceinline__ float sigmoid(float t) {
         return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
     }
     __device__ static __forceinline__ float softplus_u(float t) {
-        return fmaxf(t, 0.0f) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(t)));
+        return relu(t) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(t)));
     }
     __device__ static __forceinline__ void softplus_sigmoid(float t, float& sp_u, float& sg) {
         const float ea = __builtin_amdgcn_exp2f(-fabsf(t));
         const float l = 1.0f + ea;
-        sp_u = fmaxf(t, 0.0f) + __builtin_amdgcn_logf(l);
+        sp_u = relu(t) + __builtin_amdgcn_logf(l);
         const float r = __builtin_amdgcn_rcpf(l);
         sg = t >= 0.0f ? r : ea * r;
     }
     // Transcendentals are the scarce resource (a wave64 v_exp/v_log/v_rcp occupies the SIMD ~8x longer
     // than an FMA): the two reciprocals 1/(1+2^-f) and 1/(1+2^-|s|) share ONE v_rcp of the product.
     __device__ static __forceinline__ void deriv(float f, float sv, float& sf, float& sp_u, float& ss) {
-        const float a1 = 1.0f + __builtin_amdgcn_exp2f(fminf(-f, 126.0f));   // clamp: a1 * l must stay finite
+        const float a1 = 1.0f + exp2_neg_capped(f);
         const float ea = __builtin_amdgcn_exp2f(-fabsf(sv));
         const float l = 1.0f + ea;
         const float r = __builtin_amdgcn_rcpf(a1 * l);
         sf = r * l;
         const float rl = r * a1;
-        sp_u = fmaxf(sv, 0.0f) + __builtin_amdgcn_logf(l);
+        sp_u = relu(sv) + __builtin_amdgcn_logf(l);
         ss = sv >= 0.0f ? rl : ea * rl;
     }
 };
