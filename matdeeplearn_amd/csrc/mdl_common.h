@@ -44,6 +44,32 @@ template <> struct Elem<bf16_t> {
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
+// ---- 16-byte row vectors (W elements) <-> floats ------------------------------------------------
+template <typename T> struct Vec;
+template <> struct Vec<bf16_t> {
+    static constexpr int W = 8;
+    typedef bf16x8 raw;
+    __device__ static __forceinline__ void ld(const bf16_t* p, float* v) {
+        const raw r = *reinterpret_cast<const raw*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bf2f((bf16_t)r[j]);
+    }
+    __device__ static __forceinline__ void st(bf16_t* p, const float* v) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u4;
+        *reinterpret_cast<u4*>(p) = u4{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+    }
+};
+template <> struct Vec<float> {
+    static constexpr int W = 4;
+    __device__ static __forceinline__ void ld(const float* p, float* v) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(p);
+        v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3];
+    }
+    __device__ static __forceinline__ void st(float* p, const float* v) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+};
+
 // ---- D-layout of the 32x32 MFMA accumulator (dtype independent on gfx950) ------------------
 // lane l, register r  ->  row = (r&3) + 8*(r>>2) + 4*(l>>5),  col = l&31
 __device__ __forceinline__ int d_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }

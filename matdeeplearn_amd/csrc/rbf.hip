@@ -7,8 +7,7 @@
 namespace mdl {
 
 // One thread produces VEC consecutive elements of the flattened [E*G] output (dense case
-// ld_out == G) so every store is a full 16-byte (fp32 x4) / 8-byte (bf16 x4) vector and a
-// wave writes 1 KiB / 512 B contiguous.  exp() is the precise ocml expf: the kernel is bound by
+// ld_out == G) so every store is a full 16-byte vector (fp32 x4 / bf16 x8) and a wave writes 1 KiB contiguous.  exp() is the precise ocml expf: the kernel is bound by
 // the store stream (50 exps per 104..204 bytes), not by VALU.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void rbf_dense_kernel(const float* __restrict__ d,
@@ -49,6 +48,10 @@ __global__ __launch_bounds__(256) void rbf_dense_kernel(const float* __restrict_
         if (base + VEC <= total) {
             if constexpr (sizeof(T) == 4) {
                 *reinterpret_cast<f32x4*>(out + base) = f32x4{v[0], v[1], v[2], v[3]};
+            } else if constexpr (VEC == 8) {
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                *reinterpret_cast<u32x4*>(out + base) =
+                    u32x4{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
             } else {
                 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
                 *reinterpret_cast<u32x2*>(out + base) = u32x2{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
@@ -81,9 +84,10 @@ static int launch_rbf(const float* d, const float* offsets, float coeff, T* out,
     if (E == 0) return MDL_OK;
     const int64_t total = E * G;
     if (ld == G && (reinterpret_cast<uintptr_t>(out) % 16) == 0) {
-        int64_t blocks = cdiv(cdiv(total, 4), 256);
+        constexpr int VEC = 16 / (int)sizeof(T);       // 16-byte stores: 4 floats / 8 bf16 per thread
+        int64_t blocks = cdiv(cdiv(total, VEC), 256);
         if (blocks > 256 * 8) blocks = 256 * 8;
-        hipLaunchKernelGGL((rbf_dense_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), 0, st, d, offsets, coeff,
+        hipLaunchKernelGGL((rbf_dense_kernel<T, VEC>), dim3((unsigned)blocks), dim3(256), 0, st, d, offsets, coeff,
                            out, total, G);
     } else {
         int64_t blocks = cdiv(total, 256);

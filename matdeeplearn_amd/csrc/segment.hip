@@ -82,6 +82,70 @@ __global__ __launch_bounds__(256) void seg_bwd_max_kernel(const T* __restrict__ 
     }
 }
 
+// 16-byte fast paths (sum / mean, rows in place, C a multiple of the vector width): one thread owns W channels of one
+// segment and streams its rows with 16-byte loads, four in flight; the backward writes one 16-byte vector per thread.
+template <typename T, int REDUCE>
+__global__ __launch_bounds__(256) void seg_fwd_vec_kernel(const T* __restrict__ src, const int32_t* __restrict__ rowptr,
+                                                          T* __restrict__ out, int64_t N, int CG) {
+    constexpr int W = Vec<T>::W, U = 4;
+    const int64_t total = N * CG;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / CG;
+        const int cg = (int)(i - n * CG);
+        const int b = rowptr[n], e = rowptr[n + 1];
+        float acc[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[j] = 0.0f;
+        const T* base = src + (int64_t)cg * W;
+        const int64_t ld = (int64_t)CG * W;
+        for (int k = b; k < e; k += U) {
+            float v[U][W];
+#pragma unroll
+            for (int u = 0; u < U; ++u) Vec<T>::ld(base + (int64_t)min(k + u, e - 1) * ld, v[u]);     // clamp, never guard
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + u < e) {
+#pragma unroll
+                    for (int j = 0; j < W; ++j) acc[j] += v[u][j];
+                }
+        }
+        if (REDUCE == MDL_MEAN) {
+            const float cnt = (float)max(e - b, 1);
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc[j] = acc[j] / cnt;
+        }
+        Vec<T>::st(out + i * W, acc);
+    }
+}
+
+template <typename T, int REDUCE>
+__global__ __launch_bounds__(256) void seg_bwd_vec_kernel(const T* __restrict__ go, const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ seg, T* __restrict__ gs, int64_t E,
+                                                          int CG) {
+    constexpr int W = Vec<T>::W;
+    const int64_t total = E * CG;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t k = i / CG;
+        const int cg = (int)(i - k * CG);
+        const int n = seg[k];
+        float g[W];
+        Vec<T>::ld(go + ((int64_t)n * CG + cg) * W, g);
+        if (REDUCE == MDL_MEAN) {
+            const float cnt = (float)max(rowptr[n + 1] - rowptr[n], 1);
+#pragma unroll
+            for (int j = 0; j < W; ++j) g[j] = g[j] / cnt;
+        }
+        Vec<T>::st(gs + i * W, g);
+    }
+}
+
+template <typename T>
+static bool vec_ok(const void* a, const void* b, int64_t C) {
+    return C % Vec<T>::W == 0 && reinterpret_cast<uintptr_t>(a) % 16 == 0 && reinterpret_cast<uintptr_t>(b) % 16 == 0;
+}
+
 static unsigned grid_for(int64_t total) {
     int64_t b = cdiv(total, 256);
     if (b > 256 * 16) b = 256 * 16;
@@ -93,6 +157,14 @@ template <typename T>
 static int seg_fwd(const T* src, const int32_t* rowptr, const int32_t* perm, T* out, int32_t* argmax, int64_t N,
                    int64_t C, int reduce, hipStream_t st) {
     if (N * C == 0) return MDL_OK;
+    if (!perm && reduce != MDL_MAX && vec_ok<T>(src, out, C)) {
+        const int CG = (int)(C / Vec<T>::W);
+        dim3 gv(grid_for(N * CG)), bv(256);
+        if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_fwd_vec_kernel<T, MDL_SUM>), gv, bv, 0, st, src, rowptr, out, N, CG);
+        else if (reduce == MDL_MEAN) hipLaunchKernelGGL((seg_fwd_vec_kernel<T, MDL_MEAN>), gv, bv, 0, st, src, rowptr, out, N, CG);
+        else { set_error("mdl_segment_reduce_fwd: bad reduce %d", reduce); return MDL_E_ARG; }
+        return check_launch("mdl_segment_reduce_fwd");
+    }
     dim3 g(grid_for(N * C)), b(256);
     switch (reduce) {
         case MDL_SUM: hipLaunchKernelGGL((seg_fwd_kernel<T, MDL_SUM>), g, b, 0, st, src, rowptr, perm, out, argmax, N, (int)C); break;
@@ -107,6 +179,13 @@ template <typename T>
 static int seg_bwd(const T* go, const int32_t* rowptr, const int32_t* seg, const int32_t* perm,
                    const int32_t* argmax, T* gs, int64_t N, int64_t E, int64_t C, int reduce, hipStream_t st) {
     dim3 b(256);
+    if (!perm && (reduce == MDL_SUM || reduce == MDL_MEAN) && E * C != 0 && vec_ok<T>(go, gs, C)) {
+        const int CG = (int)(C / Vec<T>::W);
+        dim3 gv(grid_for(E * CG));
+        if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_SUM>), gv, b, 0, st, go, rowptr, seg, gs, E, CG);
+        else hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_MEAN>), gv, b, 0, st, go, rowptr, seg, gs, E, CG);
+        return check_launch("mdl_segment_reduce_bwd");
+    }
     switch (reduce) {
         case MDL_SUM:
             if (E * C == 0) return MDL_OK;

@@ -21,7 +21,7 @@ def dense(lin, h):
     """nn.Linear in the dtype of h with fp32 master weights."""
     if h.dtype == lin.weight.dtype:
         return lin(h)
-    return F.linear(h, lin.weight.to(h.dtype), None if lin.bias is None else lin.bias.to(h.dtype))
+    return ops.linear(h, lin.weight, lin.bias)      # bf16, many rows: HIP TN GEMM for the weight gradient
 
 
 class GraphModel(nn.Module):

@@ -74,10 +74,11 @@ def test_rbf_matches_reference_golden(dtype):
 @pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("sorted_idx", [True, False])
-def test_scatter_matches_oracle(reduce, dtype, sorted_idx):
+@pytest.mark.parametrize("C", [48, 50])          # 48: 16-byte vector path (sorted sum / mean), 50: scalar path
+def test_scatter_matches_oracle(reduce, dtype, sorted_idx, C):
     from matdeeplearn_amd import ops
     g = torch.Generator().manual_seed(3)
-    n_seg, E, C = 37, 500, 48
+    n_seg, E = 37, 500
     idx = torch.randint(0, n_seg, (E,), generator=g)
     idx[idx == 5] = 6          # an empty segment
     if sorted_idx:
@@ -296,7 +297,8 @@ def test_gather_rows_and_its_gradient(dtype):
     close(sd.grad, ref, 1e-5 if dtype == torch.float32 else 3e-2, 1e-6 if dtype == torch.float32 else 2e-2)
 
 
-@pytest.mark.parametrize("N,M,K", [(1000, 64, 114), (129, 32, 50), (5000, 100, 200), (77, 128, 256), (1, 7, 3)])
+@pytest.mark.parametrize("N,M,K", [(1000, 64, 114), (129, 32, 50), (5000, 100, 200), (77, 128, 256), (1, 7, 3), (8192, 1, 64),
+                                   (8192, 64, 64)])
 def test_gemm_tn_matches_torch(N, M, K):
     """Tall-skinny weight-gradient GEMM (bf16 in, fp32 out) vs an fp32 matmul of the same rounded inputs."""
     import ctypes
