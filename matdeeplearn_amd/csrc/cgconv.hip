@@ -93,12 +93,12 @@ extern "C" int mdl_debug_reset() {
     long long z[48] = {0};
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cg_dbg), z, sizeof(z));
 }
-#define TDECL const long long tstart = clock64(), wstart = wall_clock64(); long long tprev = tstart; long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tcount = 0
+#define TDECL const long long tstart = clock64(), wstart = wall_clock64(); long long tprev = tstart; long long tacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tcount = 0
 #define TMARK(k) do { __builtin_amdgcn_sched_barrier(0); const long long _t = clock64(); tacc[k] += _t - tprev; tprev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define TPIN16(v) do { _Pragma("unroll") for (int _r = 0; _r < 16; ++_r) asm volatile("" : "+v"(v[_r])); } while (0)
 #define TTILE() (tcount += 1)
 #define TRESET() TMARK(10)
-#define TFLUSH(base) do { if (gw == 0 && lane == 0) { for (int _k = 0; _k < 12; ++_k) g_cg_dbg[(base) + _k] += tacc[_k]; g_cg_dbg[(base) + 15] += tcount; g_cg_dbg[(base) + 14] += clock64() - tstart; g_cg_dbg[(base) + 13] += wall_clock64() - wstart; } if (lane == 0 && gw < 4096) { g_cg_life[(base) / 16][gw][0] = wstart; g_cg_life[(base) / 16][gw][1] = wall_clock64(); g_cg_life[(base) / 16][gw][2] = tcount; } } while (0)
+#define TFLUSH(base) do { if (gw == 0 && lane == 0) { for (int _k = 0; _k < 13; ++_k) g_cg_dbg[(base) + _k] += tacc[_k]; g_cg_dbg[(base) + 15] += tcount; g_cg_dbg[(base) + 14] += clock64() - tstart; g_cg_dbg[(base) + 13] += wall_clock64() - wstart; } if (lane == 0 && gw < 4096) { g_cg_life[(base) / 16][gw][0] = wstart; g_cg_life[(base) / 16][gw][1] = wall_clock64(); g_cg_life[(base) / 16][gw][2] = tcount; } } while (0)
 #else
 #define TDECL do { } while (0)
 #if MDL_CG_PHASE_BARRIERS   // keep the phases of a tile apart in the instruction schedule (no timing)
@@ -1153,6 +1153,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             if constexpr (BF) gB[f] = pack_bf16x8(v); else gB[f] = v[0];
         }
 
+        TMARK(12);           // (timing builds: prologue up to here = loads + their wait + the gB shuffles)
         f32x16 Rf, Rs;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Rf[r] = 0.0f; Rs[r] = 0.0f; }
@@ -1350,17 +1351,25 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             TTILE();
         }
 
+        // the id of the next group (requested at the top of this one) is read BEFORE the flush: behind ~100 atomics and
+        // stores, waiting for any returning operation means waiting for all of them
+        const int n0_dyn = dyn ? 32 * __builtin_amdgcn_readfirstlane(gpend) : 0;
         // flush the source window: one atomic row update per touched window node (instead of per edge)
         wave_lds_fence();
         {
-            const unsigned long long tm = *w.touched;
+            // (the mask is the same in every lane: SGPRs; d_row(r, h) = d_row(r, 0) + 4h: one per-lane shift, then constant
+            // bit tests — per-row masks 1 << sl hoisted out of the group loop are the first thing hipcc spills)
+            const unsigned long long tmv = *w.touched;
+            const unsigned long long tm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(tmv >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tmv);
+            const unsigned long long tmh = tm >> (4 * h);
             if (ch < dm.C) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int sl = 32 * mt + d_row(r, h);
-                        if ((tm >> sl) & 1ull) {
+                        if ((tmh >> (32 * mt + d_row(r, 0))) & 1ull) {          // bit sl of tm
                             float* dst = p.r_src + (int64_t)(wb + sl) * C2 + ch;
                             unsafeAtomicAdd(dst, Wf[mt][r]);
                             unsafeAtomicAdd(dst + dm.Cp, Ws[mt][r]);
@@ -1381,7 +1390,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             }
         }
         TMARK(11);
-        n0 = dyn ? 32 * __builtin_amdgcn_readfirstlane(gpend) : n1;
+        n0 = dyn ? n0_dyn : n1;
     }
 
     TFLUSH(16);

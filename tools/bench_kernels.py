@@ -55,8 +55,8 @@ try:
         if os.environ.get("MDL_CG_CB_BWD") == "1":
             cbn = ["mfma chain", "dmv", "deriv+swaps", "reductions+dwe", "oob", "group flush", "commit+tables", "loads issue", "barrier"]
             print("cb bwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[30] / n), {cbn[k]: round(v[16 + k] / n) for k in range(9)})
-        names = ["loop top", "commit+tables", "issue loads", "pre", "dmv", "gate deriv", "pack", "reduce tgt", "reduce win", "dwe+rest", "group prologue", "group epilogue"]
-        print("bwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[30] / n), {names[k]: round(v[16 + k] / n) for k in range(12)}, "sum", round(sum(v[16:28]) / n), "| shader clock %.2f GHz, wave-0 lifetime %.1f us/launch" % (v[30] / max(v[29], 1) * 0.1, v[29] / 100.0 / max(1, a.iters + 2)))
+        names = ["loop top", "commit+tables", "issue loads", "pre", "dmv", "gate deriv", "pack", "reduce tgt", "reduce win", "dwe+rest", "prologue: zero+window base", "group epilogue", "prologue: loads+wait+gB"]
+        print("bwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[30] / n), {names[k]: round(v[16 + k] / n) for k in range(13)}, "sum", round(sum(v[16:29]) / n), "| shader clock %.2f GHz, wave-0 lifetime %.1f us/launch" % (v[30] / max(v[29], 1) * 0.1, v[29] / 100.0 / max(1, a.iters + 2)))
     if hasattr(L, "mdl_debug_life"):
         import numpy as np
         for which, nm in ((0, "fwd"), (1, "bwd")):
