@@ -150,21 +150,26 @@ int mdl_assemble_batch(const int64_t* ids, const int64_t* noff, const int64_t* e
 
 /* ---- training-mode BatchNorm1d over rows, x: [N, C] row-major ------------------------------------
  * Replaces torch.nn.BatchNorm1d as applied after every conv layer (matdeeplearn/models/cgcnn.py:85-87,143)
- * and inside the MEGNet MLPs (megnet.py:47-48).  `sums` is a [2, C] fp32 scratch the caller zero-fills
- * before each *_stats call; `save` is [2, C] fp32 (mean | invstd) written by mdl_bn_apply.
+ * and inside the MEGNet MLPs (megnet.py:47-48).  `sums` is an fp32 scratch of mdl_bn_sums_rows() x C floats the
+ * caller zero-fills before each *_stats call: MDL_BN_REPLICAS copies of a [2, C] accumulator (the reduction spreads
+ * its atomics over them) followed by one [2, C] row pair of totals, which the *_apply call publishes
+ * (sums + MDL_BN_REPLICAS*2*C: after bwd_apply = dbeta | dgamma).  `save` is [2, C] fp32 (mean | invstd) written
+ * by mdl_bn_apply.
  * Supported: C a multiple of 8 (bf16) / 4 (fp32) with 256 % (C/W) == 0, C <= 256.
- *   stats:      sums[0] += sum(x - x[0,:]), sums[1] += sum((x - x[0,:])^2)   (shifted sums)
+ *   stats:      copy[0] += sum(x - x[0,:]), copy[1] += sum((x - x[0,:])^2)   (shifted sums)
  *   apply:      y = (x - mean) * rsqrt(var_biased + eps) * gamma + beta; running_mean/var (unbiased) updated
  *               with `momentum` when non-NULL
- *   bwd_stats:  sums[0] += sum(dy), sums[1] += sum(dy * xhat)       ( = dbeta, dgamma )
+ *   bwd_stats:  copy[0] += sum(dy), copy[1] += sum(dy * xhat)       ( = dbeta, dgamma )
  *   bwd_apply:  dx = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)) */
+#define MDL_BN_REPLICAS 16
+int mdl_bn_sums_rows(void);
 int mdl_bn_stats(const void* x, float* sums, int64_t N, int C, int dtype, mdlStream_t stream);
-int mdl_bn_apply(const void* x, const float* sums, const float* gamma, const float* beta, float* save,
+int mdl_bn_apply(const void* x, float* sums, const float* gamma, const float* beta, float* save,
                  float* running_mean, float* running_var, void* y, int64_t N, int C, float eps, float momentum,
                  int dtype, mdlStream_t stream);
 int mdl_bn_bwd_stats(const void* dy, const void* x, const float* save, float* sums, int64_t N, int C, int dtype,
                      mdlStream_t stream);
-int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save, const float* sums, const float* gamma, void* dx,
+int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save, float* sums, const float* gamma, void* dx,
                      int64_t N, int C, int dtype, mdlStream_t stream);
 
 /* ---- tall-skinny TN GEMM: weight gradients of node-level Linear layers ---------------------------

@@ -31,6 +31,7 @@ PROTOTYPES = {
     "mdl_cgconv_pack_node_weights": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "mdl_cgconv_assemble_grads": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mdl_assemble_batch": (_i32, [_vp] * 20 + [_i32, _i32, _i32, _i32, _i32, _vp]),
+    "mdl_bn_sums_rows": (_i32, []),
     "mdl_bn_stats": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "mdl_bn_apply": (_i32, [_vp] * 8 + [_i64, _i32, _f32, _f32, _i32, _vp]),
     "mdl_bn_bwd_stats": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -15,6 +15,23 @@
 
 namespace mdl {
 
+constexpr int BN_R = MDL_BN_REPLICAS;    // copies of the [2][C] sums the reduction scatters its atomics over
+
+// totals of the BN_R copies into LDS (tot[2C]); block 0 also publishes them in row BN_R of `sums` for the host side
+__device__ __forceinline__ void bn_totals(const float* __restrict__ sums, float* tot, int C, float* publish) {
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) {
+        float v[BN_R];
+#pragma unroll
+        for (int r = 0; r < BN_R; ++r) v[r] = sums[(size_t)r * 2 * C + c];
+        float t = 0.0f;
+#pragma unroll
+        for (int r = 0; r < BN_R; ++r) t += v[r];
+        tot[c] = t;
+        if (publish && blockIdx.x == 0) publish[c] = t;
+    }
+    __syncthreads();
+}
+
 // Block = 256 threads = (256 / CG) row lanes x CG channel groups of W channels (CG = C / W).
 // MODE 0: forward stats of x.  MODE 1: backward stats (a = dy, b = x).
 template <typename T, int MODE>
@@ -70,29 +87,42 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ a,
         const int c = threadIdx.x, g = c / W, j = c % W;
         float t0 = 0.0f, t1 = 0.0f;
         for (int r = 0; r < rows_per_block; ++r) { t0 += red[0][(r * CG + g) * W + j]; t1 += red[1][(r * CG + g) * W + j]; }
-        unsafeAtomicAdd(sums + c, t0);
-        unsafeAtomicAdd(sums + C + c, t1);
+        // 2C atomics per block on the same few cache lines serialise in L2 (10 of this kernel's 17 us with one copy):
+        // BN_R copies of the sums, chosen by block, each in its own lines; the consumers add them up
+        float* dst = sums + (size_t)(blockIdx.x % BN_R) * 2 * C;
+        unsafeAtomicAdd(dst + c, t0);
+        unsafeAtomicAdd(dst + C + c, t1);
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ sums,
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, float* __restrict__ sums,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ save, float* __restrict__ run_mean,
                                                        float* __restrict__ run_var, T* __restrict__ y, int64_t N, int C,
                                                        float eps, float momentum) {
     constexpr int W = Vec<T>::W;
+    constexpr int U = 4;                                     // four independent 16-byte loads in flight per thread
+    __shared__ float tot[512];
     const int CG = C / W;
     const int cg = threadIdx.x % CG;
     const int64_t total = N * CG;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the first rows are requested BEFORE the statistics: the block's prologue (sums -> mean / invstd -> scale / shift) is
+    // a chain of dependent loads, and a block streams only a few rows per thread — back to back they double its time
+    float v[U][W];
+#pragma unroll
+    for (int u = 0; u < U; ++u) Vec<T>::ld(x + (min(q0 + u * stride, total - 1) / CG) * C + cg * W, v[u]);
     float mean[W], scale[W], shiftv[W], sh[W];
     Vec<T>::ld(x + cg * W, sh);
+    bn_totals(sums, tot, C, sums + (size_t)BN_R * 2 * C);
     const float invn = 1.0f / (float)N;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         const int c = cg * W + j;
-        const float m1 = sums[c] * invn;
-        const float var = fmaxf(sums[C + c] * invn - m1 * m1, 0.0f);
+        const float m1 = tot[c] * invn;
+        const float var = fmaxf(tot[C + c] * invn - m1 * m1, 0.0f);
         const float istd = rsqrtf(var + eps);
         mean[j] = sh[j] + m1;
         const float g = gamma ? gamma[c] : 1.0f;
@@ -109,12 +139,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         }
     }
     // grid-stride over (row, channel group); blockDim is a multiple of CG so cg is loop invariant
-    constexpr int U = 4;                                     // four independent 16-byte loads in flight per thread
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < total; q0 += U * stride) {
-        float v[U][W];
-#pragma unroll
-        for (int u = 0; u < U; ++u) Vec<T>::ld(x + (min(q0 + u * stride, total - 1) / CG) * C + cg * W, v[u]);
+    while (true) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t q = q0 + u * stride;
@@ -122,18 +147,34 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
             for (int j = 0; j < W; ++j) v[u][j] = v[u][j] * scale[j] + shiftv[j];
             if (q < total) Vec<T>::st(y + (q / CG) * C + cg * W, v[u]);
         }
+        q0 += U * stride;
+        if (q0 >= total) break;
+#pragma unroll
+        for (int u = 0; u < U; ++u) Vec<T>::ld(x + (min(q0 + u * stride, total - 1) / CG) * C + cg * W, v[u]);
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                           const float* __restrict__ save, const float* __restrict__ sums,
+                                                           const float* __restrict__ save, float* __restrict__ sums,
                                                            const float* __restrict__ gamma, T* __restrict__ dx, int64_t N,
                                                            int C) {
     constexpr int W = Vec<T>::W;
+    constexpr int U = 2;
+    __shared__ float tot[512];
     const int CG = C / W;
     const int cg = threadIdx.x % CG;
     const int64_t total = N * CG;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float vd[U][W], vx[U][W];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                              // rows first, statistics second (see bn_apply_kernel)
+        const int64_t n = min(q0 + u * stride, total - 1) / CG;
+        Vec<T>::ld(dy + n * C + cg * W, vd[u]);
+        Vec<T>::ld(x + n * C + cg * W, vx[u]);
+    }
+    bn_totals(sums, tot, C, sums + (size_t)BN_R * 2 * C);
     const float invn = 1.0f / (float)N;
     float mean[W], istd[W], k0[W], k1[W], gs[W];
 #pragma unroll
@@ -142,25 +183,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         mean[j] = save[c];
         istd[j] = save[C + c];
         gs[j] = (gamma ? gamma[c] : 1.0f) * istd[j];
-        k0[j] = sums[c] * invn;            // mean(dy)
-        k1[j] = sums[C + c] * invn;        // mean(dy * xhat)
+        k0[j] = tot[c] * invn;            // mean(dy)
+        k1[j] = tot[C + c] * invn;        // mean(dy * xhat)
     }
-    constexpr int U = 2;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < total; q0 += U * stride) {
-        float vd[U][W], vx[U][W];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t n = min(q0 + u * stride, total - 1) / CG;
-            Vec<T>::ld(dy + n * C + cg * W, vd[u]);
-            Vec<T>::ld(x + n * C + cg * W, vx[u]);
-        }
+    while (true) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t q = q0 + u * stride;
 #pragma unroll
             for (int j = 0; j < W; ++j) vd[u][j] = gs[j] * (vd[u][j] - k0[j] - (vx[u][j] - mean[j]) * istd[j] * k1[j]);
             if (q < total) Vec<T>::st(dx + (q / CG) * C + cg * W, vd[u]);
+        }
+        q0 += U * stride;
+        if (q0 >= total) break;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t n = min(q0 + u * stride, total - 1) / CG;
+            Vec<T>::ld(dy + n * C + cg * W, vd[u]);
+            Vec<T>::ld(x + n * C + cg * W, vx[u]);
         }
     }
 }
@@ -177,11 +217,13 @@ static int bn_check(const char* name, int64_t N, int C, int dtype, const void* p
 static unsigned bn_grid(int64_t N, int C, int W) {
     const int rows = 256 / (C / W);
     int64_t g = cdiv(N, (int64_t)rows * 8);
-    if (g > 512) g = 512;         // every block ends with 2C atomics on the same addresses: few, fat blocks
+    if (g > 1024) g = 1024;       // every block ends with 2C atomics, spread over BN_R copies of the sums
     return (unsigned)(g < 1 ? 1 : g);
 }
 
 }  // namespace mdl
+
+extern "C" int mdl_bn_sums_rows(void) { return 2 * (MDL_BN_REPLICAS + 1); }
 
 extern "C" int mdl_bn_stats(const void* x, float* sums, int64_t N, int C, int dtype, mdlStream_t stream) {
     using namespace mdl;
@@ -193,7 +235,7 @@ extern "C" int mdl_bn_stats(const void* x, float* sums, int64_t N, int C, int dt
     return check_launch("mdl_bn_stats");
 }
 
-extern "C" int mdl_bn_apply(const void* x, const float* sums, const float* gamma, const float* beta, float* save,
+extern "C" int mdl_bn_apply(const void* x, float* sums, const float* gamma, const float* beta, float* save,
                             float* running_mean, float* running_var, void* y, int64_t N, int C, float eps, float momentum,
                             int dtype, mdlStream_t stream) {
     using namespace mdl;
@@ -202,7 +244,7 @@ extern "C" int mdl_bn_apply(const void* x, const float* sums, const float* gamma
     hipStream_t st = (hipStream_t)stream;
     const int W = dtype == MDL_BF16 ? 8 : 4;
     int64_t g = cdiv(N * (C / W), 256 * 4);
-    if (g > 2048) g = 2048;
+    if (g > 768) g = 768;          // 3 fat blocks per CU: the per-block statistics prologue amortises (measured 512..2048)
     if (g < 1) g = 1;
     if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)x, sums, gamma, beta, save, running_mean, running_var, (bf16_t*)y, N, C, eps, momentum);
     else hipLaunchKernelGGL((bn_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, (const float*)x, sums, gamma, beta, save, running_mean, running_var, (float*)y, N, C, eps, momentum);
@@ -220,7 +262,7 @@ extern "C" int mdl_bn_bwd_stats(const void* dy, const void* x, const float* save
     return check_launch("mdl_bn_bwd_stats");
 }
 
-extern "C" int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save, const float* sums, const float* gamma,
+extern "C" int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save, float* sums, const float* gamma,
                                 void* dx, int64_t N, int C, int dtype, mdlStream_t stream) {
     using namespace mdl;
     int rc = bn_check("mdl_bn_bwd_apply", N, C, dtype, x);
@@ -228,7 +270,7 @@ extern "C" int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save
     hipStream_t st = (hipStream_t)stream;
     const int W = dtype == MDL_BF16 ? 8 : 4;
     int64_t g = cdiv(N * (C / W), 256 * 4);
-    if (g > 2048) g = 2048;
+    if (g > 768) g = 768;          // 3 fat blocks per CU: the per-block statistics prologue amortises (measured 512..2048)
     if (g < 1) g = 1;
     if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, gamma, (bf16_t*)dx, N, C);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, (const float*)dy, (const float*)x, save, sums, gamma, (float*)dx, N, C);

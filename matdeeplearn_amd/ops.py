@@ -519,8 +519,9 @@ class _BatchNormTrain(torch.autograd.Function):
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
         N, C = x.shape
         dt = dtype_code(x)
-        buf = torch.zeros((4, C), dtype=torch.float32, device=x.device)      # rows 0-1: sums, rows 2-3: save
-        sums, save = buf[:2], buf[2:]
+        R = lib().mdl_bn_sums_rows()
+        buf = torch.zeros((R + 2, C), dtype=torch.float32, device=x.device)  # rows 0..R-1: sums (copies + totals), then save
+        sums, save = buf[:R], buf[R:]
         gw = None if weight is None else weight.detach().float().contiguous()
         gb = None if bias is None else bias.detach().float().contiguous()
         y = torch.empty_like(x)
@@ -538,13 +539,14 @@ class _BatchNormTrain(torch.autograd.Function):
         N, C = x.shape
         dy = dy.contiguous()
         dt = dtype_code(x)
-        sums = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+        R = lib().mdl_bn_sums_rows()
+        sums = torch.zeros((R, C), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x)
         check(lib().mdl_bn_bwd_stats(ptr(dy), ptr(x), ptr(save), ptr(sums), N, C, dt, stream()), "mdl_bn_bwd_stats")
         check(lib().mdl_bn_bwd_apply(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, dt, stream()),
               "mdl_bn_bwd_apply")
-        dgamma = sums[1].to(ctx.wdt) if ctx.has[0] else None
-        dbeta = sums[0].to(ctx.wdt) if ctx.has[1] else None
+        dgamma = sums[R - 1].to(ctx.wdt) if ctx.has[0] else None          # totals row pair published by bwd_apply
+        dbeta = sums[R - 2].to(ctx.wdt) if ctx.has[1] else None
         return dx, dgamma, dbeta, None, None, None, None
 
 
