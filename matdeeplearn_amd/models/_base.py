@@ -21,7 +21,16 @@ def dense(lin, h):
     """nn.Linear in the dtype of h with fp32 master weights."""
     if h.dtype == lin.weight.dtype:
         return lin(h)
-    return ops.linear(h, lin.weight, lin.bias)      # bf16, many rows: HIP TN GEMM for the weight gradient
+    return ops.linear(h, lin.weight, lin.bias, _lowp(lin))      # bf16, many rows: HIP TN GEMM for the weight gradient
+
+
+def _lowp(lin):
+    """The layer's (weight, bias) in the compute dtype if GraphModel._cast_dense made them for the CURRENT parameter
+    values (version counters), else None."""
+    sh = getattr(lin, "_mdl_lowp", None)
+    if sh is None or sh[2] != lin.weight._version or (lin.bias is not None and sh[3] != lin.bias._version):
+        return None
+    return sh[0], sh[1]
 
 
 class GraphModel(nn.Module):
@@ -68,10 +77,33 @@ class GraphModel(nn.Module):
             csr = ops.csr_for(data.edge_index, n)
         return data.x.to(cd), data.edge_attr.to(cd), csr
 
+    def _cast_dense(self, dtype):
+        """fp32 master weights of every dense layer -> compute dtype in ONE multi-tensor copy per forward (instead of two
+        small launches per layer); the copies carry the parameters' version counters so stale ones are never used."""
+        lins = [m for m in list(self.pre_lin_list) + list(self.post_lin_list) + [self.lin_out] if isinstance(m, nn.Linear)]
+        params = [p for lin in lins for p in (lin.weight, lin.bias) if p is not None]
+        if not params or not params[0].is_cuda or params[0].dtype == dtype:
+            return
+        cache = getattr(self, "_lowp_cache", None)
+        if cache is None or len(cache) != len(params) or cache[0].dtype != dtype or cache[0].device != params[0].device:
+            cache = [torch.empty_like(p, dtype=dtype) for p in params]
+            self._lowp_cache = cache
+        with torch.no_grad():
+            torch._foreach_copy_(cache, [p.detach() for p in params])
+        k = 0
+        for lin in lins:
+            w = cache[k]; k += 1
+            b = None
+            if lin.bias is not None:
+                b = cache[k]; k += 1
+            lin._mdl_lowp = (w, b, lin.weight._version, None if lin.bias is None else lin.bias._version)
+
     def _pre(self, out):
+        if out.dtype == torch.bfloat16 and torch.is_grad_enabled():
+            self._cast_dense(out.dtype)
         for k, lin in enumerate(self.pre_lin_list):
             if k == 0 and out.dtype == torch.bfloat16 and not out.requires_grad:
-                out = getattr(F, self.act)(ops.linear_input_leaf(out, lin.weight, lin.bias))   # HIP dW (K = #nodes)
+                out = getattr(F, self.act)(ops.linear_input_leaf(out, lin.weight, lin.bias, _lowp(lin)))   # HIP dW (K = #nodes)
             else:
                 out = getattr(F, self.act)(dense(lin, out))
         return out

@@ -231,12 +231,31 @@ class Set2Set(nn.Module):
 # and backward run on the HIP stream kernels when the shape allows, otherwise the library path.
 # ------------------------------------------------------------------------------------------------
 class BatchNorm1d(nn.BatchNorm1d):
+    """torch.nn.BatchNorm1d whose training-mode forward / backward run on the HIP kernels.  `num_batches_tracked` is
+    counted on the host and folded into the buffer when the state is read (state_dict, or the library path that uses
+    it): a one-element device add per layer per step is a kernel launch that computes nothing."""
+
+    def _sync_counter(self):
+        pending = getattr(self, "_nbt_pending", 0)
+        if pending and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(pending)
+        self._nbt_pending = 0
+
     def forward(self, x):
         use_batch_stats = self.training or not self.track_running_stats
         if use_batch_stats and x.dim() == 2 and ops.bn_supported(x) and self.momentum is not None:
             rm = rv = None
             if self.training and self.track_running_stats:
                 rm, rv = self.running_mean, self.running_var
-                self.num_batches_tracked.add_(1)
+                self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1
             return ops.batch_norm_train(x, self.weight, self.bias, rm, rv, self.eps, self.momentum)
+        self._sync_counter()
         return super().forward(x)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._sync_counter()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._nbt_pending = 0
+        super()._load_from_state_dict(*args, **kwargs)

@@ -469,9 +469,12 @@ def gather_mul_reduce(h, csr, w=None, scale=None, reduce="sum"):
 # ------------------------------------------------------------------------------------------------
 class _LinearTN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        w = weight.to(x.dtype)
-        out = torch.nn.functional.linear(x, w, None if bias is None else bias.to(x.dtype))
+    def forward(ctx, x, weight, bias, w_lp=None, b_lp=None):
+        # w_lp / b_lp: the caller's copies of weight / bias already in x.dtype (one multi-tensor cast per step instead of
+        # two launches per layer); gradients go to the fp32 masters
+        w = weight.to(x.dtype) if w_lp is None else w_lp
+        b = None if bias is None else (bias.to(x.dtype) if b_lp is None else b_lp)
+        out = torch.nn.functional.linear(x, w, b)
         ctx.save_for_backward(x, w)
         ctx.wdtype, ctx.has_bias, ctx.shape = weight.dtype, bias is not None, tuple(weight.shape)
         return out
@@ -486,21 +489,23 @@ class _LinearTN(torch.autograd.Function):
         check(lib().mdl_gemm_tn(ptr(g), g.stride(0), M, ptr(x), x.stride(0), K, ptr(dw), g.shape[0], dtype_code(g),
                                 stream()), "mdl_gemm_tn")
         db = g.sum(dim=0, dtype=torch.float32).to(ctx.wdtype) if ctx.has_bias else None
-        return dx, dw.to(ctx.wdtype), db
+        return dx, dw.to(ctx.wdtype), db, None, None
 
 
-def linear(x, weight, bias):
+def linear(x, weight, bias, lowp=None):
     """F.linear in the dtype of x (fp32 master weights); bf16 inputs with many rows, out <= 128, in <= 256 take the
-    HIP TN GEMM for dW, anything else the library autograd path."""
+    HIP TN GEMM for dW, anything else the library autograd path.  `lowp` = (weight, bias) already cast to x.dtype."""
     if (x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] >= 1024
             and weight.shape[0] <= 128 and weight.shape[1] <= 256 and weight.requires_grad):
+        if lowp is not None and lowp[0].dtype == x.dtype:
+            return _LinearTN.apply(x, weight, bias, lowp[0], lowp[1])
         return _LinearTN.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
 
 
-def linear_input_leaf(x, weight, bias):
+def linear_input_leaf(x, weight, bias, lowp=None):
     """Linear for an input that needs no gradient (pre-FC on the dataset features)."""
-    return linear(x, weight, bias)
+    return linear(x, weight, bias, lowp)
 
 
 # ------------------------------------------------------------------------------------------------
