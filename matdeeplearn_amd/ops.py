@@ -284,6 +284,67 @@ def _launch_timed(key, fn):
     return rc
 
 
+class ZeroArena:
+    """One zero-filled scratch per training step for the kernels' small accumulators (BatchNorm sums, the conv
+    backward's dW partials): a model step needs a dozen of them, and a dozen 5-us fill launches cost more than the
+    kernels they serve.  `with ops.zero_arena(device):` around forward + backward zero-fills ONE buffer and hands out
+    views; outside of it (or when it is full) zeros() falls back to torch.zeros.  Only for tensors that die with the
+    step — nothing that autograd may hand over as a parameter gradient."""
+
+    def __init__(self, device, nbytes=4 << 20):
+        self.buf = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        self.off = 0
+
+    def reset(self):
+        self.buf.zero_()
+        self.off = 0
+
+    def take(self, shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 63) & ~63                       # 256-byte granules keep every view 16-byte aligned
+        if self.off + n_al > self.buf.numel():
+            return None
+        t = self.buf[self.off:self.off + n].view(*shape)
+        self.off += n_al
+        return t
+
+
+_ARENA = None
+
+
+class zero_arena:
+    def __init__(self, device, nbytes=4 << 20):
+        self.key = (torch.device(device), nbytes)
+
+    _cache = {}
+
+    def __enter__(self):
+        global _ARENA
+        a = zero_arena._cache.get(self.key)
+        if a is None:
+            a = zero_arena._cache[self.key] = ZeroArena(*self.key)
+        a.reset()
+        self.prev, _ARENA = _ARENA, a
+        return a
+
+    def __exit__(self, *exc):
+        global _ARENA
+        _ARENA = self.prev
+        return False
+
+
+def _zeros_step(shape, device):
+    """fp32 zeros that live no longer than the current step (see ZeroArena)."""
+    a = _ARENA
+    if a is not None and a.buf.device == device:
+        t = a.take(shape)
+        if t is not None:
+            return t
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 _WS = {}
 
 
@@ -341,7 +402,7 @@ class _CGConvFn(torch.autograd.Function):
         dt = dtype_code(x)
         r_tgt = torch.empty((N, 2 * Cp), dtype=x.dtype, device=x.device)          # by-target sums, compute dtype
         r_src = torch.zeros((N, 2 * Cp), dtype=torch.float32, device=x.device)
-        small = torch.zeros(2 * Cp * GP + 2 * Cp + 4 * Cp * C, dtype=torch.float32, device=x.device)
+        small = _zeros_step((2 * Cp * GP + 2 * Cp + 4 * Cp * C,), x.device)
         dwe = small[:2 * Cp * GP].view(2 * Cp, GP)
         db = small[2 * Cp * GP:2 * Cp * GP + 2 * Cp]
         dwn = small[2 * Cp * GP + 2 * Cp:].view(4 * Cp, C)
@@ -485,9 +546,13 @@ class _LinearTN(torch.autograd.Function):
         g = g.contiguous()
         M, K = ctx.shape
         dx = g @ w if ctx.needs_input_grad[0] else None
-        dw = torch.zeros((M, K), dtype=torch.float32, device=g.device)
-        check(lib().mdl_gemm_tn(ptr(g), g.stride(0), M, ptr(x), x.stride(0), K, ptr(dw), g.shape[0], dtype_code(g),
+        ga, Ma = g, M
+        if M % 2:                               # the streaming kernel stages rows as dwords: pad an odd width (the model's
+            ga, Ma = torch.nn.functional.pad(g, (0, 1)), M + 1             # 1-column output layer) with a zero column
+        dw = torch.zeros((Ma, K), dtype=torch.float32, device=g.device)
+        check(lib().mdl_gemm_tn(ptr(ga), ga.stride(0), Ma, ptr(x), x.stride(0), K, ptr(dw), g.shape[0], dtype_code(g),
                                 stream()), "mdl_gemm_tn")
+        dw = dw[:M]
         db = g.sum(dim=0, dtype=torch.float32).to(ctx.wdtype) if ctx.has_bias else None
         return dx, dw.to(ctx.wdtype), db, None, None
 
@@ -525,7 +590,7 @@ class _BatchNormTrain(torch.autograd.Function):
         N, C = x.shape
         dt = dtype_code(x)
         R = lib().mdl_bn_sums_rows()
-        buf = torch.zeros((R + 2, C), dtype=torch.float32, device=x.device)  # rows 0..R-1: sums (copies + totals), then save
+        buf = _zeros_step((R + 2, C), x.device)                               # rows 0..R-1: sums (copies + totals), then save
         sums, save = buf[:R], buf[R:]
         gw = None if weight is None else weight.detach().float().contiguous()
         gb = None if bias is None else bias.detach().float().contiguous()
@@ -545,8 +610,8 @@ class _BatchNormTrain(torch.autograd.Function):
         dy = dy.contiguous()
         dt = dtype_code(x)
         R = lib().mdl_bn_sums_rows()
-        sums = torch.zeros((R, C), dtype=torch.float32, device=x.device)
-        dx = torch.empty_like(x)
+        sums = torch.zeros((R, C), dtype=torch.float32, device=x.device)     # (not from the step arena: its totals rows are
+        dx = torch.empty_like(x)                                              # returned as parameter gradients)
         check(lib().mdl_bn_bwd_stats(ptr(dy), ptr(x), ptr(save), ptr(sums), N, C, dt, stream()), "mdl_bn_bwd_stats")
         check(lib().mdl_bn_bwd_apply(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, dt, stream()),
               "mdl_bn_bwd_apply")

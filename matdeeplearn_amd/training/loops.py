@@ -8,6 +8,7 @@ Mirrors /root/reference/matdeeplearn/training/training.py: `train` (:34-54), `ev
 The loops are model-agnostic (any nn.Module whose forward takes a batch) and never force a
 host<->device sync inside an epoch: running sums stay on the device.
 """
+import contextlib
 import copy
 import time
 
@@ -29,6 +30,19 @@ def make_scheduler(optimizer, name="ReduceLROnPlateau", **scheduler_args):
     return getattr(torch.optim.lr_scheduler, name)(optimizer, **scheduler_args)
 
 
+def output_device(data):
+    x = getattr(data, "x", None)
+    return x.device if torch.is_tensor(x) else torch.device("cpu")
+
+
+def _step_arena(device):
+    """ops.zero_arena on a HIP device (one zero fill per step for the kernels' small accumulators), a no-op elsewhere."""
+    if device.type == "cuda":
+        from .. import ops
+        return ops.zero_arena(device)
+    return contextlib.nullcontext()
+
+
 def train(model, optimizer, loader, loss_method, rank=None, dp=None, stats=None):
     """One pass over `loader` in train mode.  Returns the sample-weighted mean loss (device scalar)."""
     model.train()
@@ -40,9 +54,10 @@ def train(model, optimizer, loader, loss_method, rank=None, dp=None, stats=None)
             dp.zero_grad()
         else:
             optimizer.zero_grad()
-        output = model(data)
-        loss = getattr(F, loss_method)(output, data.y)
-        loss.backward()
+        with _step_arena(output_device(data)):
+            output = model(data)
+            loss = getattr(F, loss_method)(output, data.y)
+            loss.backward()
         loss_all = loss_all + loss.detach() * output.size(0)
         if dp is not None:
             dp.reduce_grads()
