@@ -41,19 +41,43 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams p) {
     const int64_t n0s = p.node_ptr[gid], nn = p.node_ptr[gid + 1] - n0s;
     const int64_t e0s = p.edge_ptr[gid], ne = p.edge_ptr[gid + 1] - e0s;
     const int64_t no = p.noff[g], eo = p.eoff[g];
-    T* xo = static_cast<T*>(p.x) + no * p.F;
-    const float* xi = p.x_all + n0s * p.F;
-    for (int64_t q = threadIdx.x; q < nn * p.F; q += blockDim.x) Elem<T>::st(xo + q, xi[q]);
+    T* __restrict__ xo = static_cast<T*>(p.x) + no * p.F;
+    const float* __restrict__ xi = p.x_all + n0s * p.F;
+    // A block moves only ~3000 feature elements and ~330 edges: with one load in flight per thread the copy is a chain of
+    // memory round trips.  Four independent (clamped) loads are issued before the first store of every trip.
+    constexpr int U = 4;
+    const int64_t nx = nn * p.F;
+    for (int64_t q0 = threadIdx.x; q0 < nx; q0 += U * blockDim.x) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = xi[min(q0 + u * blockDim.x, nx - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q0 + u * blockDim.x < nx) Elem<T>::st(xo + q0 + u * blockDim.x, v[u]);
+    }
     for (int64_t j = threadIdx.x; j < nn; j += blockDim.x) {
         p.batch[no + j] = g;
         p.rowptr[no + j] = (int32_t)(eo + p.lrowptr[n0s + j]);
     }
     const int32_t shift = (int32_t)no;
-    for (int64_t k = threadIdx.x; k < ne; k += blockDim.x) {
-        p.src[eo + k] = p.src_l[e0s + k] + shift;
-        p.tgt[eo + k] = p.tgt_l[e0s + k] + shift;
-        p.ew[eo + k] = p.dist[e0s + k];
-        p.dn[eo + k] = p.dist_norm[e0s + k];
+    for (int64_t k0 = threadIdx.x; k0 < ne; k0 += 2 * blockDim.x) {
+        int32_t sv[2], tv[2];
+        float dv[2], nv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t k = e0s + min(k0 + u * blockDim.x, ne - 1);
+            sv[u] = p.src_l[k]; tv[u] = p.tgt_l[k]; dv[u] = p.dist[k]; nv[u] = p.dist_norm[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t k = k0 + u * blockDim.x;
+            if (k < ne) {
+                p.src[eo + k] = sv[u] + shift;
+                p.tgt[eo + k] = tv[u] + shift;
+                p.ew[eo + k] = dv[u];
+                p.dn[eo + k] = nv[u];
+            }
+        }
     }
     if (threadIdx.x == 0) {
         p.y[g] = p.y_all[gid * p.T + p.target_index];

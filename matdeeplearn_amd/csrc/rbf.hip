@@ -86,7 +86,7 @@ static int launch_rbf(const float* d, const float* offsets, float coeff, T* out,
     if (ld == G && (reinterpret_cast<uintptr_t>(out) % 16) == 0) {
         constexpr int VEC = 16 / (int)sizeof(T);       // 16-byte stores: 4 floats / 8 bf16 per thread
         int64_t blocks = cdiv(cdiv(total, VEC), 256);
-        if (blocks > 256 * 8) blocks = 256 * 8;
+        if (blocks > 256 * 256) blocks = 256 * 256;    // ~one trip per thread: a trip starts with a dependent load of d[e]
         hipLaunchKernelGGL((rbf_dense_kernel<T, VEC>), dim3((unsigned)blocks), dim3(256), 0, st, d, offsets, coeff,
                            out, total, G);
     } else {

@@ -87,35 +87,47 @@ __global__ __launch_bounds__(256) void seg_bwd_max_kernel(const T* __restrict__ 
 template <typename T, int REDUCE>
 __global__ __launch_bounds__(256) void seg_fwd_vec_kernel(const T* __restrict__ src, const int32_t* __restrict__ rowptr,
                                                           T* __restrict__ out, int64_t N, int CG) {
-    constexpr int W = Vec<T>::W, U = 4;
-    const int64_t total = N * CG;
+    // RL row lanes share one (segment, channel group): lane j takes rows b + j, b + j + RL, ... two at a time, and the
+    // partial sums meet through two xor-shuffles.  (One thread per segment walks ~25 rows as a chain of round trips.)
+    constexpr int W = Vec<T>::W, U = 2;
+    const int RL = (CG <= 16 && (CG & (CG - 1)) == 0) ? 4 : 1;        // the CG*RL lanes of a group sit in one wavefront
+    const int64_t total = N * CG * RL;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t n = i / CG;
-        const int cg = (int)(i - n * CG);
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < total; i0 += stride) {     // block-uniform trip count
+        const int64_t i = min(i0 + threadIdx.x, total - 1);
+        const int64_t n = i / (CG * RL);
+        const int rem = (int)(i - n * (CG * RL));
+        const int j = rem / CG, cg = rem - j * CG;
         const int b = rowptr[n], e = rowptr[n + 1];
         float acc[W];
 #pragma unroll
-        for (int j = 0; j < W; ++j) acc[j] = 0.0f;
+        for (int q = 0; q < W; ++q) acc[q] = 0.0f;
         const T* base = src + (int64_t)cg * W;
         const int64_t ld = (int64_t)CG * W;
-        for (int k = b; k < e; k += U) {
+        for (int k = b + j; k < e; k += U * RL) {
             float v[U][W];
 #pragma unroll
-            for (int u = 0; u < U; ++u) Vec<T>::ld(base + (int64_t)min(k + u, e - 1) * ld, v[u]);     // clamp, never guard
+            for (int u = 0; u < U; ++u) Vec<T>::ld(base + (int64_t)min(k + u * RL, e - 1) * ld, v[u]);   // clamp, never guard
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (k + u < e) {
+                if (k + u * RL < e) {
 #pragma unroll
-                    for (int j = 0; j < W; ++j) acc[j] += v[u][j];
+                    for (int q = 0; q < W; ++q) acc[q] += v[u][q];
                 }
+        }
+        if (RL == 4) {
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                acc[q] += __shfl_xor(acc[q], CG);
+                acc[q] += __shfl_xor(acc[q], 2 * CG);
+            }
         }
         if (REDUCE == MDL_MEAN) {
             const float cnt = (float)max(e - b, 1);
 #pragma unroll
-            for (int j = 0; j < W; ++j) acc[j] = acc[j] / cnt;
+            for (int q = 0; q < W; ++q) acc[q] = acc[q] / cnt;
         }
-        Vec<T>::st(out + i * W, acc);
+        if (j == 0 && i0 + threadIdx.x < total) Vec<T>::st(out + (n * CG + cg) * W, acc);
     }
 }
 
@@ -159,7 +171,7 @@ static int seg_fwd(const T* src, const int32_t* rowptr, const int32_t* perm, T* 
     if (N * C == 0) return MDL_OK;
     if (!perm && reduce != MDL_MAX && vec_ok<T>(src, out, C)) {
         const int CG = (int)(C / Vec<T>::W);
-        dim3 gv(grid_for(N * CG)), bv(256);
+        dim3 gv(grid_for(N * CG * 4)), bv(256);
         if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_fwd_vec_kernel<T, MDL_SUM>), gv, bv, 0, st, src, rowptr, out, N, CG);
         else if (reduce == MDL_MEAN) hipLaunchKernelGGL((seg_fwd_vec_kernel<T, MDL_MEAN>), gv, bv, 0, st, src, rowptr, out, N, CG);
         else { set_error("mdl_segment_reduce_fwd: bad reduce %d", reduce); return MDL_E_ARG; }

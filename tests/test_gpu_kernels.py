@@ -74,7 +74,7 @@ def test_rbf_matches_reference_golden(dtype):
 @pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("sorted_idx", [True, False])
-@pytest.mark.parametrize("C", [48, 50])          # 48: 16-byte vector path (sorted sum / mean), 50: scalar path
+@pytest.mark.parametrize("C", [48, 50, 64])      # 48 / 64: 16-byte vector paths (one / four row lanes), 50: scalar path
 def test_scatter_matches_oracle(reduce, dtype, sorted_idx, C):
     from matdeeplearn_amd import ops
     g = torch.Generator().manual_seed(3)
