@@ -178,6 +178,10 @@ int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save, float* su
  * (e.g. pre_lin_list, matdeeplearn/models/cgcnn.py:64-74,124-130).  1 <= M <= 128, 1 <= K <= 256, bf16 only. */
 int mdl_gemm_tn(const void* a, int64_t lda, int M, const void* b, int64_t ldb, int K, float* c, int64_t N, int dtype,
                 mdlStream_t stream);
+/* same, plus colsum[M] (fp32, caller zero-fills) += column sums of a — the bias gradient of that Linear
+ * (`g.sum(0)` in the reference's autograd), out of the same pass.  Needs even M, K, lda, ldb and K <= 126. */
+int mdl_gemm_tn_colsum(const void* a, int64_t lda, int M, const void* b, int64_t ldb, int K, float* c, float* colsum,
+                       int64_t N, int dtype, mdlStream_t stream);
 
 /* ---- generic gather / edge-weighted gather-reduce (SchNet CFConv, GCNConv, MEGNet, NNConv) ------
  * Replace the index_select + elementwise + torch_scatter sequence of PyG MessagePassing.propagate at

@@ -87,7 +87,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 template <int MT, int NT>
 __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const bf16_t* __restrict__ A, int lda, int M,
                                                                 const bf16_t* __restrict__ B, int ldb, int K,
-                                                                float* __restrict__ C, int64_t N) {
+                                                                float* __restrict__ C, float* __restrict__ colsum,
+                                                                int64_t N) {
+    // colsum (optional): column sums of A, i.e. the bias gradient of the Linear whose dW this is.  Column K of the B tile
+    // (padding; the launcher picks NT so that it exists) is set to 1.0 for the valid rows, so the sums fall out of the
+    // same MFMAs as column K of the product and are flushed to colsum instead of C.
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     typedef __attribute__((address_space(3))) s16x4* lds4_t;
     constexpr int TN = 64;
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const bf16_t* __
         for (int l = 0; l < NLB; ++l) {
             const int c = l * 256 + tid, row = c / (16 * NT), d = c - row * (16 * NT);
             unsigned v = breg[l];
-            if (nb + row >= N || 2 * d >= K) v = 0u;
+            if (nb + row >= N || 2 * d >= K) v = (colsum && 2 * d == K && nb + row < N) ? 0x3F80u : 0u;
             *reinterpret_cast<unsigned*>(bl + row * LB + 2 * d) = v;
         }
         __syncthreads();
@@ -173,6 +177,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const bf16_t* __
                     const int m = mt * 32 + d_row(r, h);
                     if (m < M) unsafeAtomicAdd(C + (int64_t)m * K + col, acc[j][r]);
                 }
+            } else if (colsum && col == K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mt * 32 + d_row(r, h);
+                    if (m < M) unsafeAtomicAdd(colsum + m, acc[j][r]);
+                }
             }
         }
     }
@@ -182,6 +192,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const bf16_t* __
 
 extern "C" int mdl_gemm_tn(const void* a, int64_t lda, int M, const void* b, int64_t ldb, int K, float* c, int64_t N,
                            int dtype, mdlStream_t stream) {
+    return mdl_gemm_tn_colsum(a, lda, M, b, ldb, K, c, nullptr, N, dtype, stream);
+}
+
+extern "C" int mdl_gemm_tn_colsum(const void* a, int64_t lda, int M, const void* b, int64_t ldb, int K, float* c,
+                                  float* colsum, int64_t N, int dtype, mdlStream_t stream) {
     using namespace mdl;
     MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_gemm_tn: bf16 only");
     MDL_REQUIRE(M >= 1 && M <= 128 && K >= 1 && K <= 256, MDL_E_UNSUPP, "mdl_gemm_tn: need 1<=M<=128, 1<=K<=256 (got %d, %d)", M, K);
@@ -189,7 +204,7 @@ extern "C" int mdl_gemm_tn(const void* a, int64_t lda, int M, const void* b, int
     if (N == 0) return MDL_OK;
     hipStream_t st = (hipStream_t)stream;
     {   // streaming kernel: needs dword-addressable rows and K <= 128 (LDS budget / instantiations)
-        int mt = (M + 31) / 32, nt = (K + 31) / 32;
+        int mt = (M + 31) / 32, nt = (K + (colsum ? 1 : 0) + 31) / 32;   // colsum rides in padding column K of the B tile
         if (mt == 3) mt = 4;                      // (instantiated for 1, 2, 4 tiles; the padding columns are zero)
         if (nt == 3) nt = 4;
         const bool ok = (M % 2 == 0) && (K % 2 == 0) && (lda % 2 == 0) && (ldb % 2 == 0) && nt <= 4 &&
@@ -199,7 +214,7 @@ extern "C" int mdl_gemm_tn(const void* a, int64_t lda, int M, const void* b, int
             if (sgrid > 256) sgrid = 256;     // one block per CU: every block ends with M*K atomics on the same addresses
                                               // (measured 128 / 256 / 512 / 1024 blocks: 49 / 40 / 43 / 63 us on 2e5 rows)
 #define MDL_TNS(MT_, NT_) hipLaunchKernelGGL((gemm_tn_stream_kernel<MT_, NT_>), dim3((unsigned)sgrid), dim3(256), 0, st, \
-        (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, N)
+        (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, colsum, N)
             if (mt == 1) { if (nt == 1) MDL_TNS(1, 1); else if (nt == 2) MDL_TNS(1, 2); else MDL_TNS(1, 4); }
             else if (mt == 2) { if (nt == 1) MDL_TNS(2, 1); else if (nt == 2) MDL_TNS(2, 2); else MDL_TNS(2, 4); }
             else { if (nt == 1) MDL_TNS(4, 1); else if (nt == 2) MDL_TNS(4, 2); else MDL_TNS(4, 4); }
@@ -207,6 +222,7 @@ extern "C" int mdl_gemm_tn(const void* a, int64_t lda, int M, const void* b, int
             return check_launch("mdl_gemm_tn");
         }
     }
+    MDL_REQUIRE(!colsum, MDL_E_UNSUPP, "mdl_gemm_tn_colsum: the column sums need even M, K, lda, ldb, 4-byte aligned rows and K <= 126");
     int64_t grid = cdiv(N, 128);
     if (grid > 512) grid = 512;
     const int mt = (M + 31) / 32, ntw = ((K + 31) / 32 + 3) / 4;

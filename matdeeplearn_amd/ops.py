@@ -549,11 +549,15 @@ class _LinearTN(torch.autograd.Function):
         ga, Ma = g, M
         if M % 2:                               # the streaming kernel stages rows as dwords: pad an odd width (the model's
             ga, Ma = torch.nn.functional.pad(g, (0, 1)), M + 1             # 1-column output layer) with a zero column
-        dw = torch.zeros((Ma, K), dtype=torch.float32, device=g.device)
-        check(lib().mdl_gemm_tn(ptr(ga), ga.stride(0), Ma, ptr(x), x.stride(0), K, ptr(dw), g.shape[0], dtype_code(g),
-                                stream()), "mdl_gemm_tn")
+        fused_db = ctx.has_bias and K % 2 == 0 and K <= 126 and x.stride(0) % 2 == 0 and ga.stride(0) % 2 == 0
+        buf = torch.zeros(Ma * K + Ma, dtype=torch.float32, device=g.device)          # dW | db in one zero fill
+        dw, dbv = buf[:Ma * K].view(Ma, K), buf[Ma * K:]
+        check(lib().mdl_gemm_tn_colsum(ptr(ga), ga.stride(0), Ma, ptr(x), x.stride(0), K, ptr(dw), ptr(dbv) if fused_db else None,
+                                       g.shape[0], dtype_code(g), stream()), "mdl_gemm_tn_colsum")
         dw = dw[:M]
-        db = g.sum(dim=0, dtype=torch.float32).to(ctx.wdtype) if ctx.has_bias else None
+        db = None
+        if ctx.has_bias:                          # bias gradient = column sums of g: out of the same pass when the shape allows
+            db = dbv[:M].to(ctx.wdtype) if fused_db else g.sum(dim=0, dtype=torch.float32).to(ctx.wdtype)
         return dx, dw.to(ctx.wdtype), db, None, None
 
 

@@ -298,7 +298,7 @@ def test_gather_rows_and_its_gradient(dtype):
 
 
 @pytest.mark.parametrize("N,M,K", [(1000, 64, 114), (129, 32, 50), (5000, 100, 200), (77, 128, 256), (1, 7, 3), (8192, 1, 64),
-                                   (8192, 64, 64)])
+                                   (8192, 64, 64), (3000, 2, 64), (700, 64, 126)])
 def test_gemm_tn_matches_torch(N, M, K):
     """Tall-skinny weight-gradient GEMM (bf16 in, fp32 out) vs an fp32 matmul of the same rounded inputs."""
     import ctypes
@@ -311,6 +311,12 @@ def test_gemm_tn_matches_torch(N, M, K):
                                       _lib.MDL_BF16, _lib.stream()), "mdl_gemm_tn")
     ref = a.float().t() @ b.float()
     close(c, ref, 1e-4, 1e-5)
+    if M % 2 == 0 and K % 2 == 0 and K <= 126:          # same pass + column sums of a (the Linear's bias gradient)
+        c2, cs = torch.zeros(M, K, device=dev()), torch.zeros(M, device=dev())
+        _lib.check(_lib.lib().mdl_gemm_tn_colsum(_lib.ptr(a), a.stride(0), M, _lib.ptr(b), b.stride(0), K, _lib.ptr(c2),
+                                                 _lib.ptr(cs), N, _lib.MDL_BF16, _lib.stream()), "mdl_gemm_tn_colsum")
+        close(c2, ref, 1e-4, 1e-5)
+        close(cs, a.float().sum(0), 1e-4, 1e-5)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
