@@ -6,9 +6,12 @@ export TMPDIR=/tmp
 cd /tmp
 python $GRAFT_REPO_ROOT/tools/bench_kernels.py "$@" > $OUT/plain.log 2>&1; tail -3 $OUT/plain.log
 i=0
-for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
-           "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS" \
-           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" ; do
+# PMC_ONLY=traffic: just the two HBM passes (FETCH_SIZE, WRITE_SIZE) that feed profiles/hbm_traffic.json
+GRPS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
+      "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS"
+      "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum")
+[ "${PMC_ONLY:-}" = "traffic" ] && GRPS=("FETCH_SIZE" "WRITE_SIZE")
+for grp in "${GRPS[@]}"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o p -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --iters 2 "$@" > $OUT/p$i.log 2>&1
   f=$(find $OUT/p$i -name "*counter_collection.csv" | head -1)
