@@ -172,6 +172,13 @@ int mdl_bn_bwd_stats(const void* dy, const void* x, const float* save, float* su
 int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save, float* sums, const float* gamma, void* dx,
                      int64_t N, int C, int dtype, mdlStream_t stream);
 
+/* ---- node-level dense layer forward, fused: out[N, M] = act(x[N, K] . w[M, K]^T + bias) ---------------
+ * Replaces `getattr(F, act)(lin(out))` of the pre-FC / post-FC loops (matdeeplearn/models/cgcnn.py:124-130,155-166)
+ * for the tall-skinny shapes of this path.  x: dense rows (leading dimension K), 16-byte aligned; w [M, K] and bias [M]
+ * (may be NULL) in `dtype`; act: 0 = none, 1 = ReLU.  bf16 only, K even, 4 <= K <= 256, M <= 128. */
+int mdl_linear_act(const void* x, const void* w, const void* bias, void* out, int64_t N, int K, int M, int act, int dtype,
+                   mdlStream_t stream);
+
 /* ---- tall-skinny TN GEMM: weight gradients of node-level Linear layers ---------------------------
  * c[M, K] (fp32, row-major, caller zero-fills) += a[N, M]^T . b[N, K]   a, b bf16 with leading dims lda, ldb.
  * Replaces the (out x N)(N x in) product autograd forms for dW of the reference's node-level Linears

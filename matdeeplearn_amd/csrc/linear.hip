@@ -1,0 +1,147 @@
+// linear.hip — node-level dense layer forward, fused:  out[N, M] = act(x[N, K] . W[M, K]^T + bias)   (bf16 in / out).
+// Replaces `getattr(F, act)(lin(out))` of the reference's pre-FC / post-FC loops
+// (/root/reference/matdeeplearn/models/cgcnn.py:124-130,155-166) for the tall-skinny shapes of this path (N = 2e5 nodes
+// or 8e3 graphs, K <= 256, M <= 128): the library picks a 64x64x32 macro tile for them (69 us for 2e5 x 114 x 64, plus
+// 12 us for the separate activation), while the layer is a stream: N*(K + M)*2 bytes, read / written once.
+//
+// Workgroup = 4 waves = 64 rows per step of a grid-stride loop.  W (all of it) sits in LDS for the whole kernel, rows
+// padded to an odd number of 16-byte slots.  The x tile is a CONTIGUOUS byte range (dense rows): it is fetched with
+// 16-byte buffer loads one tile ahead (range = the bytes left in the array, so the last tile needs no clamps and reads
+// zeros past the end) and scattered dword-wise into a padded LDS tile.  MFMA 32x32x16: A = x rows, B = W rows (both
+// row-wise ds_read_b128 fragments), K zero-padded to a multiple of 32 in LDS; bias + activation on the accumulators.
+#include "mdl_common.h"
+
+namespace mdl {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_l;
+
+template <int KP, int NT>     // KP: K padded to {64, 128, 256}; NT: 32-column tiles of the output (M <= 32*NT)
+__global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
+                                                            int64_t N, int K, int M, int act, unsigned inv_k2) {
+    constexpr int TN = 64;
+    constexpr int LD = KP + 8;                       // LDS row stride (bf16): odd number of 16-byte slots
+    constexpr int NLX = KP * 8 / 256;                // 16-byte chunks of the x tile per thread (tile = 64 rows x K, K <= KP)
+    constexpr int NB = (2 * NT + 3) / 4;             // (32-row, 32-col) output blocks per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* wl = reinterpret_cast<bf16_t*>(smem);    // [32*NT][LD]
+    bf16_t* xl = wl + 32 * NT * LD;                  // [TN][LD]
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k2 = K >> 1;                           // dwords per row
+
+    // W -> LDS (zero padded to [32*NT][KP]) and the zero padding of the x tile's columns K..KP-1 (never written again)
+    for (int q = tid; q < 32 * NT * (KP / 2); q += 256) {
+        const int row = q / (KP / 2), d = q - row * (KP / 2);
+        unsigned v = 0u;
+        if (row < M && d < k2) v = *reinterpret_cast<const unsigned*>(w + (int64_t)row * K + 2 * d);
+        *reinterpret_cast<unsigned*>(wl + row * LD + 2 * d) = v;
+    }
+    for (int q = tid; q < TN * (KP / 2); q += 256) {
+        const int row = q / (KP / 2), d = q - row * (KP / 2);
+        if (d >= k2) *reinterpret_cast<unsigned*>(xl + row * LD + 2 * d) = 0u;
+    }
+    float bv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int blk = wv + 4 * j, nt = blk % NT, col = nt * 32 + i;
+        bv[j] = (bias && col < M) ? bf2f(bias[col]) : 0.0f;
+    }
+
+    const int64_t n_tiles = (N + TN - 1) / TN;
+    const int tile_chunks = TN * K / 8;              // 16-byte chunks per full tile (K even -> 64*K*2 bytes, a multiple of 16)
+    u32x4_l xr[NLX];
+    auto load_tile = [&](int64_t tile) {
+        const int64_t off = tile * TN * (int64_t)K;                      // elements
+        const int64_t rem = (N * (int64_t)K - off) * 2;                  // bytes left in the array
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(x + off), 0, (int)(rem < 0x7fffffffLL ? rem : 0x7fffffffLL), 0x00020000);
+#pragma unroll
+        for (int l = 0; l < NLX; ++l) xr[l] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, l * 4096, 0);
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < n_tiles) load_tile(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int64_t nb = tile * TN;
+        __syncthreads();                                    // previous tile's fragments read; W / padding in place
+#pragma unroll
+        for (int l = 0; l < NLX; ++l) {
+            const int c = l * 256 + tid;
+            if (c < tile_chunks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned q = 4u * c + j;                       // dword of the tile -> (row, dword in row)
+                    const unsigned row = __umulhi(q, inv_k2);
+                    const unsigned d = q - row * (unsigned)k2;
+                    *reinterpret_cast<unsigned*>(xl + row * LD + 2 * d) = xr[l][j];
+                }
+            }
+        }
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) load_tile(tile + gridDim.x);      // next tile's loads fly during the MFMAs
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int blk = wv + 4 * j;
+            if (blk < 2 * NT) {
+                const int mt = blk / NT, nt = blk - mt * NT;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = bv[j];
+#pragma unroll
+                for (int kk = 0; kk < KP / 16; ++kk) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(xl + (mt * 32 + i) * LD + 16 * kk + 8 * h);
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + (nt * 32 + i) * LD + 16 * kk + 8 * h);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                }
+                const int col = nt * 32 + i;
+                const int64_t remr = N - nb - mt * 32;                    // rows of this block that exist
+                if (col < M && remr > 0) {
+                    const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
+                        out + (nb + mt * 32) * (int64_t)M, 0,
+                        (int)((remr * M * 2) < 0x7fffffffLL ? (remr * M * 2) : 0x7fffffffLL), 0x00020000);
+                    const int vo = (4 * h * M + col) * 2;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[r];
+                        if (act == 1) v = v > 0.0f ? v : 0.0f;
+                        __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(v), os, vo, ((r & 3) + 8 * (r >> 2)) * M * 2, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace mdl
+
+extern "C" int mdl_linear_act(const void* x, const void* w, const void* bias, void* out, int64_t N, int K, int M, int act,
+                              int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_linear_act: bf16 only");
+    MDL_REQUIRE(K >= 4 && K <= 256 && K % 2 == 0 && M >= 1 && M <= 128, MDL_E_UNSUPP,
+                "mdl_linear_act: need even 4<=K<=256 and 1<=M<=128 (got K=%d M=%d)", K, M);
+    MDL_REQUIRE(act == 0 || act == 1, MDL_E_ARG, "mdl_linear_act: act must be 0 (none) or 1 (relu)");
+    MDL_REQUIRE(N >= 0 && (N == 0 || (x && w && out)), MDL_E_ARG, "mdl_linear_act: bad arguments");
+    MDL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(w) % 4 == 0 &&
+                reinterpret_cast<uintptr_t>(out) % 2 == 0, MDL_E_ARG, "mdl_linear_act: misaligned pointer");
+    if (N == 0) return MDL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int kp = K <= 64 ? 64 : (K <= 128 ? 128 : 256);
+    const int nt = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
+    int64_t grid = cdiv(N, 64);
+    if (grid > 512) grid = 512;
+    const int k2 = K / 2;
+    const unsigned inv_k2 = (unsigned)((0x100000000ULL + k2 - 1) / k2);      // row = umulhi(q, inv) for q < 2^16 (k2 >= 2)
+    const int lds = (32 * nt + 64) * (kp + 8) * 2;
+#define MDL_LIN(KP_, NT_)                                                                                            \
+    do {                                                                                                             \
+        auto kf = linear_act_kernel<KP_, NT_>;                                                                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
+                           (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, inv_k2);                                 \
+    } while (0)
+    if (kp == 64) { if (nt == 1) MDL_LIN(64, 1); else if (nt == 2) MDL_LIN(64, 2); else MDL_LIN(64, 4); }
+    else if (kp == 128) { if (nt == 1) MDL_LIN(128, 1); else if (nt == 2) MDL_LIN(128, 2); else MDL_LIN(128, 4); }
+    else { if (nt == 1) MDL_LIN(256, 1); else if (nt == 2) MDL_LIN(256, 2); else MDL_LIN(256, 4); }
+#undef MDL_LIN
+    return check_launch("mdl_linear_act");
+}

@@ -24,6 +24,13 @@ def dense(lin, h):
     return ops.linear(h, lin.weight, lin.bias, _lowp(lin))      # bf16, many rows: HIP TN GEMM for the weight gradient
 
 
+def dense_act(lin, h, act):
+    """getattr(F, act)(lin(h)); for bf16 activations with many rows the forward is one fused HIP kernel."""
+    if h.dtype == lin.weight.dtype:
+        return getattr(F, act)(lin(h))
+    return ops.linear_act(h, lin.weight, lin.bias, act, _lowp(lin))
+
+
 def _lowp(lin):
     """The layer's (weight, bias) in the compute dtype if GraphModel._cast_dense made them for the CURRENT parameter
     values (version counters), else None."""
@@ -101,11 +108,8 @@ class GraphModel(nn.Module):
     def _pre(self, out):
         if out.dtype == torch.bfloat16 and torch.is_grad_enabled():
             self._cast_dense(out.dtype)
-        for k, lin in enumerate(self.pre_lin_list):
-            if k == 0 and out.dtype == torch.bfloat16 and not out.requires_grad:
-                out = getattr(F, self.act)(ops.linear_input_leaf(out, lin.weight, lin.bias, _lowp(lin)))   # HIP dW (K = #nodes)
-            else:
-                out = getattr(F, self.act)(dense(lin, out))
+        for lin in self.pre_lin_list:
+            out = dense_act(lin, out, self.act)
         return out
 
     def _bn(self, i, out):
@@ -116,7 +120,7 @@ class GraphModel(nn.Module):
 
     def _post(self, out):
         for lin in self.post_lin_list:
-            out = getattr(F, self.act)(dense(lin, out))
+            out = dense_act(lin, out, self.act)
         return dense(self.lin_out, out)
 
     def _pool(self, out, data):

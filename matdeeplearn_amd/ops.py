@@ -543,22 +543,65 @@ class _LinearTN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        g = g.contiguous()
-        M, K = ctx.shape
-        dx = g @ w if ctx.needs_input_grad[0] else None
-        ga, Ma = g, M
-        if M % 2:                               # the streaming kernel stages rows as dwords: pad an odd width (the model's
-            ga, Ma = torch.nn.functional.pad(g, (0, 1)), M + 1             # 1-column output layer) with a zero column
-        fused_db = ctx.has_bias and K % 2 == 0 and K <= 126 and x.stride(0) % 2 == 0 and ga.stride(0) % 2 == 0
-        buf = torch.zeros(Ma * K + Ma, dtype=torch.float32, device=g.device)          # dW | db in one zero fill
-        dw, dbv = buf[:Ma * K].view(Ma, K), buf[Ma * K:]
-        check(lib().mdl_gemm_tn_colsum(ptr(ga), ga.stride(0), Ma, ptr(x), x.stride(0), K, ptr(dw), ptr(dbv) if fused_db else None,
-                                       g.shape[0], dtype_code(g), stream()), "mdl_gemm_tn_colsum")
-        dw = dw[:M]
-        db = None
-        if ctx.has_bias:                          # bias gradient = column sums of g: out of the same pass when the shape allows
-            db = dbv[:M].to(ctx.wdtype) if fused_db else g.sum(dim=0, dtype=torch.float32).to(ctx.wdtype)
-        return dx, dw.to(ctx.wdtype), db, None, None
+        dx, dw, db = _linear_tn_grads(ctx, g.contiguous(), x, w)
+        return dx, dw, db, None, None
+
+
+def _linear_tn_grads(ctx, g, x, w):
+    """(dx, dW, db) of y = x W^T + b for a tall x: library GEMM for dx, one TN-GEMM launch for dW and db."""
+    M, K = ctx.shape
+    dx = g @ w if ctx.needs_input_grad[0] else None
+    ga, Ma = g, M
+    if M % 2:                               # the streaming kernel stages rows as dwords: pad an odd width (the model's
+        ga, Ma = torch.nn.functional.pad(g, (0, 1)), M + 1             # 1-column output layer) with a zero column
+    fused_db = ctx.has_bias and K % 2 == 0 and K <= 126 and x.stride(0) % 2 == 0 and ga.stride(0) % 2 == 0
+    buf = torch.zeros(Ma * K + Ma, dtype=torch.float32, device=g.device)          # dW | db in one zero fill
+    dw, dbv = buf[:Ma * K].view(Ma, K), buf[Ma * K:]
+    check(lib().mdl_gemm_tn_colsum(ptr(ga), ga.stride(0), Ma, ptr(x), x.stride(0), K, ptr(dw), ptr(dbv) if fused_db else None,
+                                   g.shape[0], dtype_code(g), stream()), "mdl_gemm_tn_colsum")
+    dw = dw[:M]
+    db = None
+    if ctx.has_bias:                          # bias gradient = column sums of g: out of the same pass when the shape allows
+        db = dbv[:M].to(ctx.wdtype) if fused_db else g.sum(dim=0, dtype=torch.float32).to(ctx.wdtype)
+    return dx, dw.to(ctx.wdtype), db
+
+
+class _LinearActTN(torch.autograd.Function):
+    """act(x W^T + b) with the forward as ONE streaming HIP kernel (GEMM + bias + activation) and the backward of
+    _LinearTN (library dX, TN GEMM for dW and db); the ReLU mask comes from the saved output."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_lp, b_lp, act):
+        w = weight.to(x.dtype) if w_lp is None else w_lp
+        b = None if bias is None else (bias.to(x.dtype) if b_lp is None else b_lp)
+        N, K = x.shape
+        M = weight.shape[0]
+        out = torch.empty((N, M), dtype=x.dtype, device=x.device)
+        check(lib().mdl_linear_act(ptr(x), ptr(w), ptr(b), ptr(out), N, K, M, 1 if act == "relu" else 0, dtype_code(x),
+                                   stream()), "mdl_linear_act")
+        ctx.save_for_backward(x, w, out if act == "relu" else None)
+        ctx.wdtype, ctx.has_bias, ctx.shape, ctx.act = weight.dtype, bias is not None, tuple(weight.shape), act
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, out = ctx.saved_tensors
+        if ctx.act == "relu":
+            g = torch.ops.aten.threshold_backward(g, out, 0)
+        dx, dw, db = _linear_tn_grads(ctx, g.contiguous(), x, w)
+        return dx, dw, db, None, None, None
+
+
+def linear_act(x, weight, bias, act, lowp=None):
+    """getattr(F, act)(F.linear(x, weight, bias)) — fused forward for bf16 inputs with dense rows, even in <= 256,
+    out <= 128 and act in (relu, none); anything else composes `linear` with the library activation."""
+    if (act in ("relu", None) and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
+            and x.shape[0] >= 1024 and weight.shape[0] <= 128 and 4 <= weight.shape[1] <= 256 and weight.shape[1] % 2 == 0
+            and x.data_ptr() % 16 == 0 and weight.requires_grad):
+        w_lp, b_lp = (lowp if lowp is not None and lowp[0].dtype == x.dtype else (None, None))
+        return _LinearActTN.apply(x, weight, bias, w_lp, b_lp, act)
+    y = linear(x, weight, bias, lowp)
+    return y if act is None else getattr(torch.nn.functional, act)(y)
 
 
 def linear(x, weight, bias, lowp=None):

@@ -319,6 +319,45 @@ def test_gemm_tn_matches_torch(N, M, K):
         close(cs, a.float().sum(0), 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("N,K,M,act,use_bias", [(1000, 114, 64, "relu", True), (1001, 114, 64, "relu", True),
+                                                (8192, 64, 64, "relu", True), (2051, 50, 20, None, False),
+                                                (1500, 256, 128, "relu", True), (1027, 4, 1, None, True), (67, 114, 64, "relu", True)])
+def test_linear_act_matches_torch(N, K, M, act, use_bias):
+    """Fused dense layer forward (GEMM + bias + activation, one streaming kernel) through the C ABI, and the autograd
+    wrapper's gradients, vs fp32 torch on the same bf16-rounded inputs.  N = 1001 / 1027 / 67: the last 16-byte chunk of
+    the input straddles the end of the array; 67: a single partial tile."""
+    from matdeeplearn_amd import _lib, ops
+    g = torch.Generator().manual_seed(N + K + M)
+    x = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev())
+    w = (torch.randn(M, K, generator=g) / K ** 0.5).to(dev())
+    b = (torch.randn(M, generator=g) * 0.1).to(dev()) if use_bias else None
+    wl, bl = w.to(torch.bfloat16), None if b is None else b.to(torch.bfloat16)
+    out = torch.empty(N, M, dtype=torch.bfloat16, device=dev())
+    _lib.check(_lib.lib().mdl_linear_act(_lib.ptr(x), _lib.ptr(wl), _lib.ptr(bl), _lib.ptr(out), N, K, M,
+                                         1 if act == "relu" else 0, _lib.MDL_BF16, _lib.stream()), "mdl_linear_act")
+    ref = torch.nn.functional.linear(x.float(), wl.float(), None if bl is None else bl.float())
+    if act == "relu":
+        ref = torch.relu(ref)
+    close(out, ref, 1e-2, 4e-3)
+    if N >= 1024:                                            # the autograd path (forward fused, dW / db on the TN GEMM)
+        wp = w.clone().requires_grad_(True)
+        bp = None if b is None else b.clone().requires_grad_(True)
+        xg = x.clone().requires_grad_(True)
+        y = ops.linear_act(xg, wp, bp, act)
+        go = torch.randn(N, M, generator=g).to(dev())
+        (y.float() * go).sum().backward()
+        xr, wr = x.float().clone().requires_grad_(True), wl.float().clone().requires_grad_(True)
+        br = None if bl is None else bl.float().clone().requires_grad_(True)
+        yr = torch.nn.functional.linear(xr, wr, br)
+        yr = torch.relu(yr) if act == "relu" else yr
+        (yr * go.to(torch.bfloat16).float()).sum().backward()
+        close(y, yr, 1e-2, 4e-3)
+        close(wp.grad, wr.grad, 3e-2, 2e-2)
+        close(xg.grad, xr.grad, 3e-2, 2e-2)
+        if bp is not None:
+            close(bp.grad, br.grad, 3e-2, 2e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,C", [(1000, 64), (37, 64), (5000, 128), (1, 32), (999, 16)])
 def test_batchnorm_train_matches_torch(dtype, N, C):
