@@ -43,15 +43,6 @@
 #ifndef MDL_FWD_XDB
 #define MDL_FWD_XDB 0     // 1: x-row gathers of tile t+1 in flight during tile t (costs 32 VGPRs)
 #endif
-#ifndef MDL_FWD_UNCOND
-#define MDL_FWD_UNCOND 1   // all-slices forward: next-tile loads issued on every path (uniform selects, no branches)
-#endif
-#ifndef MDL_EW_BUFFER
-#define MDL_EW_BUFFER 1    // edge-feature tile prefetch with buffer loads (0: global loads, clamped second path for the array tail)
-#endif
-#ifndef MDL_BWD_UNCOND
-#define MDL_BWD_UNCOND 1   // backward tile loop: next-tile loads issued unconditionally (clamped)
-#endif
 #ifndef MDL_BWD_XDB
 #define MDL_BWD_XDB 1
 #endif
@@ -303,7 +294,6 @@ struct EWords {
     // path for the last tile costs more than its instructions: every control-flow join in the tile loop makes
     // hipcc's wait-count bookkeeping assume the worse of the two paths.)
     __device__ __forceinline__ void prefetch(const CgParams& p, int lane, int eb, int /*nv*/, int /*my_ep*/) {
-#if MDL_EW_BUFFER
         constexpr int WB = EW * (int)sizeof(T);
         static_assert(WB == 4 || WB == 2, "staging word");
         const char* tb = reinterpret_cast<const char*>(p.ea) + (int64_t)eb * (G_ * (int)sizeof(T));
@@ -315,22 +305,6 @@ struct EWords {
             if constexpr (WB == 4) w[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane * WB, j * (WAVE * WB), 0);
             else w[j] = __builtin_amdgcn_raw_buffer_load_b16(rs, lane * WB, j * (WAVE * WB), 0);
         }
-#else
-        constexpr unsigned WB = EW * sizeof(T);
-        const char* tb = reinterpret_cast<const char*>(p.ea) + (int64_t)eb * (G_ * (int)sizeof(T));
-        if ((int64_t)(p.E - eb) * GW >= NW * WAVE) {
-            const char* lp = tb + lane * WB;
-#pragma unroll
-            for (int j = 0; j < NW; ++j) w[j] = *reinterpret_cast<const word_t*>(lp + j * (WAVE * WB));
-        } else {
-            const unsigned lim = (unsigned)((p.E - eb) * GW - 1);
-#pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                const unsigned q = min((unsigned)(j * WAVE + lane), lim);
-                w[j] = *reinterpret_cast<const volatile word_t*>(tb + q * WB);
-            }
-        }
-#endif
     }
     __device__ __forceinline__ void commit(T* et, int EKS, int lane) const {
 #pragma unroll
@@ -791,7 +765,6 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                 if (h == 0) reinterpret_cast<unsigned char*>(w.tsl)[i] = (i < nv) ? (unsigned char)(cur.tgt - G.n0) : 0xff;
                 wave_lds_fence();
                 TMARK(1);
-#if MDL_FWD_UNCOND
                 // The next tile's loads are issued on EVERY path, from uniform selects of the tile base (next tile of
                 // this group / first tile of the next group / this tile again when the stream ends): a path that skips
                 // them joins the loop with "the x fragments are the newest loads in flight", and the waits hipcc then
@@ -805,16 +778,6 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                     nxt.template load<false, false>(p, pe, pe1, i, pn0);
                     ew.prefetch(p, lane, pe, 32, 0);
                 }
-#else
-                if (!last) {
-                    nxt.template load<false>(p, eb + 32, G.e1, i, G.n0);
-                    ew.prefetch(p, lane, eb + 32, min(32, G.e1 - eb - 32), nxt.ep);
-                } else if (hasN && GN.e0 < GN.e1) {
-                    nextHasEdges = true;
-                    nxt.template load<false>(p, GN.e0, GN.e1, i, GN.n0);
-                    ew.prefetch(p, lane, GN.e0, min(32, GN.e1 - GN.e0), nxt.ep);
-                }
-#endif
                 TMARK(2);
                 unsigned t4[4];
 #pragma unroll
@@ -832,7 +795,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
 #if MDL_FWD_XEARLY
                     // the x rows of the NEXT tile: requested as soon as the last slice's MFMAs have consumed this
                     // tile's fragments (same registers), so their latency hides under the gate / aggregation
-                    if (sl == NSL - 1 && (MDL_FWD_UNCOND || !last || nextHasEdges)) xf.load(x, dm.C, nxt.tgt, nxt.src, h);
+                    if (sl == NSL - 1) xf.load(x, dm.C, nxt.tgt, nxt.src, h);      // unconditional, like the loads above
 #endif
                     f32x16 m;
 #pragma unroll
@@ -1199,20 +1162,12 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             TMARK(1);
 
             if constexpr (CP_ != 0 && !XDB) xf.load(x, dm.C, cur.tgt, cur.src, h);
-#if MDL_BWD_UNCOND
             // Unconditional on purpose (indices are clamped, so the last tile of a group re-reads valid rows): a path
             // that skips these loads merges into the loop with "the x fragments are the newest loads in flight", and
             // the waits hipcc then puts in front of the MFMAs drain this tile's prefetches as well.
             if constexpr (CP_ != 0 && XDB) xn.load(x, dm.C, nxt.tgt, nxt.src, h);
             nn.template load<!ST, false>(p, eb + 64, e1, i, n0);
-            if constexpr (ST) ew.prefetch(p, lane, MDL_EW_BUFFER ? eb + 32 : min(eb + 32, (int)p.E - 1), 32, nxt.ep);
-#else
-            if (eb + 32 < e1) {
-                if constexpr (CP_ != 0 && XDB) xn.load(x, dm.C, nxt.tgt, nxt.src, h);
-                if (eb + 64 < e1) nn.template load<!ST>(p, eb + 64, e1, i, n0);
-                if constexpr (ST) ew.prefetch(p, lane, eb + 32, min(32, e1 - eb - 32), nxt.ep);
-            }
-#endif
+            if constexpr (ST) ew.prefetch(p, lane, eb + 32, 32, nxt.ep);
 
             TMARK(2);
             f32x16 accf, accs;
