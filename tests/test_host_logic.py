@@ -360,3 +360,62 @@ def test_conv_kernels_register_budget():
                  "cgconv_node_stream_kernelILi64", "cgconv_node_stream_kernelILi32"):    # node-level dense half
         scratch, occ = find(frag)
         assert scratch == 0 and occ >= 2
+
+
+# ---------------------------------------------------------------------------------------------
+# host-side launch diet: per-step zero arena, lazily counted BatchNorm steps, low-precision weight copies
+# ---------------------------------------------------------------------------------------------
+def test_zero_arena_hands_out_zeroed_aligned_views_and_falls_back():
+    from matdeeplearn_amd import ops
+    cpu = torch.device("cpu")
+    assert ops._ARENA is None
+    t = ops._zeros_step((3, 5), cpu)                      # outside a step: plain zeros
+    assert t.shape == (3, 5) and float(t.abs().sum()) == 0.0
+    with ops.zero_arena(cpu, nbytes=4096) as arena:       # 1024 floats
+        a = ops._zeros_step((2, 50), cpu)
+        b = ops._zeros_step((7,), cpu)
+        assert a.data_ptr() != b.data_ptr() and (b.data_ptr() - a.data_ptr()) % 256 == 0
+        assert a.untyped_storage().data_ptr() == arena.buf.untyped_storage().data_ptr()
+        a.fill_(3.0)
+        b.fill_(4.0)
+        big = ops._zeros_step((2000,), cpu)               # does not fit: falls back to a fresh tensor
+        assert big.untyped_storage().data_ptr() != arena.buf.untyped_storage().data_ptr() and float(big.sum()) == 0.0
+    assert ops._ARENA is None
+    with ops.zero_arena(cpu, nbytes=4096):                # next step: same buffer, zero again
+        c = ops._zeros_step((2, 50), cpu)
+        assert c.data_ptr() == a.data_ptr() and float(c.abs().sum()) == 0.0
+
+
+def test_batchnorm_step_counter_is_folded_in_when_the_state_is_read():
+    from matdeeplearn_amd import nn as mnn
+    bn = mnn.BatchNorm1d(8)
+    bn.train()
+    bn(torch.randn(16, 8))                                # CPU: library path, counts on the tensor
+    assert int(bn.num_batches_tracked) == 1
+    bn._nbt_pending = 3                                   # what three HIP-path steps leave behind
+    assert int(bn.state_dict()["num_batches_tracked"]) == 4 and bn._nbt_pending == 0
+    other = mnn.BatchNorm1d(8)
+    other._nbt_pending = 5
+    other.load_state_dict(bn.state_dict())
+    assert other._nbt_pending == 0 and int(other.state_dict()["num_batches_tracked"]) == 4
+
+
+def test_low_precision_weight_copies_are_dropped_when_the_parameters_move_on():
+    from matdeeplearn_amd.models import _base
+    lin = torch.nn.Linear(6, 4)
+    assert _base._lowp(lin) is None
+    w16, b16 = lin.weight.detach().to(torch.bfloat16), lin.bias.detach().to(torch.bfloat16)
+    lin._mdl_lowp = (w16, b16, lin.weight._version, lin.bias._version)
+    assert _base._lowp(lin)[0] is w16
+    with torch.no_grad():
+        lin.weight.add_(1.0)                              # an optimizer step
+    assert _base._lowp(lin) is None
+
+
+def test_linear_act_composes_the_library_ops_off_the_fast_path():
+    from matdeeplearn_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x, w, b = torch.randn(9, 6, generator=g), torch.randn(4, 6, generator=g), torch.randn(4, generator=g)
+    assert torch.equal(ops.linear_act(x, w, b, "relu"), torch.relu(torch.nn.functional.linear(x, w, b)))
+    assert torch.equal(ops.linear_act(x, w, None, None), torch.nn.functional.linear(x, w))
+    assert torch.equal(ops.linear_act(x, w, b, "softplus"), torch.nn.functional.softplus(torch.nn.functional.linear(x, w, b)))
