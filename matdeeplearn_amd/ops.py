@@ -529,7 +529,7 @@ def gather_mul_reduce(h, csr, w=None, scale=None, reduce="sum"):
 # GEMM for the weight gradient — dW = g^T x contracts over the ROWS (2e5 nodes, 8192 graphs), a shape the
 # library handles badly (47 us for a 64 x 64 x 8192 product, 0.7 ms for 64 x 114 x 2e5)
 # ------------------------------------------------------------------------------------------------
-_TN_COLSUM = os.environ.get("MDL_TN_COLSUM", "0") == "1"
+_TN_COLSUM = os.environ.get("MDL_TN_COLSUM", "1") == "1"
 
 
 class _LinearTN(torch.autograd.Function):
@@ -558,10 +558,8 @@ def _linear_tn_grads(ctx, g, x, w):
     ga, Ma = g, M
     if M % 2:                               # the streaming kernel stages rows as dwords: pad an odd width (the model's
         ga, Ma = torch.nn.functional.pad(g, (0, 1)), M + 1             # 1-column output layer) with a zero column
-    # db out of the same pass (mdl_gemm_tn_colsum) is correct but OFF by default: the kernel flushes the column sums with one
-    # atomic instruction per row — 2 active lanes each, 8192 separate transactions on the same two cache lines per launch
-    # — which costs more (pre-FC dW 40 -> 83 us, post-FC 6 -> 34 us) than the 13-us library reduction it replaces.  The
-    # flush has to gather the 32 rows of a block into one instruction first (next round); MDL_TN_COLSUM=1 enables it.
+    # db out of the same pass (mdl_gemm_tn_colsum: the column sums of g ride in a padding column of the B tile and are
+    # flushed with one gathered atomic instruction per block); MDL_TN_COLSUM=0 falls back to the library reduction
     fused_db = (_TN_COLSUM and ctx.has_bias and K % 2 == 0 and K <= 126 and x.stride(0) % 2 == 0
                 and ga.stride(0) % 2 == 0)
     buf = torch.zeros(Ma * K + Ma, dtype=torch.float32, device=g.device)          # dW | db in one zero fill
