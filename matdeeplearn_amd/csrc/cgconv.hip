@@ -24,6 +24,11 @@
 // one-hot MFMA, forms dpre = d/d(pre) on registers and reduces it three ways:
 //   r_tgt (by target: MFMA, registers), r_src (by source: one-hot MFMA into a 64-node register window, fp32 atomics
 //   outside it), dwe = dpre^T e (MFMA).  The node-level dense products (dx, dW_tgt, dW_src) are cgconv_node.hip.
+//
+// Load discipline of the tile loops (it is worth 10-15 % of either kernel): every prefetch is issued on EVERY path —
+// uniform selects of the tile base, clamped indices, buffer loads whose range check replaces the end-of-array path —
+// because hipcc derives each s_waitcnt from the worst path into it: one path that skips the prefetches makes the waits
+// in front of the x-fragment MFMAs drain the loads issued a few instructions earlier.
 // cgconv_cb.inc (included below) holds a second, cooperative weight-stationary design of both kernels (opt-in).
 // DESIGN.md section 4 has the measured phase breakdown and the list of variants behind the MDL_* switches below.
 //
