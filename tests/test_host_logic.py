@@ -419,3 +419,34 @@ def test_linear_act_composes_the_library_ops_off_the_fast_path():
     assert torch.equal(ops.linear_act(x, w, b, "relu"), torch.relu(torch.nn.functional.linear(x, w, b)))
     assert torch.equal(ops.linear_act(x, w, None, None), torch.nn.functional.linear(x, w))
     assert torch.equal(ops.linear_act(x, w, b, "softplus"), torch.nn.functional.softplus(torch.nn.functional.linear(x, w, b)))
+
+
+# ---------------------------------------------------------------------------------------------
+# product graph builder vs the loop oracle on random inputs (the goldens pin five clouds; this covers ties,
+# duplicate distances, tiny graphs, every pbc combination)
+# ---------------------------------------------------------------------------------------------
+def test_product_graph_builder_matches_loop_oracle_on_random_clouds():
+    from hypothesis import given, settings, strategies as st
+    from matdeeplearn_amd.process import graph as pg
+    from oracle import graph as og
+
+    @settings(max_examples=40, deadline=None, derandomize=True)
+    @given(n=st.integers(1, 24), seed=st.integers(0, 10 ** 6), radius=st.sampled_from([2.5, 4.0, 8.0]),
+           k=st.sampled_from([1, 4, 12]), grid=st.booleans(), pbc=st.tuples(st.booleans(), st.booleans(), st.booleans()))
+    def check(n, seed, radius, k, grid, pbc):
+        rng = np.random.default_rng(seed)
+        cell = np.diag(rng.uniform(5.0, 9.0, size=3))
+        pos = rng.uniform(0.0, 9.0, size=(n, 3))
+        if grid:                                             # lattice points: many exactly equal distances (rank ties)
+            pos = np.round(pos / 1.5) * 1.5
+        d_p = pg.distance_matrix(pos, cell, list(pbc))
+        d_o = og.mic_distances(pos, cell, list(pbc))
+        assert np.allclose(d_p, d_o, atol=1e-12)
+        t_p, t_o = pg.threshold_sort(d_o, radius, k), og.threshold_sort(d_o, radius, k)
+        assert np.array_equal(t_p, t_o)
+        ei_p, ew_p = pg.edges_from_trimmed(t_o)
+        ei_o, ew_o = og.dense_to_edges(t_o)
+        assert np.array_equal(ei_p, ei_o) and np.array_equal(ew_p, ew_o)
+        assert np.array_equal(pg.one_hot_degree(ei_o, n, k + 1), og.one_hot_degree(ei_o, n, k + 1))
+
+    check()
