@@ -9,7 +9,6 @@ Same argument meaning, differentiable through torch.autograd.Function, errors ra
 exceptions.  Every op runs a hand-written HIP kernel; there is no eager/CPU fallback.
 """
 import collections
-import math
 import os
 
 import torch

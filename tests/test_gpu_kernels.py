@@ -301,7 +301,6 @@ def test_gather_rows_and_its_gradient(dtype):
                                    (8192, 64, 64), (3000, 2, 64), (700, 64, 126)])
 def test_gemm_tn_matches_torch(N, M, K):
     """Tall-skinny weight-gradient GEMM (bf16 in, fp32 out) vs an fp32 matmul of the same rounded inputs."""
-    import ctypes
     from matdeeplearn_amd import _lib
     g = torch.Generator().manual_seed(N + M)
     a = torch.randn(N, M, generator=g).to(torch.bfloat16).to(dev())

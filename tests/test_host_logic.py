@@ -3,7 +3,6 @@ model — the product has no CPU compute path), and the data-parallel engine ove
 import os
 import re
 import sys
-import types
 
 import numpy as np
 import pytest

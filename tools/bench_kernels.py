@@ -1,7 +1,7 @@
 import os
 #!/usr/bin/env python3
 """Micro-benchmark of the conv kernels on one synthetic batch (used for rocprofv3 --pmc passes)."""
-import argparse, sys, os, time
+import argparse, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from matdeeplearn_amd import ops, _lib
