@@ -1,4 +1,3 @@
-import os
 #!/usr/bin/env python3
 """Micro-benchmark of the conv kernels on one synthetic batch (used for rocprofv3 --pmc passes)."""
 import argparse, sys, os
