@@ -41,38 +41,44 @@ def _lowp(lin):
 
 
 class GraphModel(nn.Module):
-    def _init_skeleton(self, data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order, batch_norm,
-                       batch_track_stats, act, dropout_rate, compute_dtype, post_fc_dim=None, early_mult=1,
-                       make_bn=True):
+    """Layer CREATION order and ModuleList REGISTRATION order are the reference's (cgcnn.py:64-119, mpnn.py:66-128,
+    megnet.py:200-290): pre_lin_list, then per conv layer (conv [, gru], bn), then post_lin_list, lin_out, set2set
+    [, lin_out_2].  A seeded construction therefore draws the reference's initial weights and state_dict() lists the
+    reference's keys in the reference's order (tests/golden/wrappers.npz)."""
+
+    def _begin(self, data, dim1, pre_fc_count, gc_count, pool, pool_order, batch_norm, batch_track_stats, act,
+               dropout_rate, compute_dtype, lists=("conv_list", "bn_list")):
         assert gc_count > 0, "Need at least 1 GC layer"
         self.batch_track_stats = batch_track_stats != "False"
         self.batch_norm, self.pool, self.act = batch_norm, pool, act
         self.pool_order, self.dropout_rate = pool_order, dropout_rate
         self.compute_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[compute_dtype]
         self.gc_dim = data.num_features if pre_fc_count == 0 else dim1
-        post_in = self.gc_dim if post_fc_dim is None else post_fc_dim
         y0 = data[0].y
         self.output_dim = 1 if y0.ndim == 0 else len(y0[0])
-        s2s_early = pool == "set2set" and pool_order == "early"
-        if pool_order == "early":
+        self.pre_lin_list = nn.ModuleList(
+            [nn.Linear(data.num_features if i == 0 else dim1, dim1) for i in range(pre_fc_count)])
+        for name in lists:
+            setattr(self, name, nn.ModuleList())
+
+    def _add_bn(self, dim):
+        if self.batch_norm == "True":
+            self.bn_list.append(BatchNorm1d(dim, track_running_stats=self.batch_track_stats))
+
+    def _finish(self, dim2, post_fc_count, post_in, early_mult=1, set2set_names=("set2set",)):
+        s2s_early = self.pool == "set2set" and self.pool_order == "early"
+        if self.pool_order == "early":
             first_in = post_in * ((2 * early_mult - 1) if (s2s_early and early_mult > 1) else (2 if s2s_early else early_mult))
         else:
             first_in = post_in
-        self.pre_lin_list = nn.ModuleList(
-            [nn.Linear(data.num_features if i == 0 else dim1, dim1) for i in range(pre_fc_count)])
-        self.bn_list = nn.ModuleList(
-            [BatchNorm1d(self.gc_dim, track_running_stats=self.batch_track_stats) for _ in range(gc_count)]
-            if (batch_norm == "True" and make_bn) else [])
         self.post_lin_list = nn.ModuleList(
             [nn.Linear(first_in if i == 0 else dim2, dim2) for i in range(post_fc_count)])
         self.lin_out = nn.Linear(dim2 if post_fc_count > 0 else first_in, self.output_dim)
-        return post_in
-
-    def _make_set2set(self, post_in):
-        if self.pool == "set2set" and self.pool_order == "early":
-            self.set2set = Set2Set(post_in, processing_steps=3)
+        if s2s_early:
+            for name in set2set_names:
+                setattr(self, name, Set2Set(post_in, processing_steps=3))
         elif self.pool == "set2set" and self.pool_order == "late":
-            self.set2set = Set2Set(self.output_dim, processing_steps=3, num_layers=1)
+            setattr(self, set2set_names[0], Set2Set(self.output_dim, processing_steps=3, num_layers=1))
             self.lin_out_2 = nn.Linear(self.output_dim * 2, self.output_dim)
 
     # ---- shared forward pieces ----------------------------------------------------------------

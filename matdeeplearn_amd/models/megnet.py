@@ -69,24 +69,17 @@ class MEGNet(GraphModel):
                  post_fc_count=1, pool="global_mean_pool", pool_order="early", batch_norm="True",
                  batch_track_stats="True", act="relu", dropout_rate=0.0, compute_dtype="fp32", **kwargs):
         super().__init__()
-        self._init_skeleton(data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order, batch_norm,
-                            batch_track_stats, act, dropout_rate, compute_dtype, post_fc_dim=dim3, early_mult=3,
-                            make_bn=False)
+        self._begin(data, dim1, pre_fc_count, gc_count, pool, pool_order, batch_norm, batch_track_stats, act,
+                    dropout_rate, compute_dtype,
+                    lists=("e_embed_list", "x_embed_list", "u_embed_list", "conv_list", "bn_list"))
         self.pool_reduce = {"global_mean_pool": "mean", "global_max_pool": "max", "global_sum_pool": "sum"}.get(pool)
-        self.e_embed_list, self.x_embed_list, self.u_embed_list = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
-        self.conv_list = nn.ModuleList()
         for i in range(gc_count):
             self.e_embed_list.append(_embed(data.num_edge_features if i == 0 else dim3, dim3))
             self.x_embed_list.append(_embed(self.gc_dim if i == 0 else dim3, dim3))
             self.u_embed_list.append(_embed(data[0].u.shape[1] if i == 0 else dim3, dim3))
             args = (dim3, act, batch_norm, batch_track_stats, dropout_rate, gc_fc_count)
             self.conv_list.append(MetaLayer(Megnet_EdgeModel(*args), Megnet_NodeModel(*args), Megnet_GlobalModel(*args)))
-        if pool == "set2set" and pool_order == "early":
-            self.set2set_x = Set2Set(dim3, processing_steps=3)
-            self.set2set_e = Set2Set(dim3, processing_steps=3)
-        elif pool == "set2set" and pool_order == "late":
-            self.set2set_x = Set2Set(self.output_dim, processing_steps=3, num_layers=1)
-            self.lin_out_2 = nn.Linear(self.output_dim * 2, self.output_dim)
+        self._finish(dim2, post_fc_count, dim3, early_mult=3, set2set_names=("set2set_x", "set2set_e"))
 
     def forward(self, data):
         cd = self.compute_dtype

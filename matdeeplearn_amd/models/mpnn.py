@@ -13,15 +13,15 @@ class MPNN(GraphModel):
                  pool="global_mean_pool", pool_order="early", batch_norm="True", batch_track_stats="True",
                  act="relu", dropout_rate=0.0, compute_dtype="fp32", **kwargs):
         super().__init__()
-        post_in = self._init_skeleton(data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order,
-                                      batch_norm, batch_track_stats, act, dropout_rate, compute_dtype)
+        self._begin(data, dim1, pre_fc_count, gc_count, pool, pool_order, batch_norm, batch_track_stats, act,
+                    dropout_rate, compute_dtype, lists=("conv_list", "gru_list", "bn_list"))
         c = self.gc_dim
-        self.conv_list, self.gru_list = nn.ModuleList(), nn.ModuleList()
         for _ in range(gc_count):
             net = nn.Sequential(nn.Linear(data.num_edge_features, dim3), nn.ReLU(), nn.Linear(dim3, c * c))
             self.conv_list.append(NNConv(c, c, net, aggr="mean"))
             self.gru_list.append(nn.GRU(c, c))
-        self._make_set2set(post_in)
+            self._add_bn(c)
+        self._finish(dim2, post_fc_count, c)
 
     def forward(self, data):
         x, edge_attr, csr = self._inputs(data)

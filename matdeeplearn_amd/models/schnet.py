@@ -12,11 +12,12 @@ class SchNet(GraphModel):
                  pool="global_mean_pool", pool_order="early", batch_norm="True", batch_track_stats="True",
                  act="relu", dropout_rate=0.0, compute_dtype="fp32", **kwargs):
         super().__init__()
-        post_in = self._init_skeleton(data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order,
-                                      batch_norm, batch_track_stats, act, dropout_rate, compute_dtype)
-        self.conv_list = nn.ModuleList(
-            [InteractionBlock(self.gc_dim, data.num_edge_features, dim3, cutoff) for _ in range(gc_count)])
-        self._make_set2set(post_in)
+        self._begin(data, dim1, pre_fc_count, gc_count, pool, pool_order, batch_norm, batch_track_stats, act,
+                    dropout_rate, compute_dtype)
+        for _ in range(gc_count):
+            self.conv_list.append(InteractionBlock(self.gc_dim, data.num_edge_features, dim3, cutoff))
+            self._add_bn(self.gc_dim)
+        self._finish(dim2, post_fc_count, self.gc_dim)
 
     def forward(self, data):
         x, edge_attr, csr = self._inputs(data)

@@ -25,6 +25,7 @@ class CGConv(nn.Module):
         # same construction order / default init as PyG (torch.nn.Linear kaiming-uniform)
         self.lin_f = nn.Linear(2 * channels + dim, channels, bias=bias)
         self.lin_s = nn.Linear(2 * channels + dim, channels, bias=bias)
+        self.reset_parameters()          # as upstream: the constructor ends with a second draw of both layers
 
     def reset_parameters(self):
         self.lin_f.reset_parameters()
@@ -109,10 +110,12 @@ class InteractionBlock(nn.Module):
         self.reset_parameters()
 
     def reset_parameters(self):
-        for m in (self.mlp[0], self.mlp[2], self.lin):
+        for m in (self.mlp[0], self.mlp[2]):            # upstream order: filter network, conv, output layer
             nn.init.xavier_uniform_(m.weight)
             m.bias.data.fill_(0)
         self.conv.reset_parameters()
+        nn.init.xavier_uniform_(self.lin.weight)
+        self.lin.bias.data.fill_(0)
 
     def forward(self, x, edge_index, edge_weight, edge_attr, csr=None):
         return _lin(self.lin, self.act(self.conv(x, edge_index, edge_weight, edge_attr, csr=csr)))
@@ -129,6 +132,12 @@ class GCNConv(nn.Module):
         self.lin = nn.Linear(in_channels, out_channels, bias=False)
         nn.init.xavier_uniform_(self.lin.weight)
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.lin.weight)        # glorot, drawn again by the upstream constructor's reset
+        if self.bias is not None:
+            self.bias.data.zero_()
 
     def forward(self, x, edge_index, edge_weight=None, csr=None):
         if csr is None:
@@ -157,6 +166,16 @@ class NNConv(nn.Module):
         self.nn = nn_module
         self.lin = nn.Linear(in_channels, out_channels, bias=False) if root_weight else None
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for m in self.nn.modules():                      # upstream reset(self.nn), then root weight, bias = 0
+            if m is not self.nn and hasattr(m, "reset_parameters"):
+                m.reset_parameters()
+        if self.lin is not None:
+            self.lin.reset_parameters()
+        if self.bias is not None:
+            self.bias.data.zero_()
 
     def _messages(self, xj, edge_attr):
         w = self.nn(edge_attr).view(-1, self.in_channels, self.out_channels)
@@ -207,6 +226,7 @@ class Set2Set(nn.Module):
         self.in_channels, self.out_channels = in_channels, 2 * in_channels
         self.processing_steps, self.num_layers = processing_steps, num_layers
         self.lstm = nn.LSTM(self.out_channels, in_channels, num_layers)
+        self.lstm.reset_parameters()
 
     def forward(self, x, batch, size=None):
         b = int(batch.max()) + 1 if size is None else size

@@ -24,23 +24,32 @@ def _out_dim(data):
 
 
 class _Skeleton(nn.Module):
-    """Everything the five wrappers share (e.g. cgcnn.py:35-119)."""
+    """Everything the five wrappers share (e.g. cgcnn.py:35-119).  Layers are CREATED in the reference's order —
+    pre_lin_list -> per conv layer (conv [, gru], bn) -> post_lin_list -> lin_out -> set2set [-> lin_out_2]
+    (cgcnn.py:64-119, mpnn.py:66-128) — and the ModuleLists are REGISTERED in the reference's order, so that a
+    seeded construction draws the same initial weights and state_dict() lists the same keys in the same order
+    (pinned by tests/golden/wrappers.npz, generated from the reference files themselves)."""
 
-    set2set_late = True
-
-    def _init_common(self, data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order,
-                     batch_norm, batch_track_stats, act, dropout_rate, post_fc_dim=None, pool_mult=1):
+    def _begin(self, data, dim1, pre_fc_count, gc_count, pool, pool_order, batch_norm, batch_track_stats, act,
+               dropout_rate, lists=("conv_list", "bn_list")):
         assert gc_count > 0, "Need at least 1 GC layer"
         self.batch_track_stats = batch_track_stats != "False"
         self.batch_norm, self.pool, self.act = batch_norm, pool, act
         self.pool_order, self.dropout_rate = pool_order, dropout_rate
         self.gc_dim = data.num_features if pre_fc_count == 0 else dim1
-        post_in = self.gc_dim if post_fc_dim is None else post_fc_dim
         self.output_dim = _out_dim(data)
         self.pre_lin_list = nn.ModuleList(
             [nn.Linear(data.num_features if i == 0 else dim1, dim1) for i in range(pre_fc_count)])
-        early_s2s = pool_order == "early" and pool == "set2set"
-        if pool_order == "early":
+        for name in lists:
+            setattr(self, name, nn.ModuleList())
+
+    def _add_bn(self, dim):
+        if self.batch_norm == "True":
+            self.bn_list.append(nn.BatchNorm1d(dim, track_running_stats=self.batch_track_stats))
+
+    def _finish(self, dim2, post_fc_count, post_in, pool_mult=1, set2set_names=("set2set",)):
+        early_s2s = self.pool_order == "early" and self.pool == "set2set"
+        if self.pool_order == "early":
             first_in = post_in * (pool_mult * 2 - 1 if (early_s2s and pool_mult > 1) else
                                   (2 if early_s2s else pool_mult))
         else:
@@ -48,7 +57,12 @@ class _Skeleton(nn.Module):
         self.post_lin_list = nn.ModuleList(
             [nn.Linear(first_in if i == 0 else dim2, dim2) for i in range(post_fc_count)])
         self.lin_out = nn.Linear(dim2 if post_fc_count > 0 else first_in, self.output_dim)
-        return post_in
+        if early_s2s:
+            for name in set2set_names:
+                setattr(self, name, ops.Set2Set(post_in, processing_steps=3))
+        elif self.pool == "set2set" and self.pool_order == "late":
+            setattr(self, set2set_names[0], ops.Set2Set(self.output_dim, processing_steps=3, num_layers=1))
+            self.lin_out_2 = nn.Linear(self.output_dim * 2, self.output_dim)
 
     def _pre(self, data):
         out = data.x
@@ -58,12 +72,6 @@ class _Skeleton(nn.Module):
 
     def _bn(self, i, out):
         return self.bn_list[i](out) if self.batch_norm == "True" else out
-
-    def _make_bn(self, gc_count, dim):
-        self.bn_list = nn.ModuleList()
-        if self.batch_norm == "True":
-            for _ in range(gc_count):
-                self.bn_list.append(nn.BatchNorm1d(dim, track_running_stats=self.batch_track_stats))
 
     def _post(self, out):
         for lin in self.post_lin_list:
@@ -83,26 +91,18 @@ class _Skeleton(nn.Module):
                 out = ops.POOLS[self.pool](out, batch)
         return out.view(-1) if out.shape[1] == 1 else out
 
-    def _make_set2set(self, post_in):
-        if self.pool == "set2set" and self.pool_order == "early":
-            self.set2set = ops.Set2Set(post_in, processing_steps=3)
-        elif self.pool == "set2set" and self.pool_order == "late":
-            self.set2set = ops.Set2Set(self.output_dim, processing_steps=3, num_layers=1)
-            self.lin_out_2 = nn.Linear(self.output_dim * 2, self.output_dim)
-
 
 class CGCNN(_Skeleton):
     def __init__(self, data, dim1=64, dim2=64, pre_fc_count=1, gc_count=3, post_fc_count=1,
                  pool="global_mean_pool", pool_order="early", batch_norm="True", batch_track_stats="True",
                  act="relu", dropout_rate=0.0, **kwargs):
         super().__init__()
-        post_in = self._init_common(data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order,
-                                    batch_norm, batch_track_stats, act, dropout_rate)
-        self.conv_list = nn.ModuleList(
-            [ops.CGConv(self.gc_dim, data.num_edge_features, aggr="mean", batch_norm=False)
-             for _ in range(gc_count)])
-        self._make_bn(gc_count, self.gc_dim)
-        self._make_set2set(post_in)
+        self._begin(data, dim1, pre_fc_count, gc_count, pool, pool_order, batch_norm, batch_track_stats, act,
+                    dropout_rate)
+        for _ in range(gc_count):                                                 # cgcnn.py:77-87
+            self.conv_list.append(ops.CGConv(self.gc_dim, data.num_edge_features, aggr="mean", batch_norm=False))
+            self._add_bn(self.gc_dim)
+        self._finish(dim2, post_fc_count, self.gc_dim)
 
     def forward(self, data):
         out = self._pre(data)
@@ -117,12 +117,12 @@ class SchNet(_Skeleton):
                  pool="global_mean_pool", pool_order="early", batch_norm="True", batch_track_stats="True",
                  act="relu", dropout_rate=0.0, **kwargs):
         super().__init__()
-        post_in = self._init_common(data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order,
-                                    batch_norm, batch_track_stats, act, dropout_rate)
-        self.conv_list = nn.ModuleList(
-            [ops.InteractionBlock(self.gc_dim, data.num_edge_features, dim3, cutoff) for _ in range(gc_count)])
-        self._make_bn(gc_count, self.gc_dim)
-        self._make_set2set(post_in)
+        self._begin(data, dim1, pre_fc_count, gc_count, pool, pool_order, batch_norm, batch_track_stats, act,
+                    dropout_rate)
+        for _ in range(gc_count):                                                 # schnet.py:78-86
+            self.conv_list.append(ops.InteractionBlock(self.gc_dim, data.num_edge_features, dim3, cutoff))
+            self._add_bn(self.gc_dim)
+        self._finish(dim2, post_fc_count, self.gc_dim)
 
     def forward(self, data):
         out = self._pre(data)
@@ -137,12 +137,12 @@ class GCN(_Skeleton):
                  pool="global_mean_pool", pool_order="early", batch_norm="True", batch_track_stats="True",
                  act="relu", dropout_rate=0.0, **kwargs):
         super().__init__()
-        post_in = self._init_common(data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order,
-                                    batch_norm, batch_track_stats, act, dropout_rate)
-        self.conv_list = nn.ModuleList(
-            [ops.GCNConv(self.gc_dim, self.gc_dim, improved=True, add_self_loops=False) for _ in range(gc_count)])
-        self._make_bn(gc_count, self.gc_dim)
-        self._make_set2set(post_in)
+        self._begin(data, dim1, pre_fc_count, gc_count, pool, pool_order, batch_norm, batch_track_stats, act,
+                    dropout_rate)
+        for _ in range(gc_count):                                                 # gcn.py:77-86
+            self.conv_list.append(ops.GCNConv(self.gc_dim, self.gc_dim, improved=True, add_self_loops=False))
+            self._add_bn(self.gc_dim)
+        self._finish(dim2, post_fc_count, self.gc_dim)
 
     def forward(self, data):
         out = self._pre(data)
@@ -158,16 +158,15 @@ class MPNN(_Skeleton):
                  pool="global_mean_pool", pool_order="early", batch_norm="True", batch_track_stats="True",
                  act="relu", dropout_rate=0.0, **kwargs):
         super().__init__()
-        post_in = self._init_common(data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order,
-                                    batch_norm, batch_track_stats, act, dropout_rate)
+        self._begin(data, dim1, pre_fc_count, gc_count, pool, pool_order, batch_norm, batch_track_stats, act,
+                    dropout_rate, lists=("conv_list", "gru_list", "bn_list"))
         c = self.gc_dim
-        self.conv_list, self.gru_list = nn.ModuleList(), nn.ModuleList()
-        for _ in range(gc_count):
+        for _ in range(gc_count):                                                 # mpnn.py:78-96
             net = nn.Sequential(nn.Linear(data.num_edge_features, dim3), nn.ReLU(), nn.Linear(dim3, c * c))
             self.conv_list.append(ops.NNConv(c, c, net, aggr="mean"))
             self.gru_list.append(nn.GRU(c, c))
-        self._make_bn(gc_count, c)
-        self._make_set2set(post_in)
+            self._add_bn(c)
+        self._finish(dim2, post_fc_count, c)
 
     def forward(self, data):
         out = self._pre(data)
@@ -243,26 +242,18 @@ class MEGNet(_Skeleton):
                  post_fc_count=1, pool="global_mean_pool", pool_order="early", batch_norm="True",
                  batch_track_stats="True", act="relu", dropout_rate=0.0, **kwargs):
         super().__init__()
-        self._init_common(data, dim1, dim2, pre_fc_count, gc_count, post_fc_count, pool, pool_order,
-                          batch_norm, batch_track_stats, act, dropout_rate, post_fc_dim=dim3, pool_mult=3)
+        self._begin(data, dim1, pre_fc_count, gc_count, pool, pool_order, batch_norm, batch_track_stats, act,
+                    dropout_rate, lists=("e_embed_list", "x_embed_list", "u_embed_list", "conv_list", "bn_list"))
         self.pool_reduce = {"global_mean_pool": "mean", "global_max_pool": "max",
                             "global_sum_pool": "sum"}.get(pool)  # megnet.py:177-182 (no global_add_pool)
-        self.e_embed_list, self.x_embed_list, self.u_embed_list = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
-        self.conv_list = nn.ModuleList()
-        self.bn_list = nn.ModuleList()
-        for i in range(gc_count):
+        for i in range(gc_count):                                                 # megnet.py:213-254
             self.e_embed_list.append(_embed(data.num_edge_features if i == 0 else dim3, dim3))
             self.x_embed_list.append(_embed(self.gc_dim if i == 0 else dim3, dim3))
             self.u_embed_list.append(_embed(data[0].u.shape[1] if i == 0 else dim3, dim3))
             args = (dim3, act, batch_norm, batch_track_stats, dropout_rate, gc_fc_count)
             self.conv_list.append(ops.MetaLayer(MegnetEdgeModel(*args), MegnetNodeModel(*args),
                                                 MegnetGlobalModel(*args)))
-        if pool == "set2set" and pool_order == "early":
-            self.set2set_x = ops.Set2Set(dim3, processing_steps=3)
-            self.set2set_e = ops.Set2Set(dim3, processing_steps=3)
-        elif pool == "set2set" and pool_order == "late":
-            self.set2set_x = ops.Set2Set(self.output_dim, processing_steps=3, num_layers=1)
-            self.lin_out_2 = nn.Linear(self.output_dim * 2, self.output_dim)
+        self._finish(dim2, post_fc_count, dim3, pool_mult=3, set2set_names=("set2set_x", "set2set_e"))
 
     def forward(self, data):
         out = self._pre(data)

@@ -133,6 +133,13 @@ class CGConv(nn.Module):
         self.channels, self.dim, self.aggr = channels, dim, aggr
         self.lin_f = nn.Linear(2 * channels + dim, channels, bias=bias)
         self.lin_s = nn.Linear(2 * channels + dim, channels, bias=bias)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """Upstream CGConv.__init__ ends with reset_parameters(): both Linears are drawn a second time (this matters
+        only for reproducing a SEEDED initialisation; restated from the published 2.0.1 source, unverifiable here)."""
+        self.lin_f.reset_parameters()
+        self.lin_s.reset_parameters()
 
     def forward(self, x, edge_index, edge_attr):
         return cgconv(x, edge_index, edge_attr, self.lin_f.weight, self.lin_f.bias,
@@ -159,6 +166,9 @@ class CFConv(nn.Module):
         self.lin2 = nn.Linear(num_filters, out_channels)
         self.nn = net
         self.cutoff = cutoff
+        self.reset_parameters()
+
+    def reset_parameters(self):
         nn.init.xavier_uniform_(self.lin1.weight)
         nn.init.xavier_uniform_(self.lin2.weight)
         self.lin2.bias.data.fill_(0)
@@ -180,9 +190,16 @@ class InteractionBlock(nn.Module):
         self.conv = CFConv(hidden_channels, hidden_channels, num_filters, self.mlp, cutoff)
         self.act = ShiftedSoftplus()
         self.lin = nn.Linear(hidden_channels, hidden_channels)
-        for m in (self.mlp[0], self.mlp[2], self.lin):
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """Upstream order: mlp[0], mlp[2], conv (lin1, lin2 — drawn a second time), lin."""
+        for m in (self.mlp[0], self.mlp[2]):
             nn.init.xavier_uniform_(m.weight)
             m.bias.data.fill_(0)
+        self.conv.reset_parameters()
+        nn.init.xavier_uniform_(self.lin.weight)
+        self.lin.bias.data.fill_(0)
 
     def forward(self, x, edge_index, edge_weight, edge_attr):
         return self.lin(self.act(self.conv(x, edge_index, edge_weight, edge_attr)))
@@ -198,6 +215,18 @@ class NNConv(nn.Module):
         self.nn = net
         self.lin = nn.Linear(in_channels, out_channels, bias=False) if root_weight else None
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """Upstream NNConv.__init__ ends with reset_parameters(): reset(self.nn) re-draws every layer of the edge
+        network, then the root weight (PyG Linear 'uniform' = U(+-1/sqrt(fan_in)) = torch's default), bias = 0."""
+        for m in self.nn.modules():
+            if m is not self.nn and hasattr(m, "reset_parameters"):
+                m.reset_parameters()
+        if self.lin is not None:
+            self.lin.reset_parameters()
+        if self.bias is not None:
+            self.bias.data.zero_()
 
     def forward(self, x, edge_index, edge_attr):
         row, col = edge_index[0], edge_index[1]
@@ -220,8 +249,14 @@ class GCNConv(nn.Module):
         super().__init__()
         assert not add_self_loops, "the reference passes add_self_loops=False (gcn.py:81)"
         self.lin = nn.Linear(in_channels, out_channels, bias=False)
-        nn.init.xavier_uniform_(self.lin.weight)
+        nn.init.xavier_uniform_(self.lin.weight)            # PyG Linear(weight_initializer="glorot") draws in its ctor ...
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.reset_parameters()                             # ... and GCNConv.__init__ ends with reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.lin.weight)
+        if self.bias is not None:
+            self.bias.data.zero_()
 
     def forward(self, x, edge_index, edge_weight=None):
         row, col = edge_index[0], edge_index[1]
@@ -267,6 +302,7 @@ class Set2Set(nn.Module):
         self.in_channels, self.out_channels = in_channels, 2 * in_channels
         self.processing_steps, self.num_layers = processing_steps, num_layers
         self.lstm = nn.LSTM(self.out_channels, in_channels, num_layers)
+        self.lstm.reset_parameters()                        # upstream Set2Set.__init__ ends with reset_parameters()
 
     def forward(self, x, batch):
         b = int(batch.max()) + 1

@@ -14,6 +14,14 @@ Reference entry points exercised (file:line, relative to /root/reference):
   matdeeplearn/process/process.py:594-605  OneHotDegree            -> onehot_degree.npz
   matdeeplearn/process/process.py:626-653  GetRanges/NormalizeEdge -> normalize_edge.npz
   matdeeplearn/models/megnet.py:16-371     MEGNet + blocks         -> megnet.npz
+  matdeeplearn/models/cgcnn.py:17-174, schnet.py:16-172, mpnn.py:17-188, gcn.py:17-173
+                                           the four wrappers       -> wrappers.npz
+      (their conv operators live in torch_geometric 2.0.1, which is absent: the oracle's restatements
+       oracle.ops.{CGConv, InteractionBlock, NNConv, GCNConv, Set2Set, global_*_pool} are injected as
+       the `torch_geometric.nn` stub, so these vectors pin everything the REFERENCE files own — layer
+       creation order / seeded initialisation, state_dict key order, pre-FC -> conv -> BN -> act ->
+       dropout ordering, pooling order, set2set sizes, residuals, the GRU wiring — not the conv
+       arithmetic itself, which stays "restated from the published semantics".)
   data/test_data/test_data.tar.gz                                   -> pt10_dataset.npz (positions/targets: data)
 
 Third-party semantics needed by the stubs (torch_scatter.scatter / scatter_mean,
@@ -120,6 +128,64 @@ def load_ref_megnet():
 
 
 # --------------------------------------------------------------------------------------
+
+
+def load_ref_wrapper(fname):
+    """Import /root/reference/matdeeplearn/models/<fname>.py with the oracle operators standing in for
+    torch_geometric.nn (PyG 2.0.1 is not installable here)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import ops as oops
+    _stub("torch_scatter", scatter=_scatter, scatter_mean=_scatter_mean, scatter_add=None, scatter_max=None)
+    tg = _stub("torch_geometric")
+    nn = _stub("torch_geometric.nn", Set2Set=oops.Set2Set, CGConv=oops.CGConv, NNConv=oops.NNConv,
+               GCNConv=oops.GCNConv, MetaLayer=_MetaLayer, global_mean_pool=oops.global_mean_pool,
+               global_add_pool=oops.global_add_pool, global_max_pool=oops.global_max_pool)
+    tg.nn = nn
+    nn.models = _stub("torch_geometric.nn.models")
+    nn.models.schnet = _stub("torch_geometric.nn.models.schnet", InteractionBlock=oops.InteractionBlock)
+    return _load(os.path.join(REF, "matdeeplearn/models/%s.py" % fname), "ref_" + fname)
+
+
+# wrapper configurations stored in wrappers.npz (shared with tests/test_oracle_golden.py via the npz itself)
+WRAPPER_DIMS = dict(dim1=16, dim2=12, dim3=8, gc_count=2)
+WRAPPER_CONFIGS = [
+    ("bn", dict(pre_fc_count=1, post_fc_count=2, batch_norm="True")),
+    ("nobn_max", dict(pre_fc_count=1, post_fc_count=1, batch_norm="False", pool="global_max_pool")),
+    ("late_add", dict(pre_fc_count=2, post_fc_count=2, batch_norm="True", pool="global_add_pool", pool_order="late")),
+    ("s2s", dict(pre_fc_count=1, post_fc_count=1, batch_norm="True", pool="set2set", batch_track_stats="False")),
+    ("s2s_late", dict(pre_fc_count=1, post_fc_count=0, batch_norm="False", pool="set2set", pool_order="late")),
+    ("pre0", dict(pre_fc_count=0, post_fc_count=0, batch_norm="True", act="softplus")),
+]
+
+
+def wrapper_goldens(bt, y, DS):
+    out = {}
+    meta = {}
+    for fname, cls in [("cgcnn", "CGCNN"), ("schnet", "SchNet"), ("mpnn", "MPNN"), ("gcn", "GCN")]:
+        mod = load_ref_wrapper(fname)
+        for tag, kw in WRAPPER_CONFIGS:
+            if cls == "MPNN" and kw.get("pre_fc_count") == 0:
+                continue                      # gc_dim = 114 -> a 114*114-wide edge network: not a useful fixture
+            key = "%s/%s" % (cls, tag)
+            torch.manual_seed(4321)
+            model = getattr(mod, cls)(DS(), **WRAPPER_DIMS, **kw)
+            meta[key] = dict(kw=kw, sd_keys=list(model.state_dict().keys()))
+            for k, v in model.state_dict().items():
+                out["%s/init/%s" % (key, k)] = v.detach().numpy().copy()
+            model.train()
+            pred = model(bt)
+            loss = torch.nn.functional.l1_loss(pred, y)
+            loss.backward()
+            for k, p in model.named_parameters():
+                out["%s/grad/%s" % (key, k)] = p.grad.numpy() if p.grad is not None else np.zeros(0)
+            for k, v in model.state_dict().items():          # buffers after one training forward
+                if "running_" in k or "num_batches" in k:
+                    out["%s/post/%s" % (key, k)] = v.detach().numpy().copy()
+            out["%s/pred_train" % key] = pred.detach().numpy()
+            model.eval()
+            out["%s/pred_eval" % key] = model(bt).detach().numpy()
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    return out
 
 
 def read_pt10():
@@ -269,6 +335,14 @@ def main():
     out.update(x=x.numpy(), edge_index=edge_index.numpy(), edge_attr=edge_attr.numpy(), u=u.numpy(),
                batch=batch.numpy(), y=y.numpy())
     np.savez_compressed(os.path.join(OUT, "megnet.npz"), **out)
+
+    # (7) CGCNN / SchNet / MPNN / GCN wrappers (reference files, oracle operators injected) ----------
+    torch.manual_seed(777)
+    bt = ns(x=x, edge_index=edge_index, edge_attr=edge_attr, edge_weight=ew, u=u, batch=batch)
+    wr = wrapper_goldens(bt, y, DS)
+    wr.update(x=x.numpy(), edge_index=edge_index.numpy(), edge_attr=edge_attr.numpy(), edge_weight=ew.numpy(),
+              batch=batch.numpy(), y=y.numpy())
+    np.savez_compressed(os.path.join(OUT, "wrappers.npz"), **wr)
     print("goldens written to", OUT)
 
 

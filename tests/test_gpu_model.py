@@ -163,3 +163,58 @@ def test_other_models_fp32_match_oracle(name, kw):
         cpu_err = float((ref_grads[k].grad.double() - truth).abs().max())
         gpu_err = float((p.grad.cpu().double() - truth).abs().max()) if p.grad is not None else s
         assert gpu_err <= max(20.0 * cpu_err, 2e-4 * s), (k, gpu_err, cpu_err, s)
+
+
+# ------------------------------------------------------------------------------------------------
+# Product models against the vectors produced by the REFERENCE's own wrapper files (tests/golden/wrappers.npz,
+# make_golden.py section 7): seeded construction -> training-mode prediction, parameter gradients, BatchNorm
+# buffers after the step, eval-mode prediction.  No oracle object is involved on this path.
+# ------------------------------------------------------------------------------------------------
+import json  # noqa: E402
+
+
+def _wrapper_cases():
+    z = np.load(os.path.join(G_DIR, "wrappers.npz"))
+    return sorted(json.loads(bytes(z["meta"]).decode()))
+
+
+@pytest.mark.parametrize("case", _wrapper_cases())
+def test_product_matches_reference_wrapper_goldens(case):
+    from matdeeplearn_amd import models
+    z = np.load(os.path.join(G_DIR, "wrappers.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())[case]
+    cls = case.split("/")[0]
+    d = torch.device("cuda:0")
+    ns = types.SimpleNamespace
+    b = ns(x=torch.from_numpy(z["x"]).to(d), edge_index=torch.from_numpy(z["edge_index"]).to(d),
+           edge_attr=torch.from_numpy(z["edge_attr"]).to(d), edge_weight=torch.from_numpy(z["edge_weight"]).to(d),
+           batch=torch.from_numpy(z["batch"]).to(d), u=torch.zeros(3, 3, device=d), num_graphs=3)
+    y = torch.from_numpy(z["y"]).to(d)
+    torch.manual_seed(4321)
+    model = getattr(models, cls)(DS(), dim1=16, dim2=12, dim3=8, gc_count=2, **meta["kw"])
+    assert list(model.state_dict()) == meta["sd_keys"]
+    model.to(d).train()
+    pred = model(b)
+    ref = torch.from_numpy(z[case + "/pred_train"])
+    scale = float(ref.abs().max()) + 1e-6
+    assert torch.allclose(pred.cpu(), ref, rtol=1e-4, atol=1e-4 * scale), (pred.cpu() - ref).abs().max()
+    torch.nn.functional.l1_loss(pred, y).backward()
+    for k, p in model.named_parameters():
+        g = z["%s/grad/%s" % (case, k)]
+        if g.size == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        g = torch.from_numpy(g)
+        s = float(g.abs().max()) + 1e-9
+        # three graphs of ten near-identical atoms: BatchNorm is ill-conditioned, so the bound is loose (1e-2 of the
+        # tensor scale); the tight gradient checks are the kernel-level ones in test_gpu_kernels.py
+        assert float((p.grad.cpu() - g).abs().max()) <= 1e-2 * s + 1e-6, (k, float((p.grad.cpu() - g).abs().max()), s)
+    for k, v in model.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            r = torch.from_numpy(z["%s/post/%s" % (case, k)]).float()
+            assert torch.allclose(v.float().cpu(), r, rtol=1e-4, atol=1e-5 * (float(r.abs().max()) + 1.0)), k
+    model.eval()
+    with torch.no_grad():
+        ev = model(b).cpu()
+    ref = torch.from_numpy(z[case + "/pred_eval"])
+    assert torch.allclose(ev, ref, rtol=1e-4, atol=1e-4 * (float(ref.abs().max()) + 1e-6))

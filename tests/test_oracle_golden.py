@@ -128,3 +128,87 @@ def test_splits_match_reference():
     folds = split_data_CV(1000, num_folds=5, seed=42)
     for i, f in enumerate(folds):
         assert np.array_equal(f, z["cv5_1000_42_fold%d" % i])
+
+
+# ------------------------------------------------------------------------------------------------
+# The four wrapper files of the reference (cgcnn / schnet / mpnn / gcn), run by make_golden.py with the oracle
+# operators injected for the absent torch_geometric: layer creation order (seeded initialisation), state_dict key
+# ORDER, pre-FC -> conv -> BN -> act -> dropout ordering, pooling order, set2set sizes, GRU wiring.
+# ------------------------------------------------------------------------------------------------
+import json  # noqa: E402
+
+WRAPPER_DIMS = dict(dim1=16, dim2=12, dim3=8, gc_count=2)
+
+
+def _wrappers():
+    z = _npz("wrappers.npz")
+    return z, json.loads(bytes(z["meta"]).decode())
+
+
+def _wrapper_cases():
+    return sorted(_wrappers()[1])
+
+
+def _wrapper_batch(z):
+    ns = types.SimpleNamespace
+    return ns(x=torch.from_numpy(z["x"]), edge_index=torch.from_numpy(z["edge_index"]),
+              edge_attr=torch.from_numpy(z["edge_attr"]), edge_weight=torch.from_numpy(z["edge_weight"]),
+              batch=torch.from_numpy(z["batch"]), u=torch.zeros(3, 3)), torch.from_numpy(z["y"])
+
+
+@pytest.mark.parametrize("case", _wrapper_cases())
+def test_wrapper_matches_reference_file(case):
+    z, meta = _wrappers()
+    cls, _ = case.split("/")
+    data, y = _wrapper_batch(z)
+    torch.manual_seed(4321)
+    model = omodels.REGISTRY[cls](_DS(), **WRAPPER_DIMS, **meta[case]["kw"])
+    sd = model.state_dict()
+    assert list(sd) == meta[case]["sd_keys"], "state_dict key ORDER differs from the reference file"
+    for k, v in sd.items():                                     # same seed, same creation order: bit-identical
+        assert np.array_equal(v.numpy(), z["%s/init/%s" % (case, k)]), k
+    model.train()
+    pred = model(data)
+    assert torch.allclose(pred, torch.from_numpy(z[case + "/pred_train"]), rtol=1e-5, atol=1e-6)
+    torch.nn.functional.l1_loss(pred, y).backward()
+    for k, p in model.named_parameters():
+        ref = z["%s/grad/%s" % (case, k)]
+        if ref.size == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert torch.allclose(p.grad, torch.from_numpy(ref), rtol=1e-4, atol=1e-6), k
+    for k, v in model.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            assert torch.allclose(v.float(), torch.from_numpy(z["%s/post/%s" % (case, k)]).float(), rtol=1e-5, atol=1e-6), k
+    model.eval()
+    assert torch.allclose(model(data), torch.from_numpy(z[case + "/pred_eval"]), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", _wrapper_cases())
+def test_product_wrapper_seeded_init_and_key_order(case):
+    """The product models (constructed on the CPU; their forward needs a HIP device) draw the reference's initial
+    weights from the same seed and list the reference's state_dict keys in the reference's order."""
+    from matdeeplearn_amd import models
+
+    z, meta = _wrappers()
+    cls, _ = case.split("/")
+    torch.manual_seed(4321)
+    model = getattr(models, cls)(_DS(), **WRAPPER_DIMS, **meta[case]["kw"])
+    sd = model.state_dict()
+    assert list(sd) == meta[case]["sd_keys"]
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), z["%s/init/%s" % (case, k)]), k
+
+
+@pytest.mark.parametrize("tag,kw", [("bn", dict(batch_norm="True")), ("late", dict(batch_norm="True", pool_order="late"))])
+def test_megnet_seeded_init_and_key_order(tag, kw):
+    from matdeeplearn_amd import models
+
+    z = _npz("megnet.npz")
+    keys = [k[len(tag) + 4:] for k in z.files if k.startswith(tag + "/sd/")]        # npz keeps insertion order
+    for factory in (omodels.MEGNet, models.MEGNet):
+        torch.manual_seed(99)
+        model = factory(_DS(), dim1=32, dim2=24, dim3=16, pre_fc_count=1, gc_count=2, gc_fc_count=1, post_fc_count=2, **kw)
+        assert list(model.state_dict()) == keys
+        for k, p in model.named_parameters():
+            assert np.array_equal(p.detach().numpy(), z["%s/sd/%s" % (tag, k)]), k
