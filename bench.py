@@ -3,11 +3,18 @@
 
 Workload = BASELINE.json configs[1]: "bulk_data CGCNN dim=64, 4 conv layers, bf16 on 1 MI355X".
 The real Materials-Project bulk_data is not redistributable and absent, so the dataset is the
-synthetic bulk-like recipe of SURVEY.md 8d (matdeeplearn_amd.process.synthetic_bulk).  A "step" is
-one full training step of the hot path on one batch per GPU: device-side batch assembly (incl. the
+synthetic bulk-like recipe of SURVEY.md 8d (matdeeplearn_amd.process.synthetic_bulk, all 46,744 graphs).
+A "step" is one full training step of the hot path on one batch per GPU: device-side batch assembly (incl. the
 K1 RBF expansion), forward, l1 loss, backward, gradient all-reduce (N>1), fused AdamW.  The dataset
-is resident in HBM before the timed region.  Weak scaling: every rank processes `--batch` graphs
-per step; value = edges over all ranks / max-over-ranks time.
+is resident in HBM before the timed region.  Batches are cut from the DeviceLoader stream of the TRAIN split
+(rank r takes perm(seed, epoch)[r::world_size], the DistributedSampler contract of training.py:291-294), `--batch`
+graphs per GPU per step whatever N is: weak scaling; value = edges over all ranks / max-over-ranks time.
+
+Beside the headline the line carries (rank 0, N=1): `sustained` (>= 2 s of steps), `fp32_mode` (the parity-mode
+step), `ref_batch_100` (the reference's batch size, config.yml:136), `cpu_baseline` (the oracle on the host cores on
+the SAME batches) with the val-MAE / prediction deltas of the fp32 and bf16 HIP paths at the trained weights.
+`--model schnet|megnet` switch to the cfg3 / cfg4 workloads (SchNet_demo on MOF-like graphs, MEGNet_demo on
+bulk-like graphs) with their own roofline kernels; the default line is cfg2.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -27,24 +34,34 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
+WORKLOADS = {
+    # name: (model class, dataset generator, default graphs, default batch, model kwargs (reference config.yml), description)
+    "cgcnn": ("CGCNN", "synthetic_bulk", 46744, 8192, None, "cfg2 bulk_data CGCNN"),
+    "schnet": ("SchNet", "synthetic_mof", 4096, 1024,
+               dict(dim1=100, dim2=100, dim3=150, cutoff=8, pre_fc_count=1, gc_count=4, post_fc_count=3), "cfg3 MOF_data SchNet_demo"),
+    "megnet": ("MEGNet", "synthetic_bulk", 16384, 4096,
+               dict(dim1=100, dim2=100, dim3=100, pre_fc_count=1, gc_count=4, gc_fc_count=1, post_fc_count=3), "cfg4 bulk_data MEGNet_demo"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8192, help="graphs per GPU per step (reference default is 100)")
-    ap.add_argument("--graphs", type=int, default=16384, help="synthetic dataset size (full recipe: 46744)")
+    ap.add_argument("--model", default="cgcnn", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="graphs per GPU per step (default per workload; reference default is 100)")
+    ap.add_argument("--graphs", type=int, default=0, help="synthetic dataset size (default: the workload's recipe)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--gc", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ref-batch", action="store_true",
-                    help="also time the step at the reference's batch size 100 (off by default so that the per-kernel "
-                         "averages of a rocprofv3 trace of the default command are those of the measured workload)")
-    ap.add_argument("--cpu-graphs", type=int, default=1024, help="graphs per CPU-baseline step")
-    ap.add_argument("--cpu-steps", type=int, default=8)
-    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="headline only: skip sustained / fp32_mode / ref_batch_100 (used for the rocprofv3 pass, so that "
+                         "the per-kernel averages of the trace are those of the measured workload)")
+    ap.add_argument("--sustain-s", type=float, default=2.0)
+    ap.add_argument("--cpu-steps", type=int, default=1, help="timed oracle steps on the GPU run's own batches")
+    ap.add_argument("--seed", type=int, default=42)
     return ap.parse_args()
 
 
@@ -53,6 +70,19 @@ def algorithmic_bytes(E, N, C, G, s):
     fwd = E * (G * s + C * s + 4) + N * (2 * C * s + 4)
     bwd = E * (G * s + 2 * C * s + 4) + N * (3 * C * s + 4)
     return fwd, bwd
+
+
+def batch_stream(loader, B):
+    """Fixed-size batches of graph ids cut from the loader's epoch stream (epoch e = perm(seed, e)[rank::world])."""
+    buf = np.zeros(0, dtype=np.int64)
+    epoch = 0
+    while True:
+        while len(buf) < B:
+            loader.set_epoch(epoch)
+            buf = np.concatenate([buf, loader._order()])
+            epoch += 1
+        yield buf[:B]
+        buf = buf[B:]
 
 
 def main():
@@ -68,8 +98,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    from matdeeplearn_amd import models, ops
-    from matdeeplearn_amd.process import synthetic_bulk
+    from matdeeplearn_amd import models, ops, process
+    from matdeeplearn_amd.process import DeviceLoader, split_data
     from matdeeplearn_amd.training import FlatDataParallel, make_optimizer
 
     use_dist = world > 1 or os.environ.get("MDL_FORCE_DIST") == "1"   # the env var exercises the RCCL path on one GPU
@@ -78,39 +108,60 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # ---- data: identical synthetic dataset on every rank, resident in HBM -----------------------
+    cls_name, gen_name, n_graphs, B, mkw, wl_desc = WORKLOADS[args.model]
+    n_graphs = args.graphs or n_graphs
+    B = args.batch or B
+    if mkw is None:
+        mkw = dict(dim1=args.dim, dim2=args.dim, pre_fc_count=1, gc_count=args.gc, post_fc_count=3)
+    mkw = dict(mkw, pool="global_mean_pool", pool_order="early", batch_norm="True", batch_track_stats="True", act="relu",
+               dropout_rate=0.0)
+
+    # ---- data: identical synthetic dataset on every rank, resident in HBM; the reference's 0.8 / 0.05 / 0.15 split ----
     t0 = time.time()
-    ds = synthetic_bulk(args.graphs, seed=args.seed)
+    ds = getattr(process, gen_name)(n_graphs, seed=0)
     gen_s = time.time() - t0
     ds.to(dev)
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    tr_idx, va_idx, _ = split_data(len(ds), 0.8, 0.05, 0.15, seed=args.seed)
+    B = min(B, len(tr_idx))
+    loader = DeviceLoader(ds, tr_idx, B, shuffle=True, seed=args.seed, rank=rank, world_size=world)
+    stream = batch_stream(loader, B)
     total_steps = args.warmup + args.steps
-    rng = np.random.default_rng(1234 + rank)
-    B = min(args.batch, len(ds))
-    step_ids = [rng.choice(len(ds), size=B, replace=False) for _ in range(total_steps)]
+    step_ids = [next(stream) for _ in range(total_steps)]
 
     # ---- model ------------------------------------------------------------------------------------
     torch.manual_seed(args.seed)
-    model = models.CGCNN(ds, dim1=args.dim, dim2=args.dim, pre_fc_count=1, gc_count=args.gc, post_fc_count=3,
-                         pool="global_mean_pool", pool_order="early", batch_norm="True", batch_track_stats="True",
-                         act="relu", dropout_rate=0.0, compute_dtype=args.dtype).to(dev)
+    model = getattr(models, cls_name)(ds, compute_dtype=args.dtype, **mkw).to(dev)
     dp = FlatDataParallel(model)
     opt = make_optimizer(model.parameters(), "AdamW", lr=0.002 * world)   # lr x world_size, training.py:388-389
 
     ktimes = {"fwd": [], "bwd": []}
 
-    def step(ids, timed):
-        batch = ds.collate(ids, edge_dtype=cdt, x_dtype=cdt)
-        dp.zero_grad()
-        ops.KERNEL_EVENTS = ktimes if timed else None
-        with ops.zero_arena(dev):               # one zero fill per step for the kernels' small accumulators
-            out = model(batch)
-            loss = torch.nn.functional.l1_loss(out, batch.y)
-            loss.backward()
-        ops.KERNEL_EVENTS = None
-        dp.reduce_grads(force=use_dist)
-        opt.step()
-        return batch.num_edges, batch.num_nodes
+    def make_step(model, dp, opt, dtype):
+        pending = {}                                 # ids (bytes) -> batch assembled during the previous step's all-reduce
+
+        def step(ids, timed, next_ids=None):
+            batch = pending.pop(ids.tobytes(), None)
+            if batch is None:
+                batch = ds.collate(ids, edge_dtype=dtype, x_dtype=dtype)
+            dp.zero_grad()
+            ops.KERNEL_EVENTS = ktimes if timed else None
+            with ops.zero_arena(dev):               # one zero fill per step for the kernels' small accumulators
+                out = model(batch)
+                loss = torch.nn.functional.l1_loss(out, batch.y)
+                loss.backward()
+            ops.KERNEL_EVENTS = None
+            if dp.reduce_grads_async(force=use_dist):
+                # the collective runs on a side stream: assemble the NEXT batch (K8 + K1) on the compute stream meanwhile
+                if next_ids is not None:
+                    pending.clear()
+                    pending[next_ids.tobytes()] = ds.collate(next_ids, edge_dtype=dtype, x_dtype=dtype)
+                dp.finish()
+            opt.step()
+            return batch.num_edges, batch.num_nodes
+        return step
+
+    step = make_step(model, dp, opt, cdt)
 
     def barrier():
         if use_dist:
@@ -124,7 +175,7 @@ def main():
     t0 = time.perf_counter()
     edges = nodes = 0
     for i in range(args.warmup, total_steps):
-        e, n = step(step_ids[i], True)
+        e, n = step(step_ids[i], True, step_ids[i + 1] if i + 1 < total_steps else None)
         edges += e
         nodes += n
     barrier()
@@ -143,21 +194,35 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (HIP events recorded on the launch stream, timed region) ----
-    C, G, s = args.dim, ds.num_edge_features, (2 if args.dtype == "bf16" else 4)
+    s = 2 if args.dtype == "bf16" else 4
+    G = ds.num_edge_features
     e_step, n_step = edges / args.steps, nodes / args.steps
-    ab_fwd, ab_bwd = algorithmic_bytes(e_step, n_step, C, G, s)
     dur = {k: [a.elapsed_time(b) * 1e-3 for a, b in v] for k, v in ktimes.items()}   # seconds
     avg = {k: (sum(v) / len(v) if v else float("nan")) for k, v in dur.items()}
     tot = {k: sum(v) for k, v in dur.items()}
-    dom = "bwd" if tot["bwd"] >= tot["fwd"] else "fwd"
+    if args.model == "cgcnn":
+        ab_fwd, ab_bwd = algorithmic_bytes(e_step, n_step, mkw["dim1"], G, s)
+        kname = {"fwd": "mdl_cgconv_fwd", "bwd": "mdl_cgconv_bwd"}
+    elif args.model == "schnet":                     # E(G s + 4 + F s + 4) + N(2 F s + 4); bwd adds the dh scatter
+        F, C = mkw["dim3"], mkw["dim1"]
+        ab_fwd = e_step * (G * s + 4 + F * s + 4) + n_step * (2 * F * s + 4)
+        ab_bwd = e_step * (G * s + 4 + 2 * F * s + 4) + n_step * (3 * F * s + 4)
+        kname = {"fwd": "mdl_cfconv_fwd", "bwd": "mdl_cfconv_bwd"}
+    else:                                            # E(d s [e in] + d s [e out] + 2 d s [x rows] + 8)
+        d = mkw["dim3"]
+        ab_fwd = e_step * (4 * d * s + 8)
+        ab_bwd = e_step * (4 * d * s + 8 + 2 * d * s)
+        kname = {"fwd": "mdl_edge_linear_fwd", "bwd": "mdl_edge_linear_bwd"}
     ab = {"fwd": ab_fwd, "bwd": ab_bwd}
+    have = [k for k in ("fwd", "bwd") if dur[k]]
+    dom = max(have, key=lambda k: tot[k]) if have else None
 
     # HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes over tools/bench_kernels.py,
     # tools/gpu_pmc.sh -> profiles/hbm_traffic.json), scaled to this batch's edge count
     traffic = {}
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-        if C == 64 and args.dtype == "bf16":
+        if args.model == "cgcnn" and mkw["dim1"] == 64 and args.dtype == "bf16":
             for k in ("fwd", "bwd"):
                 if "mdl_cgconv_" + k in tj:
                     traffic[k] = int(tj["mdl_cgconv_" + k]["bytes"] * e_step / tj["E"])
@@ -166,54 +231,99 @@ def main():
 
     def roof(k):
         ach = ab[k] / avg[k] / 1e9
-        return {"kernel": "mdl_cgconv_%s" % k, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+        return {"kernel": kname[k], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(k),
                 "avg_launch_us": round(avg[k] * 1e6, 2), "launches": len(dur[k]),
                 "algorithmic_bytes_per_launch": int(ab[k])}
 
     value = edges_all / elapsed_max
+    metric = {"cgcnn": "edges/sec training CGCNN on bulk_data", "schnet": "edges/sec training SchNet on MOF_data",
+              "megnet": "edges/sec training MEGNet on bulk_data"}[args.model]
     res = {
-        "metric": "edges/sec training CGCNN on bulk_data",
+        "metric": metric,
         "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "cfg2 bulk_data CGCNN dim1=dim2=%d, %d conv layers, post_fc 3, %s; synthetic bulk-like "
-                               "graphs (SURVEY 8d recipe, %d of 46744 graphs, r=8A, 12 NN + self loop), batch %d "
-                               "graphs/GPU" % (args.dim, args.gc, args.dtype, len(ds), B),
+        "config": {"workload": "%s %s, %s; synthetic graphs (SURVEY 8d recipe %s, %d graphs, r=8A, 12 NN + self loop), "
+                               "train split 0.8 through the DeviceLoader partition, batch %d graphs/GPU"
+                               % (wl_desc, " ".join("%s=%s" % kv for kv in sorted(mkw.items()) if kv[0].startswith(("dim", "gc", "post"))),
+                                  args.dtype, gen_name, len(ds), B),
                    "batch_graphs_per_gpu": B, "edges_per_step_per_gpu": int(e_step), "nodes_per_step_per_gpu": int(n_step),
                    "parallelism": "dp%d" % world, "dataset_gen_s": round(gen_s, 1),
                    "conv_kernel_share_of_step": round((tot["fwd"] + tot["bwd"]) / elapsed, 3)},
-        "roofline": roof(dom),
-        "roofline_other": roof("fwd" if dom == "bwd" else "bwd"),
     }
+    if dom is not None:
+        res["roofline"] = roof(dom)
+        other = [k for k in have if k != dom]
+        if other:
+            res["roofline_other"] = roof(other[0])
 
-    # ---- the same training step at the reference's batch size (config.yml:136 batch_size 100): launch bound
-    if world == 1 and args.ref_batch:
-        rb = 100
-        ids_small = [rng.choice(len(ds), size=rb, replace=False) for _ in range(60)]
-        for i in range(10):
-            step(ids_small[i], False)
+    if world == 1 and not args.no_extras:
+        # ---- sustained: the same step for >= sustain_s seconds, no kernel events --------------------------------
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        e_small = 0
-        for i in range(10, 60):
-            e_small += step(ids_small[i], False)[0]
+        e_sus = n_sus = 0
+        while True:
+            e_sus += step(next(stream), False)[0]
+            n_sus += 1
+            if n_sus % 16 == 0:
+                torch.cuda.synchronize()
+                if time.perf_counter() - t1 >= args.sustain_s:
+                    break
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
-        res["ref_batch_100"] = {"value": round(e_small / dt, 1), "unit": "edges/s", "ms_per_step": round(dt / 50 * 1e3, 4),
-                                "edges_per_step": int(e_small / 50)}
+        res["sustained"] = {"value": round(e_sus / dt, 1), "unit": "edges/s", "steps": n_sus, "seconds": round(dt, 2),
+                            "ms_per_step": round(dt / n_sus * 1e3, 4)}
+
+        # ---- the same training step at the reference's batch size (config.yml:136 batch_size 100) ----------------
+        rb = 100
+        rb_loader = DeviceLoader(ds, tr_idx, rb, shuffle=True, seed=args.seed)
+        rb_stream = batch_stream(rb_loader, rb)
+        for _ in range(10):
+            step(next(rb_stream), False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        e_small, n_small = 0, 100
+        for _ in range(n_small):
+            e_small += step(next(rb_stream), False)[0]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        res["ref_batch_100"] = {"value": round(e_small / dt, 1), "unit": "edges/s", "ms_per_step": round(dt / n_small * 1e3, 4),
+                                "edges_per_step": int(e_small / n_small), "steps": n_small}
+
+        # ---- fp32 (parity) mode: same model, same batches, compute_dtype fp32 ----------------------------------
+        if args.dtype != "fp32":
+            torch.manual_seed(args.seed)
+            m32 = getattr(models, cls_name)(ds, compute_dtype="fp32", **mkw).to(dev)
+            m32.train()
+            dp32 = FlatDataParallel(m32)
+            opt32 = make_optimizer(m32.parameters(), "AdamW", lr=0.002)
+            step32 = make_step(m32, dp32, opt32, torch.float32)
+            n32 = max(3, min(args.steps, 10))
+            for i in range(2):
+                step32(step_ids[i], False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            e32 = 0
+            for i in range(n32):
+                e32 += step32(step_ids[args.warmup + i % args.steps], False)[0]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            res["fp32_mode"] = {"value": round(e32 / dt, 1), "unit": "edges/s", "ms_per_step": round(dt / n32 * 1e3, 4), "steps": n32}
+            del m32, dp32, opt32
 
     # ---- CPU baseline: the oracle (pure-torch restatement of the reference path) on host cores ----
     if world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(args, ds, model)
+        res["cpu_baseline"] = cpu_baseline(args, ds, model, cls_name, mkw, step_ids[args.warmup:], va_idx)
     if use_dist:
         dist.destroy_process_group()
     print(json.dumps(res))
 
 
-def cpu_baseline(args, ds, gpu_model):
-    """Times the oracle CGCNN (same architecture, fp32) on the host cores on a bounded sample of the
-    same workload, and checks val-MAE parity of the HIP fp32 path at fixed weights."""
+def cpu_baseline(args, ds, gpu_model, cls_name, mkw, timed_ids, va_idx):
+    """Times the oracle model (same architecture, fp32) on the host cores on the GPU run's OWN first timed batches
+    (bounded: 1 warm-up + `--cpu-steps` steps), and checks parity of the HIP fp32 and bf16 paths at the trained weights
+    on a held-out validation sample: val MAE and the largest prediction difference."""
     import copy
     from oracle import models as omodels
     from oracle import ops as oops
@@ -225,56 +335,71 @@ def cpu_baseline(args, ds, gpu_model):
     cds._dev = {}
     cds.to("cpu")
     rbf = lambda d: oops.rbf_expand(d, 0.0, 1.0, ds.num_edge_features, 0.2)
-    rng = np.random.default_rng(99)
-    nb = min(args.cpu_graphs, len(cds))
-    batches = [cds.collate(rng.choice(len(cds), size=nb, replace=False), rbf=rbf) for _ in range(args.cpu_steps + 1)]
     state = {k: v.detach().cpu() for k, v in gpu_model.state_dict().items()}
-    best = None
-    # torch's intra-op pool degrades badly when the thread count far exceeds the useful parallelism
-    # of these tensor sizes: try a few pool sizes and report the fastest (threads used = "cores").
-    for nt in sorted({min(cores, t) for t in (16, 64, cores)}):
-        torch.set_num_threads(nt)
-        torch.manual_seed(args.seed)
-        om = omodels.CGCNN(cds, dim1=args.dim, dim2=args.dim, pre_fc_count=1, gc_count=args.gc, post_fc_count=3)
+    okw = {k: v for k, v in mkw.items()}
+
+    def oracle():
+        om = getattr(omodels, cls_name)(cds, **okw)
         om.load_state_dict(state)
-        opt = make_optimizer(om.parameters(), "AdamW", lr=0.002)
+        return om
+
+    def one_step(om, opt, b):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = torch.nn.functional.l1_loss(om(b), b.y)
+        loss.backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    # thread-pool size: torch's intra-op pool degrades when the thread count far exceeds the useful parallelism of these
+    # tensor sizes; pick the faster of two sizes on a small probe batch, then time the identical batches with it
+    probe = cds.collate(timed_ids[0][:512], rbf=rbf)
+    best_nt, best_t = None, None
+    for nt in sorted({min(cores, t) for t in (16, 64)}):
+        torch.set_num_threads(nt)
+        om = oracle()
         om.train()
-        edges, t_total = 0, 0.0
-        for i, b in enumerate(batches):
-            t0 = time.perf_counter()
-            opt.zero_grad()
-            loss = torch.nn.functional.l1_loss(om(b), b.y)
-            loss.backward()
-            opt.step()
-            dt = time.perf_counter() - t0
-            if i > 0:                       # first step = warm-up
-                edges += b.num_edges
-                t_total += dt
-            if t_total > 20.0:
-                break
-        if best is None or edges / t_total > best[0]:
-            best = (edges / t_total, nt, edges, t_total)
-    rate, nt, edges, t_total = best
-    torch.set_num_threads(nt)
-    out = {"value": round(rate, 1), "unit": "edges/s", "cores": nt, "host_cores": cores, "kind": "port",
-           "sample": "%d fp32 training steps of the oracle CGCNN (dim %d, %d conv) on batches of %d synthetic graphs "
-                     "(%d edges), %.1f s" % (args.cpu_steps, args.dim, args.gc, nb, edges, t_total)}
-    # val-MAE parity at fixed weights: HIP fp32 path vs oracle on the same held-out sample
-    om.load_state_dict(state)
+        opt = make_optimizer(om.parameters(), "AdamW", lr=0.002)
+        one_step(om, opt, probe)
+        t = one_step(om, opt, probe)
+        if best_t is None or t < best_t:
+            best_nt, best_t = nt, t
+    torch.set_num_threads(best_nt)
+    om = oracle()
+    om.train()
+    opt = make_optimizer(om.parameters(), "AdamW", lr=0.002)
+    nsteps = max(1, min(args.cpu_steps, len(timed_ids) - 1))
+    batches = [cds.collate(timed_ids[i], rbf=rbf) for i in range(nsteps + 1)]
+    one_step(om, opt, batches[0])                                  # warm-up on the GPU run's first timed batch
+    edges, t_total = 0, 0.0
+    for b in batches[1:]:
+        t_total += one_step(om, opt, b)
+        edges += b.num_edges
+    out = {"value": round(edges / t_total, 1), "unit": "edges/s", "cores": best_nt, "host_cores": cores, "kind": "port",
+           "sample": "%d fp32 training step(s) of the oracle %s on the GPU run's own timed batch(es) (%d graphs, %d edges) "
+                     "after 1 warm-up step, %.1f s" % (nsteps, cls_name, len(timed_ids[1]), edges, t_total)}
+
+    # parity at the trained weights on held-out graphs: oracle (CPU fp32) vs HIP fp32 vs HIP bf16
+    om = oracle()
     om.eval()
-    gm = models.CGCNN(ds, dim1=args.dim, dim2=args.dim, pre_fc_count=1, gc_count=args.gc, post_fc_count=3,
-                      compute_dtype="fp32").to(ds.device)
-    gm.load_state_dict(gpu_model.state_dict())
-    gm.eval()
-    ids = rng.choice(len(cds), size=nb, replace=False)
+    ids = np.asarray(va_idx[:1024])
     with torch.no_grad():
         bc = cds.collate(ids, rbf=rbf)
-        mae_cpu = float(torch.nn.functional.l1_loss(om(bc), bc.y))
-        bg = ds.collate(ids, edge_dtype=torch.float32)
-        mae_gpu = float(torch.nn.functional.l1_loss(gm(bg), bg.y))
+        p_cpu = om(bc)
+        mae_cpu = float(torch.nn.functional.l1_loss(p_cpu, bc.y))
+        scale = float(p_cpu.abs().max()) + 1e-12
+        for tag, cd, dt in (("fp32", "fp32", torch.float32), ("bf16", "bf16", torch.bfloat16)):
+            gm = getattr(models, cls_name)(ds, compute_dtype=cd, **mkw).to(ds.device)
+            gm.load_state_dict(gpu_model.state_dict())
+            gm.eval()
+            bg = ds.collate(ids, edge_dtype=dt, x_dtype=dt)
+            p = gm(bg)
+            mae = float(torch.nn.functional.l1_loss(p, bg.y))
+            out["val_mae_hip_" + tag] = mae
+            out["val_mae_delta" + ("" if tag == "fp32" else "_bf16")] = abs(mae - mae_cpu)
+            out["pred_max_rel_delta_" + tag] = float((p.cpu() - p_cpu).abs().max()) / scale
     out["val_mae_oracle_cpu"] = mae_cpu
-    out["val_mae_hip_fp32"] = mae_gpu
-    out["val_mae_delta"] = abs(mae_cpu - mae_gpu)
+    out["val_graphs"] = int(len(ids))
     return out
 
 

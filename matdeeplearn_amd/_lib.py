@@ -81,10 +81,21 @@ def dtype_code(t):
 
 
 def require_hip(*tensors):
+    """Every op starts here: operands must live on a HIP device, and on the CURRENT one — the kernels are launched on
+    torch.cuda.current_stream() of the current device, so a tensor of another device would be touched from a foreign
+    stream (one process per GPU: call torch.cuda.set_device(rank) first; ddp_setup / train_regular do)."""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise MdlError("matdeeplearn_amd ops need tensors on a HIP device (got %s); there is no CPU path — "
                            "the CPU restatement lives in oracle/ and is test infrastructure only" % t.device)
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise MdlError("tensor on %s but the current HIP device is cuda:%d — call torch.cuda.set_device(%d) in "
+                           "this process before using matdeeplearn_amd" % (t.device, cur, t.device.index))
 
 
 def ptr(t):

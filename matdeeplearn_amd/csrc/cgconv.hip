@@ -1420,6 +1420,25 @@ __global__ __launch_bounds__(256) void cgconv_pack_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 static constexpr int LDS_CAP = 160 * 1024;
 
+// Experiment switches from the environment, read ONCE (first launch) — the launch path itself is stateless.
+struct CgEnv {
+    int64_t grid_cap;     // MDL_GRID_CAP: upper bound on the grid (0 = none)
+    int cb_fwd, cb_bwd;   // MDL_CG_CB / MDL_CG_CB_BWD: cooperative column-block kernels (-1 = compile-time default)
+    int cb_wgs;           // MDL_CB_WGS: their workgroups per CU (0 = default)
+};
+static const CgEnv& cg_env() {
+    static const CgEnv e = [] {
+        CgEnv v;
+        const char* s;
+        v.grid_cap = (s = getenv("MDL_GRID_CAP")) ? atoll(s) : 0;
+        v.cb_fwd = (s = getenv("MDL_CG_CB")) ? (atoi(s) != 0) : -1;
+        v.cb_bwd = (s = getenv("MDL_CG_CB_BWD")) ? (atoi(s) != 0) : -1;
+        v.cb_wgs = (s = getenv("MDL_CB_WGS")) ? atoi(s) : 0;
+        return v;
+    }();
+    return e;
+}
+
 template <typename T>
 static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const char* name) {
     const CgDims d = cg_dims(p.C, p.G, dtype);
@@ -1461,7 +1480,8 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     // backward is register-allocated for MDL_BWD_WAVES waves per SIMD: 1 -> one 4-wave workgroup per CU
     const int64_t cap = 256 * ((bwd && MDL_BWD_WAVES == 1) ? 1 : wg_per_cu);
     if (grid > cap) grid = cap;
-    if (const char* gc = getenv("MDL_GRID_CAP")) { const int64_t c = atoll(gc); if (c > 0 && grid > c) grid = c; }   // experiments
+    const CgEnv& env = cg_env();
+    if (env.grid_cap > 0 && grid > env.grid_cap) grid = env.grid_cap;   // experiments
     // total waves must be a multiple of NS so that every wave keeps one channel slice
     while ((grid * waves) % d.NS) ++grid;
     // dynamic group scheduling only pays when every wave gets several 32-node groups
@@ -1475,13 +1495,11 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
 
     // cooperative column-block kernels (cgconv_cb.inc): bf16 static shapes
     if constexpr (sizeof(T) == 2) {
-        const char* cbe = getenv("MDL_CG_CB");
-        const bool use_cb = cbe ? atoi(cbe) != 0 : (MDL_CG_CB_DEFAULT != 0);
+        const bool use_cb = env.cb_fwd >= 0 ? env.cb_fwd != 0 : (MDL_CG_CB_DEFAULT != 0);
         if (use_cb && fast && !bwd && p.E >= 64 && p.bias_col) {   // (E >= 64: the kernels' edge-feature window is 1024 dwords)
-            int cb_wgs = MDL_CB_FWD_WG_PER_CU;
-            if (const char* e2 = getenv("MDL_CB_WGS")) cb_wgs = atoi(e2);   // experiments
+            const int cb_wgs = env.cb_wgs > 0 ? env.cb_wgs : MDL_CB_FWD_WG_PER_CU;
             int64_t cb_grid = std::min<int64_t>(256 * cb_wgs, ranges);
-            if (const char* gc = getenv("MDL_GRID_CAP")) { const int64_t c = atoll(gc); if (c > 0 && cb_grid > c) cb_grid = c; }   // experiments
+            if (env.grid_cap > 0 && cb_grid > env.grid_cap) cb_grid = env.grid_cap;
             if (d.Cp == 64) {
                 const int cb_lds = 2 * cb::Cfg<64>::BUF_FWD;
                 hipLaunchKernelGGL(cb::fwd_kernel<64>, dim3((unsigned)cb_grid), dim3(cb::Cfg<64>::NT), cb_lds, st, p);
@@ -1491,11 +1509,9 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
             }
             return check_launch(name);
         }
-        const char* cbb = getenv("MDL_CG_CB_BWD");
-        const bool use_cbb = cbb ? atoi(cbb) != 0 : (MDL_CG_CB_BWD_DEFAULT != 0);
+        const bool use_cbb = env.cb_bwd >= 0 ? env.cb_bwd != 0 : (MDL_CG_CB_BWD_DEFAULT != 0);
         if (use_cbb && fast && bwd && p.E >= 64 && p.bias_col) {
-            int cb_wgs = MDL_CB_BWD_OCC;
-            if (const char* e2 = getenv("MDL_CB_WGS")) cb_wgs = atoi(e2);   // experiments
+            const int cb_wgs = env.cb_wgs > 0 ? env.cb_wgs : MDL_CB_BWD_OCC;
             const int64_t cb_grid = std::min<int64_t>(256 * cb_wgs, ranges);
             if (d.Cp == 64) {
                 const int cb_lds = 2 * cb::BwdLds<64>::BUF + cb::Cfg<64>::NCB * 32 * (cb::Cfg<64>::KE + 8) * 2;

@@ -103,19 +103,32 @@ def build_csr(edge_index, num_nodes, assume_sorted=False):
 
 
 _CSR_CACHE = collections.OrderedDict()
-_CSR_CACHE_MAX = 64
+_CSR_CACHE_MAX = 64                      # entries
+_CSR_CACHE_MAX_BYTES = 256 << 20         # and bytes pinned (an entry keeps ~40 B/edge of index tensors alive)
+_csr_cache_bytes = 0
 
 
 def _key(edge_index, n):
     return (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(n), edge_index.device.index)
 
 
+def _csr_entry_bytes(edge_index, csr):
+    return edge_index.numel() * edge_index.element_size() + 4 * (3 * csr.E + csr.N + 1) + (4 * csr.E if csr.eperm is not None else 0)
+
+
 def register_csr(edge_index, csr):
-    """Attach a pre-built CSR to an edge_index tensor (used by the product loader)."""
+    """Attach a pre-built CSR to an edge_index tensor (used by the product loader).  The cache is bounded by entries AND
+    by the device bytes it pins; the newest entry always stays."""
+    global _csr_cache_bytes
     k = _key(edge_index, csr.N)
-    _CSR_CACHE[k] = (csr, edge_index)  # keep the tensor alive so data_ptr cannot be recycled
-    while len(_CSR_CACHE) > _CSR_CACHE_MAX:
-        _CSR_CACHE.popitem(last=False)
+    old = _CSR_CACHE.pop(k, None)
+    if old is not None:
+        _csr_cache_bytes -= old[2]
+    nb = _csr_entry_bytes(edge_index, csr)
+    _CSR_CACHE[k] = (csr, edge_index, nb)  # keep the tensor alive so data_ptr cannot be recycled
+    _csr_cache_bytes += nb
+    while len(_CSR_CACHE) > 1 and (len(_CSR_CACHE) > _CSR_CACHE_MAX or _csr_cache_bytes > _CSR_CACHE_MAX_BYTES):
+        _csr_cache_bytes -= _CSR_CACHE.popitem(last=False)[1][2]
 
 
 def csr_for(edge_index, num_nodes):
@@ -362,6 +375,9 @@ class _CGConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, edge_attr, w_f, b_f, w_s, b_s, csr, aggr):
         require_hip(x, edge_attr, w_f, w_s)
+        if edge_attr.requires_grad:
+            raise MdlError("cgconv: gradients w.r.t. edge_attr are not implemented (the reference's edge features are "
+                           "constants, cgcnn.py:136-145); detach() them or use a differentiable composition")
         if edge_attr.dtype != x.dtype:
             raise MdlError("cgconv: x (%s) and edge_attr (%s) must share a dtype" % (x.dtype, edge_attr.dtype))
         x, edge_attr = x.contiguous(), edge_attr.contiguous()
@@ -481,6 +497,9 @@ class _GatherMulReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, w, scale, csr, reduce):
         require_hip(h)
+        if scale is not None and scale.requires_grad:
+            raise MdlError("gather_mul_reduce: gradients w.r.t. the per-edge scale are not implemented (cutoff / GCN "
+                           "norm are functions of constant distances on the reference path)")
         h = h.contiguous()
         N, F = csr.N, h.shape[1]
         if w is not None:
@@ -560,7 +579,7 @@ def _linear_tn_grads(ctx, g, x, w):
     # db out of the same pass (mdl_gemm_tn_colsum: the column sums of g ride in a padding column of the B tile and are
     # flushed with one gathered atomic instruction per block); MDL_TN_COLSUM=0 falls back to the library reduction
     fused_db = (_TN_COLSUM and ctx.has_bias and K % 2 == 0 and K <= 126 and x.stride(0) % 2 == 0
-                and ga.stride(0) % 2 == 0)
+                and ga.stride(0) % 2 == 0 and x.data_ptr() % 4 == 0 and ga.data_ptr() % 4 == 0)
     buf = torch.zeros(Ma * K + Ma, dtype=torch.float32, device=g.device)          # dW | db in one zero fill
     dw, dbv = buf[:Ma * K].view(Ma, K), buf[Ma * K:]
     check(lib().mdl_gemm_tn_colsum(ptr(ga), ga.stride(0), Ma, ptr(x), x.stride(0), K, ptr(dw), ptr(dbv) if fused_db else None,
@@ -621,11 +640,6 @@ def linear(x, weight, bias, lowp=None):
     return torch.nn.functional.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
 
 
-def linear_input_leaf(x, weight, bias, lowp=None):
-    """Linear for an input that needs no gradient (pre-FC on the dataset features)."""
-    return linear(x, weight, bias, lowp)
-
-
 # ------------------------------------------------------------------------------------------------
 # training-mode BatchNorm1d over rows (HIP streams instead of four slow library passes)
 # ------------------------------------------------------------------------------------------------
@@ -634,7 +648,8 @@ def bn_supported(x):
         return False
     w = 8 if x.dtype == torch.bfloat16 else 4
     c = x.shape[1]
-    return x.shape[0] >= 1 and c % w == 0 and c <= 256 and 256 % (c // w) == 0
+    # (N == 1 in training mode goes to the library path, which raises like torch does)
+    return x.shape[0] >= 2 and c % w == 0 and c <= 256 and 256 % (c // w) == 0 and x.data_ptr() % 16 == 0
 
 
 class _BatchNormTrain(torch.autograd.Function):

@@ -227,6 +227,26 @@ def from_structures(structs, ys, ids, radius=8.0, max_neighbors=12, num_edge_fea
     return from_graphs(graphs, ys, ids, num_edge_features)
 
 
+def _synthetic(sizes, boxes, rng, seed, radius, max_neighbors, num_edge_features, tag):
+    """Shared body of the synthetic generators: uniform positions in an orthorhombic periodic box per graph,
+    minimum-image distances, the reference graph rule (process.py:284-305), Z ~ U[1,89], y ~ Normal(0,1) seed+1."""
+    graphs = []
+    for n, box in zip(sizes, boxes):
+        box = np.asarray(box, dtype=np.float64)
+        pos = rng.uniform(0.0, 1.0, size=(n, 3)) * box[:3]
+        if len(box) > 3:                                     # slab: atoms only in the lowest box[3] of the z axis
+            pos[:, 2] *= box[3] / box[2]
+        numbers = rng.integers(1, 90, size=n)
+        d = pos[None, :, :] - pos[:, None, :]
+        d -= box[:3] * np.rint(d / box[:3])                  # minimum image, orthorhombic cell
+        dm = np.sqrt((d * d).sum(-1))
+        ei, ew = pg.edges_from_trimmed(pg.threshold_sort(dm, radius, max_neighbors))
+        x = np.concatenate([pg.atom_features(numbers), pg.one_hot_degree(ei, n, max_neighbors + 1)], 1)
+        graphs.append({"x": x, "edge_index": ei, "edge_weight": ew, "z": numbers})
+    ys = np.random.default_rng(seed + 1).normal(0.0, 1.0, size=(len(sizes), 1)).astype(np.float32)
+    return from_graphs(graphs, ys, ["%s%d" % (tag, i) for i in range(len(sizes))], num_edge_features)
+
+
 def synthetic_bulk(n_graphs=46744, seed=0, density=0.05, mean_atoms=20.0, sigma=0.7, min_atoms=1, max_atoms=200,
                    radius=8.0, max_neighbors=12, num_edge_features=50):
     """Synthetic "bulk-like" stand-in for the absent Materials-Project bulk_data:
@@ -234,19 +254,31 @@ def synthetic_bulk(n_graphs=46744, seed=0, density=0.05, mean_atoms=20.0, sigma=
     (n/density)^(1/3); uniform positions; the reference graph rule; Z ~ U[1,89]; y ~ Normal(0,1) seed+1."""
     rng = np.random.default_rng(seed)
     sizes = np.clip(np.rint(np.exp(rng.normal(np.log(mean_atoms), sigma, n_graphs))), min_atoms, max_atoms).astype(int)
-    graphs = []
+    boxes = [((n / density) ** (1.0 / 3.0),) * 3 for n in sizes]
+    return _synthetic(sizes, boxes, rng, seed, radius, max_neighbors, num_edge_features, "syn")
+
+
+def synthetic_mof(n_graphs=18000, seed=0, density=0.03, mean_atoms=100.0, sigma=0.5, min_atoms=20, max_atoms=500,
+                  radius=8.0, max_neighbors=12, num_edge_features=50):
+    """Synthetic "MOF-like" stand-in for the absent MOF_data: 18 k porous graphs of 20-500 atoms,
+    n ~ clip(round(exp(Normal(ln 100, 0.5))), 20, 500), density 0.03 atoms/A^3, the reference graph rule."""
+    rng = np.random.default_rng(seed)
+    sizes = np.clip(np.rint(np.exp(rng.normal(np.log(mean_atoms), sigma, n_graphs))), min_atoms, max_atoms).astype(int)
+    boxes = [((n / density) ** (1.0 / 3.0),) * 3 for n in sizes]
+    return _synthetic(sizes, boxes, rng, seed, radius, max_neighbors, num_edge_features, "mof")
+
+
+def synthetic_surface(n_graphs=37000, seed=0, density=0.06, min_atoms=40, max_atoms=80, slab=8.0, vacuum=15.0,
+                      radius=8.0, max_neighbors=12, num_edge_features=50):
+    """Synthetic "surface-like" stand-in for the absent surface_data: periodic slabs of 40-80 atoms,
+    `slab` A thick with `vacuum` A of empty space along z (the minimum image never crosses the vacuum)."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(min_atoms, max_atoms + 1, size=n_graphs)
+    boxes = []
     for n in sizes:
-        L = (n / density) ** (1.0 / 3.0)
-        pos = rng.uniform(0.0, L, size=(n, 3))
-        numbers = rng.integers(1, 90, size=n)
-        d = pos[None, :, :] - pos[:, None, :]
-        d -= L * np.rint(d / L)                              # minimum image, cubic cell
-        dm = np.sqrt((d * d).sum(-1))
-        ei, ew = pg.edges_from_trimmed(pg.threshold_sort(dm, radius, max_neighbors))
-        x = np.concatenate([pg.atom_features(numbers), pg.one_hot_degree(ei, n, max_neighbors + 1)], 1)
-        graphs.append({"x": x, "edge_index": ei, "edge_weight": ew, "z": numbers})
-    ys = np.random.default_rng(seed + 1).normal(0.0, 1.0, size=(n_graphs, 1)).astype(np.float32)
-    return from_graphs(graphs, ys, ["syn%d" % i for i in range(n_graphs)], num_edge_features)
+        a = (n / (density * slab)) ** 0.5
+        boxes.append((a, a, slab + vacuum, slab))
+    return _synthetic(sizes, boxes, rng, seed, radius, max_neighbors, num_edge_features, "surf")
 
 
 class DeviceLoader:

@@ -13,14 +13,64 @@ import json
 import numpy as np
 
 
+def reduce_cell(cell, pbc):
+    """Pairwise (Gauss / Minkowski-style) reduction of the PERIODIC cell vectors: repeatedly subtract integer
+    multiples of the shorter vector of a pair from the longer one until no vector gets shorter.  For a basis reduced
+    this way the minimum image of a wrapped difference vector lies within the 27 neighbouring images — which is how
+    ase.geometry.find_mic (behind get_all_distances(mic=True), process.py:258) treats skewed cells."""
+    c = np.array(cell, dtype=np.float64)
+    per = [k for k in range(3) if pbc[k]]
+    for _ in range(64):
+        changed = False
+        for a in per:
+            for b in per:
+                if a == b:
+                    continue
+                nb = c[b] @ c[b]
+                if nb < 1e-24:
+                    continue
+                k = np.rint((c[a] @ c[b]) / nb)
+                if k != 0.0:
+                    new = c[a] - k * c[b]
+                    if new @ new < c[a] @ c[a] - 1e-12:
+                        c[a] = new
+                        changed = True
+        if not changed:
+            break
+    return c
+
+
 def distance_matrix(positions, cell=None, pbc=None):
-    """All-pairs minimum-image distances (ase get_all_distances(mic=True) for cells whose minimum
-    image lies within the 27 neighbouring images; exact for the orthorhombic cells used here)."""
+    """All-pairs minimum-image distances, ase get_all_distances(mic=True) semantics (process.py:258): the periodic cell
+    vectors are lattice-reduced, difference vectors are wrapped into the reduced cell, then the 27 neighbouring images
+    are searched — exact for skewed / thin triclinic cells too (tests/test_host_logic.py compares with a wide brute
+    force)."""
     p = np.asarray(positions, dtype=np.float64)
     d = p[None, :, :] - p[:, None, :]                       # d[i, j] = p_j - p_i
     if pbc is None or not np.any(pbc):
         return np.sqrt((d * d).sum(-1))
-    cell = np.asarray(cell, dtype=np.float64)
+    pbc = [bool(b) for b in pbc]
+    cell = reduce_cell(cell, pbc)
+    # fractional coordinates are taken in a basis whose NON-periodic directions are orthogonal to the periodic ones
+    # (whatever the file stores there, possibly nothing): wrapping the periodic fractions then brings the component of
+    # d inside the periodic subspace into the reduced cell
+    full = cell.copy()
+    per = [cell[k] for k in range(3) if pbc[k]]
+    free = [k for k in range(3) if not pbc[k]]
+    if len(per) == 2:
+        v = np.cross(per[0], per[1])
+        full[free[0]] = v / np.sqrt(v @ v)
+    elif len(per) == 1:
+        u = per[0] / np.sqrt(per[0] @ per[0])
+        e = np.eye(3)[int(np.argmin(np.abs(u)))]
+        v1 = np.cross(u, e)
+        v1 /= np.sqrt(v1 @ v1)
+        full[free[0]], full[free[1]] = v1, np.cross(u, v1)
+    frac = d @ np.linalg.inv(full)
+    for k in range(3):
+        if pbc[k]:
+            frac[..., k] -= np.rint(frac[..., k])
+    d = frac @ full
     rng = [(-1, 0, 1) if b else (0,) for b in pbc]
     best = None
     for a in rng[0]:

@@ -29,8 +29,15 @@ def ddp_setup(rank, world_size, backend=None, master_addr="127.0.0.1", master_po
     os.environ.setdefault("MASTER_PORT", str(master_port))
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        # one process per GPU: bind it before anything allocates or launches (the HIP ops launch on the current
+        # device's stream) and hand the binding to RCCL so the communicator is created on this device
+        local = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
+        kw["device_id"] = torch.device("cuda", local)
     if not dist.is_initialized():
-        dist.init_process_group(backend, rank=int(rank), world_size=int(world_size))
+        dist.init_process_group(backend, rank=int(rank), world_size=int(world_size), **kw)
     return True
 
 
@@ -84,10 +91,7 @@ class FlatDataParallel:
         for p in self.params:
             p.grad = None
 
-    def reduce_grads(self, force=False):
-        """Sum over ranks, then average (DDP semantics).  One pack + one collective per step."""
-        if not (self.world_size > 1 or (force and dist.is_initialized())):
-            return
+    def _pack(self):
         srcs, dsts = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
@@ -97,10 +101,47 @@ class FlatDataParallel:
                 dsts.append(v)
         if srcs:
             torch._foreach_copy_(dsts, srcs)
-        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def reduce_grads_async(self, force=False):
+        """Start the gradient exchange: pack + ONE all_reduce(SUM).  On HIP devices both run on a side stream that
+        waits for the backward through an event, so whatever the caller enqueues next on the compute stream (the next
+        batch's assembly and RBF expansion in bench.py / the training loop) overlaps with the collective; finish() makes
+        the compute stream wait for it.  Returns False when there is nothing to exchange (one rank)."""
+        if not (self.world_size > 1 or (force and dist.is_initialized())):
+            return False
+        if self.flat_grad.is_cuda:
+            dev = self.flat_grad.device
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=dev)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                self._pack()
+                self._work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._pack()
+            self._work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return True
+
+    def finish(self):
+        """Wait for the exchange started by reduce_grads_async (the compute stream waits; the host does not), average
+        (DDP semantics) and leave every .grad a view into the flat buffer."""
+        work = getattr(self, "_work", None)
+        if work is None:
+            return
+        work.wait()
+        self._work = None
+        if self.flat_grad.is_cuda:
+            torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
         self.flat_grad.mul_(1.0 / self.world_size)
         for p, v in zip(self.params, self.views):
             p.grad = v
+
+    def reduce_grads(self, force=False):
+        """Sum over ranks, then average (DDP semantics).  One pack + one collective per step."""
+        if self.reduce_grads_async(force):
+            self.finish()
 
     def grad_bytes(self):
         return self.flat_grad.numel() * 4

@@ -46,6 +46,32 @@ def write_results(rows, path):
         wr.writerows(rows.tolist())
 
 
+def _enter_dist(rank, world_size):
+    """(distributed, owned): join the process group; `owned` = this call created it (and must destroy it)."""
+    import torch.distributed as dist
+    was = dist.is_available() and dist.is_initialized()
+    distributed = ddp_setup(rank, world_size)
+    return distributed, distributed and not was
+
+
+def resolve_seed(seed, sync=None):
+    """config.yml's `seed: 0` means "draw one" (main.py:239-241 draws it ONCE, before the ranks are spawned).  Here the
+    ranks are already running, so rank 0 draws and everyone else receives its value: split, loader permutation
+    and torch.manual_seed must agree across ranks or the shards overlap and the test set leaks into training."""
+    import torch.distributed as dist
+    seed = int(seed or 0)
+    if sync is None:
+        sync = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if sync:
+        if seed == 0:
+            seed = int(np.random.randint(1, 1e6))
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([seed], dtype=torch.int64, device=dev)
+        dist.broadcast(t, src=0)
+        return int(t.item())
+    return seed or int(np.random.randint(1, 1e6))
+
+
 def _loaders(dataset, splits, batch_size, seed, rank, world_size, edge_dtype, rbf):
     tr, va, te = splits
     r = rank if isinstance(rank, int) else 0
@@ -59,11 +85,13 @@ def train_regular(rank, world_size, dataset, job, training, model_params, splits
                   rbf=None, edge_dtype=torch.float32, log=print):
     """One training job.  Returns dict(train_error, val_error, test_error, history, model)."""
     model_factory = model_factory or default_model_factory
-    distributed = ddp_setup(rank, world_size)
+    distributed, owned = _enter_dist(rank, world_size)
+    if dataset.device is not None and dataset.device.type == "cuda":
+        torch.cuda.set_device(dataset.device)                                 # the HIP ops launch on the current device
     params = dict(model_params)
     lr = params.get("lr", 0.001) * (world_size if distributed else 1)        # training.py:388-389
     dataset.target_index = training.get("target_index", 0)
-    seed = job.get("seed", 0) or int(np.random.randint(1, 1e6))
+    seed = resolve_seed(job.get("seed", 0), sync=distributed)                 # one seed for split, loader, init on all ranks
     if splits is None:
         splits = split_data(len(dataset), training["train_ratio"], training["val_ratio"], training["test_ratio"], seed)
     train_loader, val_loader, test_loader = _loaders(dataset, splits, params.get("batch_size", 100), seed, rank,
@@ -99,7 +127,7 @@ def train_regular(rank, world_size, dataset, job, training, model_params, splits
                         "scheduler_state_dict": sch.state_dict()}, job.get("model_path", "my_model.pth"))
         log("Train Error: {:.5f}, Val Error: {:.5f}, Test Error: {:.5f}".format(
             out["train_error"], out["val_error"], out["test_error"]))
-    if distributed:
+    if owned:
         ddp_cleanup()
     return out
 
@@ -121,32 +149,102 @@ def predict(dataset, model_name, model_params, state_path, loss="l1_loss", model
 def train_repeat(rank, world_size, dataset, job, training, model_params, **kw):
     """training.py:719-843 — `repeat_trials` trainings with fresh seeds; mean/std of the errors."""
     trials = int(job.get("repeat_trials", 5))
+    _, owned = _enter_dist(rank, world_size)
     errs = []
     for i in range(trials):
-        j = dict(job, seed=int(np.random.randint(1, 1e6)), job_name="%s%d" % (job.get("job_name", "repeat"), i))
+        j = dict(job, seed=resolve_seed(0), job_name="%s%d" % (job.get("job_name", "repeat"), i))   # fresh, rank-agreed seed
         r = train_regular(rank, world_size, dataset, j, training, model_params, **kw)
         errs.append([r.get("train_error", np.nan), r.get("val_error", np.nan), r.get("test_error", np.nan)])
+    if owned:
+        ddp_cleanup()
     errs = np.array(errs)
     return dict(errors=errs, mean=errs.mean(0), std=errs.std(0))
 
 
+def _gather_objects(obj, world_size):
+    import torch.distributed as dist
+    bucket = [None] * world_size
+    dist.all_gather_object(bucket, obj)
+    return bucket
+
+
+def train_repeat_replicas(rank, world_size, dataset, job, training, model_params, **kw):
+    """Repeat mode sharded as REPLICAS (option 2): trial t runs entirely on rank t % world_size — a
+    single-GPU training with no gradient exchange — and the error table is gathered at the end.  Same trials and same
+    statistics as train_repeat (training.py:719-843, which runs the trials one after the other, each data-parallel over
+    all GPUs); zero communication on the data path, so N GPUs finish N trials in the time of one."""
+    trials = int(job.get("repeat_trials", 5))
+    distributed, owned = _enter_dist(rank, world_size)
+    r_id = int(rank) if distributed else 0
+    ws = world_size if distributed else 1
+    seeds = [resolve_seed(0) for _ in range(trials)]                     # agreed on all ranks
+    mine = {}
+    for t in range(r_id, trials, ws):
+        j = dict(job, seed=seeds[t], job_name="%s%d" % (job.get("job_name", "repeat"), t))
+        r = train_regular("cuda" if dataset.device is not None and dataset.device.type == "cuda" else "cpu", 1, dataset,
+                          j, training, model_params, **kw)             # world_size 1: a local, independent training
+        mine[t] = [r.get("train_error", np.nan), r.get("val_error", np.nan), r.get("test_error", np.nan)]
+    allr = {}
+    for part in (_gather_objects(mine, ws) if distributed else [mine]):
+        allr.update(part)
+    if owned:
+        ddp_cleanup()
+    errs = np.array([allr[t] for t in range(trials)])
+    return dict(errors=errs, mean=errs.mean(0), std=errs.std(0), seeds=seeds)
+
+
+def train_ensemble_replicas(rank, world_size, dataset, job, training, models_params, **kw):
+    """Ensemble mode sharded as replicas: model k trains on rank k % world_size on the SAME split (one agreed seed);
+    the test predictions are gathered and averaged exactly as training.py:1153 does."""
+    distributed, owned = _enter_dist(rank, world_size)
+    r_id = int(rank) if distributed else 0
+    ws = world_size if distributed else 1
+    seed = resolve_seed(job.get("seed", 0))
+    splits = split_data(len(dataset), training["train_ratio"], training["val_ratio"], training["test_ratio"], seed)
+    mine = {}
+    for k in range(r_id, len(models_params), ws):
+        r = train_regular("cuda" if dataset.device is not None and dataset.device.type == "cuda" else "cpu", 1, dataset,
+                          dict(job, seed=seed, job_name="%s_%d" % (job.get("job_name", "ens"), k)), training,
+                          models_params[k], splits=splits, **kw)
+        mine[k] = (r.get("test_error", np.nan), r.get("test_rows"))
+    allr = {}
+    for part in (_gather_objects(mine, ws) if distributed else [mine]):
+        allr.update(part)
+    if owned:
+        ddp_cleanup()
+    out = dict(model_errors=np.array([allr[k][0] for k in range(len(models_params))]))
+    rows = [allr[k][1] for k in range(len(models_params)) if allr[k][1] is not None]
+    if rows:
+        ncol = (rows[0].shape[1] - 1) // 2
+        ens = np.mean([r[:, 1 + ncol:].astype(np.float64) for r in rows], axis=0)
+        target = rows[0][:, 1:1 + ncol].astype(np.float64)
+        out["ensemble_error"] = float(np.abs(ens - target).mean())
+        out["ensemble_prediction"] = ens
+    return out
+
+
 def train_CV(rank, world_size, dataset, job, training, model_params, **kw):
     """training.py:587-715 — k-fold: fold i is the test set, the rest is training (no validation)."""
-    folds = split_data_CV(len(dataset), int(job.get("cv_folds", 5)), job.get("seed", 0) or int(np.random.randint(1, 1e6)))
+    _, owned = _enter_dist(rank, world_size)
+    seed = resolve_seed(job.get("seed", 0))
+    folds = split_data_CV(len(dataset), int(job.get("cv_folds", 5)), seed)
     errs, rows = [], []
     for i in range(len(folds)):
         tr = np.concatenate([f for k, f in enumerate(folds) if k != i])
-        r = train_regular(rank, world_size, dataset, dict(job, job_name="%s_fold%d" % (job.get("job_name", "cv"), i)),
+        r = train_regular(rank, world_size, dataset, dict(job, seed=seed, job_name="%s_fold%d" % (job.get("job_name", "cv"), i)),
                           training, model_params, splits=(tr, np.array([], dtype=np.int64), folds[i]), **kw)
         errs.append(r.get("test_error", np.nan))
         if "test_rows" in r:
             rows.append(r["test_rows"])
+    if owned:
+        ddp_cleanup()
     return dict(fold_errors=np.array(errs), cv_error=float(np.mean(errs)), rows=np.concatenate(rows) if rows else None)
 
 
 def train_ensemble(rank, world_size, dataset, job, training, models_params, **kw):
     """training.py:1069-1196 — one training per listed model on the SAME split; ensemble = mean prediction."""
-    seed = job.get("seed", 0) or int(np.random.randint(1, 1e6))
+    _, owned = _enter_dist(rank, world_size)
+    seed = resolve_seed(job.get("seed", 0))
     splits = split_data(len(dataset), training["train_ratio"], training["val_ratio"], training["test_ratio"], seed)
     per_model, preds, target = [], [], None
     for k, mp in enumerate(models_params):
@@ -158,6 +256,8 @@ def train_ensemble(rank, world_size, dataset, job, training, models_params, **kw
             ncol = (rows.shape[1] - 1) // 2
             preds.append(rows[:, 1 + ncol:].astype(np.float64))
             target = rows[:, 1:1 + ncol].astype(np.float64)
+    if owned:
+        ddp_cleanup()
     out = dict(model_errors=np.array(per_model))
     if preds:
         ens = np.mean(preds, axis=0)                                              # training.py:1153

@@ -51,13 +51,13 @@ def one_hot_degree(edge_index, num_nodes, max_degree):
     return out
 
 
-def mic_distances(positions, cell, pbc):
-    """ase.Atoms.get_all_distances(mic=True) (process.py:284) for cells whose minimum image lies
-    within the 27 neighbouring images (true for the orthorhombic / mildly skewed cells used here)."""
+def mic_distances(positions, cell, pbc, images=4):
+    """ase.Atoms.get_all_distances(mic=True) (process.py:284): the TRUE minimum over lattice translations, found here
+    by brute force over +-`images` cells per periodic axis (ase reduces the cell and wraps first; the result is the
+    same whenever the range is wide enough — small test cases only)."""
     p = np.asarray(positions, dtype=np.float64)
     n = len(p)
-    shifts = [np.zeros(3)]
-    rng = [(-1, 0, 1) if b else (0,) for b in pbc]
+    rng = [tuple(range(-images, images + 1)) if b else (0,) for b in pbc]
     shifts = [a * cell[0] + b * cell[1] + c * cell[2] for a in rng[0] for b in rng[1] for c in rng[2]]
     d = np.zeros((n, n))
     for i in range(n):

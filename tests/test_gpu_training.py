@@ -48,3 +48,50 @@ def test_bf16_models_train_finite():
         assert out.dtype == torch.float32 and out.shape == (48,)
         torch.nn.functional.l1_loss(out, b.y).backward()
         assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters()), name
+
+
+_RCCL_SNIPPET = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from matdeeplearn_amd.training import FlatDataParallel
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+torch.manual_seed(0)
+m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 1)).to(dev)
+dp = FlatDataParallel(m)
+dp.broadcast_state()                      # one flat broadcast per dtype over RCCL
+x = torch.randn(32, 8, device=dev)
+dp.zero_grad()
+m(x).sum().backward()
+ref = [p.grad.clone() for p in m.parameters()]
+dp.reduce_grads(force=True)               # pack + all_reduce(SUM) on the side stream + average: identity at world size 1
+torch.cuda.synchronize()
+for p, r in zip(m.parameters(), ref):
+    assert p.grad.data_ptr() != r.data_ptr() and torch.equal(p.grad, r), "all-reduce at world size 1 must be the identity"
+assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(dp.params, dp.views))
+t = torch.ones(4, device=dev); dist.all_reduce(t); assert float(t.sum()) == 4.0
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_rccl_backend_executes_on_one_gpu():
+    """The `nccl` (= RCCL) branch of the data-parallel engine on real hardware at world size 1: process-group init bound
+    to the device, flat broadcast, the side-stream pack + all-reduce, and bench.py's distributed path (MDL_FORCE_DIST=1)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_SNIPPET], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    env["MDL_FORCE_DIST"] = "1"
+    env["MASTER_PORT"] = "29534"
+    r = subprocess.run([sys.executable, "bench.py", "--graphs", "640", "--batch", "256", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extras"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1])
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["roofline"]["launches"] == 3 * 4

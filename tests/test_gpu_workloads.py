@@ -1,0 +1,237 @@
+"""GPU parity on the BASELINE.json workloads, product (HIP) against the oracle (CPU) on the SAME batches:
+
+  cfg2  synthetic bulk-like graphs (1..200 atoms, graphs wider than the backward's 64-node source window included),
+        CGCNN dim 64 x 4 conv: kernel level (forward + every gradient, fp32 and bf16, large enough for the backward's
+        dynamic group schedule) and model level (prediction / val-MAE at fixed weights, fp32 and bf16)
+  cfg3  synthetic MOF-like graphs (20..500 atoms: long segments, sources far outside any window), SchNet_demo
+        hyper-parameters of the reference's config.yml:162-183 (dim1 100, dim2 100, dim3 150, 4 interaction blocks)
+  cfg4  bulk-like graphs, MEGNet_demo hyper-parameters (config.yml:184-205: dims 100, 4 blocks, gc_fc_count 1)
+  cfg5  surface-like slabs, the five-model ensemble driver on the device against the same driver on the oracle
+
+Tolerances (stated once): fp32 predictions 1e-4 of the tensor scale, |dMAE| < 1e-5; fp32 gradients no worse than
+20 x the fp32-CPU error against an fp64 truth (floor 2e-4 of the scale); bf16 predictions 5e-2 of the scale,
+bf16 kernel outputs / gradients 3e-2 of the scale (inputs pre-rounded to bf16 on both sides).
+"""
+import copy
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as omodels
+from oracle import ops as oops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cpu_twin(ds):
+    c = copy.copy(ds)
+    c._dev = {}
+    c.to("cpu")
+    return c
+
+
+def _composition_targets(ds):
+    """A target the models can actually fit (mean atomic number of the graph, standardised): with the recipe's N(0,1)
+    noise targets every model scores MAE ~ E|y| and an MAE comparison could not tell two models apart."""
+    z = np.add.reduceat(ds.z.astype(np.float64), ds.node_ptr[:-1]) / np.diff(ds.node_ptr)
+    ds.y = ((z - z.mean()) / z.std()).astype(np.float32).reshape(-1, 1)
+    return ds
+
+
+def _batches(ds, ids, dtype=torch.float32):
+    rbf = lambda d: oops.rbf_expand(d, 0.0, 1.0, ds.num_edge_features, 0.2)
+    bc = _cpu_twin(ds).collate(ids, rbf=rbf)
+    bg = ds.collate(ids, edge_dtype=dtype, x_dtype=dtype)
+    return bc, bg
+
+
+def _close(a, b, rel, what=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    s = float(b.abs().max()) + 1e-12
+    err = float((a - b).abs().max())
+    assert err <= rel * s, "%s: max err %.3e vs scale %.3e (allowed %.1e of scale)" % (what, err, s, rel)
+
+
+def _model_parity(name, kw, ds, ids, grads=True):
+    """fp32 product vs fp32 oracle (same state_dict, same batch): train-mode prediction, gradients against the fp64
+    oracle, eval-mode MAE; then the bf16 product against the same oracle prediction."""
+    from matdeeplearn_amd import models
+    torch.manual_seed(0)
+    ref_model = getattr(omodels, name)(ds, **kw)
+    model = getattr(models, name)(ds, **kw)
+    assert list(model.state_dict()) == list(ref_model.state_dict())
+    model.load_state_dict(ref_model.state_dict())
+    model.to(DEV)
+    bc, bg = _batches(ds, ids)
+    ref_model.train(); model.train()
+    ref = ref_model(bc)
+    torch.nn.functional.l1_loss(ref, bc.y).backward()
+    out = model(bg)
+    torch.nn.functional.l1_loss(out, bg.y).backward()
+    _close(out, ref, 1e-4, name + " fp32 train prediction")
+    if grads:
+        m64 = copy.deepcopy(ref_model).double()
+        m64.zero_grad()
+        b64 = types.SimpleNamespace(**{k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v)
+                                       for k, v in vars(bc).items() if not k.startswith("_")})
+        b64.edge_index = bc.edge_index
+        torch.nn.functional.l1_loss(m64(b64), b64.y).backward()
+        rg, g64 = dict(ref_model.named_parameters()), dict(m64.named_parameters())
+        for k, p in model.named_parameters():
+            if g64[k].grad is None:
+                continue
+            truth = g64[k].grad
+            s = float(truth.abs().max()) + 1e-12
+            cpu_err = float((rg[k].grad.double() - truth).abs().max())
+            gpu_err = float((p.grad.cpu().double() - truth).abs().max()) if p.grad is not None else s
+            assert gpu_err <= max(20.0 * cpu_err, 2e-4 * s), (name, k, gpu_err, cpu_err, s)
+    # weights as they are after construction; BatchNorm buffers moved by the one training forward on BOTH sides
+    ref_model.eval(); model.eval()
+    with torch.no_grad():
+        pr, pg_ = ref_model(bc), model(bg)
+        mae_ref = float(torch.nn.functional.l1_loss(pr, bc.y))
+        mae = float(torch.nn.functional.l1_loss(pg_, bg.y))
+    _close(pg_, pr, 1e-4, name + " fp32 eval prediction")
+    assert abs(mae - mae_ref) < 1e-5 * max(1.0, abs(mae_ref)), (name, mae, mae_ref)
+    # bf16 compute mode against the fp32 oracle
+    m16 = getattr(models, name)(ds, compute_dtype="bf16", **kw)
+    m16.load_state_dict(ref_model.state_dict())
+    m16.to(DEV).eval()
+    _, bg16 = _batches(ds, ids, torch.bfloat16)
+    with torch.no_grad():
+        p16 = m16(bg16)
+    _close(p16, pr, 5e-2, name + " bf16 eval prediction")
+    mae16 = float(torch.nn.functional.l1_loss(p16, bg16.y))
+    assert abs(mae16 - mae_ref) < 2e-2 * max(1.0, abs(mae_ref)), (name, mae16, mae_ref)
+    m16.train()
+    out16 = m16(bg16)
+    torch.nn.functional.l1_loss(out16, bg16.y).backward()
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m16.parameters()), name
+    return mae_ref, mae, mae16
+
+
+# ------------------------------------------------------------------------------------------------ cfg2
+@pytest.fixture(scope="module")
+def bulk():
+    from matdeeplearn_amd.process import synthetic_bulk
+    ds = _composition_targets(synthetic_bulk(3072, seed=3))
+    assert np.diff(ds.node_ptr).max() > 64                    # graphs wider than the source window are present
+    return ds.to(DEV)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cfg2_cgconv_kernels_on_bulk_batch(bulk, dtype):
+    """K2 / K3 / K3c on a whole bulk-like batch (N ~ 7.8e4, E ~ 1.0e6: >= 4 node groups per backward wave, so the
+    dynamic schedule is the one that runs) against the oracle op: forward and every gradient."""
+    from matdeeplearn_amd import ops
+    ids = np.arange(3072)
+    bc, bg = _batches(bulk, ids, dtype)
+    assert bg.num_nodes // 32 * 2 >= 4 * 1024                # the condition under which cg_launch goes dynamic
+    C, G = 64, 50
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x = rnd(bc.x.shape[0], C).to(dtype).float()
+    ea = bc.edge_attr.to(dtype).float()
+    k = 3.0 / (2 * C + G) ** 0.5
+    wf, ws = (rnd(C, 2 * C + G) * k).to(dtype).float(), (rnd(C, 2 * C + G) * k).to(dtype).float()
+    bf, bs = rnd(C) * 0.1, rnd(C) * 0.1
+    gout = rnd(bc.x.shape[0], C).to(dtype).float()
+    xo, wfo, wso, bfo, bso = [t.clone().requires_grad_(True) for t in (x, wf, ws, bf, bs)]
+    ref = oops.cgconv(xo, bc.edge_index, ea, wfo, bfo, wso, bso, "mean")
+    (ref * gout).sum().backward()
+    xd = x.to(DEV).to(dtype).requires_grad_(True)
+    wfd, wsd, bfd, bsd = [t.to(DEV).clone().requires_grad_(True) for t in (wf, ws, bf, bs)]
+    out = ops.cgconv(xd, None, bg.edge_attr if dtype == torch.float32 else ea.to(DEV).to(dtype), wfd, bfd, wsd, bsd, "mean", csr=bg.csr)
+    (out.float() * gout.to(DEV)).sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    wtol = 1e-4 if dtype == torch.float32 else 3e-2          # weight gradients sum 1e6 edge terms in a different order
+    _close(out, ref, tol, "out")
+    _close(xd.grad, xo.grad, tol, "dx")
+    _close(wfd.grad, wfo.grad, wtol, "dW_f")
+    _close(wsd.grad, wso.grad, wtol, "dW_s")
+    _close(bfd.grad, bfo.grad, wtol, "db_f")
+    _close(bsd.grad, bso.grad, wtol, "db_s")
+
+
+def test_cfg2_cgcnn_model_fp32_and_bf16(bulk):
+    kw = dict(dim1=64, dim2=64, pre_fc_count=1, gc_count=4, post_fc_count=3)
+    mae_ref, mae, mae16 = _model_parity("CGCNN", kw, bulk, np.arange(1024))
+    assert np.isfinite([mae_ref, mae, mae16]).all()
+
+
+# ------------------------------------------------------------------------------------------------ cfg3
+@pytest.fixture(scope="module")
+def mof():
+    from matdeeplearn_amd.process import synthetic_mof
+    ds = _composition_targets(synthetic_mof(96, seed=4))
+    assert np.diff(ds.node_ptr).max() > 200
+    return ds.to(DEV)
+
+
+def test_cfg3_schnet_demo_on_mof_like_graphs(mof):
+    kw = dict(dim1=100, dim2=100, dim3=150, cutoff=8, pre_fc_count=1, gc_count=4, post_fc_count=3)   # config.yml:162-183
+    _model_parity("SchNet", kw, mof, np.arange(64))
+
+
+def test_cfg3_schnet_interaction_block_bf16(mof):
+    """One InteractionBlock (K4 path) in bf16 against the fp32 oracle on bf16-rounded operands: output and the
+    gradients w.r.t. x and every parameter, 3e-2 of the tensor scale."""
+    from matdeeplearn_amd import nn as pnn
+    bc, bg = _batches(mof, np.arange(48), torch.bfloat16)
+    torch.manual_seed(2)
+    C, F = 100, 150
+    ob = oops.InteractionBlock(C, 50, F, 8.0)
+    with torch.no_grad():
+        for p in ob.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p)).copy_(p.to(torch.bfloat16).float())
+    pb = pnn.InteractionBlock(C, 50, F, 8.0)
+    pb.load_state_dict(ob.state_dict())
+    pb.to(DEV)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(bc.x.shape[0], C, generator=g).to(torch.bfloat16).float()
+    gout = torch.randn(bc.x.shape[0], C, generator=g)
+    ea = bc.edge_attr.to(torch.bfloat16).float()
+    xo = x.clone().requires_grad_(True)
+    ref = ob(xo, bc.edge_index, bc.edge_weight, ea)
+    (ref * gout).sum().backward()
+    xd = x.to(DEV).to(torch.bfloat16).requires_grad_(True)
+    out = pb(xd, None, bg.edge_weight, ea.to(DEV).to(torch.bfloat16), csr=bg.csr)
+    (out.float() * gout.to(DEV)).sum().backward()
+    _close(out, ref, 3e-2, "InteractionBlock out")
+    _close(xd.grad, xo.grad, 3e-2, "dx")
+    og = dict(ob.named_parameters())
+    for k, p in pb.named_parameters():
+        _close(p.grad, og[k].grad, 4e-2, k)
+
+
+# ------------------------------------------------------------------------------------------------ cfg4
+def test_cfg4_megnet_demo_on_bulk_like_graphs(bulk):
+    kw = dict(dim1=100, dim2=100, dim3=100, pre_fc_count=1, gc_count=4, gc_fc_count=1, post_fc_count=3)  # config.yml:184-205
+    _model_parity("MEGNet", kw, bulk, np.arange(256))
+
+
+# ------------------------------------------------------------------------------------------------ cfg5
+def test_cfg5_five_model_ensemble_on_surface_like_slabs():
+    """The Ensemble driver with all five models on the device (product kernels) against the same driver on the oracle:
+    same seed -> same split, same initial weights, same batches; one epoch of fp32 training stays within 2e-3."""
+    from matdeeplearn_amd.process import synthetic_surface
+    from matdeeplearn_amd.training import train_ensemble
+    ds = _composition_targets(synthetic_surface(96, seed=6))
+    training = dict(target_index=0, loss="l1_loss", train_ratio=0.7, val_ratio=0.1, test_ratio=0.2, verbosity=0)
+    base = dict(dim1=32, dim2=32, dim3=24, pre_fc_count=1, gc_count=2, gc_fc_count=1, post_fc_count=1, epochs=1, lr=0.002,
+                batch_size=24, optimizer="AdamW", optimizer_args={}, scheduler="ReduceLROnPlateau",
+                scheduler_args={"mode": "min", "factor": 0.8, "patience": 10})
+    mps = [dict(base, model=m) for m in ("CGCNN", "SchNet", "MPNN", "MEGNet", "GCN")]
+    job = dict(job_name="ens", seed=17, save_model="False", write_output="False")
+    quiet = lambda *a: None
+    gpu = train_ensemble("cuda", 1, copy.copy(ds).to(DEV), job, training, mps, log=quiet)
+    cpu = train_ensemble("cpu", 1, _cpu_twin(ds), job, training, mps, log=quiet,
+                         model_factory=lambda n: omodels.REGISTRY[n], rbf=lambda d: oops.rbf_expand(d))
+    assert gpu["model_errors"].shape == (5,)
+    assert np.allclose(gpu["model_errors"], cpu["model_errors"], rtol=2e-3, atol=2e-3), (gpu["model_errors"], cpu["model_errors"])
+    assert abs(gpu["ensemble_error"] - cpu["ensemble_error"]) < 2e-3 * max(1.0, cpu["ensemble_error"])

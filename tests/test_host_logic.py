@@ -253,6 +253,75 @@ def test_flat_data_parallel_world_size_2_gloo(tmp_path):
     assert open(out).read().startswith("ok")
 
 
+def _replica_worker(rank, world, port, out_path):
+    """Seed agreement + replica-per-rank Repeat / Ensemble drivers on a world_size-2 gloo group."""
+    import torch.distributed as dist
+    from matdeeplearn_amd.process import from_structures
+    from matdeeplearn_amd.training import (ddp_cleanup, ddp_setup, resolve_seed, train_ensemble_replicas,
+                                           train_repeat_replicas)
+    from oracle import models as omodels, ops as oops
+    os.environ["MASTER_PORT"] = str(port)
+    ddp_setup(rank, world, backend="gloo", master_port=port)
+    np.random.seed(100 + rank)                                    # ranks would draw DIFFERENT seeds on their own
+    seeds = [resolve_seed(0), resolve_seed(0), resolve_seed(7)]
+    got = [None, None]
+    dist.all_gather_object(got, seeds)
+    assert got[0] == got[1] and got[0][2] == 7 and got[0][0] != got[0][1]
+    z = np.load(os.path.join(G, "pt10_dataset.npz"))
+    n = 60
+    structs = [dict(positions=z["positions"][s], numbers=z["numbers"][s], cell=z["cell"][s], pbc=z["pbc"][s]) for s in range(n)]
+    ds = from_structures(structs, z["y"][:n], [str(v) for v in z["ids"][:n]]).to("cpu")
+    training = dict(target_index=0, loss="l1_loss", train_ratio=0.7, val_ratio=0.1, test_ratio=0.2, verbosity=0)
+    mp_ = dict(model="CGCNN", dim1=8, dim2=8, gc_count=1, post_fc_count=1, epochs=1, lr=0.005, batch_size=20,
+               optimizer="AdamW", optimizer_args={}, scheduler="ReduceLROnPlateau", scheduler_args={"mode": "min"})
+    kw = dict(model_factory=lambda name: omodels.REGISTRY[name], rbf=lambda d: oops.rbf_expand(d), log=lambda *a: None)
+    job = dict(job_name="r", seed=0, save_model="False", write_output="False", repeat_trials=3)
+    rep = train_repeat_replicas(rank, world, ds, job, training, mp_, **kw)
+    assert rep["errors"].shape == (3, 3) and np.isfinite(rep["errors"]).all()
+    ens = train_ensemble_replicas(rank, world, ds, dict(job, seed=5), training, [mp_, dict(mp_, model="GCN"), dict(mp_, dim1=12)], **kw)
+    assert ens["model_errors"].shape == (3,) and np.isfinite(ens["ensemble_error"])
+    both = [None, None]
+    dist.all_gather_object(both, (rep["errors"].tolist(), ens["ensemble_error"]))
+    assert both[0] == both[1]                                     # every rank holds the same gathered table
+    if rank == 0:
+        open(out_path, "w").write("ok")
+    ddp_cleanup()
+
+
+def test_seed_agreement_and_replica_drivers_world_size_2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    out = str(tmp_path / "rep.txt")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    mp.spawn(_replica_worker, args=(2, port, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_minimum_image_distances_in_skewed_cells():
+    """distance_matrix == brute force over a wide image range for thin / strongly skewed triclinic cells (where the true
+    minimum image lies outside the +-1 images of the raw cell), mixed pbc, and is unchanged for orthorhombic cells."""
+    from matdeeplearn_amd.process import graph as pg
+    rng = np.random.default_rng(5)
+    cells = [np.array([[4.0, 0, 0], [3.6, 1.2, 0], [0.3, 0.2, 9.0]]),            # thin, strongly skewed in the ab plane
+             np.array([[5.0, 0, 0], [9.0, 2.0, 0], [7.0, 5.0, 3.0]]),            # every pair far from orthogonal
+             np.diag([6.0, 7.0, 8.0])]
+    for cell in cells:
+        for pbc in ([True, True, True], [True, True, False]):
+            frac = rng.uniform(0, 1, size=(9, 3))
+            pos = frac @ cell
+            got = pg.distance_matrix(pos, cell, pbc)
+            d = pos[None] - pos[:, None]
+            best = np.full(d.shape[:2], np.inf)
+            R = range(-6, 7)
+            for a in (R if pbc[0] else [0]):
+                for b in (R if pbc[1] else [0]):
+                    for c in (R if pbc[2] else [0]):
+                        v = d + a * cell[0] + b * cell[1] + c * cell[2]
+                        best = np.minimum(best, np.sqrt((v * v).sum(-1)))
+            assert np.allclose(got, best, atol=1e-9), (cell, pbc, np.abs(got - best).max())
+
+
 # ---------------------------------------------------------------------------------------------
 # job drivers (Training / Repeat / CV / Ensemble / Predict) on CPU with the oracle models
 # ---------------------------------------------------------------------------------------------
