@@ -26,6 +26,12 @@ import os
 import sys
 import time
 
+# Batch sizes differ by a few percent from step to step, so every step asks the caching allocator for slightly different
+# block sizes; with exact-size blocks it keeps calling hipMalloc / hipFree (which synchronise) once the first few dozen
+# steps have fragmented its pool.  Size classes (1/8-of-a-power-of-two steps) make the blocks reusable.
+for _k in ("PYTORCH_ALLOC_CONF", "PYTORCH_HIP_ALLOC_CONF", "PYTORCH_CUDA_ALLOC_CONF"):
+    os.environ.setdefault(_k, "roundup_power2_divisions:8")
+
 import numpy as np
 import torch
 
@@ -261,19 +267,29 @@ def main():
     if world == 1 and not args.no_extras:
         # ---- sustained: the same step for >= sustain_s seconds, no kernel events --------------------------------
         torch.cuda.synchronize()
+        ms0 = torch.cuda.memory_stats(dev)
         t1 = time.perf_counter()
         e_sus = n_sus = 0
+        marks, enq = [], []
         while True:
             e_sus += step(next(stream), False)[0]
             n_sus += 1
             if n_sus % 16 == 0:
+                enq.append(time.perf_counter() - t1)              # host has enqueued 16 more steps
                 torch.cuda.synchronize()
-                if time.perf_counter() - t1 >= args.sustain_s:
+                marks.append(time.perf_counter() - t1)
+                if marks[-1] >= args.sustain_s:
                     break
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
+        ms1 = torch.cuda.memory_stats(dev)
         res["sustained"] = {"value": round(e_sus / dt, 1), "unit": "edges/s", "steps": n_sus, "seconds": round(dt, 2),
-                            "ms_per_step": round(dt / n_sus * 1e3, 4)}
+                            "device_mallocs": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+                            "device_frees": int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)),
+                            "reserved_gb": round(ms1.get("reserved_bytes.all.current", 0) / 2 ** 30, 2),
+                            "ms_per_step": round(dt / n_sus * 1e3, 4),
+                            "ms_per_step_by_16": [round((b - a) / 16 * 1e3, 2) for a, b in zip([0.0] + marks[:-1], marks)],
+                            "host_enqueue_ms_per_step_by_16": [round((b - a) / 16 * 1e3, 2) for a, b in zip([0.0] + marks[:-1], enq)]}
 
         # ---- the same training step at the reference's batch size (config.yml:136 batch_size 100) ----------------
         rb = 100

@@ -111,6 +111,22 @@ int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, 
                    const void* grad_out, void* r_tgt, float* r_src, float* dwe, float* db, int64_t N,
                    int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes, mdlStream_t stream);
 
+/* Saved-gate variant of the pair above (dtype MDL_BF16, C in {32, 64}, G = 50, edge features in CSR order; row bytes 0 =
+ * unsupported).  The training forward also writes, per edge and channel, the two factors the backward needs
+ *     A = d m / d pre_f = sigmoid'(pre_f) softplus(pre_s),   B = d m / d pre_s = sigmoid(pre_f) sigmoid(pre_s)
+ * as one packed bf16 pair: gate [E, C, 2] = mdl_cgconv_gate_row_bytes(C, G, dtype) (= 4C) bytes per edge, caller-owned.
+ * mdl_cgconv_bwd_saved then produces the SAME r_tgt / r_src / dwe / db as mdl_cgconv_bwd from grad_out, the indices,
+ * the edge features and `gate` alone — no x, no weights, no recompute of the gate: it trades 8C bytes of HBM traffic per
+ * edge and layer for 24 of the 46 MFMAs, every transcendental and the x gathers of the recomputing pass. */
+size_t mdl_cgconv_gate_row_bytes(int C, int G, int dtype);
+int mdl_cgconv_fwd_save(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
+                        const int32_t* tgt, const void* wpack, const float* bpack, void* out, void* gate,
+                        int64_t N, int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream);
+int mdl_cgconv_bwd_saved(const void* edge_attr, const int32_t* rowptr, const int32_t* src, const int32_t* tgt,
+                         const void* gate, const void* grad_out, void* r_tgt, float* r_src, float* dwe, float* db,
+                         int64_t N, int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
+                         mdlStream_t stream);
+
 /* Optional scratch for mdl_cgconv_bwd (caller-owned device memory, contents ignored; the library zeroes what it
  * uses, on the stream).  With it the backward hands 32-node groups to its waves dynamically (large problems);
  * without it (NULL / 0) every wave gets a fixed edge-balanced node range.  Same results up to the order of the

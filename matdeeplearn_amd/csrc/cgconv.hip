@@ -128,6 +128,8 @@ struct CgParams {
     float* dwe;         // bwd [2Cp, GP]
     float* db;          // bwd [2Cp] bias gradient = column sums of r_tgt (may be null)
     unsigned* ctr;      // bwd, optional: NS zeroed work counters (caller workspace) -> dynamic group scheduling
+    void* ab;           // saved gate factors [E][Cp][2] bf16 (A | B per channel): written by the training forward, read by
+                        // the saved-gate backward (cgconv_bwd_ab_kernel)
     int64_t N, E;
     int C, G, Cp, KE, KT, WS, EKS, NS, GP, aggr;
     int GW;             // staging words per e row
@@ -293,7 +295,10 @@ struct EWords {
 
     // The static kernels are only launched for target-sorted edge features (no eperm; the host permutes
     // once).  Buffer loads: a fresh resource per tile (uniform base in SGPRs, range = the bytes that remain in
-    // the array), ONE per-lane 32-bit offset, the word index j in the immediate.  No predication and no second
+    // the array), ONE per-lane 32-bit offset, the word index j in the instruction's 12-bit immediate.  The constant is
+    // written as part of the VOFFSET expression (the compiler splits it into register + immediate): the hardware range
+    // check covers voffset + immediate only — an SGPR soffset is added AFTER the check, so rows addressed through it
+    // would read (or, for stores, write) past the end of the array instead of being dropped.  No predication and no second
     // code path: rows past the end of the group belong to later edges (finite data, multiplied by exact zeros
     // downstream), words past the end of the array fail the range check and read as zeros.  (A clamped second
     // path for the last tile costs more than its instructions: every control-flow join in the tile loop makes
@@ -307,8 +312,8 @@ struct EWords {
             const_cast<char*>(tb), 0, (int)(rem < 0 ? 0 : (rem < 0x7fffffffLL ? rem : 0x7fffffffLL)), 0x00020000);
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            if constexpr (WB == 4) w[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane * WB, j * (WAVE * WB), 0);
-            else w[j] = __builtin_amdgcn_raw_buffer_load_b16(rs, lane * WB, j * (WAVE * WB), 0);
+            if constexpr (WB == 4) w[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane * WB + j * (WAVE * WB), 0, 0);
+            else w[j] = __builtin_amdgcn_raw_buffer_load_b16(rs, lane * WB + j * (WAVE * WB), 0, 0);
         }
     }
     __device__ __forceinline__ void commit(T* et, int EKS, int lane) const {
@@ -683,7 +688,7 @@ struct GroupInfo {
 #define MDL_FWD_THREADS 256     // workgroup size of the forward kernel (waves share one LDS copy of W)
 #define MDL_FWD_WAVES 2         // waves per SIMD it is register-allocated for
 #endif
-template <typename T, int CP_, int G_, int VEC, int EW, int WM>   // WM: 0 global, 1 LDS, 2 registers
+template <typename T, int CP_, int G_, int VEC, int EW, int WM, bool AB_ = false>   // WM: 0 global, 1 LDS, 2 registers
 __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_kernel(CgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Mma<T> M;
@@ -787,6 +792,12 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                 unsigned t4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) t4[j] = w.tsl[2 * j + h];
+                // training forward: the gate factors of this tile's edges go to HBM (rows past the group's end are
+                // dropped by the range check of the store resource: they belong to the next group's owner)
+                constexpr int ROWB = 4 * CP_;
+                __amdgpu_buffer_rsrc_t abrs;
+                if constexpr (AB_)
+                    abrs = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(p.ab) + (int64_t)eb * ROWB, 0, nv * ROWB, 0x00020000);
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl) {
                     f32x16 accf, accs;
@@ -803,8 +814,25 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                     if (sl == NSL - 1) xf.load(x, dm.C, nxt.tgt, nxt.src, h);      // unconditional, like the loads above
 #endif
                     f32x16 m;
+                    if constexpr (AB_) {
+                        // m and, for the backward, A = dm/dpre_f = sigmoid'(f) softplus(s), B = dm/dpre_s = sigmoid(f) sigmoid(s)
+                        // (same four transcendentals as the plain gate: the two reciprocals share one v_rcp), packed
+                        // as one dword per (edge, channel): a row of a slice is 128 contiguous bytes
+                        // (row offsets: two per-lane bases + an immediate < 4096, all inside the range check)
+                        const int vo0 = 4 * h * ROWB + sl * 128 + i * 4, vo1 = vo0 + 16 * ROWB;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m[r] = GT::sigmoid(accf[r]) * GT::softplus_u(accs[r]);
+                        for (int r = 0; r < 16; ++r) {
+                            float sf, sp_u, ss;
+                            GT::deriv(accf[r], accs[r], sf, sp_u, ss);
+                            const float mm = sf * sp_u;
+                            m[r] = mm;
+                            __builtin_amdgcn_raw_buffer_store_b32(pk_bf16((mm * GT::M_SCALE) * (1.0f - sf), sf * ss), abrs,
+                                                                  (r < 8 ? vo0 : vo1) + ((r & 3) + 8 * ((r >> 2) & 1)) * ROWB, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) m[r] = GT::sigmoid(accf[r]) * GT::softplus_u(accs[r]);
+                    }
                     TPIN16(m);
                     TMARK(4 + 3 * sl);
                     seg_reduce_mma<T>(m, t4, i, acc_out[sl]);
@@ -1377,6 +1405,280 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward edge pass from SAVED gate factors (static bf16 shapes).
+// The training forward stores, per (edge, channel), A = dm/dpre_f and B = dm/dpre_s as one packed dword (256 B per
+// edge at C = 64).  This pass then needs neither x, nor the weights, nor any transcendental: per 32-edge tile it
+// streams the tile's A|B rows (coalesced 128-byte row segments straight into D-layout registers) and its edge
+// features (LDS tile, for dwe), expands grad_out/deg to the edges with the one-hot MFMA, multiplies, and reduces
+// dpre the same three ways as cgconv_bwd_kernel (r_tgt by target, r_src by source window + atomics, dwe = dpre^T e).
+// It trades 2 x 4Cp bytes of HBM traffic per edge and layer for the whole recompute (24 of 46 MFMAs, ~90 VALU
+// cycles per element of gate derivative, the x gathers and their registers): on a part with 8 TB/s that is the
+// better side of the trade — the recomputing kernel sat at 0.24 of the HBM roofline, compute/latency bound.
+// Work distribution, group prologue, one-hot tables, window and flushes are those of cgconv_bwd_kernel.
+// ------------------------------------------------------------------------------------------
+template <int CP_>
+struct ABWords {
+    static constexpr int ROWB = 4 * CP_;
+    unsigned w[16];
+    // rows eb .. eb+31 of the saved factors, this lane's channel of slice s; rows past E read as zeros
+    __device__ __forceinline__ void prefetch(const CgParams& p, int eb, int s, int i, int h) {
+        const char* tb = static_cast<const char*>(p.ab) + (int64_t)eb * ROWB;
+        const int64_t rem = (p.E - (int64_t)eb) * ROWB;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(tb), 0, (int)(rem < 0 ? 0 : (rem < 0x7fffffffLL ? rem : 0x7fffffffLL)), 0x00020000);
+        const int vo0 = 4 * h * ROWB + s * 128 + i * 4, vo1 = vo0 + 16 * ROWB;     // + immediate < 4096: range-checked
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            w[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (r < 8 ? vo0 : vo1) + ((r & 3) + 8 * ((r >> 2) & 1)) * ROWB, 0, 0);
+    }
+};
+
+template <int CP_, int G_>
+__global__ __launch_bounds__(256, 1) void cgconv_bwd_ab_kernel(CgParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef bf16_t T;
+    constexpr int EW = 2;
+    typedef Dims<T, CP_, G_, EW> D;
+    const D dm(p);
+    WaveCtx<T> w;
+    setup_wave<T>(p, dm, smem, false, w);
+
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int total_waves = gridDim.x * (blockDim.x >> 6);
+    constexpr int NS = CP_ / 32;
+    const int s = gw % NS;
+    const int gstride = total_waves / NS;
+    const int ch = s * 32 + i;
+    const T* go = static_cast<const T*>(p.gout);
+    constexpr int C2 = 2 * CP_;
+
+    constexpr int GNT = (G_ + 31) / 32;
+    f32x16 dwe_acc[2][GNT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < GNT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dwe_acc[a][b][r] = 0.0f;
+
+    float dbf_acc = 0.0f, dbs_acc = 0.0f;
+    int oh_ts = -1, oh_ss = -1;
+    const bool dyn = p.ctr != nullptr;
+    NodeRange R{0, 0};
+    if (!dyn) R = NodeRange(p, __builtin_amdgcn_readfirstlane(gw / NS), gstride, lane);
+    const int nend = dyn ? (int)p.N : R.nb;
+    int gpend = 0;
+    if (dyn && lane == 0) gpend = (int)atomicAdd(p.ctr + s, 1u);
+    int n0 = dyn ? 32 * __builtin_amdgcn_readfirstlane(gpend) : R.na;
+    while (n0 < nend) {
+        const int n1 = min(n0 + 32, nend);
+        if (dyn && lane == 0) gpend = (int)atomicAdd(p.ctr + s, 1u);
+        const int e0 = p.rowptr[n0];
+        const int e1 = p.rowptr[n1];
+
+        // ---- group prologue: every load unconditional on a clamped index, all issued before the first use
+        const int nd = min(n0 + i, n1 - 1);
+        const int dg0 = p.rowptr[nd], dg1 = p.rowptr[nd + 1];
+        float graw[2][8];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                graw[f][q] = Elem<T>::ld(go + (int64_t)min(n0 + 16 * f + 8 * h + q, n1 - 1) * CP_ + ch);
+        int wb = 0x7fffffff;
+        for (int eb = e0; eb < e1; eb += 8 * WAVE) {
+            int sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv[u] = p.src[min(eb + u * WAVE + lane, e1 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wb = min(wb, sv[u]);
+        }
+        TileIdx cur, nxt, nn;
+        EWords<T, G_, EW> ew;
+        ABWords<CP_> ab, abn;
+        cur.template load<false>(p, e0, e1, i, n0);
+        nxt = cur;
+        if (e0 + 32 < e1) nxt.template load<false>(p, e0 + 32, e1, i, n0);
+        nn = nxt;
+        ew.prefetch(p, lane, e0, 32, 0);
+        ab.prefetch(p, e0, s, i, h);
+
+        const float invd = (p.aggr == MDL_MEAN) ? 1.0f / (float)max(dg1 - dg0, 1) : 1.0f;
+        bf16x8 gB[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int ns = 16 * f + 8 * h + q;
+                const float sc = __shfl(invd, ns);
+                v[q] = (n0 + ns < n1) ? graw[f][q] * sc : 0.0f;
+            }
+            gB[f] = pack_bf16x8(v);
+        }
+
+        f32x16 Rf, Rs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Rf[r] = 0.0f; Rs[r] = 0.0f; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wb = min(wb, __shfl_xor(wb, o));
+        wb = __builtin_amdgcn_readfirstlane(wb);
+        f32x16 Wf[2], Ws[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { Wf[mt][r] = 0.0f; Ws[mt][r] = 0.0f; }
+        if (lane == 0) *w.touched = 0ull;
+
+        for (int eb = e0; eb < e1; eb += 32) {
+            const int nv = min(32, e1 - eb);
+            const bool valid_i = i < nv;
+            const int my_ts = valid_i ? (cur.tgt - n0) : 0xff;
+            const unsigned my_ss = (unsigned)(cur.src - wb);
+            const bool in_win = valid_i && my_ss < 64u;
+            const bool oob = valid_i && !in_win;
+            wave_lds_fence();
+            ew.commit(w.et, dm.EKS, lane);
+            if (h == 0) {
+                w.srcl[i] = oob ? cur.src : -1;
+                if (in_win) atomicOr(w.touched, 1ull << my_ss);
+                const int nts = valid_i ? my_ts : -1, nss = in_win ? (int)my_ss : -1;
+                oh_update(w.oh_t, oh_ts, nts, oh_pos(i));
+                oh_update(w.oh_w, oh_ss, nss, oh_pos(i));
+                if (oh_ts != nts) {
+                    if (oh_ts >= 0) w.oh_e[i * OHS + oh_ts] = 0;
+                    if (nts >= 0) w.oh_e[i * OHS + nts] = 0x3F80;
+                }
+                oh_ts = nts;
+                oh_ss = nss;
+            }
+            wave_lds_fence();
+
+            // next tile's loads, unconditional (clamped indices / range-checked buffer loads)
+            nn.template load<false, false>(p, eb + 64, e1, i, n0);
+            ew.prefetch(p, lane, eb + 32, 32, 0);
+            abn.prefetch(p, eb + 32, s, i, h);
+
+            // dmv[edge slot][ch] = grad_out[tgt(edge)][ch] / deg : one-hot(edge -> node slot) x gB
+            f32x16 dmv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dmv[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                dmv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh_frag(w.oh_e, i, ks, h), gB[ks], dmv, 0, 0, 0);
+
+            // dpre = dmv * (A | B).  dmv is an exact 0 for edge slots >= nv (empty one-hot row), so whatever the rows
+            // past the group's end hold (the next group's factors, finite) contributes exact zeros.
+            f32x16 accf, accs;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accf[r] = dmv[r] * __uint_as_float(ab.w[r] << 16);
+                accs[r] = dmv[r] * __uint_as_float(ab.w[r] & 0xffff0000u);
+            }
+
+            if (__any(oob)) {
+                typedef __attribute__((ext_vector_type(4))) int i32x4;
+                int sj[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const i32x4 v = *reinterpret_cast<const i32x4*>(w.srcl + 8 * q + 4 * h);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sj[4 * q + k] = v[k];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (sj[r] >= 0) {
+                        float* dst = p.r_src + (int64_t)sj[r] * C2 + ch;
+                        unsafeAtomicAdd(dst, accf[r]);
+                        unsafeAtomicAdd(dst + CP_, accs[r]);
+                    }
+                }
+            }
+
+            DFrags<T> dp;
+            dp.pack(accf, accs);
+            seg_reduce2_tab(dp, w.oh_t, i, h, Rf, Rs);                                          // by target -> r_tgt
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) seg_reduce2_tab(dp, w.oh_w, i + 32 * mt, h, Wf[mt], Ws[mt]);   // by source window
+
+            // dwe[ch][gcol] += sum_slot dpre[slot][ch] * e[slot][gcol]   (B = e-tile columns via the LDS transpose read)
+#pragma unroll
+            for (int nt = 0; nt < GNT; ++nt) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    typedef __attribute__((ext_vector_type(4))) short s16x4;
+                    typedef __attribute__((address_space(3))) s16x4* lds4_t;
+                    const int t = i & 15;
+                    const bf16_t* base = w.et + (16 * ks + 4 * h + (t >> 2)) * dm.EKS + nt * 32 + (i & 16) + 4 * (t & 3);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(base));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(base + 8 * dm.EKS));
+                    const bf16x8 b = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    dwe_acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp.f[ks], b, dwe_acc[0][nt], 0, 0, 0);
+                    dwe_acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp.s[ks], b, dwe_acc[1][nt], 0, 0, 0);
+                }
+            }
+            cur = nxt;
+            nxt = nn;
+            ab = abn;
+        }
+
+        const int n0_dyn = dyn ? 32 * __builtin_amdgcn_readfirstlane(gpend) : 0;
+        wave_lds_fence();
+        {
+            const unsigned long long tmv = *w.touched;
+            const unsigned long long tm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(tmv >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tmv);
+            const unsigned long long tmh = tm >> (4 * h);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sl = 32 * mt + d_row(r, h);
+                    if ((tmh >> (32 * mt + d_row(r, 0))) & 1ull) {
+                        float* dst = p.r_src + (int64_t)(wb + sl) * C2 + ch;
+                        unsafeAtomicAdd(dst, Wf[mt][r]);
+                        unsafeAtomicAdd(dst + CP_, Ws[mt][r]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dbf_acc += Rf[r]; dbs_acc += Rs[r]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + d_row(r, h);
+            if (n < n1) {
+                T* dst = static_cast<T*>(p.r_tgt) + (int64_t)n * C2 + ch;
+                Elem<T>::st(dst, Rf[r]);
+                Elem<T>::st(dst + CP_, Rs[r]);
+            }
+        }
+        n0 = dyn ? n0_dyn : n1;
+    }
+
+    if (p.db) {
+        dbf_acc += __shfl_xor(dbf_acc, 32);
+        dbs_acc += __shfl_xor(dbs_acc, 32);
+        if (h == 0) {
+            unsafeAtomicAdd(p.db + ch, dbf_acc);
+            unsafeAtomicAdd(p.db + CP_ + ch, dbs_acc);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < GNT; ++nt) {
+        const int gcol = nt * 32 + i;
+        if (gcol < G_) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = s * 32 + d_row(r, h);
+                unsafeAtomicAdd(p.dwe + (int64_t)c * p.GP + gcol, dwe_acc[0][nt][r]);
+                unsafeAtomicAdd(p.dwe + (int64_t)(CP_ + c) * p.GP + gcol, dwe_acc[1][nt][r]);
+            }
+        }
+    }
+}
+
 #include "cgconv_cb.inc"   // namespace mdl::cb
 
 // ------------------------------------------------------------------------------------------
@@ -1425,6 +1727,7 @@ struct CgEnv {
     int64_t grid_cap;     // MDL_GRID_CAP: upper bound on the grid (0 = none)
     int cb_fwd, cb_bwd;   // MDL_CG_CB / MDL_CG_CB_BWD: cooperative column-block kernels (-1 = compile-time default)
     int cb_wgs;           // MDL_CB_WGS: their workgroups per CU (0 = default)
+    int ab_wgs;           // MDL_AB_WGS: workgroups per CU of the saved-gate backward (0 = default 1)
 };
 static const CgEnv& cg_env() {
     static const CgEnv e = [] {
@@ -1434,6 +1737,7 @@ static const CgEnv& cg_env() {
         v.cb_fwd = (s = getenv("MDL_CG_CB")) ? (atoi(s) != 0) : -1;
         v.cb_bwd = (s = getenv("MDL_CG_CB_BWD")) ? (atoi(s) != 0) : -1;
         v.cb_wgs = (s = getenv("MDL_CB_WGS")) ? atoi(s) : 0;
+        v.ab_wgs = (s = getenv("MDL_AB_WGS")) ? atoi(s) : 0;
         return v;
     }();
     return e;
@@ -1490,6 +1794,26 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
             if (hipMemsetAsync(p.ctr, 0, 64, st) != hipSuccess) { set_error("%s: workspace memset failed", name); return MDL_E_LAUNCH; }
         } else {
             p.ctr = nullptr;
+        }
+    }
+
+    // training forward that also stores the gate factors for cgconv_bwd_ab_kernel (static bf16 shapes only)
+    if constexpr (sizeof(T) == 2) {
+        if (!bwd && p.ab) {
+            if (!(fast && all_slices && p.bias_col)) {
+                set_error("%s: the saved-gate forward supports bf16, C in {32, 64}, G = 50, target-sorted edge features", name);
+                return MDL_E_UNSUPP;
+            }
+            if (d.Cp == 64) {
+                auto kf = cgconv_fwd_kernel<T, 64, 50, 9, 2, 1, true>;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
+            } else {
+                auto kf = cgconv_fwd_kernel<T, 32, 50, 9, 2, 1, true>;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
+            }
+            return check_launch(name);
         }
     }
 
@@ -1559,6 +1883,45 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     return check_launch(name);
 }
 
+// saved-gate backward (cgconv_bwd_ab_kernel): bf16, C in {32, 64}, G = 50, target-sorted edge features
+static int cg_launch_bwd_ab(CgParams& p, hipStream_t st, const char* name) {
+    const CgDims d = cg_dims(p.C, p.G, MDL_BF16);
+    p.Cp = d.Cp; p.KE = d.KE; p.KT = d.KT; p.WS = d.WS; p.EKS = d.EKS; p.NS = d.NS; p.GP = d.GP;
+    p.w_elems = 0;
+    p.bias_col = 1;
+    p.n_groups = (int)cdiv(p.N, 32);
+    if (p.n_groups == 0) return MDL_OK;
+    p.GW = p.G / 2;
+    p.gw_inv = (unsigned)((0x100000000ull + p.GW - 1) / p.GW);
+    const int et_bytes = (32 * d.EKS * 2 + 15) & ~15;
+    p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16 + 128 * OHS * 2;
+    const int waves = 4;
+    const int lds = waves * p.wave_lds_bytes;
+    const int64_t ranges = std::max<int64_t>(1, std::min<int64_t>(cdiv(p.E, 64), p.N));
+    int64_t grid = cdiv(ranges * d.NS, waves);
+    const CgEnv& env = cg_env();
+    const int64_t cap = 256 * (env.ab_wgs > 0 ? env.ab_wgs : 1);
+    if (grid > cap) grid = cap;
+    while ((grid * waves) % d.NS) ++grid;
+    if (p.ctr) {
+        if ((int64_t)p.n_groups * d.NS >= 4 * grid * waves) {
+            if (hipMemsetAsync(p.ctr, 0, 64, st) != hipSuccess) { set_error("%s: workspace memset failed", name); return MDL_E_LAUNCH; }
+        } else {
+            p.ctr = nullptr;
+        }
+    }
+    if (d.Cp == 64) {
+        auto kf = cgconv_bwd_ab_kernel<64, 50>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
+    } else {
+        auto kf = cgconv_bwd_ab_kernel<32, 50>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
+    }
+    return check_launch(name);
+}
+
 static int cg_check(const char* name, const void* x, const void* ea, const int32_t* rowptr, const int32_t* src,
                     const int32_t* tgt, const void* wpack, const float* bpack, int64_t N, int64_t E, int C, int G,
                     int aggr, int dtype) {
@@ -1622,6 +1985,49 @@ extern "C" int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_
 }
 
 extern "C" size_t mdl_cgconv_workspace_bytes(int64_t, int64_t, int, int, int) { return 64; }
+
+extern "C" size_t mdl_cgconv_gate_row_bytes(int C, int G, int dtype) {
+    return (dtype == MDL_BF16 && G == 50 && (C == 32 || C == 64)) ? (size_t)4 * C : 0;
+}
+
+extern "C" int mdl_cgconv_fwd_save(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
+                                   const int32_t* tgt, const void* wpack, const float* bpack, void* out, void* gate,
+                                   int64_t N, int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    int rc = cg_check("mdl_cgconv_fwd_save", x, edge_attr, rowptr, src, tgt, wpack, bpack, N, E, C, G, aggr, dtype);
+    if (rc) return rc;
+    MDL_REQUIRE(mdl_cgconv_gate_row_bytes(C, G, dtype) != 0, MDL_E_UNSUPP,
+                "mdl_cgconv_fwd_save: unsupported C=%d G=%d dtype=%d (bf16, C in {32, 64}, G = 50)", C, G, dtype);
+    MDL_REQUIRE(N == 0 || out, MDL_E_ARG, "mdl_cgconv_fwd_save: null out");
+    MDL_REQUIRE(E == 0 || (gate && reinterpret_cast<uintptr_t>(gate) % 4 == 0), MDL_E_ARG, "mdl_cgconv_fwd_save: bad gate buffer");
+    MDL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(edge_attr) % 4 == 0, MDL_E_ARG,
+                "mdl_cgconv_fwd_save: x must be 16-byte and edge_attr 4-byte aligned");
+    CgParams p = {};
+    p.x = x; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = nullptr;
+    p.wpack = wpack; p.bpack = bpack; p.out = out; p.ab = E ? gate : nullptr; p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr;
+    return cg_launch<bf16_t>(false, p, dtype, (hipStream_t)stream, "mdl_cgconv_fwd_save");
+}
+
+extern "C" int mdl_cgconv_bwd_saved(const void* edge_attr, const int32_t* rowptr, const int32_t* src, const int32_t* tgt,
+                                    const void* gate, const void* grad_out, void* r_tgt, float* r_src, float* dwe, float* db,
+                                    int64_t N, int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
+                                    mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(mdl_cgconv_gate_row_bytes(C, G, dtype) != 0, MDL_E_UNSUPP,
+                "mdl_cgconv_bwd_saved: unsupported C=%d G=%d dtype=%d (bf16, C in {32, 64}, G = 50)", C, G, dtype);
+    MDL_REQUIRE(N >= 0 && E >= 0 && N < (1ll << 31) - 64 && E < (1ll << 31) - 64, MDL_E_ARG, "mdl_cgconv_bwd_saved: bad N=%lld E=%lld",
+                (long long)N, (long long)E);
+    MDL_REQUIRE(aggr == MDL_MEAN || aggr == MDL_SUM, MDL_E_UNSUPP, "mdl_cgconv_bwd_saved: unsupported aggr %d", aggr);
+    MDL_REQUIRE(N == 0 || (rowptr && grad_out && r_tgt && r_src && dwe), MDL_E_ARG, "mdl_cgconv_bwd_saved: null pointer");
+    MDL_REQUIRE(E == 0 || (edge_attr && src && tgt && gate), MDL_E_ARG, "mdl_cgconv_bwd_saved: null edge pointer");
+    MDL_REQUIRE(reinterpret_cast<uintptr_t>(gate) % 4 == 0 && reinterpret_cast<uintptr_t>(edge_attr) % 4 == 0, MDL_E_ARG,
+                "mdl_cgconv_bwd_saved: gate / edge_attr must be 4-byte aligned");
+    CgParams p = {};
+    p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.ab = const_cast<void*>(gate); p.gout = grad_out;
+    p.r_tgt = r_tgt; p.r_src = r_src; p.dwe = dwe; p.db = db; p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr;
+    p.ctr = (workspace && ws_bytes >= 64) ? static_cast<unsigned*>(workspace) : nullptr;
+    return cg_launch_bwd_ab(p, (hipStream_t)stream, "mdl_cgconv_bwd_saved");
+}
 
 extern "C" int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
                               const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,

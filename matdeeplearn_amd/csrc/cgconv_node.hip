@@ -78,8 +78,9 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
     constexpr int TROWS = 256 / TCH, SROWS = 256 / SCH, XROWS = 256 / XCH;     // rows covered by one load of the workgroup
     const int trow0 = tid / TCH, tcc = tid % TCH, srow0 = tid / SCH, scc = tid % SCH, xrow0 = tid / XCH, xcc = tid % XCH;
     // Buffer loads: the tile base is uniform (a fresh resource per tile, so any N works), each thread keeps ONE 32-bit
-    // byte offset per array, the per-l row strides go into the scalar offset, and rows past N read as zeros (range
-    // check against the bytes that remain) — no clamps, no separate last-tile path.
+    // byte offset per array plus a constant per-l row stride in the same VOFFSET expression (the range check covers
+    // voffset + immediate, NOT an SGPR soffset), and rows past N read as zeros / are dropped on stores (range check
+    // against the bytes that remain) — no clamps, no separate last-tile path.
     const int to = (trow0 * (2 * CP) + 8 * tcc) * 2, so = (srow0 * (2 * CP) + 4 * scc) * 4, xo = (xrow0 * CP + 8 * xcc) * 2;
     auto rsrc = [](const void* base, int64_t bytes) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7fffffffLL ? bytes : 0x7fffffffLL), 0x00020000);
@@ -90,12 +91,12 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
         const __amdgpu_buffer_rsrc_t sr = rsrc(r_src + nb * (2 * CP), rem * (2 * CP * 4));
         const __amdgpu_buffer_rsrc_t xr = rsrc(x + nb * CP, rem * (CP * 2));
 #pragma unroll
-        for (int l = 0; l < NTL; ++l) treg[l] = __builtin_amdgcn_raw_buffer_load_b128(tr, to, l * (TROWS * 2 * CP * 2), 0);
+        for (int l = 0; l < NTL; ++l) treg[l] = __builtin_amdgcn_raw_buffer_load_b128(tr, to + l * (TROWS * 2 * CP * 2), 0, 0);
 #pragma unroll
         for (int l = 0; l < NSL; ++l)
-            sreg[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sr, so, l * (SROWS * 2 * CP * 4), 0));
+            sreg[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sr, so + l * (SROWS * 2 * CP * 4), 0, 0));
 #pragma unroll
-        for (int l = 0; l < NXL; ++l) xreg[l] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo, l * (XROWS * CP * 2), 0);
+        for (int l = 0; l < NXL; ++l) xreg[l] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo + l * (XROWS * CP * 2), 0, 0);
     };
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) load_tile(tile);
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
             short gv[16];
             const __amdgpu_buffer_rsrc_t gr = rsrc(gout + (nb + mt0 * 32) * CP, (remg > 0 ? remg : 0) * (CP * 2));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gv[r] = __builtin_amdgcn_raw_buffer_load_b16(gr, go, ((r & 3) + 8 * (r >> 2)) * CP * 2, 0);
+            for (int r = 0; r < 16; ++r) gv[r] = __builtin_amdgcn_raw_buffer_load_b16(gr, go + ((r & 3) + 8 * (r >> 2)) * CP * 2, 0, 0);
             if (more) load_tile(tile + gridDim.x);
             f32x16 acc;
 #pragma unroll
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
             const __amdgpu_buffer_rsrc_t dr = rsrc(dx + (nb + mt0 * 32) * CP, (remg > 0 ? remg : 0) * (CP * 2));
 #pragma unroll
             for (int r = 0; r < 16; ++r)                                 // rows past N fall outside the resource: dropped
-                __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(bf2f((bf16_t)gv[r]) + acc[r]), dr, go, ((r & 3) + 8 * (r >> 2)) * CP * 2, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(bf2f((bf16_t)gv[r]) + acc[r]), dr, go + ((r & 3) + 8 * (r >> 2)) * CP * 2, 0, 0);
         }
         // ---- dWn blocks of this wave: rows = 32 columns of R, cols = 32 features, K = the tile's 64 nodes
 #pragma unroll

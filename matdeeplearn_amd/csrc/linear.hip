@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<bf16_t*>(x + off), 0, (int)(rem < 0x7fffffffLL ? rem : 0x7fffffffLL), 0x00020000);
 #pragma unroll
-        for (int l = 0; l < NLX; ++l) xr[l] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, l * 4096, 0);
+        for (int l = 0; l < NLX; ++l) xr[l] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16 + l * 4096, 0, 0);
     };
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) load_tile(tile);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[r];
                         if (act == 1) v = v > 0.0f ? v : 0.0f;
-                        __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(v), os, vo, ((r & 3) + 8 * (r >> 2)) * M * 2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(v), os, vo + ((r & 3) + 8 * (r >> 2)) * M * 2, 0, 0);
                     }
                 }
             }

@@ -115,29 +115,29 @@ template <> struct Gate<false> {
 template <> struct Gate<true> {
     static constexpr float W_SCALE = LOG2E_F;
     static constexpr float M_SCALE = LN2_F;
-    // max(t, c) as ONE instruction: fmaxf() costs an extra canonicalising v_max (IEEE mode quiets signalling NaNs
-    // first), which these kernels do not need.  Plain VALU ops on compiler-managed registers: no hazards to mind.
-    __device__ static __forceinline__ float relu(float t) {
-        float r;
-        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(t));
-        return r;
-    }
-    // 2^-max(f, -126): the clamp keeps (1 + 2^-f)(1 + 2^-|s|) finite
+    // NO inline asm in the gate: the compiler's hazard recogniser does not look inside asm statements, and both kinds of
+    // producer here need wait states before a VALU consumer — MFMA results (the arguments of these functions) and the
+    // results of the transcendental unit (v_exp / v_log / v_rcp).  An asm `v_max` right behind the MFMA chain read the
+    // accumulator before the matrix core had written it back; an asm `v_min` behind a `v_exp` read lanes the
+    // transcendental pipe had not finished.  fmaxf / fminf cost two instructions each (IEEE mode canonicalises first), so:
+    //   max(t, 0) + c   =  0.5 * (t + |t|) + c     one add (|t| is a source modifier) + one fma, both exact
+    //   2^-max(f, -126) =  min(2^-f, 2^126)        as an INTEGER min on the bit pattern (2^-f >= 0: same order), one op
+    __device__ static __forceinline__ float relu_plus(float t, float c) { return fmaf(0.5f, t + fabsf(t), c); }
+    // min(2^-f, 2^126): keeps (1 + 2^-f)(1 + 2^-|s|) finite
     __device__ static __forceinline__ float exp2_neg_capped(float f) {
-        float r;
-        asm("v_max_f32 %0, 0xc2fc0000, %1" : "=v"(r) : "v"(f));
-        return __builtin_amdgcn_exp2f(-r);
+        const unsigned e = __float_as_uint(__builtin_amdgcn_exp2f(-f));
+        return __uint_as_float(e < 0x7e800000u ? e : 0x7e800000u);
     }
     __device__ static __forceinline__ float sigmoid(float t) {
         return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
     }
     __device__ static __forceinline__ float softplus_u(float t) {
-        return relu(t) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(t)));
+        return relu_plus(t, __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(t))));
     }
     __device__ static __forceinline__ void softplus_sigmoid(float t, float& sp_u, float& sg) {
         const float ea = __builtin_amdgcn_exp2f(-fabsf(t));
         const float l = 1.0f + ea;
-        sp_u = relu(t) + __builtin_amdgcn_logf(l);
+        sp_u = relu_plus(t, __builtin_amdgcn_logf(l));
         const float r = __builtin_amdgcn_rcpf(l);
         sg = t >= 0.0f ? r : ea * r;
     }
@@ -150,7 +150,7 @@ template <> struct Gate<true> {
         const float r = __builtin_amdgcn_rcpf(a1 * l);
         sf = r * l;
         const float rl = r * a1;
-        sp_u = relu(sv) + __builtin_amdgcn_logf(l);
+        sp_u = relu_plus(sv, __builtin_amdgcn_logf(l));
         ss = sv >= 0.0f ? rl : ea * rl;
     }
 };

@@ -371,6 +371,9 @@ def _workspace(device, nbytes):
     return t
 
 
+_SAVE_GATE = os.environ.get("MDL_CG_SAVE_GATE", "1") != "0"
+
+
 class _CGConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, edge_attr, w_f, b_f, w_s, b_s, csr, aggr):
@@ -399,9 +402,20 @@ class _CGConvFn(torch.autograd.Function):
                                         stream()), "mdl_cgconv_pack_weights")
         out = torch.empty_like(x)
         edge_attr = csr.sorted_attr(edge_attr)          # CSR order: the kernels never go through eperm
-        check(_launch_timed("fwd", lambda: L.mdl_cgconv_fwd(
-            ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
-            ptr(bpack), ptr(out), N, E, C, G, aggr, dt, stream())), "mdl_cgconv_fwd")
+        # training forward on the static bf16 shapes: also store the gate factors (4C bytes per edge) so that the
+        # backward edge pass needs no recompute (MDL_CG_SAVE_GATE=0 keeps the recomputing backward)
+        row_bytes = L.mdl_cgconv_gate_row_bytes(C, G, dt) if (_SAVE_GATE and any(ctx.needs_input_grad)) else 0
+        gate = None
+        if row_bytes and E > 0 and x.data_ptr() % 16 == 0 and edge_attr.data_ptr() % 4 == 0:
+            gate = torch.empty((E, row_bytes // 2), dtype=torch.bfloat16, device=x.device)
+            check(_launch_timed("fwd", lambda: L.mdl_cgconv_fwd_save(
+                ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(bpack), ptr(out),
+                ptr(gate), N, E, C, G, aggr, dt, stream())), "mdl_cgconv_fwd_save")
+        else:
+            check(_launch_timed("fwd", lambda: L.mdl_cgconv_fwd(
+                ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
+                ptr(bpack), ptr(out), N, E, C, G, aggr, dt, stream())), "mdl_cgconv_fwd")
+        ctx.gate = gate
         ctx.save_for_backward(x, edge_attr, wf32, ws32, wpack, bpack)
         ctx.csr, ctx.aggr, ctx.has_bias = csr, aggr, (b_f is not None, b_s is not None)
         ctx.wdtypes = (w_f.dtype, w_s.dtype)
@@ -423,10 +437,17 @@ class _CGConvFn(torch.autograd.Function):
         db = small[2 * Cp * GP:2 * Cp * GP + 2 * Cp]
         dwn = small[2 * Cp * GP + 2 * Cp:].view(4 * Cp, C)
         ws = _workspace(x.device, lib().mdl_cgconv_workspace_bytes(N, E, C, G, dt))
-        check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd(
-            ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
-            ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt,
-            ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd")
+        gate, ctx.gate = ctx.gate, None
+        if gate is not None:
+            check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_saved(
+                ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(gate), ptr(g), ptr(r_tgt), ptr(r_src),
+                ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd_saved")
+            del gate
+        else:
+            check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd(
+                ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
+                ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt,
+                ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd")
         # node-level dense part: rows of Wn / dWn = (f_tgt, s_tgt, f_src, s_src)
         if dt == _lib.MDL_BF16 and C == Cp and C in (32, 64):
             wn_t = torch.empty((C, 4 * Cp), dtype=torch.bfloat16, device=x.device)                 # Wn^T

@@ -213,6 +213,127 @@ def test_cgconv_c_abi_eperm_and_workspace_paths():
     close(rs0, rs1, 1e-2, 1e-2)
 
 
+def test_cgconv_recomputing_backward_still_matches_oracle(monkeypatch):
+    """bf16 static shapes train through the saved-gate pair by default; the recomputing backward (MDL_CG_SAVE_GATE=0, and
+    every other shape / dtype) must stay correct too."""
+    from matdeeplearn_amd import ops
+    monkeypatch.setattr(ops, "_SAVE_GATE", False)
+    _cgconv_case(200, 64, 50, torch.bfloat16, True, seed=9)
+    _cgconv_case(77, 32, 50, torch.bfloat16, False, seed=10)
+
+
+@pytest.mark.parametrize("C", [64, 32])
+def test_cgconv_saved_gate_pair_matches_recompute_through_the_c_abi(C):
+    """mdl_cgconv_fwd_save + mdl_cgconv_bwd_saved against mdl_cgconv_fwd + mdl_cgconv_bwd on the same operands: same
+    output (bit-identical messages are not required: the gate is evaluated with a shared reciprocal), r_tgt / r_src /
+    dwe / db within bf16 rounding of the stored factors; graphs wider than the source window and a ragged tail included."""
+    from matdeeplearn_amd import _lib, ops
+    d = dev()
+    L, P, st = _lib.lib(), _lib.ptr, _lib.stream
+    G, dt = 50, _lib.MDL_BF16
+    g = torch.Generator().manual_seed(17)
+    n = 9001
+    tgt = torch.arange(n).repeat_interleave(9)
+    src = (tgt + torch.randint(-90, 91, (tgt.numel(),), generator=g)).clamp_(0, n - 1)       # ~1/3 outside a 64-node window
+    E = tgt.numel()
+    csr = ops.build_csr(torch.stack([src, tgt]).to(d), n, assume_sorted=True)
+    x = torch.randn(n, C, generator=g).to(d).to(torch.bfloat16)
+    ea = torch.rand(E, G, generator=g).to(d).to(torch.bfloat16)
+    gout = torch.randn(n, C, generator=g).to(d).to(torch.bfloat16)
+    k = 3.0 / (2 * C + G) ** 0.5
+    wf, ws = (torch.randn(C, 2 * C + G, generator=g) * k).to(d), (torch.randn(C, 2 * C + G, generator=g) * k).to(d)
+    bf, bs = (torch.randn(C, generator=g) * 0.1).to(d), (torch.randn(C, generator=g) * 0.1).to(d)
+    wpack = torch.empty(L.mdl_cgconv_wpack_bytes(C, G, dt), dtype=torch.uint8, device=d)
+    bpack = torch.empty(2 * C, dtype=torch.float32, device=d)
+    _lib.check(L.mdl_cgconv_pack_weights(P(wf), P(bf), P(ws), P(bs), C, G, P(wpack), P(bpack), dt, st()), "pack")
+    rb = L.mdl_cgconv_gate_row_bytes(C, G, dt)
+    assert rb == 4 * C and L.mdl_cgconv_gate_row_bytes(100, G, dt) == 0 and L.mdl_cgconv_gate_row_bytes(C, G, _lib.MDL_F32) == 0
+    o1, o2 = torch.empty_like(x), torch.empty_like(x)
+    gate = torch.full((E, rb // 2), float("nan"), dtype=torch.bfloat16, device=d)
+    _lib.check(L.mdl_cgconv_fwd(P(x), P(ea), P(csr.rowptr), P(csr.src), P(csr.tgt), None, P(wpack), P(bpack), P(o1),
+                                n, E, C, G, 1, dt, st()), "fwd")
+    _lib.check(L.mdl_cgconv_fwd_save(P(x), P(ea), P(csr.rowptr), P(csr.src), P(csr.tgt), P(wpack), P(bpack), P(o2), P(gate),
+                                     n, E, C, G, 1, dt, st()), "fwd_save")
+    close(o2, o1, 1e-2, 1e-2)
+    assert torch.isfinite(gate.float()).all()                        # every (edge, channel) pair was written exactly once
+    res = []
+    for saved in (False, True):
+        r_tgt = torch.empty(n, 2 * C, device=d, dtype=torch.bfloat16)
+        r_src = torch.zeros(n, 2 * C, device=d)
+        dwe = torch.zeros(2 * C, 64, device=d)
+        db = torch.zeros(2 * C, device=d)
+        if saved:
+            _lib.check(L.mdl_cgconv_bwd_saved(P(ea), P(csr.rowptr), P(csr.src), P(csr.tgt), P(gate), P(gout), P(r_tgt), P(r_src),
+                                              P(dwe), P(db), n, E, C, G, 1, dt, None, 0, st()), "bwd_saved")
+        else:
+            _lib.check(L.mdl_cgconv_bwd(P(x), P(ea), P(csr.rowptr), P(csr.src), P(csr.tgt), None, P(wpack), P(bpack), P(gout),
+                                        P(r_tgt), P(r_src), P(dwe), P(db), n, E, C, G, 1, dt, None, 0, st()), "bwd")
+        res.append((r_tgt, r_src, dwe, db))
+    for a, b, what in zip(res[1], res[0], ("r_tgt", "r_src", "dwe", "db")):
+        close(a, b, 2e-2, 1e-2)
+
+
+def test_buffer_stores_past_the_last_row_are_dropped():
+    """Kernels that end a row range with range-checked buffer stores (dense-layer forward, node-level backward, the gate
+    factors of the training forward) must not touch memory behind their outputs when the row count is not a multiple of
+    the tile: outputs are carved out of a sentinel-filled arena and the bytes behind them are checked."""
+    from matdeeplearn_amd import _lib, ops
+    d = dev()
+    L, P, st = _lib.lib(), _lib.ptr, _lib.stream
+    g = torch.Generator().manual_seed(23)
+    SENT = -17.5
+
+    def carve(rows, cols, dtype=torch.bfloat16, slack=64):
+        arena = torch.full(((rows + slack) * cols,), SENT, dtype=dtype, device=d)
+        return arena, arena[:rows * cols].view(rows, cols)
+
+    def guard_ok(arena, rows, cols):
+        return bool((arena[rows * cols:].float() == SENT).all())
+
+    # dense layer forward: N = 1000 rows (tile 64), K = 114, M = 64
+    N, K, M = 1000, 114, 64
+    x = torch.randn(N, K, generator=g).to(d).to(torch.bfloat16)
+    w = (torch.randn(M, K, generator=g) * 0.1).to(d).to(torch.bfloat16)
+    b = torch.randn(M, generator=g).to(d).to(torch.bfloat16)
+    arena, out = carve(N, M)
+    _lib.check(L.mdl_linear_act(P(x), P(w), P(b), P(out), N, K, M, 1, _lib.MDL_BF16, st()), "linear_act")
+    torch.cuda.synchronize()
+    assert guard_ok(arena, N, M)
+    close(out, torch.relu(x.float() @ w.float().t() + b.float()), 2e-2, 2e-2)
+
+    # conv: training forward (gate rows) and node-level backward (dx rows) on a graph whose sizes are odd
+    n, C, G = 1003, 64, 50
+    tgt = torch.arange(n).repeat_interleave(7)
+    src = (tgt + torch.randint(-9, 10, (tgt.numel(),), generator=g)).clamp_(0, n - 1)
+    E = tgt.numel()
+    csr = ops.build_csr(torch.stack([src, tgt]).to(d), n, assume_sorted=True)
+    xx = torch.randn(n, C, generator=g).to(d).to(torch.bfloat16)
+    ea = torch.rand(E, G, generator=g).to(d).to(torch.bfloat16)
+    wf, ws = (torch.randn(C, 2 * C + G, generator=g) * 0.1).to(d), (torch.randn(C, 2 * C + G, generator=g) * 0.1).to(d)
+    dt = _lib.MDL_BF16
+    wpack = torch.empty(L.mdl_cgconv_wpack_bytes(C, G, dt), dtype=torch.uint8, device=d)
+    bpack = torch.empty(2 * C, dtype=torch.float32, device=d)
+    _lib.check(L.mdl_cgconv_pack_weights(P(wf), None, P(ws), None, C, G, P(wpack), P(bpack), dt, st()), "pack")
+    ga, gate = carve(E, 2 * C)
+    oa, o = carve(n, C)
+    _lib.check(L.mdl_cgconv_fwd_save(P(xx), P(ea), P(csr.rowptr), P(csr.src), P(csr.tgt), P(wpack), P(bpack), P(o), P(gate),
+                                     n, E, C, G, 1, dt, st()), "fwd_save")
+    torch.cuda.synchronize()
+    assert guard_ok(ga, E, 2 * C) and guard_ok(oa, n, C)
+    r_tgt = torch.randn(n, 2 * C, generator=g).to(d).to(torch.bfloat16)
+    r_src = torch.randn(n, 2 * C, generator=g).to(d)
+    gout = torch.randn(n, C, generator=g).to(d).to(torch.bfloat16)
+    wn_t = torch.empty(C, 4 * C, dtype=torch.bfloat16, device=d)
+    _lib.check(L.mdl_cgconv_pack_node_weights(P(wf), P(ws), C, G, P(wn_t), dt, st()), "pack_node")
+    da, dx = carve(n, C)
+    dwn = torch.zeros(4 * C, C, device=d)
+    _lib.check(L.mdl_cgconv_bwd_node(P(xx), P(gout), P(r_tgt), P(r_src), P(wn_t), P(dx), P(dwn), n, C, dt, st()), "bwd_node")
+    torch.cuda.synchronize()
+    assert guard_ok(da, n, C)
+    R = torch.cat([r_tgt.float(), r_src.to(torch.bfloat16).float()], dim=1)
+    close(dx, gout.float() + R @ wn_t.float().t(), 3e-2, 3e-2)
+
+
 def test_cgconv_rejects_cpu_tensors_and_bad_shapes():
     from matdeeplearn_amd import ops
     x = torch.randn(4, 64)

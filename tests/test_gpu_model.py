@@ -199,6 +199,8 @@ def test_product_matches_reference_wrapper_goldens(case):
     scale = float(ref.abs().max()) + 1e-6
     assert torch.allclose(pred.cpu(), ref, rtol=1e-4, atol=1e-4 * scale), (pred.cpu() - ref).abs().max()
     torch.nn.functional.l1_loss(pred, y).backward()
+    gmax = max(float(np.abs(z["%s/grad/%s" % (case, k)]).max()) for k, _ in model.named_parameters()
+               if z["%s/grad/%s" % (case, k)].size)
     for k, p in model.named_parameters():
         g = z["%s/grad/%s" % (case, k)]
         if g.size == 0:
@@ -206,9 +208,10 @@ def test_product_matches_reference_wrapper_goldens(case):
             continue
         g = torch.from_numpy(g)
         s = float(g.abs().max()) + 1e-9
-        # three graphs of ten near-identical atoms: BatchNorm is ill-conditioned, so the bound is loose (1e-2 of the
-        # tensor scale); the tight gradient checks are the kernel-level ones in test_gpu_kernels.py
-        assert float((p.grad.cpu() - g).abs().max()) <= 1e-2 * s + 1e-6, (k, float((p.grad.cpu() - g).abs().max()), s)
+        # 1e-2 of the tensor's own scale plus 1e-4 of the model's largest gradient (a bias in front of BatchNorm has a
+        # mathematically zero gradient: both sides hold rounding noise); the tight gradient checks are the kernel-level
+        # ones in test_gpu_kernels.py
+        assert float((p.grad.cpu() - g).abs().max()) <= 1e-2 * s + 1e-4 * gmax, (k, float((p.grad.cpu() - g).abs().max()), s, gmax)
     for k, v in model.state_dict().items():
         if "running_" in k or "num_batches" in k:
             r = torch.from_numpy(z["%s/post/%s" % (case, k)]).float()

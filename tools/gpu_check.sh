@@ -6,7 +6,7 @@ TAG=${1:-run}; shift || true
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-( timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -x 2>&1 | grep -vE "^\s*$" | tail -60 ) > $OUT/pytest.log
+( timeout 1500 python -m pytest tests -m gpu -q --timeout 600 --maxfail=8 2>&1 | grep -vE "^\s*$" | tail -60 ) > $OUT/pytest.log
 grep -E "passed|failed" $OUT/pytest.log | tail -3
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ) > $OUT/smoke.log; tail -2 $OUT/smoke.log
 ( timeout 900 python bench.py "$@" 2>&1 | tail -30 ) > $OUT/bench.log; tail -5 $OUT/bench.log
