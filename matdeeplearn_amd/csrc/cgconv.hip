@@ -765,6 +765,21 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
             }
             nxt = cur;
             bool nextHasEdges = false;                        // evaluated at the last tile (GN arrives by then)
+            // saved-gate forward: the packed factors of a tile's LAST slice wait in registers and are stored during the
+            // next tile (see below); abq_eb < 0 = nothing pending
+            constexpr int ROWB = 4 * CP_;
+            unsigned abq[16];
+            int abq_eb = -1, abq_nv = 0;
+            auto ab_store = [&](const unsigned (&v)[16], int eb_, int nv_, int sl_) {
+                // rows past the group's end are dropped by the range check of the store resource (they belong to the
+                // next group's owner); row offsets = two per-lane bases + an immediate < 4096, all inside the range check
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    static_cast<char*>(p.ab) + (int64_t)eb_ * ROWB, 0, nv_ * ROWB, 0x00020000);
+                const int vo0 = 4 * h * ROWB + sl_ * 128 + i * 4, vo1 = vo0 + 16 * ROWB;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(v[r], rs, (r < 8 ? vo0 : vo1) + ((r & 3) + 8 * ((r >> 2) & 1)) * ROWB, 0, 0);
+            };
             TRESET();
             for (int eb = G.e0; eb < G.e1; eb += 32) {
                 const int nv = min(32, G.e1 - eb);
@@ -792,12 +807,6 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                 unsigned t4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) t4[j] = w.tsl[2 * j + h];
-                // training forward: the gate factors of this tile's edges go to HBM (rows past the group's end are
-                // dropped by the range check of the store resource: they belong to the next group's owner)
-                constexpr int ROWB = 4 * CP_;
-                __amdgpu_buffer_rsrc_t abrs;
-                if constexpr (AB_)
-                    abrs = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(p.ab) + (int64_t)eb * ROWB, 0, nv * ROWB, 0x00020000);
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl) {
                     f32x16 accf, accs;
@@ -808,6 +817,15 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                     pre_tile<T, CP_, VEC, WM, NKW, MDL_FWD_PRE_DEPTH>(p, dm, w, lane, sl, cur.tgt, cur.src, xf, wr, accf, accs);
                     TPIN16(accf); TPIN16(accs);
                     TMARK(3 + 3 * sl);
+                    if constexpr (AB_) {
+                        // Stores poison the wait counters: loads and stores complete out of order with respect to each
+                        // other, so the next wait for ANY load (top of the next tile) also waits for every store in
+                        // flight.  A slice's factors stored right after its gate leave the last slice ~10 % of a tile
+                        // to complete before that wait (measured: +1500 cycles per tile in the first MFMA chain).  So the
+                        // last slice's dwords stay in registers and go out HERE, behind the first slice's MFMA chain of
+                        // the NEXT tile: more than half a tile ahead of the next wait.
+                        if (sl == 0 && abq_eb >= 0) { ab_store(abq, abq_eb, abq_nv, NSL - 1); abq_eb = -1; }
+                    }
 #if MDL_FWD_XEARLY
                     // the x rows of the NEXT tile: requested as soon as the last slice's MFMAs have consumed this
                     // tile's fragments (same registers), so their latency hides under the gate / aggregation
@@ -818,16 +836,22 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                         // m and, for the backward, A = dm/dpre_f = sigmoid'(f) softplus(s), B = dm/dpre_s = sigmoid(f) sigmoid(s)
                         // (same four transcendentals as the plain gate: the two reciprocals share one v_rcp), packed
                         // as one dword per (edge, channel): a row of a slice is 128 contiguous bytes
-                        // (row offsets: two per-lane bases + an immediate < 4096, all inside the range check)
-                        const int vo0 = 4 * h * ROWB + sl * 128 + i * 4, vo1 = vo0 + 16 * ROWB;
+                        unsigned abv[16];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             float sf, sp_u, ss;
                             GT::deriv(accf[r], accs[r], sf, sp_u, ss);
                             const float mm = sf * sp_u;
                             m[r] = mm;
-                            __builtin_amdgcn_raw_buffer_store_b32(pk_bf16((mm * GT::M_SCALE) * (1.0f - sf), sf * ss), abrs,
-                                                                  (r < 8 ? vo0 : vo1) + ((r & 3) + 8 * ((r >> 2) & 1)) * ROWB, 0, 0);
+                            abv[r] = pk_bf16((mm * GT::M_SCALE) * (1.0f - sf), sf * ss);
+                        }
+                        if (sl == NSL - 1) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) abq[r] = abv[r];
+                            abq_eb = eb;
+                            abq_nv = nv;
+                        } else {
+                            ab_store(abv, eb, nv, sl);
                         }
                     } else {
 #pragma unroll
@@ -845,6 +869,9 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
 #endif
                 cur = nxt;
                 TTILE();
+            }
+            if constexpr (AB_) {
+                if (abq_eb >= 0) ab_store(abq, abq_eb, abq_nv, NSL - 1);        // the group's last tile
             }
             // epilogue: out = x + acc / deg.  All residual rows are requested first (clamped row index, no
             // guards), so the group pays one memory round trip instead of one per row.

@@ -371,7 +371,11 @@ def _workspace(device, nbytes):
     return t
 
 
-_SAVE_GATE = os.environ.get("MDL_CG_SAVE_GATE", "1") != "0"
+# Saved-gate training pair (mdl_cgconv_fwd_save / mdl_cgconv_bwd_saved): opt-in.  Measured on the bench batch it moves
+# 110 us per layer from the backward (530 -> 420 us) into the forward (178 -> 300 us: the factor stores stall the
+# forward's load pipeline), i.e. no net gain, for 2.7 GB of saved activations per step — so the recomputing backward stays
+# the default.
+_SAVE_GATE = os.environ.get("MDL_CG_SAVE_GATE", "0") == "1"
 
 
 class _CGConvFn(torch.autograd.Function):
@@ -402,8 +406,8 @@ class _CGConvFn(torch.autograd.Function):
                                         stream()), "mdl_cgconv_pack_weights")
         out = torch.empty_like(x)
         edge_attr = csr.sorted_attr(edge_attr)          # CSR order: the kernels never go through eperm
-        # training forward on the static bf16 shapes: also store the gate factors (4C bytes per edge) so that the
-        # backward edge pass needs no recompute (MDL_CG_SAVE_GATE=0 keeps the recomputing backward)
+        # opt-in (MDL_CG_SAVE_GATE=1): training forward on the static bf16 shapes also stores the gate factors (4C bytes
+        # per edge) and the backward edge pass skips the recompute
         row_bytes = L.mdl_cgconv_gate_row_bytes(C, G, dt) if (_SAVE_GATE and any(ctx.needs_input_grad)) else 0
         gate = None
         if row_bytes and E > 0 and x.data_ptr() % 16 == 0 and edge_attr.data_ptr() % 4 == 0:

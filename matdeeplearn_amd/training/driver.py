@@ -86,7 +86,7 @@ def train_regular(rank, world_size, dataset, job, training, model_params, splits
     """One training job.  Returns dict(train_error, val_error, test_error, history, model)."""
     model_factory = model_factory or default_model_factory
     distributed, owned = _enter_dist(rank, world_size)
-    if dataset.device is not None and dataset.device.type == "cuda":
+    if dataset.device is not None and dataset.device.type == "cuda" and dataset.device.index is not None:
         torch.cuda.set_device(dataset.device)                                 # the HIP ops launch on the current device
     params = dict(model_params)
     lr = params.get("lr", 0.001) * (world_size if distributed else 1)        # training.py:388-389

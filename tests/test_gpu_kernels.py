@@ -213,13 +213,14 @@ def test_cgconv_c_abi_eperm_and_workspace_paths():
     close(rs0, rs1, 1e-2, 1e-2)
 
 
-def test_cgconv_recomputing_backward_still_matches_oracle(monkeypatch):
-    """bf16 static shapes train through the saved-gate pair by default; the recomputing backward (MDL_CG_SAVE_GATE=0, and
-    every other shape / dtype) must stay correct too."""
+def test_cgconv_saved_gate_training_pair_matches_oracle(monkeypatch):
+    """The opt-in saved-gate pair (MDL_CG_SAVE_GATE=1: training forward stores the gate factors, backward edge pass
+    without recompute) through the autograd op, against the oracle; the default is the recomputing backward."""
     from matdeeplearn_amd import ops
-    monkeypatch.setattr(ops, "_SAVE_GATE", False)
+    monkeypatch.setattr(ops, "_SAVE_GATE", True)
     _cgconv_case(200, 64, 50, torch.bfloat16, True, seed=9)
     _cgconv_case(77, 32, 50, torch.bfloat16, False, seed=10)
+    _cgconv_case(150, 64, 50, torch.bfloat16, True, seed=5, aggr="add", empty_frac=0.5)
 
 
 @pytest.mark.parametrize("C", [64, 32])
