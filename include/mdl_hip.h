@@ -164,6 +164,11 @@ int mdl_assemble_batch(const int64_t* ids, const int64_t* noff, const int64_t* e
                        void* x, int64_t* batch, int32_t* rowptr, int32_t* src, int32_t* tgt, float* ew, float* dn,
                        float* y, int B, int F, int T, int target_index, int dtype, mdlStream_t stream);
 
+/* Tail of a padded static batch (buffers sized for n_cap nodes, the batch fills the first N = noff[B], read on the device):
+ * padding nodes get rowptr = E (no edges) and batch = B (a dummy graph).  Part of the HIP-graph replay path. */
+int mdl_pad_batch_tail(const int64_t* noff, const int64_t* eoff, int B, int64_t n_cap, int32_t* rowptr, int64_t* batch,
+                       mdlStream_t stream);
+
 /* ---- training-mode BatchNorm1d over rows, x: [N, C] row-major ------------------------------------
  * Replaces torch.nn.BatchNorm1d as applied after every conv layer (matdeeplearn/models/cgcnn.py:85-87,143)
  * and inside the MEGNet MLPs (megnet.py:47-48).  `sums` is an fp32 scratch of mdl_bn_sums_rows() x C floats the
@@ -179,6 +184,17 @@ int mdl_assemble_batch(const int64_t* ids, const int64_t* noff, const int64_t* e
  *   bwd_apply:  dx = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)) */
 #define MDL_BN_REPLICAS 16
 int mdl_bn_sums_rows(void);
+/* The *_n variants take the number of rows that EXIST from device memory (n_rows_dev, may be NULL = all N): rows
+ * [*n_rows_dev, N) are padding of a static batch — excluded from the statistics, written as zeros by the apply passes.
+ * They exist for HIP-graph replays, where launch arguments are frozen at capture but the batch changes every step. */
+int mdl_bn_stats_n(const void* x, float* sums, int64_t N, int C, const int64_t* n_rows_dev, int dtype, mdlStream_t stream);
+int mdl_bn_apply_n(const void* x, float* sums, const float* gamma, const float* beta, float* save, float* running_mean,
+                   float* running_var, void* y, int64_t N, int C, float eps, float momentum, const int64_t* n_rows_dev,
+                   int dtype, mdlStream_t stream);
+int mdl_bn_bwd_stats_n(const void* dy, const void* x, const float* save, float* sums, int64_t N, int C,
+                       const int64_t* n_rows_dev, int dtype, mdlStream_t stream);
+int mdl_bn_bwd_apply_n(const void* dy, const void* x, const float* save, float* sums, const float* gamma, void* dx,
+                       int64_t N, int C, const int64_t* n_rows_dev, int dtype, mdlStream_t stream);
 int mdl_bn_stats(const void* x, float* sums, int64_t N, int C, int dtype, mdlStream_t stream);
 int mdl_bn_apply(const void* x, float* sums, const float* gamma, const float* beta, float* save,
                  float* running_mean, float* running_var, void* y, int64_t N, int C, float eps, float momentum,

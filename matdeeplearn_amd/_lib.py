@@ -34,7 +34,12 @@ PROTOTYPES = {
     "mdl_cgconv_pack_node_weights": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "mdl_cgconv_assemble_grads": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mdl_assemble_batch": (_i32, [_vp] * 20 + [_i32, _i32, _i32, _i32, _i32, _vp]),
+    "mdl_pad_batch_tail": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "mdl_bn_sums_rows": (_i32, []),
+    "mdl_bn_stats_n": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "mdl_bn_apply_n": (_i32, [_vp] * 8 + [_i64, _i32, _f32, _f32, _vp, _i32, _vp]),
+    "mdl_bn_bwd_stats_n": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "mdl_bn_bwd_apply_n": (_i32, [_vp] * 6 + [_i64, _i32, _vp, _i32, _vp]),
     "mdl_bn_stats": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "mdl_bn_apply": (_i32, [_vp] * 8 + [_i64, _i32, _f32, _f32, _i32, _vp]),
     "mdl_bn_bwd_stats": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
@@ -106,4 +111,5 @@ def ptr(t):
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw hipStream_t of torch's current stream on the current device (no Stream object: this runs once per launch)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))

@@ -85,7 +85,29 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams p) {
     }
 }
 
+// Tail of a PADDED static batch (HIP-graph replays need fixed shapes: the buffers hold n_cap nodes, the batch fills the
+// first N = noff[B]): padding nodes get no edges (rowptr = E) and belong to a dummy graph B, so every kernel that walks
+// rowptr / batch sees well-formed, empty rows.  N and E are read on the device — the launch is part of the graph.
+__global__ __launch_bounds__(256) void pad_tail_kernel(const int64_t* __restrict__ noff, const int64_t* __restrict__ eoff,
+                                                       int B, int64_t n_cap, int32_t* __restrict__ rowptr,
+                                                       int64_t* __restrict__ batch) {
+    const int64_t N = noff[B];
+    const int32_t E = (int32_t)eoff[B];
+    for (int64_t n = N + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < n_cap; n += (int64_t)gridDim.x * blockDim.x) {
+        batch[n] = B;
+        rowptr[n + 1] = E;
+    }
+}
+
 }  // namespace mdl
+
+extern "C" int mdl_pad_batch_tail(const int64_t* noff, const int64_t* eoff, int B, int64_t n_cap, int32_t* rowptr,
+                                  int64_t* batch, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(noff && eoff && rowptr && batch && B >= 1 && n_cap >= 1, MDL_E_ARG, "mdl_pad_batch_tail: bad arguments");
+    hipLaunchKernelGGL(pad_tail_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, noff, eoff, B, n_cap, rowptr, batch);
+    return check_launch("mdl_pad_batch_tail");
+}
 
 extern "C" int mdl_assemble_batch(const int64_t* ids, const int64_t* noff, const int64_t* eoff, const int64_t* node_ptr,
                                   const int64_t* edge_ptr, const float* x_all, const int32_t* src_l, const int32_t* tgt_l,

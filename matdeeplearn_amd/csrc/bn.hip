@@ -37,8 +37,11 @@ __device__ __forceinline__ void bn_totals(const float* __restrict__ sums, float*
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                         const float* __restrict__ save, float* __restrict__ sums,
-                                                        int64_t N, int C) {
+                                                        int64_t Ncap, int C, const int64_t* __restrict__ n_dev) {
     constexpr int W = Vec<T>::W;
+    // rows that exist: all Ncap of them, or the device-side count of a padded static batch (HIP-graph replays: the
+    // launch arguments are frozen at capture, the true row count changes with every batch)
+    const int64_t N = n_dev ? max((int64_t)1, min(*n_dev, Ncap)) : Ncap;
     __shared__ float red[2][256 * 8 / 8 * 8];   // 2 x 256 x W floats max (W <= 8)
     const int CG = C / W;
     const int rows_per_block = 256 / CG;
@@ -99,10 +102,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, float* __restrict__ sums,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ save, float* __restrict__ run_mean,
-                                                       float* __restrict__ run_var, T* __restrict__ y, int64_t N, int C,
-                                                       float eps, float momentum) {
+                                                       float* __restrict__ run_var, T* __restrict__ y, int64_t Ncap, int C,
+                                                       float eps, float momentum, const int64_t* __restrict__ n_dev) {
     constexpr int W = Vec<T>::W;
     constexpr int U = 4;                                     // four independent 16-byte loads in flight per thread
+    const int64_t N = n_dev ? max((int64_t)1, min(*n_dev, Ncap)) : Ncap;
     __shared__ float tot[512];
     const int CG = C / W;
     const int cg = threadIdx.x % CG;
@@ -152,15 +156,24 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int u = 0; u < U; ++u) Vec<T>::ld(x + (min(q0 + u * stride, total - 1) / CG) * C + cg * W, v[u]);
     }
+    // padding rows of a static batch: exact zeros (they must not carry anything into the layers behind)
+    if (N < Ncap) {
+        float z[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) z[j] = 0.0f;
+        for (int64_t q = total + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < Ncap * CG; q += stride)
+            Vec<T>::st(y + (q / CG) * C + cg * W, z);
+    }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ save, float* __restrict__ sums,
-                                                           const float* __restrict__ gamma, T* __restrict__ dx, int64_t N,
-                                                           int C) {
+                                                           const float* __restrict__ gamma, T* __restrict__ dx, int64_t Ncap,
+                                                           int C, const int64_t* __restrict__ n_dev) {
     constexpr int W = Vec<T>::W;
     constexpr int U = 2;
+    const int64_t N = n_dev ? max((int64_t)1, min(*n_dev, Ncap)) : Ncap;
     __shared__ float tot[512];
     const int CG = C / W;
     const int cg = threadIdx.x % CG;
@@ -203,6 +216,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             Vec<T>::ld(x + n * C + cg * W, vx[u]);
         }
     }
+    if (N < Ncap) {                                           // padding rows: no gradient
+        float z[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) z[j] = 0.0f;
+        for (int64_t q = total + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < Ncap * CG; q += stride)
+            Vec<T>::st(dx + (q / CG) * C + cg * W, z);
+    }
 }
 
 static int bn_check(const char* name, int64_t N, int C, int dtype, const void* p) {
@@ -226,18 +246,26 @@ static unsigned bn_grid(int64_t N, int C, int W) {
 extern "C" int mdl_bn_sums_rows(void) { return 2 * (MDL_BN_REPLICAS + 1); }
 
 extern "C" int mdl_bn_stats(const void* x, float* sums, int64_t N, int C, int dtype, mdlStream_t stream) {
+    return mdl_bn_stats_n(x, sums, N, C, nullptr, dtype, stream);
+}
+extern "C" int mdl_bn_stats_n(const void* x, float* sums, int64_t N, int C, const int64_t* n_dev, int dtype, mdlStream_t stream) {
     using namespace mdl;
     int rc = bn_check("mdl_bn_stats", N, C, dtype, x);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), dim3(bn_grid(N, C, 8)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, sums, N, C);
-    else hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(bn_grid(N, C, 4)), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, sums, N, C);
+    if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), dim3(bn_grid(N, C, 8)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
+    else hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(bn_grid(N, C, 4)), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
     return check_launch("mdl_bn_stats");
 }
 
 extern "C" int mdl_bn_apply(const void* x, float* sums, const float* gamma, const float* beta, float* save,
                             float* running_mean, float* running_var, void* y, int64_t N, int C, float eps, float momentum,
                             int dtype, mdlStream_t stream) {
+    return mdl_bn_apply_n(x, sums, gamma, beta, save, running_mean, running_var, y, N, C, eps, momentum, nullptr, dtype, stream);
+}
+extern "C" int mdl_bn_apply_n(const void* x, float* sums, const float* gamma, const float* beta, float* save,
+                              float* running_mean, float* running_var, void* y, int64_t N, int C, float eps, float momentum,
+                              const int64_t* n_dev, int dtype, mdlStream_t stream) {
     using namespace mdl;
     int rc = bn_check("mdl_bn_apply", N, C, dtype, x);
     if (rc) return rc;
@@ -246,24 +274,32 @@ extern "C" int mdl_bn_apply(const void* x, float* sums, const float* gamma, cons
     int64_t g = cdiv(N * (C / W), 256 * 4);
     if (g > 768) g = 768;          // 3 fat blocks per CU: the per-block statistics prologue amortises (measured 512..2048)
     if (g < 1) g = 1;
-    if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)x, sums, gamma, beta, save, running_mean, running_var, (bf16_t*)y, N, C, eps, momentum);
-    else hipLaunchKernelGGL((bn_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, (const float*)x, sums, gamma, beta, save, running_mean, running_var, (float*)y, N, C, eps, momentum);
+    if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)x, sums, gamma, beta, save, running_mean, running_var, (bf16_t*)y, N, C, eps, momentum, n_dev);
+    else hipLaunchKernelGGL((bn_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, (const float*)x, sums, gamma, beta, save, running_mean, running_var, (float*)y, N, C, eps, momentum, n_dev);
     return check_launch("mdl_bn_apply");
 }
 
 extern "C" int mdl_bn_bwd_stats(const void* dy, const void* x, const float* save, float* sums, int64_t N, int C,
                                 int dtype, mdlStream_t stream) {
+    return mdl_bn_bwd_stats_n(dy, x, save, sums, N, C, nullptr, dtype, stream);
+}
+extern "C" int mdl_bn_bwd_stats_n(const void* dy, const void* x, const float* save, float* sums, int64_t N, int C,
+                                  const int64_t* n_dev, int dtype, mdlStream_t stream) {
     using namespace mdl;
     int rc = bn_check("mdl_bn_bwd_stats", N, C, dtype, x);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(bn_grid(N, C, 8)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, N, C);
-    else hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), dim3(bn_grid(N, C, 4)), dim3(256), 0, st, (const float*)dy, (const float*)x, save, sums, N, C);
+    if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(bn_grid(N, C, 8)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, N, C, n_dev);
+    else hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), dim3(bn_grid(N, C, 4)), dim3(256), 0, st, (const float*)dy, (const float*)x, save, sums, N, C, n_dev);
     return check_launch("mdl_bn_bwd_stats");
 }
 
 extern "C" int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save, float* sums, const float* gamma,
                                 void* dx, int64_t N, int C, int dtype, mdlStream_t stream) {
+    return mdl_bn_bwd_apply_n(dy, x, save, sums, gamma, dx, N, C, nullptr, dtype, stream);
+}
+extern "C" int mdl_bn_bwd_apply_n(const void* dy, const void* x, const float* save, float* sums, const float* gamma,
+                                  void* dx, int64_t N, int C, const int64_t* n_dev, int dtype, mdlStream_t stream) {
     using namespace mdl;
     int rc = bn_check("mdl_bn_bwd_apply", N, C, dtype, x);
     if (rc) return rc;
@@ -272,7 +308,7 @@ extern "C" int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save
     int64_t g = cdiv(N * (C / W), 256 * 4);
     if (g > 768) g = 768;          // 3 fat blocks per CU: the per-block statistics prologue amortises (measured 512..2048)
     if (g < 1) g = 1;
-    if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, gamma, (bf16_t*)dx, N, C);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, (const float*)dy, (const float*)x, save, sums, gamma, (float*)dx, N, C);
+    if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, gamma, (bf16_t*)dx, N, C, n_dev);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, (const float*)dy, (const float*)x, save, sums, gamma, (float*)dx, N, C, n_dev);
     return check_launch("mdl_bn_bwd_apply");
 }

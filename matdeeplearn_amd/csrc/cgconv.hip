@@ -650,12 +650,15 @@ __device__ __forceinline__ void seg_reduce_cnt(const f32x16& v, const unsigned t
 // 64-ary search on rowptr.  Ranges partition [0, N); a node's edges are never split, so no cross-wave
 // combination is needed, every wave carries the same number of edge tiles (+-1) whatever N is, and small
 // batches still spread over the whole chip.  Inside its range a wave walks groups of up to 32 nodes.
+// The balanced quantity is w(n) = rowptr[n] + n (edges + nodes in front of node n): strictly increasing, so nodes WITHOUT
+// edges are spread over the waves too — the padding nodes of a static batch (thousands of empty rows behind the last real
+// node) would otherwise all fall to the last wave, which then walks them group by group while the chip idles.
 __device__ __forceinline__ int wave_lower_bound(const int32_t* __restrict__ rowptr, int N, int64_t b, int lane) {
-    int lo = 0, hi = N;                        // answer = first n in [lo, hi] with rowptr[n] >= b  (rowptr[N] = E >= b)
+    int lo = 0, hi = N;                        // answer = first n in [lo, hi] with w(n) >= b  (w(N) = E + N >= b)
     while (lo < hi) {
         const int step = (hi - lo + 63) >> 6;  // >= 1
         const int n = min(lo + lane * step, hi);
-        const unsigned long long ge = __ballot((int64_t)rowptr[n] >= b);   // monotone in lane
+        const unsigned long long ge = __ballot((int64_t)rowptr[n] + n >= b);   // monotone in lane
         if (ge == 0ull) { lo = min(lo + 63 * step, hi) + 1; continue; }   // all probes below b
         const int fl = __builtin_ctzll(ge);
         if (fl == 0) { hi = lo; break; }
@@ -668,7 +671,10 @@ struct NodeRange {
     int na, nb;
     __device__ __forceinline__ NodeRange(int a, int b) : na(a), nb(b) {}
     __device__ __forceinline__ NodeRange(const CgParams& p, int wi, int W, int lane) {
-        const int64_t b0 = p.E * (int64_t)wi / W, b1 = p.E * (int64_t)(wi + 1) / W;
+        // the edges that exist = rowptr[N], which may be fewer than the p.E slots of the edge arrays (padded static
+        // batches of the HIP-graph path): balancing on p.E would search for edge counts rowptr never reaches
+        const int64_t Et = (int64_t)p.rowptr[p.N] + p.N;
+        const int64_t b0 = Et * (int64_t)wi / W, b1 = Et * (int64_t)(wi + 1) / W;
         na = (wi == 0) ? 0 : wave_lower_bound(p.rowptr, (int)p.N, b0, lane);
         nb = (wi == W - 1) ? (int)p.N : wave_lower_bound(p.rowptr, (int)p.N, b1, lane);
     }
@@ -740,16 +746,44 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
         while (true) {
             const bool hasN = G.n1 < R.nb;
             if (hasN) GN.load(p, G.n1, R.nb);
-            if (G.e0 == G.e1) {                                  // group without edges: out = x
-#pragma unroll
-                for (int sl = 0; sl < NSL; ++sl)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int n = G.n0 + d_row(r, h);
-                        if (n < G.n1) out[(int64_t)n * dm.C + sl * 32 + i] = x[(int64_t)n * dm.C + sl * 32 + i];
+            if (G.e0 == G.e1) {
+                // Nodes without edges: out = x.  The whole RUN of edge-less nodes of this wave's range is copied at once
+                // with 16-byte vectors (8 rows per trip) — the padding rows of a static batch come as thousands of such
+                // nodes in a row, and walking them as 32-node groups (a scalar rowptr round trip + 32 two-byte copies
+                // each) made the waves that own them 3x slower than the rest of the launch.
+                int ne = G.n1;
+                {
+                    int lo = G.n1, hi = R.nb;                      // first node in [n1, nb] whose rowptr exceeds e0
+                    while (lo < hi) {
+                        const int step = (hi - lo + 63) >> 6;
+                        const int n = min(lo + lane * step, hi);
+                        const unsigned long long gt = __ballot(n < R.nb ? p.rowptr[n + 1] > G.e0 : true);
+                        if (gt == 0ull) { lo = min(lo + 63 * step, hi) + 1; continue; }
+                        const int fl = __builtin_ctzll(gt);
+                        if (fl == 0) { hi = lo; break; }
+                        hi = min(lo + fl * step, hi);
+                        lo = lo + (fl - 1) * step + 1;
                     }
-                if (!hasN) break;
-                G = GN;
+                    ne = min(__builtin_amdgcn_readfirstlane(lo), R.nb);
+                }
+                {
+                    constexpr int VW = 16 / (int)sizeof(T);        // elements per 16-byte vector
+                    constexpr int VPR = CP_ / VW;                    // vectors per row (CP_ == C for the static shapes)
+                    typedef __attribute__((ext_vector_type(4))) unsigned u32x4c;
+                    const int64_t v0 = (int64_t)G.n0 * VPR, v1 = (int64_t)ne * VPR;
+                    const u32x4c* __restrict__ xs = reinterpret_cast<const u32x4c*>(x);
+                    u32x4c* __restrict__ os = reinterpret_cast<u32x4c*>(out);
+                    for (int64_t q = v0 + lane; q < v1; q += 4 * WAVE) {
+                        u32x4c v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = xs[min(q + u * WAVE, v1 - 1)];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (q + u * WAVE < v1) os[q + u * WAVE] = v[u];
+                    }
+                }
+                if (ne >= R.nb) break;
+                G.load(p, ne, R.nb);
                 primed = false;
                 continue;
             }
@@ -1798,7 +1832,8 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     const int waves = bwd ? 4 : MDL_FWD_THREADS / 64;
     // static fast shapes keep W in registers (no LDS copy); otherwise LDS if it fits, else global
     const bool fast = !p.eperm && p.G == 50 && p.C == d.Cp && (d.Cp == 32 || d.Cp == 64) &&
-                      (sizeof(T) == 2 ? (vec == 8 && EW == 2) : d.Cp == 64);
+                      (sizeof(T) == 2 ? (vec == 8 && EW == 2) : d.Cp == 64) &&
+                      (bwd || (reinterpret_cast<uintptr_t>(p.out) % 16 == 0 && reinterpret_cast<uintptr_t>(p.x) % 16 == 0));
     const bool w_lds = (!fast || MDL_CG_WM != 2) && w_bytes + waves * p.wave_lds_bytes <= LDS_CAP;
     const int lds = (w_lds ? w_bytes : 0) + waves * p.wave_lds_bytes;
     const int wg_per_cu = lds * 2 <= LDS_CAP ? 2 : 1;
@@ -1833,11 +1868,11 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
             }
             if (d.Cp == 64) {
                 auto kf = cgconv_fwd_kernel<T, 64, 50, 9, 2, 1, true>;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
                 hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
             } else {
                 auto kf = cgconv_fwd_kernel<T, 32, 50, 9, 2, 1, true>;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
                 hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
             }
             return check_launch(name);
@@ -1867,12 +1902,12 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
             if (d.Cp == 64) {
                 const int cb_lds = 2 * cb::BwdLds<64>::BUF + cb::Cfg<64>::NCB * 32 * (cb::Cfg<64>::KE + 8) * 2;
                 auto kf = cb::bwd_kernel<64>;
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds);
+                set_max_dynamic_lds(reinterpret_cast<const void*>(kf), cb_lds);
                 hipLaunchKernelGGL(kf, dim3((unsigned)cb_grid), dim3(cb::Cfg<64>::NT), cb_lds, st, p);
             } else {
                 const int cb_lds = 2 * cb::BwdLds<32>::BUF + cb::Cfg<32>::NCB * 32 * (cb::Cfg<32>::KE + 8) * 2;
                 auto kf = cb::bwd_kernel<32>;
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, cb_lds);
+                set_max_dynamic_lds(reinterpret_cast<const void*>(kf), cb_lds);
                 hipLaunchKernelGGL(kf, dim3((unsigned)cb_grid), dim3(cb::Cfg<32>::NT), cb_lds, st, p);
             }
             return check_launch(name);
@@ -1882,8 +1917,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
 #define MDL_CG_LAUNCH(CP_, G_, VEC_, EW_, WM_)                                                               \
     do {                                                                                                     \
         auto kf = bwd ? cgconv_bwd_kernel<T, CP_, G_, VEC_, EW_, WM_> : cgconv_fwd_kernel<T, CP_, G_, VEC_, EW_, WM_>; \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf),                                \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);                 \
+        hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                 \
         if (e != hipSuccess) { set_error("%s: LDS attribute (%d B): %s", name, lds, hipGetErrorString(e)); return MDL_E_LAUNCH; } \
         hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);                           \
     } while (0)
@@ -1939,11 +1973,11 @@ static int cg_launch_bwd_ab(CgParams& p, hipStream_t st, const char* name) {
     }
     if (d.Cp == 64) {
         auto kf = cgconv_bwd_ab_kernel<64, 50>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
         hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
     } else {
         auto kf = cgconv_bwd_ab_kernel<32, 50>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
         hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
     }
     return check_launch(name);

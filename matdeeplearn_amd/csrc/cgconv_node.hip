@@ -85,18 +85,22 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
     auto rsrc = [](const void* base, int64_t bytes) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7fffffffLL ? bytes : 0x7fffffffLL), 0x00020000);
     };
+    // the per-l strides (multiples of 4096: too large for the 12-bit immediate) are added to the per-thread offset right
+    // at the load from an SGPR the optimiser cannot see through — hoisted out of the tile loop they would be 11 more
+    // loop-invariant VGPRs in a kernel that sits at the 256-register limit (they spilled, and a reload drains the queue)
+    auto opaque = [](int v) { asm volatile("" : "+s"(v)); return v; };
     auto load_tile = [&](int64_t tile) {
         const int64_t nb = tile * TN, rem = N - nb;
         const __amdgpu_buffer_rsrc_t tr = rsrc(r_tgt + nb * (2 * CP), rem * (2 * CP * 2));
         const __amdgpu_buffer_rsrc_t sr = rsrc(r_src + nb * (2 * CP), rem * (2 * CP * 4));
         const __amdgpu_buffer_rsrc_t xr = rsrc(x + nb * CP, rem * (CP * 2));
 #pragma unroll
-        for (int l = 0; l < NTL; ++l) treg[l] = __builtin_amdgcn_raw_buffer_load_b128(tr, to + l * (TROWS * 2 * CP * 2), 0, 0);
+        for (int l = 0; l < NTL; ++l) treg[l] = __builtin_amdgcn_raw_buffer_load_b128(tr, to + opaque(l * (TROWS * 2 * CP * 2)), 0, 0);
 #pragma unroll
         for (int l = 0; l < NSL; ++l)
-            sreg[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sr, so + l * (SROWS * 2 * CP * 4), 0, 0));
+            sreg[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sr, so + opaque(l * (SROWS * 2 * CP * 4)), 0, 0));
 #pragma unroll
-        for (int l = 0; l < NXL; ++l) xreg[l] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo + l * (XROWS * CP * 2), 0, 0);
+        for (int l = 0; l < NXL; ++l) xreg[l] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo + opaque(l * (XROWS * CP * 2)), 0, 0);
     };
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) load_tile(tile);
@@ -248,7 +252,7 @@ extern "C" int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const vo
     if (C == 64) {
         const int lds = (64 * (256 + 8) + 64 * (256 + 8) + 64 * (64 + 8)) * 2;
         auto kf = cgconv_node_stream_kernel<64>;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
         hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
                            (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N);
     } else {

@@ -135,7 +135,7 @@ extern "C" int mdl_linear_act(const void* x, const void* w, const void* bias, vo
 #define MDL_LIN(KP_, NT_)                                                                                            \
     do {                                                                                                             \
         auto kf = linear_act_kernel<KP_, NT_>;                                                                       \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds); \
         hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
                            (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, inv_k2);                                 \
     } while (0)

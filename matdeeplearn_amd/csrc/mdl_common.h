@@ -158,6 +158,7 @@ template <> struct Gate<true> {
 // ---- error plumbing ----------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+hipError_t set_max_dynamic_lds(const void* kernel, int bytes);   // cached hipFuncSetAttribute(MaxDynamicSharedMemorySize)
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -133,7 +133,7 @@ class GraphModel(nn.Module):
         num_graphs = getattr(data, "num_graphs", None)
         if self.pool == "set2set":
             return self.set2set(out, data.batch, num_graphs)
-        return ops.POOLS[self.pool](out, data.batch, num_graphs)
+        return ops.POOLS[self.pool](out, data.batch, num_graphs, seg_index=getattr(data, "pool_index", None))
 
     def _head(self, out, data):
         if self.pool_order == "early":

@@ -133,6 +133,8 @@ def register_csr(edge_index, csr):
 
 def csr_for(edge_index, num_nodes):
     """CSR of a PyG-style edge_index; built on first use (device sort) and cached per tensor."""
+    if NO_INDEX_CACHE:
+        return build_csr(edge_index, num_nodes)
     k = _key(edge_index, num_nodes)
     hit = _CSR_CACHE.get(k)
     if hit is not None:
@@ -183,7 +185,14 @@ class _SegIndex:
 _SEG_CACHE = collections.OrderedDict()
 
 
+# Static buffers (HIP-graph path) are rewritten in place by kernels the version counter does not see: with NO_INDEX_CACHE
+# every index structure is rebuilt (and the building kernels become part of the captured graph).
+NO_INDEX_CACHE = False
+
+
 def _seg_index(index, dim_size, assume_sorted):
+    if NO_INDEX_CACHE:
+        return _seg_index_build(index, dim_size, assume_sorted)
     key = (index.data_ptr(), index._version, index.numel(), int(dim_size), bool(assume_sorted), index.device.index)
     hit = _SEG_CACHE.get(key)
     if hit is not None:
@@ -234,18 +243,29 @@ class _SegmentReduce(torch.autograd.Function):
         return gs, None, None
 
 
-def scatter(src, index, dim=0, dim_size=None, reduce="sum", assume_sorted=False):
+def scatter(src, index, dim=0, dim_size=None, reduce="sum", assume_sorted=False, seg_index=None):
     """torch_scatter.scatter(src, index, dim=0, dim_size, reduce) semantics.  When
-    dim_size is None it is index.max()+1, which costs a host sync — pass dim_size on hot paths."""
+    dim_size is None it is index.max()+1, which costs a host sync — pass dim_size on hot paths.
+    `seg_index`: a prebuilt segment index (make_seg_index) for `index`, e.g. the loader's node -> graph map."""
     if dim != 0:
         raise MdlError("scatter: only dim=0 is on the hot path")
     require_hip(src, index)
     if reduce not in _lib.REDUCE:
         raise MdlError("scatter: unsupported reduce %r" % (reduce,))
-    if dim_size is None:
-        dim_size = int(index.max()) + 1 if index.numel() else 0
-    si = _seg_index(index, dim_size, assume_sorted)
-    return _SegmentReduce.apply(src, si, _lib.REDUCE[reduce])
+    if seg_index is None:
+        if dim_size is None:
+            dim_size = int(index.max()) + 1 if index.numel() else 0
+        seg_index = _seg_index(index, dim_size, assume_sorted)
+    return _SegmentReduce.apply(src, seg_index, _lib.REDUCE[reduce])
+
+
+def make_seg_index(rowptr_i32, seg_i32):
+    """Segment index over a SORTED segment id vector from its row pointers (rowptr [S+1] int32, seg [E] int32): what the
+    loaders know anyway (graph -> first node), so pooling needs neither a sort nor a search."""
+    si = _SegIndex()
+    si.N, si.E = rowptr_i32.numel() - 1, seg_i32.numel()
+    si.rowptr, si.seg, si.perm = rowptr_i32, seg_i32, None
+    return si
 
 
 def scatter_mean(src, index, dim=0, dim_size=None, assume_sorted=False):
@@ -256,17 +276,17 @@ def scatter_add(src, index, dim=0, dim_size=None, assume_sorted=False):
     return scatter(src, index, dim, dim_size, "sum", assume_sorted)
 
 
-def global_mean_pool(x, batch, size=None):
+def global_mean_pool(x, batch, size=None, seg_index=None):
     """`batch` is non-decreasing by construction (PyG collate / the product loader)."""
-    return scatter(x, batch, 0, size, "mean", assume_sorted=True)
+    return scatter(x, batch, 0, size, "mean", assume_sorted=True, seg_index=seg_index)
 
 
-def global_add_pool(x, batch, size=None):
-    return scatter(x, batch, 0, size, "sum", assume_sorted=True)
+def global_add_pool(x, batch, size=None, seg_index=None):
+    return scatter(x, batch, 0, size, "sum", assume_sorted=True, seg_index=seg_index)
 
 
-def global_max_pool(x, batch, size=None):
-    return scatter(x, batch, 0, size, "max", assume_sorted=True)
+def global_max_pool(x, batch, size=None, seg_index=None):
+    return scatter(x, batch, 0, size, "max", assume_sorted=True, seg_index=seg_index)
 
 
 POOLS = {"global_mean_pool": global_mean_pool, "global_add_pool": global_add_pool,
@@ -677,6 +697,28 @@ def bn_supported(x):
     return x.shape[0] >= 2 and c % w == 0 and c <= 256 and 256 % (c // w) == 0 and x.data_ptr() % 16 == 0
 
 
+# Static (padded) batches of the HIP-graph path: the tensors hold `capacity` rows, the first *n_rows (a device scalar)
+# exist.  Row-count-dependent kernels (BatchNorm) read it on the device.  None = every row exists.
+_TRUE_ROWS = None
+
+
+class true_rows:
+    """`with ops.true_rows(n_dev):` — n_dev: int64 device tensor with one element, the number of node rows that exist."""
+
+    def __init__(self, n_dev):
+        self.n_dev = n_dev
+
+    def __enter__(self):
+        global _TRUE_ROWS
+        self.prev, _TRUE_ROWS = _TRUE_ROWS, self.n_dev
+        return self
+
+    def __exit__(self, *exc):
+        global _TRUE_ROWS
+        _TRUE_ROWS = self.prev
+        return False
+
+
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
@@ -688,9 +730,11 @@ class _BatchNormTrain(torch.autograd.Function):
         gw = None if weight is None else weight.detach().float().contiguous()
         gb = None if bias is None else bias.detach().float().contiguous()
         y = torch.empty_like(x)
-        check(lib().mdl_bn_stats(ptr(x), ptr(sums), N, C, dt, stream()), "mdl_bn_stats")
-        check(lib().mdl_bn_apply(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
-                                 ptr(y), N, C, float(eps), float(momentum), dt, stream()), "mdl_bn_apply")
+        nd = _TRUE_ROWS
+        check(lib().mdl_bn_stats_n(ptr(x), ptr(sums), N, C, ptr(nd), dt, stream()), "mdl_bn_stats")
+        check(lib().mdl_bn_apply_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
+                                   ptr(y), N, C, float(eps), float(momentum), ptr(nd), dt, stream()), "mdl_bn_apply")
+        ctx.n_dev = nd
         ctx.save_for_backward(x, save, gw)
         ctx.has = (weight is not None, bias is not None)
         ctx.wdt = None if weight is None else weight.dtype
@@ -705,8 +749,9 @@ class _BatchNormTrain(torch.autograd.Function):
         R = lib().mdl_bn_sums_rows()
         sums = torch.zeros((R, C), dtype=torch.float32, device=x.device)     # (not from the step arena: its totals rows are
         dx = torch.empty_like(x)                                              # returned as parameter gradients)
-        check(lib().mdl_bn_bwd_stats(ptr(dy), ptr(x), ptr(save), ptr(sums), N, C, dt, stream()), "mdl_bn_bwd_stats")
-        check(lib().mdl_bn_bwd_apply(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, dt, stream()),
+        nd = ctx.n_dev
+        check(lib().mdl_bn_bwd_stats_n(ptr(dy), ptr(x), ptr(save), ptr(sums), N, C, ptr(nd), dt, stream()), "mdl_bn_bwd_stats")
+        check(lib().mdl_bn_bwd_apply_n(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, ptr(nd), dt, stream()),
               "mdl_bn_bwd_apply")
         dgamma = sums[R - 1].to(ctx.wdt) if ctx.has[0] else None          # totals row pair published by bwd_apply
         dbeta = sums[R - 2].to(ctx.wdt) if ctx.has[1] else None

@@ -281,6 +281,105 @@ def synthetic_surface(n_graphs=37000, seed=0, density=0.06, min_atoms=40, max_at
     return _synthetic(sizes, boxes, rng, seed, radius, max_neighbors, num_edge_features, "surf")
 
 
+class StaticBatch:
+    """Fixed-shape (padded) batch buffers for HIP-graph replays of a training step.
+
+    A captured graph freezes every launch argument and every address, while batches differ in node / edge count.  So
+    the batch lives in buffers sized for `n_cap` nodes / `e_cap` edges; `load(ids)` (host side, outside the graph) uploads
+    the graph ids and the prefix offsets, `assemble()` (inside the graph) runs K8 + the tail padding + K1 into the same
+    buffers.  Padding nodes have no edges and belong to a dummy graph `B` (the models see num_graphs = B + 1; the caller
+    drops the last prediction); the number of rows that exist is `n_dev`, a device scalar that the row-count-dependent
+    kernels (BatchNorm) read through ops.true_rows().  Edge slots past the batch's last edge are referenced by no rowptr
+    range."""
+
+    def __init__(self, ds, batch_size, n_cap, e_cap, x_dtype=torch.float32, edge_dtype=torch.float32, ring=8):
+        if ds.device is None or ds.device.type != "cuda":
+            raise ops.MdlError("StaticBatch: the dataset must be resident on a HIP device")
+        dev = ds.device
+        B, F, G = int(batch_size), ds.num_features, ds.num_edge_features
+        self.ds, self.B, self.n_cap, self.e_cap = ds, B, int(n_cap), int(e_cap)
+        self.pack = torch.zeros(3 * B + 2, dtype=torch.int64, device=dev)      # ids [B] | noff [B+1] | eoff [B+1]
+        self.n_dev = self.pack[2 * B:2 * B + 1]                                # noff[B] = number of nodes that exist
+        self.e_dev = self.pack[3 * B + 1:3 * B + 2]
+        self.x = torch.zeros((self.n_cap, F), dtype=x_dtype, device=dev)
+        self.batch_idx = torch.full((self.n_cap,), B, dtype=torch.int64, device=dev)
+        self.rowptr = torch.zeros(self.n_cap + 1, dtype=torch.int32, device=dev)
+        self.src = torch.zeros(self.e_cap, dtype=torch.int32, device=dev)
+        self.tgt = torch.zeros(self.e_cap, dtype=torch.int32, device=dev)
+        self.ew = torch.zeros(self.e_cap, dtype=torch.float32, device=dev)
+        self.dn = torch.zeros(self.e_cap, dtype=torch.float32, device=dev)
+        self.y = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.edge_attr = torch.zeros((self.e_cap, G), dtype=edge_dtype, device=dev)
+        csr = ops.EdgeCSR(self.rowptr, self.src, self.tgt, None, self.n_cap, self.e_cap)
+        self.pool_rowptr = torch.zeros(B + 2, dtype=torch.int32, device=dev)
+        self.pool_seg = torch.full((self.n_cap,), B, dtype=torch.int32, device=dev)
+        self.batch = Batch(pool_index=ops.make_seg_index(self.pool_rowptr, self.pool_seg), x=self.x, edge_attr=self.edge_attr, edge_weight=self.ew, batch=self.batch_idx, y=self.y,
+                           u=torch.zeros(B + 1, 3, device=dev), num_graphs=B + 1, csr=csr, num_nodes=self.n_cap,
+                           num_edges=self.e_cap, n_dev=self.n_dev, structure_id=None)
+        self._pinned = [torch.zeros(3 * B + 2, dtype=torch.int64).pin_memory() for _ in range(ring)]
+        self._events = [None] * ring
+        self._slot = 0
+        self.true_nodes = self.true_edges = 0
+
+    def fits(self, ids):
+        ids = np.asarray(ids, dtype=np.int64)
+        n = int((self.ds.node_ptr[ids + 1] - self.ds.node_ptr[ids]).sum())
+        e = int((self.ds.edge_ptr[ids + 1] - self.ds.edge_ptr[ids]).sum())
+        return len(ids) == self.B and n <= self.n_cap and e <= self.e_cap
+
+    def load(self, ids):
+        """Host side of a step: ids + exclusive prefix sums -> the device `pack` (one async copy from a pinned ring)."""
+        ds = self.ds
+        ids = np.asarray(ids, dtype=np.int64)
+        noff = np.concatenate([[0], np.cumsum(ds.node_ptr[ids + 1] - ds.node_ptr[ids])])
+        eoff = np.concatenate([[0], np.cumsum(ds.edge_ptr[ids + 1] - ds.edge_ptr[ids])])
+        if len(ids) != self.B or noff[-1] > self.n_cap or eoff[-1] > self.e_cap:
+            raise ops.MdlError("StaticBatch.load: batch (%d graphs, %d nodes, %d edges) exceeds the static capacity "
+                               "(%d, %d, %d)" % (len(ids), noff[-1], eoff[-1], self.B, self.n_cap, self.e_cap))
+        k = self._slot
+        self._slot = (k + 1) % len(self._pinned)
+        if self._events[k] is not None:
+            self._events[k].synchronize()                       # the copy that last used this pinned slot has finished
+        self._pinned[k].copy_(torch.from_numpy(np.concatenate([ids, noff, eoff])))
+        self.pack.copy_(self._pinned[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[k] = ev
+        self.true_nodes, self.true_edges = int(noff[-1]), int(eoff[-1])
+
+    def assemble(self):
+        """Device side (part of the captured graph): K8 batch assembly, tail padding, K1 RBF expansion."""
+        from .. import _lib
+        ds, B = self.ds, self.B
+        d = ds._dev
+        p = _lib.ptr
+        ids_d, noff_d, eoff_d = self.pack[:B], self.pack[B:2 * B + 1], self.pack[2 * B + 1:]
+        _lib.check(_lib.lib().mdl_assemble_batch(
+            p(ids_d), p(noff_d), p(eoff_d), p(d["node_ptr"]), p(d["edge_ptr"]), p(d["x"]), p(d["src"]), p(d["tgt"]),
+            p(d["dist"]), p(d["dist_norm"]), p(d["lrowptr"]), p(d["y"]), p(self.x), p(self.batch_idx), p(self.rowptr),
+            p(self.src), p(self.tgt), p(self.ew), p(self.dn), p(self.y), B, ds.num_features, ds.y.shape[1],
+            int(ds.target_index), _lib.dtype_code(self.x), _lib.stream()), "mdl_assemble_batch")
+        _lib.check(_lib.lib().mdl_pad_batch_tail(p(noff_d), p(eoff_d), B, self.n_cap, p(self.rowptr), p(self.batch_idx),
+                                                 _lib.stream()), "mdl_pad_batch_tail")
+        ops.rbf_expand(self.dn, 0.0, 1.0, ds.num_edge_features, 0.2, offsets=d["offsets"], out=self.edge_attr)
+        # node -> graph pooling index straight from the prefix offsets.  The dummy graph B is EMPTY here (the padding rows
+        # belong to no segment): as one segment of thousands of rows it would be walked by a single lane group
+        self.pool_rowptr.copy_(torch.cat([noff_d, noff_d[-1:]]))
+        self.pool_seg.copy_(self.batch_idx)
+        return self.batch
+
+
+def static_capacity(ds, batch_size, indices=None, slack=6.0, quantum=1024):
+    """(n_cap, e_cap) for StaticBatch: mean + `slack` standard deviations of a random batch's node / edge count, rounded
+    up — a batch that still exceeds it takes the eager path."""
+    idx = np.arange(len(ds)) if indices is None else np.asarray(indices)
+    nn = (ds.node_ptr[idx + 1] - ds.node_ptr[idx]).astype(np.float64)
+    ne = (ds.edge_ptr[idx + 1] - ds.edge_ptr[idx]).astype(np.float64)
+    B = float(batch_size)
+    cap = lambda v: int(-(-(B * v.mean() + slack * v.std() * np.sqrt(B)) // quantum) * quantum)
+    return cap(nn), cap(ne)
+
+
 class DeviceLoader:
     """Mini-batch iterator over a subset of a device-resident GraphDataset.
 

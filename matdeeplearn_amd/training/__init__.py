@@ -3,5 +3,6 @@
 batches, plus the data-parallel engine (one flat gradient buffer, one RCCL all-reduce per step)."""
 from .loops import train, evaluate, trainer, make_optimizer, make_scheduler  # noqa: F401
 from .dp import ddp_setup, ddp_cleanup, FlatDataParallel  # noqa: F401
+from .graphed import GraphedStep  # noqa: F401
 from .driver import (load_config, train_regular, train_repeat, train_CV, train_ensemble, predict,  # noqa: F401
                      write_results, train_repeat_replicas, train_ensemble_replicas, resolve_seed)

@@ -1,0 +1,153 @@
+"""HIP-graph replay of a whole training step ("hard parts" item 1: tiny default batches).
+
+At the reference's batch size (config.yml:136: 100 graphs = ~32 k edges) a step is ~100 kernel launches that each run
+for microseconds: Python, the autograd engine and the launch path cost 2-3 ms per step while the device needs a few hundred
+microseconds — and at the large bench batch the host (5-9 ms of enqueueing once the queue is deep) falls behind the device
+(3.9 ms) too.  GraphedStep captures  batch assembly (K8 + padding + K1) -> forward -> loss -> backward [-> fused AdamW]
+once, on static padded buffers (process.StaticBatch), and replays it with one hipGraphLaunch per step; the host's share
+drops to the upload of B graph ids.
+
+What makes a step capturable here:
+  * shapes are frozen at (n_cap, e_cap) with padding nodes that have no edges and sit in a dummy graph B; the one
+    row-count-dependent operator (BatchNorm) reads the number of existing rows on the device (ops.true_rows);
+  * every index structure is rebuilt inside the graph (ops.NO_INDEX_CACHE) and every scratch comes from static arenas;
+  * the library never allocates or synchronises, so its launches land in the capturing stream like torch's own.
+A batch that does not fit the static capacity (or a ragged last batch) runs eagerly — same arithmetic, no padding.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from ..nn import BatchNorm1d
+from ..process import StaticBatch, static_capacity
+
+
+class GraphedStep:
+    def __init__(self, dataset, model, optimizer, batch_size, compute_dtype=torch.float32, loss="l1_loss", indices=None,
+                 dp=None, capacity=None, optimizer_in_graph=None, warmup_ids=None):
+        self.ds, self.model, self.opt, self.loss_name, self.dp = dataset, model, optimizer, loss, dp
+        self.B, self.cdt = int(batch_size), compute_dtype
+        n_cap, e_cap = capacity if capacity is not None else static_capacity(dataset, batch_size, indices)
+        self.sb = StaticBatch(dataset, batch_size, n_cap, e_cap, x_dtype=compute_dtype, edge_dtype=compute_dtype)
+        self.dev = dataset.device
+        distributed = dp is not None and dp.world_size > 1
+        self.opt_in_graph = (not distributed) if optimizer_in_graph is None else bool(optimizer_in_graph)
+        if self.opt_in_graph and not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise ops.MdlError("GraphedStep: the optimizer step is captured — build it with capturable=True "
+                               "(training.make_optimizer(..., capturable=True))")
+        self.loss_value = torch.zeros((), dtype=torch.float32, device=self.dev)
+        self.graph = None
+        self.bn_layers = [m for m in model.modules() if isinstance(m, BatchNorm1d)]
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.replays = self.eager_steps = 0
+        self._warmup_ids = warmup_ids
+
+    # ---- the step on the static buffers (what gets captured) ------------------------------------------------------
+    def _body(self):
+        sb = self.sb
+        batch = sb.assemble()
+        with ops.true_rows(sb.n_dev), ops.zero_arena(self.dev):
+            out = self.model(batch)
+            loss = getattr(F, self.loss_name)(out[:self.B], sb.y)
+            loss.backward()
+        self.loss_value.copy_(loss.detach())
+        if self.opt_in_graph:
+            self.opt.step()
+
+    def capture(self, ids):
+        """Warm up on a side stream (allocator / lazy-init effects must not land in the graph), then capture."""
+        if not self.sb.fits(ids):
+            raise ops.MdlError("GraphedStep.capture: the warm-up batch does not fit the static capacity")
+        self.model.train()
+        prev = ops.NO_INDEX_CACHE
+        ops.NO_INDEX_CACHE = True
+        try:
+            self.sb.load(ids)
+            # The warm-up iterations run the real step (allocator pools, lazy optimizer state, low-precision weight copies
+            # must exist before the capture) — but they must not train: parameters, buffers, optimizer state and the
+            # host-side BatchNorm step counters are put back afterwards, so the captured step is the FIRST step.
+            keep = [t for t in list(self.model.parameters()) + list(self.model.buffers())]
+            saved = [t.detach().clone() for t in keep]
+            fresh_opt = len(self.opt.state) == 0
+            opt_saved = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                         for p, st in self.opt.state.items()}
+            nbt = [getattr(m, "_nbt_pending", 0) for m in self.bn_layers]
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._zero_grad()
+                    self._body()
+                    if not self.opt_in_graph:
+                        self._finish_eager()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            torch.cuda.synchronize(self.dev)
+            self._zero_grad()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._body()
+            self.static_grads = [p.grad for p in self.params]
+            with torch.no_grad():
+                for t, s in zip(keep, saved):
+                    t.copy_(s)
+                for p, st in self.opt.state.items():
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            if fresh_opt:
+                                v.zero_()
+                            else:
+                                v.copy_(opt_saved[id(p)][k])
+            for m, n in zip(self.bn_layers, nbt):
+                m._nbt_pending = n
+            # the capture itself executed nothing; replay once so that this batch's step is actually taken
+            self._replay()
+        finally:
+            ops.NO_INDEX_CACHE = prev
+        return self
+
+    def _zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def _bump_bn(self, n=1):
+        for m in self.bn_layers:                                   # num_batches_tracked is counted on the host
+            if m.training and m.track_running_stats:
+                m._nbt_pending = getattr(m, "_nbt_pending", 0) + n
+
+    def _finish_eager(self):
+        if self.dp is not None:
+            self.dp.reduce_grads()
+        self.opt.step()
+
+    def _replay(self):
+        self.graph.replay()
+        self._bump_bn(1)
+        self.replays += 1
+        if not self.opt_in_graph:
+            for p, g in zip(self.params, self.static_grads):       # the graph writes into ITS gradient tensors
+                p.grad = g
+            self._finish_eager()
+
+    # ---- public step ------------------------------------------------------------------------------------------------
+    def step(self, ids):
+        """One training step on the graphs `ids`.  Returns (edges, nodes) of the batch (true counts, no padding)."""
+        if self.sb.fits(ids):
+            if self.graph is None:
+                self.capture(ids)
+            else:
+                self.sb.load(ids)
+                self._replay()
+            return self.sb.true_edges, self.sb.true_nodes
+        return self._eager(ids)
+
+    def _eager(self, ids):
+        batch = self.ds.collate(ids, edge_dtype=self.cdt, x_dtype=self.cdt)
+        self._zero_grad()
+        with ops.zero_arena(self.dev):
+            out = self.model(batch)
+            loss = getattr(F, self.loss_name)(out, batch.y)
+            loss.backward()
+        self.loss_value.copy_(loss.detach())
+        self._finish_eager()
+        self.eager_steps += 1
+        return batch.num_edges, batch.num_nodes

@@ -18,7 +18,8 @@ import torch.nn.functional as F
 
 
 def make_optimizer(params, name="AdamW", lr=0.002, **optimizer_args):
-    """getattr(torch.optim, name)(params, lr, **optimizer_args) — training.py:429-432."""
+    """getattr(torch.optim, name)(params, lr, **optimizer_args) — training.py:429-432.  `capturable=True` (Adam family)
+    keeps the step counter on the device so that the step can be part of a captured HIP graph (training.GraphedStep)."""
     kw = dict(optimizer_args)
     plist = list(params)
     if name in ("Adam", "AdamW") and plist and plist[0].is_cuda and "fused" not in kw and "foreach" not in kw:

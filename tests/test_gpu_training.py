@@ -95,3 +95,55 @@ def test_rccl_backend_executes_on_one_gpu():
     assert line, r.stdout[-2000:] + r.stderr[-2000:]
     res = json.loads(line[-1])
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["roofline"]["launches"] == 3 * 4
+
+
+def test_graph_replayed_step_matches_the_eager_step():
+    """training.GraphedStep (batch assembly + forward + loss + backward + fused AdamW captured once on padded static
+    buffers, replayed per step) against the same steps run eagerly from the same initial weights: the padding must be
+    invisible — same losses, same parameters (BatchNorm statistics over the rows that exist), same running stats and
+    step counters — fp32 to rounding, bf16 to its own noise."""
+    import copy
+    from matdeeplearn_amd import models, ops
+    from matdeeplearn_amd.process import synthetic_bulk
+    from matdeeplearn_amd.training import GraphedStep, make_optimizer
+    dev = torch.device("cuda:0")
+    ds = synthetic_bulk(640, seed=11).to(dev)
+    B = 96
+    rng = np.random.default_rng(0)
+    batches = [rng.choice(len(ds), size=B, replace=False) for _ in range(6)]
+    for cd, dt, tol in (("fp32", torch.float32, 2e-4), ("bf16", torch.bfloat16, 3e-2)):
+        torch.manual_seed(3)
+        m_e = models.CGCNN(ds, dim1=64, dim2=64, gc_count=3, post_fc_count=2, compute_dtype=cd).to(dev)
+        m_g = copy.deepcopy(m_e)
+        o_e = make_optimizer(m_e.parameters(), "AdamW", lr=0.002)
+        o_g = make_optimizer(m_g.parameters(), "AdamW", lr=0.002, capturable=True)
+        gs = GraphedStep(ds, m_g, o_g, B, compute_dtype=dt)
+        assert gs.sb.n_cap > max(int((ds.node_ptr[b + 1] - ds.node_ptr[b]).sum()) for b in batches)
+        m_e.train()
+        losses_e, losses_g = [], []
+        for ids in batches:
+            batch = ds.collate(ids, edge_dtype=dt, x_dtype=dt)
+            o_e.zero_grad(set_to_none=True)
+            with ops.zero_arena(dev):
+                loss = torch.nn.functional.l1_loss(m_e(batch), batch.y)
+                loss.backward()
+            o_e.step()
+            losses_e.append(float(loss))
+            e, n = gs.step(ids)
+            assert (e, n) == (batch.num_edges, batch.num_nodes)
+            losses_g.append(float(gs.loss_value))
+        assert gs.replays == len(batches) and gs.eager_steps == 0
+        assert np.allclose(losses_g, losses_e, rtol=tol, atol=tol), (cd, losses_g, losses_e)
+        sd_e, sd_g = m_e.state_dict(), m_g.state_dict()
+        for k in sd_e:
+            a, b = sd_g[k].float(), sd_e[k].float()
+            # fp32: rounding only.  bf16: Adam divides by sqrt(v), so bf16 noise in a small gradient moves a parameter
+            # by a sizeable fraction of lr (0.002) per step: six steps -> an absolute bound of a few lr
+            bound = tol * (float(b.abs().max()) + 1e-3) * 5 if cd == "fp32" else 6 * 0.002
+            assert float((a - b).abs().max()) <= bound, (cd, k)
+        assert int(sd_g["bn_list.0.num_batches_tracked"]) == int(sd_e["bn_list.0.num_batches_tracked"])
+        # a batch that does not fit the static capacity takes the eager path with the same optimizer state
+        big = np.argsort(-(ds.node_ptr[1:] - ds.node_ptr[:-1]))[:B]
+        if not gs.sb.fits(big):
+            gs.step(big)
+            assert gs.eager_steps == 1

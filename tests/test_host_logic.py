@@ -422,8 +422,12 @@ def test_conv_kernels_register_budget():
         return hits[0]
     scratch, occ = find("cgconv_bwd_kernelItLi64ELi50")          # per-wave backward, bf16 C=64 G=50
     assert scratch == 0 and occ == 1
-    scratch, occ = find("cgconv_fwd_kernelItLi64ELi50")          # all-slices forward
+    scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb0")          # all-slices forward
     assert scratch == 0 and occ == 2
+    scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb1")          # opt-in saved-gate forward: the 16 pending
+    assert scratch <= 256 and occ == 2                                           # factor dwords spill at GROUP level only
+    scratch, occ = find("cgconv_bwd_ab_kernelILi64")                              # opt-in saved-gate backward
+    assert scratch == 0 and occ == 1
     for frag in ("2cb10fwd_kernelILi64", "2cb10bwd_kernelILi64",    # cooperative kernels
                  "cgconv_node_stream_kernelILi64", "cgconv_node_stream_kernelILi32"):    # node-level dense half
         scratch, occ = find(frag)
