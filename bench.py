@@ -268,7 +268,11 @@ def main():
         from matdeeplearn_amd.training import GraphedStep
 
         def run_for(step_fn, it, min_s=None, n=None):
-            """step_fn over batches from `it` for >= min_s seconds (or exactly n steps); (edges, steps, seconds, marks)."""
+            """step_fn over batches from `it` for >= min_s seconds (or exactly n steps); (edges, steps, seconds, marks).
+            No device synchronisation inside the loop: an idle gap lets the GPU drop its clocks, and the ramp back up
+            costs tens of milliseconds (seen as 2 ms/step on every 16-step chunk that followed a sync).  The host is
+            throttled by the steps themselves (pinned-ring events / the launch queue), so host wall-clock marks are a
+            fair per-chunk reading and the final sync closes the measurement."""
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             e_tot = k = 0
@@ -280,7 +284,6 @@ def main():
                     if k >= n:
                         break
                 elif k % 16 == 0:
-                    torch.cuda.synchronize()
                     marks.append(time.perf_counter() - t1)
                     if marks[-1] >= min_s:
                         break
@@ -305,7 +308,8 @@ def main():
             res["sustained"].update({"value": round(e_sus / dt, 1), "unit": "edges/s", "steps": n_sus, "seconds": round(dt, 2),
                                      "ms_per_step": round(dt / n_sus * 1e3, 4), "mode": "hip-graph replay",
                                      "replays": gs.replays, "eager_fallback_steps": gs.eager_steps,
-                                     "capacity": [gs.sb.n_cap, gs.sb.e_cap]})
+                                     "capacity": [gs.sb.n_cap, gs.sb.e_cap],
+                                     "ms_per_step_by_16": [round((b - a) / 16 * 1e3, 2) for a, b in zip([0.0] + marks[:-1], marks)]})
         except Exception as exc:                                 # report, never hide: the eager figure stands in
             res["sustained"].update({"value": eager["value"], "unit": "edges/s", "ms_per_step": eager["ms_per_step"],
                                      "steps": eager["steps"], "mode": "eager", "graph_error": repr(exc)[:300]})

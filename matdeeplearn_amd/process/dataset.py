@@ -383,7 +383,7 @@ def static_capacity(ds, batch_size, indices=None, slack=6.0, quantum=1024):
 class DeviceLoader:
     """Mini-batch iterator over a subset of a device-resident GraphDataset.
 
-    Shuffling reseeds from (seed, epoch) like torch's DistributedSampler; with world_size > 1 rank r
+    Shuffling reseeds from (seed, epoch) like torch's DistributedSampler (same contract, numpy's bit generator); with world_size > 1 rank r
     takes perm[r::world_size] of the (padded) index list — the DistributedSampler contract the
     reference relies on at training.py:291-294 — and every rank draws `batch_size` graphs per step."""
 
@@ -400,8 +400,10 @@ class DeviceLoader:
     def _order(self):
         idx = self.indices
         if self.shuffle:
-            g = torch.Generator().manual_seed(self.seed + self.epoch)
-            idx = idx[torch.randperm(len(idx), generator=g).numpy()]
+            # numpy's generator, not torch.randperm: torch's CPU ops enter the intra-op thread pool, and on a many-core
+            # host shared with other jobs waking 128 threads for a 37 k-element permutation stalled the training thread
+            # for milliseconds — every epoch boundary, in the middle of an otherwise device-bound step stream
+            idx = idx[np.random.default_rng(self.seed + self.epoch).permutation(len(idx))]
         if self.world_size > 1:
             total = -(-len(idx) // self.world_size) * self.world_size
             idx = np.concatenate([idx, idx[: total - len(idx)]])[self.rank::self.world_size]
