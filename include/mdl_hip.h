@@ -164,6 +164,19 @@ int mdl_assemble_batch(const int64_t* ids, const int64_t* noff, const int64_t* e
                        void* x, int64_t* batch, int32_t* rowptr, int32_t* src, int32_t* tgt, float* ew, float* dn,
                        float* y, int B, int F, int T, int target_index, int dtype, mdlStream_t stream);
 
+/* ---- K7: NNConv edge contraction without the E x C x C weight tensor --------------------------------------------------
+ * torch_geometric.nn.NNConv(in, out, nn, aggr) at matdeeplearn/models/mpnn.py:83-88,148-157: m_e = x_j^T reshape(nn(e), [Ci, Co]).
+ * With the last layer of `nn` = Linear(D3, Ci*Co) (weight W2, bias b2) the product is re-associated as
+ *     m_e = Y_j (Co x D3) . h_e + Z_j,   Y = x @ W2.view(Ci, Co*D3),  Z = x @ b2.view(Ci, Co),  h_e = nn[:-1](e)
+ * (two dense GEMMs over the NODES, done by the caller) and these kernels do the per-edge part, walking the edges BY SOURCE:
+ *     fwd: m[eid, :]  = Y[j] . h[eid, :]                         for every slot s in [rowptr_s[j], rowptr_s[j+1]), eid = eid_s[s]
+ *     bwd: dh[eid, :] = Y[j]^T . dm[eid, :];   dY[j] = sum_s dm[eid] (x) h[eid]    (dY rows of nodes without out-edges = 0)
+ * Y, dY: [N, Co*D3]; h, dh: [E, D3]; m, dm: [E, Co]; all `dtype` (fp32 accumulation); eid_s may be NULL (slot = edge id). */
+int mdl_nnconv_msg_fwd(const void* Y, const void* h, const int32_t* rowptr_s, const int32_t* eid_s, void* m, int64_t N,
+                       int Co, int D3, int dtype, mdlStream_t stream);
+int mdl_nnconv_msg_bwd(const void* Y, const void* h, const void* dm, const int32_t* rowptr_s, const int32_t* eid_s,
+                       void* dh, void* dY, int64_t N, int Co, int D3, int dtype, mdlStream_t stream);
+
 /* Tail of a padded static batch (buffers sized for n_cap nodes, the batch fills the first N = noff[B], read on the device):
  * padding nodes get rowptr = E (no edges) and batch = B (a dummy graph).  Part of the HIP-graph replay path. */
 int mdl_pad_batch_tail(const int64_t* noff, const int64_t* eoff, int B, int64_t n_cap, int32_t* rowptr, int64_t* batch,

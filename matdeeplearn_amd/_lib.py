@@ -34,6 +34,8 @@ PROTOTYPES = {
     "mdl_cgconv_pack_node_weights": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "mdl_cgconv_assemble_grads": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mdl_assemble_batch": (_i32, [_vp] * 20 + [_i32, _i32, _i32, _i32, _i32, _vp]),
+    "mdl_nnconv_msg_fwd": (_i32, [_vp] * 5 + [_i64, _i32, _i32, _i32, _vp]),
+    "mdl_nnconv_msg_bwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _vp]),
     "mdl_pad_batch_tail": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "mdl_bn_sums_rows": (_i32, []),
     "mdl_bn_stats_n": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp]),

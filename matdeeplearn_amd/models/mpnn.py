@@ -25,12 +25,12 @@ class MPNN(GraphModel):
 
     def forward(self, data):
         x, edge_attr, csr = self._inputs(data)
-        out = self._pre(x.float())          # NNConv / GRU run in fp32 (library kernels)
-        edge_attr = edge_attr.float()
-        h = out.unsqueeze(0)
+        cd = self.compute_dtype
+        out = self._pre(x)                  # NNConv (K7) + BatchNorm in the compute dtype; the GRU (library) in fp32
+        h = out.float().unsqueeze(0)
         for i, conv in enumerate(self.conv_list):
             m = self._bn(i, conv(out, None, edge_attr, csr=csr))
             m = self._drop(getattr(F, self.act)(m))
-            out, h = self.gru_list[i](m.unsqueeze(0), h)
-            out = out.squeeze(0)
+            out32, h = self.gru_list[i](m.float().unsqueeze(0), h)
+            out = out32.squeeze(0).to(cd)
         return self._head(out, data)

@@ -155,9 +155,12 @@ class GCNConv(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
-# NNConv(aggr="mean") — mpnn.py:83-88,148-157 (A.4).  The per-edge C x C weight is produced and
-# consumed chunk by chunk (library GEMMs) so that the E x C^2 tensor of the reference never exists;
-# gather / mean-aggregation run on the HIP kernels.
+# NNConv(aggr="mean") — mpnn.py:83-88,148-157 (A.4).  K7: with the last layer of the edge network a
+# Linear(d3, C_in*C_out) the message is re-associated as m_e = Y[src_e] . h_e + Z[src_e] with
+# Y = x @ W2.view(C_in, C_out*d3), Z = x @ b2.view(C_in, C_out) (two dense GEMMs over the nodes) and the
+# per-edge mat-vec runs in csrc/nnconv.hip: neither the E x C^2 tensor of the reference nor per-edge
+# C x C GEMMs exist (2 MFLOP -> 20 kFLOP per edge at C = d3 = 100).  Other edge networks fall back to
+# chunked per-edge GEMMs.
 # ------------------------------------------------------------------------------------------------
 class NNConv(nn.Module):
     def __init__(self, in_channels, out_channels, nn_module, aggr="add", root_weight=True, bias=True, chunk=32768):
@@ -181,10 +184,35 @@ class NNConv(nn.Module):
         w = self.nn(edge_attr).view(-1, self.in_channels, self.out_channels)
         return torch.bmm(xj.unsqueeze(1), w).squeeze(1)
 
+    def _last_linear(self):
+        """The edge network's last layer if it is the Linear(d3, C_in*C_out) the re-association needs, else None."""
+        last = self.nn[-1] if isinstance(self.nn, nn.Sequential) and len(self.nn) > 0 else None
+        if isinstance(last, nn.Linear) and last.out_features == self.in_channels * self.out_channels:
+            return last
+        return None
+
     def forward(self, x, edge_index, edge_attr, csr=None):
         from torch.utils.checkpoint import checkpoint
         if csr is None:
             csr = ops.csr_for(edge_index, x.shape[0])
+        last = self._last_linear()
+        ci, co = self.in_channels, self.out_channels
+        if last is not None and (co * (last.in_features + 1) + last.in_features + co) * 4 <= 160 * 1024:
+            hdn = edge_attr
+            for mod in list(self.nn)[:-1]:
+                hdn = _lin(mod, hdn) if isinstance(mod, nn.Linear) else mod(hdn)
+            d3 = last.in_features
+            w2 = last.weight.view(ci, co * d3).to(x.dtype)
+            Y = x @ w2                                                    # [N, C_out*d3]: the only large dense product
+            m = ops.nnconv_msg(Y, hdn.to(x.dtype), csr, co)
+            if last.bias is not None:
+                m = m + ops.gather(x @ last.bias.view(ci, co).to(x.dtype), csr.row)
+            out = ops.scatter(m, csr.col, 0, x.shape[0], self.aggr)
+            if self.lin is not None:
+                out = out + _lin(self.lin, x)
+            if self.bias is not None:
+                out = out + self.bias.to(out.dtype)
+            return out
         xj = ops.gather(x, csr.row)                                   # caller's edge order
         parts = []
         for s in range(0, csr.E, self.chunk):

@@ -588,6 +588,44 @@ def gather_mul_reduce(h, csr, w=None, scale=None, reduce="sum"):
 
 
 # ------------------------------------------------------------------------------------------------
+# K7 — NNConv edge contraction  m_e = Y[src_e] (Co x D3) . h_e   (csrc/nnconv.hip)
+# ------------------------------------------------------------------------------------------------
+class _NNConvMsg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Y, h, csr, Co, D3):
+        require_hip(Y, h)
+        if Y.dtype != h.dtype:
+            raise MdlError("nnconv_msg: Y (%s) and h (%s) must share a dtype" % (Y.dtype, h.dtype))
+        Y, h = Y.contiguous(), h.contiguous()
+        rowptr_s, _, eid_s, _ = csr.transposed()
+        m = torch.empty((csr.E, Co), dtype=Y.dtype, device=Y.device)
+        check(lib().mdl_nnconv_msg_fwd(ptr(Y), ptr(h), ptr(rowptr_s), ptr(eid_s), ptr(m), csr.N, Co, D3, dtype_code(Y),
+                                       stream()), "mdl_nnconv_msg_fwd")
+        ctx.csr, ctx.dims = csr, (Co, D3)
+        ctx.save_for_backward(Y, h)
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        Y, h = ctx.saved_tensors
+        Co, D3 = ctx.dims
+        rowptr_s, _, eid_s, _ = ctx.csr.transposed()
+        dm = dm.contiguous()
+        dh, dY = torch.empty_like(h), torch.empty_like(Y)
+        check(lib().mdl_nnconv_msg_bwd(ptr(Y), ptr(h), ptr(dm), ptr(rowptr_s), ptr(eid_s), ptr(dh), ptr(dY), ctx.csr.N, Co,
+                                       D3, dtype_code(Y), stream()), "mdl_nnconv_msg_bwd")
+        return dY, dh, None, None, None
+
+
+def nnconv_msg(Y, h, csr, out_channels):
+    """m[e] = Y[src_e].view(Co, D3) @ h[e]  (caller's edge order): Y [N, Co*D3], h [E, D3] -> [E, Co]."""
+    D3 = h.shape[1]
+    if Y.shape[1] != out_channels * D3:
+        raise MdlError("nnconv_msg: Y has %d columns, expected %d x %d" % (Y.shape[1], out_channels, D3))
+    return _NNConvMsg.apply(Y, h, csr, int(out_channels), int(D3))
+
+
+# ------------------------------------------------------------------------------------------------
 # dense Linear on many rows (nodes / graphs): library GEMMs for the forward and dX, the tall-skinny TN HIP
 # GEMM for the weight gradient — dW = g^T x contracts over the ROWS (2e5 nodes, 8192 graphs), a shape the
 # library handles badly (47 us for a 64 x 64 x 8192 product, 0.7 ms for 64 x 114 x 2e5)

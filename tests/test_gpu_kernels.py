@@ -274,6 +274,41 @@ def test_cgconv_saved_gate_pair_matches_recompute_through_the_c_abi(C):
         close(a, b, 2e-2, 1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,Ci,Co,D3", [(300, 100, 100, 100), (57, 24, 24, 16), (40, 20, 36, 50)])
+def test_nnconv_contraction_matches_oracle(dtype, n, Ci, Co, D3):
+    """K7 through nn.NNConv (Y = x W2r per node, per-edge mat-vec by source) against the oracle's NNConv, which builds the
+    per-edge Ci x Co matrices like the reference does: output and every gradient (x, edge network, root weight, bias)."""
+    from matdeeplearn_amd import nn as pnn
+    g = torch.Generator().manual_seed(n + Ci)
+    ei = rand_graph(n, n + Co, sort=False, empty_frac=0.15)
+    E = ei.shape[1]
+    torch.manual_seed(n)
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(50, D3), torch.nn.ReLU(), torch.nn.Linear(D3, Ci * Co))
+    oc = oops.NNConv(Ci, Co, mk(), aggr="mean")
+    with torch.no_grad():
+        for p in oc.parameters():
+            p.copy_((p * (1.0 if p.dim() > 1 else 1.0) + (0.05 * torch.randn(p.shape, generator=g) if p.dim() == 1 else 0)).to(dtype).float())
+    pc = pnn.NNConv(Ci, Co, mk(), aggr="mean")
+    pc.load_state_dict(oc.state_dict())
+    pc.to(dev())
+    x = torch.randn(n, Ci, generator=g).to(dtype).float()
+    ea = torch.rand(E, 50, generator=g).to(dtype).float()
+    gout = torch.randn(n, Co, generator=g)
+    xo = x.clone().requires_grad_(True)
+    ref = oc(xo, ei, ea)
+    (ref * gout).sum().backward()
+    xd = x.to(dev()).to(dtype).requires_grad_(True)
+    out = pc(xd, ei.to(dev()), ea.to(dev()).to(dtype))
+    (out.float() * gout.to(dev())).sum().backward()
+    tol = (1e-4, 1e-4) if dtype == torch.float32 else (4e-2, 4e-2)
+    close(out, ref, *tol)
+    close(xd.grad, xo.grad, *tol)
+    og = dict(oc.named_parameters())
+    for k, p in pc.named_parameters():
+        close(p.grad, og[k].grad, *tol)
+
+
 def test_buffer_stores_past_the_last_row_are_dropped():
     """Kernels that end a row range with range-checked buffer stores (dense-layer forward, node-level backward, the gate
     factors of the training forward) must not touch memory behind their outputs when the row count is not a multiple of
