@@ -164,6 +164,15 @@ int mdl_assemble_batch(const int64_t* ids, const int64_t* noff, const int64_t* e
                        void* x, int64_t* batch, int32_t* rowptr, int32_t* src, int32_t* tgt, float* ew, float* dn,
                        float* y, int B, int F, int T, int target_index, int dtype, mdlStream_t stream);
 
+/* ---- K6: dense layer over edge rows with gathered addends (MEGNet edge block, megnet.py:41-56) ----------------------
+ *     out[e, :] = act( x[e, :] W^T + bias + p1[idx1[e], :] + p2[idx2[e], :] + p3[idx3[e], :] )        bf16, act 0 none / 1 relu
+ * x: [N, K] (the edge state), W: [M, K], p_i: [rows_i, M] per-node / per-graph projections of the OTHER column blocks of
+ * the reference's concatenated input [x[row] | x[col] | e | u[batch]] (any p_i may be NULL).  The [E, 4d] concatenation and
+ * its K = 4d product never exist.  Same shape limits as mdl_linear_act (even 4 <= K <= 256, M <= 128). */
+int mdl_linear_gather_act(const void* x, const void* w, const void* bias, const void* p1, const int32_t* idx1,
+                          const void* p2, const int32_t* idx2, const void* p3, const int32_t* idx3, void* out,
+                          int64_t N, int K, int M, int act, int dtype, mdlStream_t stream);
+
 /* ---- K7: NNConv edge contraction without the E x C x C weight tensor --------------------------------------------------
  * torch_geometric.nn.NNConv(in, out, nn, aggr) at matdeeplearn/models/mpnn.py:83-88,148-157: m_e = x_j^T reshape(nn(e), [Ci, Co]).
  * With the last layer of `nn` = Linear(D3, Ci*Co) (weight W2, bias b2) the product is re-associated as

@@ -15,10 +15,22 @@ namespace mdl {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_l;
 
-template <int KP, int NT>     // KP: K padded to {64, 128, 256}; NT: 32-column tiles of the output (M <= 32*NT)
+// K6 (MEGNet edge / node blocks, megnet.py:41-56,84-101): the first layer of those MLPs acts on a concatenation of
+// GATHERED rows — [x[row] | x[col] | e | u[batch]] — which the reference materialises as an [E, 4d] tensor.  Split by
+// column blocks of the weight, W [x[row] | x[col] | e | u[b]]^T = e Wc^T + (x Wa^T)[row] + (x Wb^T)[col] + (u Wd^T + b)[b]:
+// three small per-node / per-graph projections (done by the caller) and ONE streaming GEMM over the edge state, whose
+// epilogue adds the three gathered projection rows before the activation.  The concatenation never exists and the dense
+// product shrinks from K = 4d to K = d.
+struct GatherAdd {
+    const bf16_t* p[3];        // projection tables [rows_i, M] (NULL = unused)
+    const int32_t* idx[3];     // row of table i for every row of x
+};
+
+template <int KP, int NT, bool GATHER = false>     // KP: K padded to {64, 128, 256}; NT: 32-column tiles of the output (M <= 32*NT)
 __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
-                                                            int64_t N, int K, int M, int act, unsigned inv_k2) {
+                                                            int64_t N, int K, int M, int act, unsigned inv_k2,
+                                                            GatherAdd ga) {
     constexpr int TN = 64;
     constexpr int LD = KP + 8;                       // LDS row stride (bf16): odd number of 16-byte slots
     constexpr int NLX = KP * 8 / 256;                // 16-byte chunks of the x tile per thread (tile = 64 rows x K, K <= KP)
@@ -94,6 +106,25 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
                 }
                 const int col = nt * 32 + i;
                 const int64_t remr = N - nb - mt * 32;                    // rows of this block that exist
+                if constexpr (GATHER) {
+                    // + the gathered projection rows (clamped row index: rows past N are computed on a valid row and then
+                    // dropped by the store's range check).  All index loads first, then all table loads: two round trips.
+                    const int colc = min(col, M - 1);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        if (ga.p[t]) {
+                            int id[16];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                id[r] = ga.idx[t][min(nb + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, N - 1)];
+                            float v[16];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) v[r] = bf2f(ga.p[t][(int64_t)id[r] * M + colc]);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[r] += v[r];
+                        }
+                    }
+                }
                 if (col < M && remr > 0) {
                     const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
                         out + (nb + mt * 32) * (int64_t)M, 0,
@@ -115,8 +146,17 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
 
 extern "C" int mdl_linear_act(const void* x, const void* w, const void* bias, void* out, int64_t N, int K, int M, int act,
                               int dtype, mdlStream_t stream) {
+    return mdl_linear_gather_act(x, w, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out, N, K, M, act, dtype, stream);
+}
+
+extern "C" int mdl_linear_gather_act(const void* x, const void* w, const void* bias, const void* p1, const int32_t* idx1,
+                                     const void* p2, const int32_t* idx2, const void* p3, const int32_t* idx3, void* out,
+                                     int64_t N, int K, int M, int act, int dtype, mdlStream_t stream) {
     using namespace mdl;
     MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_linear_act: bf16 only");
+    MDL_REQUIRE((!p1 || idx1) && (!p2 || idx2) && (!p3 || idx3), MDL_E_ARG, "mdl_linear_gather_act: table without index");
+    const bool gather = p1 || p2 || p3;
+    GatherAdd ga = {{(const bf16_t*)p1, (const bf16_t*)p2, (const bf16_t*)p3}, {idx1, idx2, idx3}};
     MDL_REQUIRE(K >= 4 && K <= 256 && K % 2 == 0 && M >= 1 && M <= 128, MDL_E_UNSUPP,
                 "mdl_linear_act: need even 4<=K<=256 and 1<=M<=128 (got K=%d M=%d)", K, M);
     MDL_REQUIRE(act == 0 || act == 1, MDL_E_ARG, "mdl_linear_act: act must be 0 (none) or 1 (relu)");
@@ -134,10 +174,17 @@ extern "C" int mdl_linear_act(const void* x, const void* w, const void* bias, vo
     const int lds = (32 * nt + 64) * (kp + 8) * 2;
 #define MDL_LIN(KP_, NT_)                                                                                            \
     do {                                                                                                             \
-        auto kf = linear_act_kernel<KP_, NT_>;                                                                       \
-        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds); \
-        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
-                           (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, inv_k2);                                 \
+        if (gather) {                                                                                                \
+            auto kf = linear_act_kernel<KP_, NT_, true>;                                                             \
+            (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                       \
+            hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,     \
+                               (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, inv_k2, ga);                         \
+        } else {                                                                                                     \
+            auto kf = linear_act_kernel<KP_, NT_, false>;                                                            \
+            (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                       \
+            hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,     \
+                               (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, inv_k2, GatherAdd{});                \
+        }                                                                                                            \
     } while (0)
     if (kp == 64) { if (nt == 1) MDL_LIN(64, 1); else if (nt == 2) MDL_LIN(64, 2); else MDL_LIN(64, 4); }
     else if (kp == 128) { if (nt == 1) MDL_LIN(128, 1); else if (nt == 2) MDL_LIN(128, 2); else MDL_LIN(128, 4); }

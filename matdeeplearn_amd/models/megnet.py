@@ -2,14 +2,18 @@
 (:16-56, :59-101, :104-147): Linear -> act -> BatchNorm1d -> dropout (act BEFORE BN), scatter_mean of
 the edge state at the SOURCE row (:86,130), MetaLayer wiring (:235-253), residual rule (first layer adds
 the embedded inputs, later layers the running state, :313-336), 3-way pooling [x | e | u] (:339-349).
-Gathers and scatters run on the HIP kernels; the MLPs are library GEMMs."""
+Gathers and scatters run on the HIP kernels.  In bf16 mode every Linear is the streaming HIP dense layer (forward) +
+TN GEMM (dW), and the edge block's first layer is K6: the [E, 4d] concatenation [x[row] | x[col] | e | u[batch]] of the
+reference is never built — the weight is split by column blocks into three per-node / per-graph projections and one K = d
+product over the edge state whose epilogue adds the gathered projection rows (csrc/linear.hip).  fp32 (parity) mode keeps
+the reference's formulation on library GEMMs."""
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
 from ..nn import BatchNorm1d, MetaLayer, Set2Set
-from ._base import GraphModel, dense
+from ._base import GraphModel, dense, dense_act
 
 
 class _Mlp(nn.Module):
@@ -22,14 +26,19 @@ class _Mlp(nn.Module):
         self.bn_list = nn.ModuleList(
             [BatchNorm1d(dim, track_running_stats=track) for _ in range(fc_layers + 1)] if batch_norm == "True" else [])
 
-    def run(self, comb):
-        out = comb
-        for i, lin in enumerate(getattr(self, self.list_name)):
-            out = getattr(F, self.act)(dense(lin, out))
+    def _tail(self, out, first):
+        """BatchNorm / dropout of layer `first`, then the remaining Linear -> act -> BatchNorm -> dropout layers."""
+        lins = getattr(self, self.list_name)
+        for i in range(first, len(lins)):
+            if i > first:
+                out = dense_act(lins[i], out, self.act)
             if self.batch_norm == "True":
                 out = self.bn_list[i](out)
             out = F.dropout(out, p=self.dropout_rate, training=self.training)
         return out
+
+    def run(self, comb):
+        return self._tail(dense_act(getattr(self, self.list_name)[0], comb, self.act), 0)
 
 
 class Megnet_EdgeModel(_Mlp):
@@ -38,6 +47,23 @@ class Megnet_EdgeModel(_Mlp):
 
     def forward(self, src, dest, edge_attr, u, batch):
         return self.run(torch.cat([src, dest, edge_attr, ops.gather(u, batch)], dim=1))
+
+    def fused_ok(self, x, edge_attr):
+        d = self.edge_mlp[0].out_features
+        return (edge_attr.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and self.act == "relu" and d <= 128
+                and d % 2 == 0 and edge_attr.is_contiguous() and edge_attr.data_ptr() % 16 == 0)
+
+    def forward_fused(self, x, row, col, edge_attr, u, batch_e):
+        """K6: same function as forward(x[row], x[col], edge_attr, u, batch_e) without the gathers and the concatenation."""
+        lin = self.edge_mlp[0]
+        d = lin.out_features
+        cd = x.dtype
+        wa, wb, wc, wd = (lin.weight[:, k * d:(k + 1) * d] for k in range(4))       # column blocks: src | dest | e | u
+        p_src = F.linear(x, wa.to(cd))                                              # [N, d] per-node projections
+        p_dst = F.linear(x, wb.to(cd))
+        p_glb = F.linear(u, wd.to(cd), None if lin.bias is None else lin.bias.to(cd))  # [B, d] per graph (+ bias)
+        out = ops.linear_gather_act(edge_attr, wc, None, self.act, [(p_src, row), (p_dst, col), (p_glb, batch_e)])
+        return self._tail(out, 0)
 
 
 class Megnet_NodeModel(_Mlp):
@@ -64,6 +90,36 @@ def _embed(i, d):
     return nn.Sequential(nn.Linear(i, d), nn.ReLU(), nn.Linear(d, d), nn.ReLU())
 
 
+def _run_embed(seq, h):
+    """Sequential(Linear, ReLU, Linear, ReLU) (megnet.py:222-247) with each Linear + ReLU pair as one fused dense layer."""
+    mods = list(seq)
+    k = 0
+    while k < len(mods):
+        if isinstance(mods[k], nn.Linear) and k + 1 < len(mods) and isinstance(mods[k + 1], nn.ReLU):
+            h = dense_act(mods[k], h, "relu")
+            k += 2
+        else:
+            h = dense(mods[k], h) if isinstance(mods[k], nn.Linear) else mods[k](h)
+            k += 1
+    return h
+
+
+class _FusedMetaLayer(MetaLayer):
+    """MetaLayer (megnet.py:235-253) that hands the edge model the UNGATHERED node state when it can fuse the gathers."""
+
+    def forward(self, x, edge_index, edge_attr=None, u=None, batch=None, idx=None):
+        em = self.edge_model
+        if idx is not None and em is not None and hasattr(em, "forward_fused") and em.fused_ok(x, edge_attr):
+            row32, col32, be32 = idx
+            edge_attr = em.forward_fused(x, row32, col32, edge_attr, u, be32)
+            if self.node_model is not None:
+                x = self.node_model(x, edge_index, edge_attr, u, batch)
+            if self.global_model is not None:
+                u = self.global_model(x, edge_index, edge_attr, u, batch)
+            return x, edge_attr, u
+        return super().forward(x, edge_index, edge_attr, u, batch)
+
+
 class MEGNet(GraphModel):
     def __init__(self, data, dim1=64, dim2=64, dim3=64, pre_fc_count=1, gc_count=3, gc_fc_count=2,
                  post_fc_count=1, pool="global_mean_pool", pool_order="early", batch_norm="True",
@@ -78,7 +134,7 @@ class MEGNet(GraphModel):
             self.x_embed_list.append(_embed(self.gc_dim if i == 0 else dim3, dim3))
             self.u_embed_list.append(_embed(data[0].u.shape[1] if i == 0 else dim3, dim3))
             args = (dim3, act, batch_norm, batch_track_stats, dropout_rate, gc_fc_count)
-            self.conv_list.append(MetaLayer(Megnet_EdgeModel(*args), Megnet_NodeModel(*args), Megnet_GlobalModel(*args)))
+            self.conv_list.append(_FusedMetaLayer(Megnet_EdgeModel(*args), Megnet_NodeModel(*args), Megnet_GlobalModel(*args)))
         self._finish(dim2, post_fc_count, dim3, early_mult=3, set2set_names=("set2set_x", "set2set_e"))
 
     def forward(self, data):
@@ -86,12 +142,16 @@ class MEGNet(GraphModel):
         out = self._pre(data.x.to(cd))
         ei = data.edge_index
         nb = getattr(data, "num_graphs", None) or data.u.shape[0]
+        idx = None
+        if cd == torch.bfloat16:                     # int32 gather indices of the fused edge block, once per batch
+            row, col = ei[0], ei[1]
+            idx = (row.to(torch.int32), col.to(torch.int32), data.batch.index_select(0, row).to(torch.int32))
         x = e = u = None
         for i, conv in enumerate(self.conv_list):
-            e_t = self.e_embed_list[i](data.edge_attr.float() if i == 0 else e)
-            x_t = self.x_embed_list[i](out.float() if i == 0 else x)
-            u_t = self.u_embed_list[i](data.u.float() if i == 0 else u)
-            x_o, e_o, u_o = conv(x_t, ei, e_t, u_t, data.batch)
+            e_t = _run_embed(self.e_embed_list[i], data.edge_attr.to(cd) if i == 0 else e)
+            x_t = _run_embed(self.x_embed_list[i], out if i == 0 else x)
+            u_t = _run_embed(self.u_embed_list[i], data.u.to(cd) if i == 0 else u)
+            x_o, e_o, u_o = conv(x_t, ei, e_t, u_t, data.batch, idx=idx)
             if i == 0:
                 x, e, u = x_o + x_t, e_o + e_t, u_o + u_t
             else:

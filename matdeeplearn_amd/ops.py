@@ -700,6 +700,56 @@ class _LinearActTN(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class _LinearGatherAct(torch.autograd.Function):
+    """K6: act(x W^T + bias + sum_i p_i[idx_i]) in one streaming HIP kernel; backward = masked gradient -> library dX,
+    TN GEMM for dW (+ db), segmented sums of the gradient rows for the gathered tables."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, idx, *tables):
+        w = weight.to(x.dtype)
+        b = None if bias is None else bias.to(x.dtype)
+        N, K = x.shape
+        M = weight.shape[0]
+        tabs = [None if t is None else t.contiguous() for t in tables]
+        tabs += [None] * (3 - len(tabs))
+        ids = list(idx) + [None] * (3 - len(idx))
+        out = torch.empty((N, M), dtype=x.dtype, device=x.device)
+        check(lib().mdl_linear_gather_act(ptr(x), ptr(w), ptr(b), ptr(tabs[0]), ptr(ids[0]), ptr(tabs[1]), ptr(ids[1]),
+                                          ptr(tabs[2]), ptr(ids[2]), ptr(out), N, K, M, 1 if act == "relu" else 0,
+                                          dtype_code(x), stream()), "mdl_linear_gather_act")
+        ctx.save_for_backward(x, w, out if act == "relu" else None)
+        ctx.idx, ctx.rows = ids, [None if t is None else t.shape[0] for t in tabs]
+        ctx.wdtype, ctx.has_bias, ctx.shape, ctx.act, ctx.ntab = weight.dtype, bias is not None, tuple(weight.shape), act, len(tables)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, out = ctx.saved_tensors
+        if ctx.act == "relu":
+            g = torch.ops.aten.threshold_backward(g, out, 0)
+        g = g.contiguous()
+        dx, dw, db = _linear_tn_grads(ctx, g, x, w)
+        dts = []
+        for t in range(ctx.ntab):
+            need = ctx.needs_input_grad[5 + t] and ctx.rows[t] is not None
+            dts.append(scatter(g, ctx.idx[t], 0, ctx.rows[t], "sum") if need else None)
+        return (dx, dw, db, None, None) + tuple(dts)
+
+
+def linear_gather_act(x, weight, bias, act, gathered):
+    """act(x W^T + bias + sum_i table_i[index_i]) for bf16 rows; `gathered` = [(table [rows, M], index [N] int), ...] (<= 3)."""
+    ok = (act in ("relu", None) and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
+          and weight.shape[0] <= 128 and 4 <= weight.shape[1] <= 256 and weight.shape[1] % 2 == 0 and x.data_ptr() % 16 == 0
+          and len(gathered) <= 3 and x.shape[0] > 0)
+    if not ok:
+        y = linear(x, weight, bias)
+        for tab, ix in gathered:
+            y = y + gather(tab, ix)
+        return y if act is None else getattr(torch.nn.functional, act)(y)
+    idx = [ix if ix.dtype == torch.int32 else ix.to(torch.int32) for _, ix in gathered]
+    return _LinearGatherAct.apply(x, weight, bias, act, idx, *[t.to(x.dtype) for t, _ in gathered])
+
+
 def linear_act(x, weight, bias, act, lowp=None):
     """getattr(F, act)(F.linear(x, weight, bias)) — fused forward for bf16 inputs with dense rows, even in <= 256,
     out <= 128 and act in (relu, none); anything else composes `linear` with the library activation."""

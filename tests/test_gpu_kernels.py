@@ -309,6 +309,44 @@ def test_nnconv_contraction_matches_oracle(dtype, n, Ci, Co, D3):
         close(p.grad, og[k].grad, *tol)
 
 
+@pytest.mark.parametrize("E,d", [(5003, 100), (1500, 64), (70, 24)])
+def test_megnet_edge_block_first_layer_without_concatenation(E, d):
+    """K6 (ops.linear_gather_act) against the reference's formulation relu(Linear(cat[x[row], x[col], e, u[b]])) in fp32 on
+    bf16-rounded operands: output and the gradients w.r.t. the edge state, the node state, u, weight and bias."""
+    from matdeeplearn_amd import ops
+    d_ = dev()
+    g = torch.Generator().manual_seed(E + d)
+    N, B = 301, 17
+    row = torch.randint(0, N, (E,), generator=g)
+    col = torch.sort(torch.randint(0, N, (E,), generator=g)).values
+    be = torch.sort(torch.randint(0, B, (E,), generator=g)).values
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x, e, u = bf(torch.randn(N, d, generator=g)), bf(torch.randn(E, d, generator=g)), bf(torch.randn(B, d, generator=g))
+    W, b = bf(torch.randn(d, 4 * d, generator=g) / (4 * d) ** 0.5), bf(torch.randn(d, generator=g) * 0.1)
+    gout = torch.randn(E, d, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x, e, u, W, b)]
+    xo, eo, uo, Wo, bo = leaves
+    pre = torch.nn.functional.linear(torch.cat([xo[row], xo[col], eo, uo[be]], 1), Wo, bo)
+    # relu' jumps at 0: a pre-activation within bf16 rounding of the kink flips its mask and moves a gradient by a whole
+    # |gout| — not a kernel property.  The upstream gradient is therefore switched off in a band around the kink.
+    gout = gout * (pre.detach().abs() > 0.05)
+    ref = torch.relu(pre)
+    (ref * gout).sum().backward()
+    xd, ed, ud = [t.to(d_).to(torch.bfloat16).requires_grad_(True) for t in (x, e, u)]
+    Wd, bd = W.to(d_).requires_grad_(True), b.to(d_).requires_grad_(True)
+    cd = torch.bfloat16
+    wa, wb, wc, wdd = (Wd[:, k * d:(k + 1) * d] for k in range(4))
+    p1 = torch.nn.functional.linear(xd, wa.to(cd))
+    p2 = torch.nn.functional.linear(xd, wb.to(cd))
+    p3 = torch.nn.functional.linear(ud, wdd.to(cd), bd.to(cd))
+    out = ops.linear_gather_act(ed, wc, None, "relu", [(p1, row.to(d_).int()), (p2, col.to(d_).int()), (p3, be.to(d_).int())])
+    assert out.dtype == torch.bfloat16
+    (out.float() * gout.to(d_)).sum().backward()
+    close(out, ref, 3e-2, 3e-2)
+    for a, r in ((xd, xo), (ed, eo), (ud, uo), (Wd, Wo), (bd, bo)):
+        close(a.grad, r.grad, 4e-2, 4e-2)
+
+
 def test_buffer_stores_past_the_last_row_are_dropped():
     """Kernels that end a row range with range-checked buffer stores (dense-layer forward, node-level backward, the gate
     factors of the training forward) must not touch memory behind their outputs when the row count is not a multiple of
