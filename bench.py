@@ -141,7 +141,7 @@ def main():
     dp = FlatDataParallel(model)
     opt = make_optimizer(model.parameters(), "AdamW", lr=0.002 * world)   # lr x world_size, training.py:388-389
 
-    ktimes = {"fwd": [], "bwd": []}
+    ktimes = {"cgcnn": {"fwd": [], "bwd": []}, "schnet": {"gmr_fwd": []}, "megnet": {"edge_linear": []}}[args.model]
 
     def make_step(model, dp, opt, dtype):
         pending = {}                                 # ids (bytes) -> batch assembled during the previous step's all-reduce
@@ -208,19 +208,17 @@ def main():
     tot = {k: sum(v) for k, v in dur.items()}
     if args.model == "cgcnn":
         ab_fwd, ab_bwd = algorithmic_bytes(e_step, n_step, mkw["dim1"], G, s)
+        ab = {"fwd": ab_fwd, "bwd": ab_bwd}
         kname = {"fwd": "mdl_cgconv_fwd", "bwd": "mdl_cgconv_bwd"}
-    elif args.model == "schnet":                     # E(G s + 4 + F s + 4) + N(2 F s + 4); bwd adds the dh scatter
-        F, C = mkw["dim3"], mkw["dim1"]
-        ab_fwd = e_step * (G * s + 4 + F * s + 4) + n_step * (2 * F * s + 4)
-        ab_bwd = e_step * (G * s + 4 + 2 * F * s + 4) + n_step * (3 * F * s + 4)
-        kname = {"fwd": "mdl_cfconv_fwd", "bwd": "mdl_cfconv_bwd"}
-    else:                                            # E(d s [e in] + d s [e out] + 2 d s [x rows] + 8)
+    elif args.model == "schnet":                     # K4a (aggregation only): E(2 F s + 8) + N(F s + 4)   (csrc/gather.hip)
+        F_ = mkw["dim3"]
+        ab = {"gmr_fwd": e_step * (2 * F_ * s + 8) + n_step * (F_ * s + 4)}
+        kname = {"gmr_fwd": "mdl_gather_mul_reduce"}
+    else:                                            # K6: E(d s [e in] + d s [out] + 3 d s [gathered rows] + 12)
         d = mkw["dim3"]
-        ab_fwd = e_step * (4 * d * s + 8)
-        ab_bwd = e_step * (4 * d * s + 8 + 2 * d * s)
-        kname = {"fwd": "mdl_edge_linear_fwd", "bwd": "mdl_edge_linear_bwd"}
-    ab = {"fwd": ab_fwd, "bwd": ab_bwd}
-    have = [k for k in ("fwd", "bwd") if dur[k]]
+        ab = {"edge_linear": e_step * (5 * d * s + 12)}
+        kname = {"edge_linear": "mdl_linear_gather_act"}
+    have = [k for k in ab if dur.get(k)]
     dom = max(have, key=lambda k: tot[k]) if have else None
 
     # HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes over tools/bench_kernels.py,
@@ -256,7 +254,7 @@ def main():
                                   args.dtype, gen_name, len(ds), B),
                    "batch_graphs_per_gpu": B, "edges_per_step_per_gpu": int(e_step), "nodes_per_step_per_gpu": int(n_step),
                    "parallelism": "dp%d" % world, "dataset_gen_s": round(gen_s, 1),
-                   "conv_kernel_share_of_step": round((tot["fwd"] + tot["bwd"]) / elapsed, 3)},
+                   "conv_kernel_share_of_step": round(sum(tot.values()) / elapsed, 3)},
     }
     if dom is not None:
         res["roofline"] = roof(dom)

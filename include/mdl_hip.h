@@ -164,11 +164,15 @@ int mdl_assemble_batch(const int64_t* ids, const int64_t* noff, const int64_t* e
                        void* x, int64_t* batch, int32_t* rowptr, int32_t* src, int32_t* tgt, float* ew, float* dn,
                        float* y, int B, int F, int T, int target_index, int dtype, mdlStream_t stream);
 
+/* dx = g * sigmoid(pre) for y = softplus(pre) - ln 2 given y (the SchNet activation; sigmoid(pre) = 1 - exp(-(y + ln 2))): one
+ * bf16 pass instead of six library elementwise launches.  n = number of elements (even). */
+int mdl_ssp_bwd(const void* g, const void* y, void* dx, int64_t n, int dtype, mdlStream_t stream);
+
 /* ---- K6: dense layer over edge rows with gathered addends (MEGNet edge block, megnet.py:41-56) ----------------------
  *     out[e, :] = act( x[e, :] W^T + bias + p1[idx1[e], :] + p2[idx2[e], :] + p3[idx3[e], :] )        bf16, act 0 none / 1 relu
  * x: [N, K] (the edge state), W: [M, K], p_i: [rows_i, M] per-node / per-graph projections of the OTHER column blocks of
  * the reference's concatenated input [x[row] | x[col] | e | u[batch]] (any p_i may be NULL).  The [E, 4d] concatenation and
- * its K = 4d product never exist.  Same shape limits as mdl_linear_act (even 4 <= K <= 256, M <= 128). */
+ * its K = 4d product never exist.  Same shape limits as mdl_linear_act. */
 int mdl_linear_gather_act(const void* x, const void* w, const void* bias, const void* p1, const int32_t* idx1,
                           const void* p2, const int32_t* idx2, const void* p3, const int32_t* idx3, void* out,
                           int64_t N, int K, int M, int act, int dtype, mdlStream_t stream);
@@ -229,14 +233,15 @@ int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save, float* su
 /* ---- node-level dense layer forward, fused: out[N, M] = act(x[N, K] . w[M, K]^T + bias) ---------------
  * Replaces `getattr(F, act)(lin(out))` of the pre-FC / post-FC loops (matdeeplearn/models/cgcnn.py:124-130,155-166)
  * for the tall-skinny shapes of this path.  x: dense rows (leading dimension K), 16-byte aligned; w [M, K] and bias [M]
- * (may be NULL) in `dtype`; act: 0 = none, 1 = ReLU.  bf16 only, K even, 4 <= K <= 256, M <= 128. */
+ * (may be NULL) in `dtype`; act: 0 = none, 1 = ReLU, 2 = shifted softplus (softplus(v) - ln 2, the SchNet filter
+ * activation).  bf16 only, K even, 4 <= K <= 256, M <= 128 — or M <= 160 with K <= 160 (SchNet's 150-wide filters). */
 int mdl_linear_act(const void* x, const void* w, const void* bias, void* out, int64_t N, int K, int M, int act, int dtype,
                    mdlStream_t stream);
 
 /* ---- tall-skinny TN GEMM: weight gradients of node-level Linear layers ---------------------------
  * c[M, K] (fp32, row-major, caller zero-fills) += a[N, M]^T . b[N, K]   a, b bf16 with leading dims lda, ldb.
  * Replaces the (out x N)(N x in) product autograd forms for dW of the reference's node-level Linears
- * (e.g. pre_lin_list, matdeeplearn/models/cgcnn.py:64-74,124-130).  1 <= M <= 128, 1 <= K <= 256, bf16 only. */
+ * (e.g. pre_lin_list, matdeeplearn/models/cgcnn.py:64-74,124-130).  1 <= M <= 128, 1 <= K <= 256 (or even M <= 160, K <= 160), bf16 only. */
 int mdl_gemm_tn(const void* a, int64_t lda, int M, const void* b, int64_t ldb, int K, float* c, int64_t N, int dtype,
                 mdlStream_t stream);
 /* same, plus colsum[M] (fp32, caller zero-fills) += column sums of a — the bias gradient of that Linear

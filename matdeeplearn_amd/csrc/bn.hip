@@ -34,24 +34,24 @@ __device__ __forceinline__ void bn_totals(const float* __restrict__ sums, float*
 
 // Block = 256 threads = (256 / CG) row lanes x CG channel groups of W channels (CG = C / W).
 // MODE 0: forward stats of x.  MODE 1: backward stats (a = dy, b = x).
-template <typename T, int MODE>
+template <typename T, int MODE, int W>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                         const float* __restrict__ save, float* __restrict__ sums,
                                                         int64_t Ncap, int C, const int64_t* __restrict__ n_dev) {
-    constexpr int W = Vec<T>::W;
+    typedef VecW<T, W> V;
     // rows that exist: all Ncap of them, or the device-side count of a padded static batch (HIP-graph replays: the
     // launch arguments are frozen at capture, the true row count changes with every batch)
     const int64_t N = n_dev ? max((int64_t)1, min(*n_dev, Ncap)) : Ncap;
     __shared__ float red[2][256 * 8 / 8 * 8];   // 2 x 256 x W floats max (W <= 8)
     const int CG = C / W;
-    const int rows_per_block = 256 / CG;
+    const int rows_per_block = (int)blockDim.x / CG;          // blockDim = rows_per_block * CG (<= 256)
     const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
     const bool active = rl < rows_per_block;
     float s0[W], s1[W], p0[W], p1[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) { s0[j] = 0.0f; s1[j] = 0.0f; }
     if (MODE == 0) {
-        Vec<T>::ld(a + cg * W, p0);                           // shift = first row
+        V::ld(a + cg * W, p0);                           // shift = first row
     } else {
 #pragma unroll
         for (int j = 0; j < W; ++j) { p0[j] = save[cg * W + j]; p1[j] = save[C + cg * W + j]; }   // mean, invstd
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ a,
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t n = min(n0 + u * stride, N - 1);
-                Vec<T>::ld(a + n * C + cg * W, va[u]);
-                if (MODE != 0) Vec<T>::ld(b + n * C + cg * W, vb[u]);
+                V::ld(a + n * C + cg * W, va[u]);
+                if (MODE != 0) V::ld(b + n * C + cg * W, vb[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -98,13 +98,13 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ a,
     }
 }
 
-template <typename T>
+template <typename T, int W>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, float* __restrict__ sums,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ save, float* __restrict__ run_mean,
                                                        float* __restrict__ run_var, T* __restrict__ y, int64_t Ncap, int C,
                                                        float eps, float momentum, const int64_t* __restrict__ n_dev) {
-    constexpr int W = Vec<T>::W;
+    typedef VecW<T, W> V;
     constexpr int U = 4;                                     // four independent 16-byte loads in flight per thread
     const int64_t N = n_dev ? max((int64_t)1, min(*n_dev, Ncap)) : Ncap;
     __shared__ float tot[512];
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     // a chain of dependent loads, and a block streams only a few rows per thread — back to back they double its time
     float v[U][W];
 #pragma unroll
-    for (int u = 0; u < U; ++u) Vec<T>::ld(x + (min(q0 + u * stride, total - 1) / CG) * C + cg * W, v[u]);
+    for (int u = 0; u < U; ++u) V::ld(x + (min(q0 + u * stride, total - 1) / CG) * C + cg * W, v[u]);
     float mean[W], scale[W], shiftv[W], sh[W];
-    Vec<T>::ld(x + cg * W, sh);
+    V::ld(x + cg * W, sh);
     bn_totals(sums, tot, C, sums + (size_t)BN_R * 2 * C);
     const float invn = 1.0f / (float)N;
 #pragma unroll
@@ -149,12 +149,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
             const int64_t q = q0 + u * stride;
 #pragma unroll
             for (int j = 0; j < W; ++j) v[u][j] = v[u][j] * scale[j] + shiftv[j];
-            if (q < total) Vec<T>::st(y + (q / CG) * C + cg * W, v[u]);
+            if (q < total) V::st(y + (q / CG) * C + cg * W, v[u]);
         }
         q0 += U * stride;
         if (q0 >= total) break;
 #pragma unroll
-        for (int u = 0; u < U; ++u) Vec<T>::ld(x + (min(q0 + u * stride, total - 1) / CG) * C + cg * W, v[u]);
+        for (int u = 0; u < U; ++u) V::ld(x + (min(q0 + u * stride, total - 1) / CG) * C + cg * W, v[u]);
     }
     // padding rows of a static batch: exact zeros (they must not carry anything into the layers behind)
     if (N < Ncap) {
@@ -162,16 +162,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int j = 0; j < W; ++j) z[j] = 0.0f;
         for (int64_t q = total + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < Ncap * CG; q += stride)
-            Vec<T>::st(y + (q / CG) * C + cg * W, z);
+            V::st(y + (q / CG) * C + cg * W, z);
     }
 }
 
-template <typename T>
+template <typename T, int W>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ save, float* __restrict__ sums,
                                                            const float* __restrict__ gamma, T* __restrict__ dx, int64_t Ncap,
                                                            int C, const int64_t* __restrict__ n_dev) {
-    constexpr int W = Vec<T>::W;
+    typedef VecW<T, W> V;
     constexpr int U = 2;
     const int64_t N = n_dev ? max((int64_t)1, min(*n_dev, Ncap)) : Ncap;
     __shared__ float tot[512];
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int u = 0; u < U; ++u) {                              // rows first, statistics second (see bn_apply_kernel)
         const int64_t n = min(q0 + u * stride, total - 1) / CG;
-        Vec<T>::ld(dy + n * C + cg * W, vd[u]);
-        Vec<T>::ld(x + n * C + cg * W, vx[u]);
+        V::ld(dy + n * C + cg * W, vd[u]);
+        V::ld(x + n * C + cg * W, vx[u]);
     }
     bn_totals(sums, tot, C, sums + (size_t)BN_R * 2 * C);
     const float invn = 1.0f / (float)N;
@@ -205,15 +205,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             const int64_t q = q0 + u * stride;
 #pragma unroll
             for (int j = 0; j < W; ++j) vd[u][j] = gs[j] * (vd[u][j] - k0[j] - (vx[u][j] - mean[j]) * istd[j] * k1[j]);
-            if (q < total) Vec<T>::st(dx + (q / CG) * C + cg * W, vd[u]);
+            if (q < total) V::st(dx + (q / CG) * C + cg * W, vd[u]);
         }
         q0 += U * stride;
         if (q0 >= total) break;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t n = min(q0 + u * stride, total - 1) / CG;
-            Vec<T>::ld(dy + n * C + cg * W, vd[u]);
-            Vec<T>::ld(x + n * C + cg * W, vx[u]);
+            V::ld(dy + n * C + cg * W, vd[u]);
+            V::ld(x + n * C + cg * W, vx[u]);
         }
     }
     if (N < Ncap) {                                           // padding rows: no gradient
@@ -221,16 +221,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
         for (int j = 0; j < W; ++j) z[j] = 0.0f;
         for (int64_t q = total + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < Ncap * CG; q += stride)
-            Vec<T>::st(dx + (q / CG) * C + cg * W, z);
+            V::st(dx + (q / CG) * C + cg * W, z);
     }
 }
 
+// vector width: 16 bytes when the channel count allows it (bf16: C % 8), else 4 elements (bf16 C = 100, 150: 8 bytes)
+static int bn_width(int C, int dtype) { return (dtype == MDL_BF16 && C % 8 == 0) ? 8 : 4; }
+// threads per block: a whole number of rows, each CG = C / W lanes wide
+static int bn_threads(int C, int W) { const int cg = C / W; return 256 / cg * cg; }
+
 static int bn_check(const char* name, int64_t N, int C, int dtype, const void* p) {
     MDL_REQUIRE(dtype == MDL_F32 || dtype == MDL_BF16, MDL_E_UNSUPP, "%s: unsupported dtype %d", name, dtype);
-    const int W = dtype == MDL_BF16 ? 8 : 4;
-    MDL_REQUIRE(N >= 1 && C >= W && C % W == 0 && C <= 256 && 256 % (C / W) == 0, MDL_E_UNSUPP,
-                "%s: need N>=1 and C a multiple of %d with 256 %% (C/%d) == 0, C<=256 (got N=%lld C=%d)", name, W, W, (long long)N, C);
-    MDL_REQUIRE(p && reinterpret_cast<uintptr_t>(p) % 16 == 0, MDL_E_ARG, "%s: null or misaligned tensor", name);
+    MDL_REQUIRE(N >= 1 && C >= 4 && C % 4 == 0 && C <= 256, MDL_E_UNSUPP,
+                "%s: need N>=1 and C a multiple of 4, C<=256 (got N=%lld C=%d)", name, (long long)N, C);
+    MDL_REQUIRE(p && reinterpret_cast<uintptr_t>(p) % (bn_width(C, dtype) * (dtype == MDL_BF16 ? 2 : 4)) == 0, MDL_E_ARG,
+                "%s: null or misaligned tensor", name);
     return MDL_OK;
 }
 
@@ -253,8 +258,10 @@ extern "C" int mdl_bn_stats_n(const void* x, float* sums, int64_t N, int C, cons
     int rc = bn_check("mdl_bn_stats", N, C, dtype, x);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), dim3(bn_grid(N, C, 8)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
-    else hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(bn_grid(N, C, 4)), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
+    const int W = bn_width(C, dtype);
+    if (dtype == MDL_BF16 && W == 8) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0, 8>), dim3(bn_grid(N, C, W)), dim3(bn_threads(C, 8)), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
+    else if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0, 4>), dim3(bn_grid(N, C, W)), dim3(bn_threads(C, 4)), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
+    else hipLaunchKernelGGL((bn_reduce_kernel<float, 0, 4>), dim3(bn_grid(N, C, W)), dim3(bn_threads(C, 4)), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
     return check_launch("mdl_bn_stats");
 }
 
@@ -270,12 +277,13 @@ extern "C" int mdl_bn_apply_n(const void* x, float* sums, const float* gamma, co
     int rc = bn_check("mdl_bn_apply", N, C, dtype, x);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int W = dtype == MDL_BF16 ? 8 : 4;
-    int64_t g = cdiv(N * (C / W), 256 * 4);
+    int64_t g = cdiv(N * (C / bn_width(C, dtype)), 256 * 4);
     if (g > 768) g = 768;          // 3 fat blocks per CU: the per-block statistics prologue amortises (measured 512..2048)
     if (g < 1) g = 1;
-    if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)x, sums, gamma, beta, save, running_mean, running_var, (bf16_t*)y, N, C, eps, momentum, n_dev);
-    else hipLaunchKernelGGL((bn_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, (const float*)x, sums, gamma, beta, save, running_mean, running_var, (float*)y, N, C, eps, momentum, n_dev);
+    const int W = bn_width(C, dtype);
+    if (dtype == MDL_BF16 && W == 8) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 8>), dim3((unsigned)g), dim3(bn_threads(C, 8)), 0, st, (const bf16_t*)x, sums, gamma, beta, save, running_mean, running_var, (bf16_t*)y, N, C, eps, momentum, n_dev);
+    else if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 4>), dim3((unsigned)g), dim3(bn_threads(C, 4)), 0, st, (const bf16_t*)x, sums, gamma, beta, save, running_mean, running_var, (bf16_t*)y, N, C, eps, momentum, n_dev);
+    else hipLaunchKernelGGL((bn_apply_kernel<float, 4>), dim3((unsigned)g), dim3(bn_threads(C, 4)), 0, st, (const float*)x, sums, gamma, beta, save, running_mean, running_var, (float*)y, N, C, eps, momentum, n_dev);
     return check_launch("mdl_bn_apply");
 }
 
@@ -289,8 +297,10 @@ extern "C" int mdl_bn_bwd_stats_n(const void* dy, const void* x, const float* sa
     int rc = bn_check("mdl_bn_bwd_stats", N, C, dtype, x);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(bn_grid(N, C, 8)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, N, C, n_dev);
-    else hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), dim3(bn_grid(N, C, 4)), dim3(256), 0, st, (const float*)dy, (const float*)x, save, sums, N, C, n_dev);
+    const int W = bn_width(C, dtype);
+    if (dtype == MDL_BF16 && W == 8) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1, 8>), dim3(bn_grid(N, C, W)), dim3(bn_threads(C, 8)), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, N, C, n_dev);
+    else if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1, 4>), dim3(bn_grid(N, C, W)), dim3(bn_threads(C, 4)), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, N, C, n_dev);
+    else hipLaunchKernelGGL((bn_reduce_kernel<float, 1, 4>), dim3(bn_grid(N, C, W)), dim3(bn_threads(C, 4)), 0, st, (const float*)dy, (const float*)x, save, sums, N, C, n_dev);
     return check_launch("mdl_bn_bwd_stats");
 }
 
@@ -304,11 +314,12 @@ extern "C" int mdl_bn_bwd_apply_n(const void* dy, const void* x, const float* sa
     int rc = bn_check("mdl_bn_bwd_apply", N, C, dtype, x);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int W = dtype == MDL_BF16 ? 8 : 4;
-    int64_t g = cdiv(N * (C / W), 256 * 4);
+    int64_t g = cdiv(N * (C / bn_width(C, dtype)), 256 * 4);
     if (g > 768) g = 768;          // 3 fat blocks per CU: the per-block statistics prologue amortises (measured 512..2048)
     if (g < 1) g = 1;
-    if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, gamma, (bf16_t*)dx, N, C, n_dev);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, (const float*)dy, (const float*)x, save, sums, gamma, (float*)dx, N, C, n_dev);
+    const int W = bn_width(C, dtype);
+    if (dtype == MDL_BF16 && W == 8) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 8>), dim3((unsigned)g), dim3(bn_threads(C, 8)), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, gamma, (bf16_t*)dx, N, C, n_dev);
+    else if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 4>), dim3((unsigned)g), dim3(bn_threads(C, 4)), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, gamma, (bf16_t*)dx, N, C, n_dev);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), dim3((unsigned)g), dim3(bn_threads(C, 4)), 0, st, (const float*)dy, (const float*)x, save, sums, gamma, (float*)dx, N, C, n_dev);
     return check_launch("mdl_bn_bwd_apply");
 }

@@ -67,6 +67,82 @@ __global__ __launch_bounds__(256) void edge_mul_kernel(const T* __restrict__ a, 
     }
 }
 
+// ---- two-channel (dword) versions for bf16 rows with an even channel count (SchNet: F = 150 -> 75 dwords per row) ----
+// One thread owns one dword of one output row; the threads of a row are consecutive, so every gathered h row and every w
+// row is read as one contiguous run; rows are walked four slots at a time with all loads issued before the first use.
+template <bool MEAN>
+__global__ __launch_bounds__(256) void gmr2_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ w,
+                                                   const float* __restrict__ scale, const int32_t* __restrict__ rowptr,
+                                                   const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
+                                                   bf16_t* __restrict__ out, int64_t N, int F2) {
+    const int npb = (int)blockDim.x / F2;                       // nodes per block
+    const int ln = threadIdx.x / F2, d = threadIdx.x - ln * F2;
+    const int64_t n = (int64_t)blockIdx.x * npb + ln;
+    if (ln >= npb || n >= N) return;
+    const unsigned* __restrict__ h2 = reinterpret_cast<const unsigned*>(h);
+    const unsigned* __restrict__ w2 = reinterpret_cast<const unsigned*>(w);
+    const int b = rowptr[n], e = rowptr[n + 1];
+    float a0 = 0.0f, a1 = 0.0f;
+    constexpr int U = 4;
+    for (int k0 = b; k0 < e; k0 += U) {
+        int64_t id[U];
+        int c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = min(k0 + u, e - 1);
+            id[u] = eid ? eid[k] : k;
+            c[u] = col[k];
+        }
+        unsigned hv[U], wv[U];
+        float sc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            hv[u] = h2[(int64_t)c[u] * F2 + d];
+            wv[u] = w ? w2[id[u] * F2 + d] : 0x3F803F80u;
+            sc[u] = scale ? scale[id[u]] : 1.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k0 + u < e) {
+                a0 = fmaf(__uint_as_float(hv[u] << 16) * __uint_as_float(wv[u] << 16), sc[u], a0);
+                a1 = fmaf(__uint_as_float(hv[u] & 0xffff0000u) * __uint_as_float(wv[u] & 0xffff0000u), sc[u], a1);
+            }
+        }
+    }
+    if (MEAN) { const float inv = 1.0f / (float)max(e - b, 1); a0 *= inv; a1 *= inv; }
+    reinterpret_cast<unsigned*>(out)[n * F2 + d] = pk_bf16(a0, a1);
+}
+
+__global__ __launch_bounds__(256) void edge_mul2_kernel(const bf16_t* __restrict__ a, const int32_t* __restrict__ ia,
+                                                        const bf16_t* __restrict__ b, const int32_t* __restrict__ ib,
+                                                        const float* __restrict__ scale, bf16_t* __restrict__ out, int64_t E,
+                                                        int F2) {
+    const int epb = (int)blockDim.x / F2;
+    const int le = threadIdx.x / F2, d = threadIdx.x - le * F2;
+    if (le >= epb) return;
+    const unsigned* __restrict__ a2 = reinterpret_cast<const unsigned*>(a);
+    const unsigned* __restrict__ b2 = reinterpret_cast<const unsigned*>(b);
+    for (int64_t e = (int64_t)blockIdx.x * epb + le; e < E; e += (int64_t)gridDim.x * epb) {
+        const unsigned av = a2[(int64_t)ia[e] * F2 + d], bv = b2[(int64_t)ib[e] * F2 + d];
+        const float sc = scale ? scale[e] : 1.0f;
+        reinterpret_cast<unsigned*>(out)[e * F2 + d] = pk_bf16(__uint_as_float(av << 16) * __uint_as_float(bv << 16) * sc,
+                                                               __uint_as_float(av & 0xffff0000u) * __uint_as_float(bv & 0xffff0000u) * sc);
+    }
+}
+
+// dx = g * sigmoid(pre) for y = softplus(pre) - ln2 given y:  sigmoid(pre) = 1 - exp(-(y + ln2))   (bf16 rows, one pass)
+__global__ __launch_bounds__(256) void ssp_bwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ y,
+                                                      bf16_t* __restrict__ dx, int64_t n2) {
+    const unsigned* __restrict__ g2 = reinterpret_cast<const unsigned*>(g);
+    const unsigned* __restrict__ y2 = reinterpret_cast<const unsigned*>(y);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned gv = g2[i], yv = y2[i];
+        const float s0 = 1.0f - __expf(-(__uint_as_float(yv << 16) + 0.6931471805599453f));
+        const float s1 = 1.0f - __expf(-(__uint_as_float(yv & 0xffff0000u) + 0.6931471805599453f));
+        reinterpret_cast<unsigned*>(dx)[i] = pk_bf16(__uint_as_float(gv << 16) * s0, __uint_as_float(gv & 0xffff0000u) * s1);
+    }
+}
+
 static unsigned g_grid(int64_t total) {
     int64_t b = cdiv(total, 256);
     if (b > 256 * 16) b = 256 * 16;
@@ -97,6 +173,14 @@ extern "C" int mdl_gather_mul_reduce(const void* h, const void* w, const float* 
     MDL_REQUIRE(reduce == MDL_SUM || reduce == MDL_MEAN, MDL_E_UNSUPP, "mdl_gather_mul_reduce: reduce must be sum or mean");
     if (N == 0) return MDL_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == MDL_BF16 && F % 2 == 0 && F <= 512 && reinterpret_cast<uintptr_t>(h) % 4 == 0 &&
+        reinterpret_cast<uintptr_t>(w) % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 4 == 0) {
+        const int F2 = (int)(F / 2), npb = 256 / F2;
+        const dim3 g2((unsigned)cdiv(N, npb)), b2((unsigned)(npb * F2));
+        if (reduce == MDL_MEAN) hipLaunchKernelGGL((gmr2_kernel<true>), g2, b2, 0, st, (const bf16_t*)h, (const bf16_t*)w, scale, rowptr, col, eid, (bf16_t*)out, N, F2);
+        else hipLaunchKernelGGL((gmr2_kernel<false>), g2, b2, 0, st, (const bf16_t*)h, (const bf16_t*)w, scale, rowptr, col, eid, (bf16_t*)out, N, F2);
+        return check_launch("mdl_gather_mul_reduce");
+    }
     dim3 g(g_grid(N * F)), b(256);
 #define MDL_GMR(T_, M_) hipLaunchKernelGGL((gmr_kernel<T_, M_>), g, b, 0, st, (const T_*)h, (const T_*)w, scale, rowptr, col, eid, (T_*)out, N, (int)F)
     if (dtype == MDL_F32) { if (reduce == MDL_MEAN) MDL_GMR(float, true); else MDL_GMR(float, false); }
@@ -112,10 +196,30 @@ extern "C" int mdl_edge_mul(const void* a, const int32_t* ia, const void* b, con
     MDL_REQUIRE(E >= 0 && F > 0 && (E == 0 || (a && ia && b && ib && out)), MDL_E_ARG, "mdl_edge_mul: bad arguments");
     if (E == 0) return MDL_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == MDL_BF16 && F % 2 == 0 && F <= 512 && reinterpret_cast<uintptr_t>(a) % 4 == 0 &&
+        reinterpret_cast<uintptr_t>(b) % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 4 == 0) {
+        const int F2 = (int)(F / 2), epb = 256 / F2;
+        int64_t grid = cdiv(E, epb);
+        if (grid > 256 * 32) grid = 256 * 32;
+        hipLaunchKernelGGL(edge_mul2_kernel, dim3((unsigned)grid), dim3((unsigned)(epb * F2)), 0, st, (const bf16_t*)a, ia, (const bf16_t*)b, ib, scale, (bf16_t*)out, E, F2);
+        return check_launch("mdl_edge_mul");
+    }
     if (dtype == MDL_F32)
         hipLaunchKernelGGL((edge_mul_kernel<float>), dim3(g_grid(E * F)), dim3(256), 0, st, (const float*)a, ia, (const float*)b, ib, scale, (float*)out, E, (int)F);
     else if (dtype == MDL_BF16)
         hipLaunchKernelGGL((edge_mul_kernel<bf16_t>), dim3(g_grid(E * F)), dim3(256), 0, st, (const bf16_t*)a, ia, (const bf16_t*)b, ib, scale, (bf16_t*)out, E, (int)F);
     else { set_error("mdl_edge_mul: unsupported dtype %d", dtype); return MDL_E_UNSUPP; }
     return check_launch("mdl_edge_mul");
+}
+
+extern "C" int mdl_ssp_bwd(const void* g, const void* y, void* dx, int64_t n, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(dtype == MDL_BF16 && n % 2 == 0, MDL_E_UNSUPP, "mdl_ssp_bwd: bf16 with an even element count only");
+    MDL_REQUIRE(n == 0 || (g && y && dx && (reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dx)) % 4 == 0),
+                MDL_E_ARG, "mdl_ssp_bwd: null or misaligned pointer");
+    if (n == 0) return MDL_OK;
+    int64_t grid = cdiv(n / 2, 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(ssp_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)y, (bf16_t*)dx, n / 2);
+    return check_launch("mdl_ssp_bwd");
 }

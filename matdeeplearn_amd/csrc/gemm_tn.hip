@@ -84,8 +84,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 // dword loads (registers, one tile ahead), written to row-major LDS tiles, and both MFMA operands — which must be
 // k-major over the ROWS — come out of those tiles with the LDS transpose read ds_read_b64_tr_b16.
 // Wave w owns the (32 x 32) blocks w, w+4, ... of C (row-major over (m-tile, n-tile)).
+// (the 5-tile instantiations — SchNet's 150-wide filters — carry up to 7 accumulator tiles and 40 staging dwords per thread:
+// they are register-allocated for ONE workgroup per CU, which is how the kernel is launched anyway; at two they spilled
+// 664 bytes and ran 12x slower)
 template <int MT, int NT>
-__global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const bf16_t* __restrict__ A, int lda, int M,
+__global__ __launch_bounds__(256, (MT > 4 || NT > 4) ? 1 : 2) void gemm_tn_stream_kernel(const bf16_t* __restrict__ A, int lda, int M,
                                                                 const bf16_t* __restrict__ B, int ldb, int K,
                                                                 float* __restrict__ C, float* __restrict__ colsum,
                                                                 int64_t N) {
@@ -213,15 +216,16 @@ extern "C" int mdl_gemm_tn_colsum(const void* a, int64_t lda, int M, const void*
                                   float* colsum, int64_t N, int dtype, mdlStream_t stream) {
     using namespace mdl;
     MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_gemm_tn: bf16 only");
-    MDL_REQUIRE(M >= 1 && M <= 128 && K >= 1 && K <= 256, MDL_E_UNSUPP, "mdl_gemm_tn: need 1<=M<=128, 1<=K<=256 (got %d, %d)", M, K);
+    MDL_REQUIRE(M >= 1 && M <= 160 && K >= 1 && K <= 256 && (M <= 128 || (K <= 160 && M % 2 == 0 && K % 2 == 0)), MDL_E_UNSUPP,
+                "mdl_gemm_tn: need 1<=M<=160, 1<=K<=256 (even M, K <= 160 when M > 128) (got %d, %d)", M, K);
     MDL_REQUIRE(N >= 0 && lda >= M && ldb >= K && (N == 0 || (a && b && c)), MDL_E_ARG, "mdl_gemm_tn: bad arguments");
     if (N == 0) return MDL_OK;
     hipStream_t st = (hipStream_t)stream;
     {   // streaming kernel: needs dword-addressable rows and K <= 128 (LDS budget / instantiations)
         int mt = (M + 31) / 32, nt = (K + (colsum ? 1 : 0) + 31) / 32;   // colsum rides in padding column K of the B tile
-        if (mt == 3) mt = 4;                      // (instantiated for 1, 2, 4 tiles; the padding columns are zero)
+        if (mt == 3) mt = 4;                      // (instantiated for 1, 2, 4, 5 tiles; the padding columns are zero)
         if (nt == 3) nt = 4;
-        const bool ok = (M % 2 == 0) && (K % 2 == 0) && (lda % 2 == 0) && (ldb % 2 == 0) && nt <= 4 &&
+        const bool ok = (M % 2 == 0) && (K % 2 == 0) && (lda % 2 == 0) && (ldb % 2 == 0) && nt <= 5 &&
                         reinterpret_cast<uintptr_t>(a) % 4 == 0 && reinterpret_cast<uintptr_t>(b) % 4 == 0;
         if (ok) {
             int64_t sgrid = cdiv(N, 64);
@@ -229,9 +233,10 @@ extern "C" int mdl_gemm_tn_colsum(const void* a, int64_t lda, int M, const void*
                                               // (measured 128 / 256 / 512 / 1024 blocks: 49 / 40 / 43 / 63 us on 2e5 rows)
 #define MDL_TNS(MT_, NT_) hipLaunchKernelGGL((gemm_tn_stream_kernel<MT_, NT_>), dim3((unsigned)sgrid), dim3(256), 0, st, \
         (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, colsum, N)
-            if (mt == 1) { if (nt == 1) MDL_TNS(1, 1); else if (nt == 2) MDL_TNS(1, 2); else MDL_TNS(1, 4); }
-            else if (mt == 2) { if (nt == 1) MDL_TNS(2, 1); else if (nt == 2) MDL_TNS(2, 2); else MDL_TNS(2, 4); }
-            else { if (nt == 1) MDL_TNS(4, 1); else if (nt == 2) MDL_TNS(4, 2); else MDL_TNS(4, 4); }
+            if (mt == 1) { if (nt == 1) MDL_TNS(1, 1); else if (nt == 2) MDL_TNS(1, 2); else if (nt == 4) MDL_TNS(1, 4); else MDL_TNS(1, 5); }
+            else if (mt == 2) { if (nt == 1) MDL_TNS(2, 1); else if (nt == 2) MDL_TNS(2, 2); else if (nt == 4) MDL_TNS(2, 4); else MDL_TNS(2, 5); }
+            else if (mt == 4) { if (nt == 1) MDL_TNS(4, 1); else if (nt == 2) MDL_TNS(4, 2); else if (nt == 4) MDL_TNS(4, 4); else MDL_TNS(4, 5); }
+            else { if (nt == 1) MDL_TNS(5, 1); else if (nt == 2) MDL_TNS(5, 2); else if (nt == 4) MDL_TNS(5, 4); else MDL_TNS(5, 5); }
 #undef MDL_TNS
             return check_launch("mdl_gemm_tn");
         }

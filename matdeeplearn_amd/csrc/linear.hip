@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[r];
                         if (act == 1) v = v > 0.0f ? v : 0.0f;
+                        else if (act == 2) v = fmaxf(v, 0.0f) + __logf(1.0f + __expf(-fabsf(v))) - 0.6931471805599453f;   // shifted softplus
                         __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(v), os, vo + ((r & 3) + 8 * (r >> 2)) * M * 2, 0, 0);
                     }
                 }
@@ -157,16 +158,16 @@ extern "C" int mdl_linear_gather_act(const void* x, const void* w, const void* b
     MDL_REQUIRE((!p1 || idx1) && (!p2 || idx2) && (!p3 || idx3), MDL_E_ARG, "mdl_linear_gather_act: table without index");
     const bool gather = p1 || p2 || p3;
     GatherAdd ga = {{(const bf16_t*)p1, (const bf16_t*)p2, (const bf16_t*)p3}, {idx1, idx2, idx3}};
-    MDL_REQUIRE(K >= 4 && K <= 256 && K % 2 == 0 && M >= 1 && M <= 128, MDL_E_UNSUPP,
-                "mdl_linear_act: need even 4<=K<=256 and 1<=M<=128 (got K=%d M=%d)", K, M);
-    MDL_REQUIRE(act == 0 || act == 1, MDL_E_ARG, "mdl_linear_act: act must be 0 (none) or 1 (relu)");
+    MDL_REQUIRE(K >= 4 && K <= 256 && K % 2 == 0 && M >= 1 && M <= 160 && (M <= 128 || K <= 160), MDL_E_UNSUPP,
+                "mdl_linear_act: need even 4<=K<=256 and 1<=M<=160 (K<=160 when M>128) (got K=%d M=%d)", K, M);
+    MDL_REQUIRE(act >= 0 && act <= 2, MDL_E_ARG, "mdl_linear_act: act must be 0 (none), 1 (relu) or 2 (shifted softplus)");
     MDL_REQUIRE(N >= 0 && (N == 0 || (x && w && out)), MDL_E_ARG, "mdl_linear_act: bad arguments");
     MDL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(w) % 4 == 0 &&
                 reinterpret_cast<uintptr_t>(out) % 2 == 0, MDL_E_ARG, "mdl_linear_act: misaligned pointer");
     if (N == 0) return MDL_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int kp = K <= 64 ? 64 : (K <= 128 ? 128 : 256);
-    const int nt = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
+    const int kp = K <= 64 ? 64 : (K <= 128 ? 128 : (K <= 160 ? 160 : 256));
+    const int nt = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 128 ? 4 : 5));
     int64_t grid = cdiv(N, 64);
     if (grid > 512) grid = 512;
     const int k2 = K / 2;
@@ -186,8 +187,9 @@ extern "C" int mdl_linear_gather_act(const void* x, const void* w, const void* b
                                (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, inv_k2, GatherAdd{});                \
         }                                                                                                            \
     } while (0)
-    if (kp == 64) { if (nt == 1) MDL_LIN(64, 1); else if (nt == 2) MDL_LIN(64, 2); else MDL_LIN(64, 4); }
-    else if (kp == 128) { if (nt == 1) MDL_LIN(128, 1); else if (nt == 2) MDL_LIN(128, 2); else MDL_LIN(128, 4); }
+    if (kp == 64) { if (nt == 1) MDL_LIN(64, 1); else if (nt == 2) MDL_LIN(64, 2); else if (nt == 4) MDL_LIN(64, 4); else MDL_LIN(64, 5); }
+    else if (kp == 128) { if (nt == 1) MDL_LIN(128, 1); else if (nt == 2) MDL_LIN(128, 2); else if (nt == 4) MDL_LIN(128, 4); else MDL_LIN(128, 5); }
+    else if (kp == 160) { if (nt == 1) MDL_LIN(160, 1); else if (nt == 2) MDL_LIN(160, 2); else if (nt == 4) MDL_LIN(160, 4); else MDL_LIN(160, 5); }
     else { if (nt == 1) MDL_LIN(256, 1); else if (nt == 2) MDL_LIN(256, 2); else MDL_LIN(256, 4); }
 #undef MDL_LIN
     return check_launch("mdl_linear_act");

@@ -70,6 +70,23 @@ template <> struct Vec<float> {
     }
 };
 
+// ---- row vectors of a chosen width: 16 bytes where the channel count allows it, 8 bytes (4 bf16) for widths like 100 / 150 ----
+template <typename T, int W> struct VecW;
+template <> struct VecW<bf16_t, 8> : Vec<bf16_t> {};
+template <> struct VecW<float, 4> : Vec<float> {};
+template <> struct VecW<bf16_t, 4> {
+    static constexpr int W = 4;
+    __device__ static __forceinline__ void ld(const bf16_t* p, float* v) {
+        const bf16x4 r = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = bf2f((bf16_t)r[j]);
+    }
+    __device__ static __forceinline__ void st(bf16_t* p, const float* v) {
+        typedef __attribute__((ext_vector_type(2))) unsigned u2;
+        *reinterpret_cast<u2*>(p) = u2{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
+    }
+};
+
 // ---- D-layout of the 32x32 MFMA accumulator (dtype independent on gfx950) ------------------
 // lane l, register r  ->  row = (r&3) + 8*(r>>2) + 4*(l>>5),  col = l&31
 __device__ __forceinline__ int d_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }

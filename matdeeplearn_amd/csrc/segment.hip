@@ -84,12 +84,14 @@ __global__ __launch_bounds__(256) void seg_bwd_max_kernel(const T* __restrict__ 
 
 // 16-byte fast paths (sum / mean, rows in place, C a multiple of the vector width): one thread owns W channels of one
 // segment and streams its rows with 16-byte loads, four in flight; the backward writes one 16-byte vector per thread.
-template <typename T, int REDUCE>
+template <typename T, int REDUCE, int W>
 __global__ __launch_bounds__(256) void seg_fwd_vec_kernel(const T* __restrict__ src, const int32_t* __restrict__ rowptr,
-                                                          T* __restrict__ out, int64_t N, int CG) {
+                                                          const int32_t* __restrict__ perm, T* __restrict__ out, int64_t N,
+                                                          int CG) {
     // RL row lanes share one (segment, channel group): lane j takes rows b + j, b + j + RL, ... two at a time, and the
     // partial sums meet through two xor-shuffles.  (One thread per segment walks ~25 rows as a chain of round trips.)
-    constexpr int W = Vec<T>::W, U = 2;
+    constexpr int U = 2;
+    typedef VecW<T, W> V;
     const int RL = (CG <= 16 && (CG & (CG - 1)) == 0) ? 4 : 1;        // the CG*RL lanes of a group sit in one wavefront
     const int64_t total = N * CG * RL;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -107,7 +109,10 @@ __global__ __launch_bounds__(256) void seg_fwd_vec_kernel(const T* __restrict__ 
         for (int k = b + j; k < e; k += U * RL) {
             float v[U][W];
 #pragma unroll
-            for (int u = 0; u < U; ++u) Vec<T>::ld(base + (int64_t)min(k + u * RL, e - 1) * ld, v[u]);   // clamp, never guard
+            for (int u = 0; u < U; ++u) {                                                       // clamp, never guard
+                const int kk = min(k + u * RL, e - 1);
+                V::ld(base + (int64_t)(perm ? perm[kk] : kk) * ld, v[u]);
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (k + u * RL < e) {
@@ -127,15 +132,15 @@ __global__ __launch_bounds__(256) void seg_fwd_vec_kernel(const T* __restrict__ 
 #pragma unroll
             for (int q = 0; q < W; ++q) acc[q] = acc[q] / cnt;
         }
-        if (j == 0 && i0 + threadIdx.x < total) Vec<T>::st(out + (n * CG + cg) * W, acc);
+        if (j == 0 && i0 + threadIdx.x < total) V::st(out + (n * CG + cg) * W, acc);
     }
 }
 
-template <typename T, int REDUCE>
+template <typename T, int REDUCE, int W>
 __global__ __launch_bounds__(256) void seg_bwd_vec_kernel(const T* __restrict__ go, const int32_t* __restrict__ rowptr,
-                                                          const int32_t* __restrict__ seg, T* __restrict__ gs, int64_t E,
-                                                          int CG) {
-    constexpr int W = Vec<T>::W;
+                                                          const int32_t* __restrict__ seg, const int32_t* __restrict__ perm,
+                                                          T* __restrict__ gs, int64_t E, int CG) {
+    typedef VecW<T, W> V;
     const int64_t total = E * CG;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -143,19 +148,23 @@ __global__ __launch_bounds__(256) void seg_bwd_vec_kernel(const T* __restrict__ 
         const int cg = (int)(i - k * CG);
         const int n = seg[k];
         float g[W];
-        Vec<T>::ld(go + ((int64_t)n * CG + cg) * W, g);
+        V::ld(go + ((int64_t)n * CG + cg) * W, g);
         if (REDUCE == MDL_MEAN) {
             const float cnt = (float)max(rowptr[n + 1] - rowptr[n], 1);
 #pragma unroll
             for (int j = 0; j < W; ++j) g[j] = g[j] / cnt;
         }
-        Vec<T>::st(gs + i * W, g);
+        V::st(gs + ((int64_t)(perm ? perm[k] : k) * CG + cg) * W, g);
     }
 }
 
+// vector width of the fast paths: 16 bytes when the row length allows it, else 4 elements (8 bytes of bf16: C = 100, 150)
 template <typename T>
-static bool vec_ok(const void* a, const void* b, int64_t C) {
-    return C % Vec<T>::W == 0 && reinterpret_cast<uintptr_t>(a) % 16 == 0 && reinterpret_cast<uintptr_t>(b) % 16 == 0;
+static int vec_width(const void* a, const void* b, int64_t C) {
+    const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b);
+    if (C % Vec<T>::W == 0 && al % 16 == 0) return Vec<T>::W;
+    if (sizeof(T) == 2 && C % 4 == 0 && al % 8 == 0) return 4;
+    return 0;
 }
 
 static unsigned grid_for(int64_t total) {
@@ -169,12 +178,20 @@ template <typename T>
 static int seg_fwd(const T* src, const int32_t* rowptr, const int32_t* perm, T* out, int32_t* argmax, int64_t N,
                    int64_t C, int reduce, hipStream_t st) {
     if (N * C == 0) return MDL_OK;
-    if (!perm && reduce != MDL_MAX && vec_ok<T>(src, out, C)) {
-        const int CG = (int)(C / Vec<T>::W);
+    const int vw = reduce != MDL_MAX ? vec_width<T>(src, out, C) : 0;
+    if (vw) {
+        const int CG = (int)(C / vw);
         dim3 gv(grid_for(N * CG * 4)), bv(256);
-        if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_fwd_vec_kernel<T, MDL_SUM>), gv, bv, 0, st, src, rowptr, out, N, CG);
-        else if (reduce == MDL_MEAN) hipLaunchKernelGGL((seg_fwd_vec_kernel<T, MDL_MEAN>), gv, bv, 0, st, src, rowptr, out, N, CG);
-        else { set_error("mdl_segment_reduce_fwd: bad reduce %d", reduce); return MDL_E_ARG; }
+        if (reduce != MDL_SUM && reduce != MDL_MEAN) { set_error("mdl_segment_reduce_fwd: bad reduce %d", reduce); return MDL_E_ARG; }
+        if constexpr (sizeof(T) == 2) {
+            if (vw == 4) {
+                if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_fwd_vec_kernel<T, MDL_SUM, 4>), gv, bv, 0, st, src, rowptr, perm, out, N, CG);
+                else hipLaunchKernelGGL((seg_fwd_vec_kernel<T, MDL_MEAN, 4>), gv, bv, 0, st, src, rowptr, perm, out, N, CG);
+                return check_launch("mdl_segment_reduce_fwd");
+            }
+        }
+        if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_fwd_vec_kernel<T, MDL_SUM, Vec<T>::W>), gv, bv, 0, st, src, rowptr, perm, out, N, CG);
+        else hipLaunchKernelGGL((seg_fwd_vec_kernel<T, MDL_MEAN, Vec<T>::W>), gv, bv, 0, st, src, rowptr, perm, out, N, CG);
         return check_launch("mdl_segment_reduce_fwd");
     }
     dim3 g(grid_for(N * C)), b(256);
@@ -191,11 +208,19 @@ template <typename T>
 static int seg_bwd(const T* go, const int32_t* rowptr, const int32_t* seg, const int32_t* perm,
                    const int32_t* argmax, T* gs, int64_t N, int64_t E, int64_t C, int reduce, hipStream_t st) {
     dim3 b(256);
-    if (!perm && (reduce == MDL_SUM || reduce == MDL_MEAN) && E * C != 0 && vec_ok<T>(go, gs, C)) {
-        const int CG = (int)(C / Vec<T>::W);
+    const int vw = ((reduce == MDL_SUM || reduce == MDL_MEAN) && E * C != 0) ? vec_width<T>(go, gs, C) : 0;
+    if (vw) {
+        const int CG = (int)(C / vw);
         dim3 gv(grid_for(E * CG));
-        if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_SUM>), gv, b, 0, st, go, rowptr, seg, gs, E, CG);
-        else hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_MEAN>), gv, b, 0, st, go, rowptr, seg, gs, E, CG);
+        if constexpr (sizeof(T) == 2) {
+            if (vw == 4) {
+                if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_SUM, 4>), gv, b, 0, st, go, rowptr, seg, perm, gs, E, CG);
+                else hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_MEAN, 4>), gv, b, 0, st, go, rowptr, seg, perm, gs, E, CG);
+                return check_launch("mdl_segment_reduce_bwd");
+            }
+        }
+        if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_SUM, Vec<T>::W>), gv, b, 0, st, go, rowptr, seg, perm, gs, E, CG);
+        else hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_MEAN, Vec<T>::W>), gv, b, 0, st, go, rowptr, seg, perm, gs, E, CG);
         return check_launch("mdl_segment_reduce_bwd");
     }
     switch (reduce) {

@@ -53,16 +53,19 @@ class Megnet_EdgeModel(_Mlp):
         return (edge_attr.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and self.act == "relu" and d <= 128
                 and d % 2 == 0 and edge_attr.is_contiguous() and edge_attr.data_ptr() % 16 == 0)
 
-    def forward_fused(self, x, row, col, edge_attr, u, batch_e):
+    def forward_fused(self, x, row, col, edge_attr, u, batch_n):
         """K6: same function as forward(x[row], x[col], edge_attr, u, batch_e) without the gathers and the concatenation."""
         lin = self.edge_mlp[0]
         d = lin.out_features
         cd = x.dtype
         wa, wb, wc, wd = (lin.weight[:, k * d:(k + 1) * d] for k in range(4))       # column blocks: src | dest | e | u
         p_src = F.linear(x, wa.to(cd))                                              # [N, d] per-node projections
-        p_dst = F.linear(x, wb.to(cd))
         p_glb = F.linear(u, wd.to(cd), None if lin.bias is None else lin.bias.to(cd))  # [B, d] per graph (+ bias)
-        out = ops.linear_gather_act(edge_attr, wc, None, self.act, [(p_src, row), (p_dst, col), (p_glb, batch_e)])
+        # batch[row] == batch[col] (an edge stays inside its graph): the per-graph row is folded into the TARGET node's row, so
+        # the kernel gathers two tables, and the per-graph gradient is a 25-row reduction over nodes instead of a
+        # 325-row one over edges
+        p_dst = F.linear(x, wb.to(cd)) + ops.gather(p_glb, batch_n)
+        out = ops.linear_gather_act(edge_attr, wc, None, self.act, [(p_src, row), (p_dst, col)])
         return self._tail(out, 0)
 
 
@@ -145,7 +148,7 @@ class MEGNet(GraphModel):
         idx = None
         if cd == torch.bfloat16:                     # int32 gather indices of the fused edge block, once per batch
             row, col = ei[0], ei[1]
-            idx = (row.to(torch.int32), col.to(torch.int32), data.batch.index_select(0, row).to(torch.int32))
+            idx = (row.to(torch.int32), col.to(torch.int32), data.batch)
         x = e = u = None
         for i, conv in enumerate(self.conv_list):
             e_t = _run_embed(self.e_embed_list[i], data.edge_attr.to(cd) if i == 0 else e)

@@ -53,16 +53,31 @@ import torch
 import torch.nn.functional as F
 
 
-def _lin(lin, h):
-    """nn.Linear applied in the dtype of h (fp32 master weights, bf16 activations)."""
+def _lin(lin, h, act=None):
+    """nn.Linear (+ activation) applied in the dtype of h (fp32 master weights, bf16 activations): the streaming HIP dense
+    layer for bf16 rows, the library otherwise."""
     if h.dtype == lin.weight.dtype:
-        return lin(h)
-    return ops.linear(h, lin.weight, lin.bias)
+        y = lin(h)
+        if act is None:
+            return y
+        return F.softplus(y) - math.log(2.0) if act == "ssp" else getattr(F, act)(y)
+    return ops.linear_act(h, lin.weight, lin.bias, act)
 
 
 def _seq(seq, h):
-    for m in seq:
-        h = _lin(m, h) if isinstance(m, nn.Linear) else m(h)
+    """Sequential of Linear / activation modules; a Linear followed by ShiftedSoftplus / ReLU runs as ONE fused dense layer."""
+    mods = list(seq)
+    k = 0
+    while k < len(mods):
+        m = mods[k]
+        if isinstance(m, nn.Linear):
+            nxt = mods[k + 1] if k + 1 < len(mods) else None
+            act = "ssp" if isinstance(nxt, ShiftedSoftplus) else ("relu" if isinstance(nxt, nn.ReLU) else None)
+            h = _lin(m, h, act)
+            k += 2 if act else 1
+        else:
+            h = m(h)
+            k += 1
     return h
 
 
@@ -198,9 +213,7 @@ class NNConv(nn.Module):
         last = self._last_linear()
         ci, co = self.in_channels, self.out_channels
         if last is not None and (co * (last.in_features + 1) + last.in_features + co) * 4 <= 160 * 1024:
-            hdn = edge_attr
-            for mod in list(self.nn)[:-1]:
-                hdn = _lin(mod, hdn) if isinstance(mod, nn.Linear) else mod(hdn)
+            hdn = _seq(list(self.nn)[:-1], edge_attr)
             d3 = last.in_features
             w2 = last.weight.view(ci, co * d3).to(x.dtype)
             Y = x @ w2                                                    # [N, C_out*d3]: the only large dense product

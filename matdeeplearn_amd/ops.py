@@ -554,8 +554,9 @@ class _GatherMulReduce(torch.autograd.Function):
         if scale is not None:
             scale = scale.float().contiguous()
         out = torch.empty((N, F), dtype=h.dtype, device=h.device)
-        check(lib().mdl_gather_mul_reduce(ptr(h), ptr(w), ptr(scale), ptr(csr.rowptr), ptr(csr.src), ptr(csr.eperm),
-                                          ptr(out), N, F, reduce, dtype_code(h), stream()), "mdl_gather_mul_reduce")
+        check(_launch_timed("gmr_fwd", lambda: lib().mdl_gather_mul_reduce(
+            ptr(h), ptr(w), ptr(scale), ptr(csr.rowptr), ptr(csr.src), ptr(csr.eperm), ptr(out), N, F, reduce, dtype_code(h),
+            stream())), "mdl_gather_mul_reduce")
         ctx.csr, ctx.reduce = csr, reduce
         ctx.save_for_backward(h, w, scale)
         return out
@@ -652,10 +653,31 @@ class _LinearTN(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+def _hip_shape_ok(M, K):
+    """(out, in) features the streaming dense kernels take: linear.hip forward and gemm_tn.hip weight gradient."""
+    return 1 <= M <= 160 and 4 <= K <= 256 and K % 2 == 0 and (M <= 128 or (K <= 160 and M % 2 == 0))
+
+
+def _dx_hip(g, w):
+    """dX = g W for a tall bf16 g through the streaming dense kernel (the 'weight' of that product is W^T): the library
+    picks a 64x64x256 macro tile for [1.5e6, 150] x [150, 150] and runs it at 35 TFLOP/s (1.9 ms); as a stream it is
+    E*(M+K)*2 bytes."""
+    M, K = w.shape
+    if (g.dtype == torch.bfloat16 and g.is_cuda and g.shape[0] >= 1024 and g.is_contiguous() and g.data_ptr() % 16 == 0
+            and _hip_shape_ok(K, M) and M % 2 == 0):
+        wt = w.t().contiguous()
+        dx = torch.empty((g.shape[0], K), dtype=g.dtype, device=g.device)
+        check(lib().mdl_linear_act(ptr(g), ptr(wt), None, ptr(dx), g.shape[0], M, K, 0, dtype_code(g), stream()),
+              "mdl_linear_act(dX)")
+        return dx
+    return g @ w
+
+
 def _linear_tn_grads(ctx, g, x, w):
-    """(dx, dW, db) of y = x W^T + b for a tall x: library GEMM for dx, one TN-GEMM launch for dW and db."""
+    """(dx, dW, db) of y = x W^T + b for a tall x: streaming HIP product (or library GEMM) for dx, one TN-GEMM launch for dW
+    and db."""
     M, K = ctx.shape
-    dx = g @ w if ctx.needs_input_grad[0] else None
+    dx = _dx_hip(g, w) if ctx.needs_input_grad[0] else None
     ga, Ma = g, M
     if M % 2:                               # the streaming kernel stages rows as dwords: pad an odd width (the model's
         ga, Ma = torch.nn.functional.pad(g, (0, 1)), M + 1             # 1-column output layer) with a zero column
@@ -685,9 +707,9 @@ class _LinearActTN(torch.autograd.Function):
         N, K = x.shape
         M = weight.shape[0]
         out = torch.empty((N, M), dtype=x.dtype, device=x.device)
-        check(lib().mdl_linear_act(ptr(x), ptr(w), ptr(b), ptr(out), N, K, M, 1 if act == "relu" else 0, dtype_code(x),
+        check(lib().mdl_linear_act(ptr(x), ptr(w), ptr(b), ptr(out), N, K, M, {"relu": 1, "ssp": 2}.get(act, 0), dtype_code(x),
                                    stream()), "mdl_linear_act")
-        ctx.save_for_backward(x, w, out if act == "relu" else None)
+        ctx.save_for_backward(x, w, out if act in ("relu", "ssp") else None)
         ctx.wdtype, ctx.has_bias, ctx.shape, ctx.act = weight.dtype, bias is not None, tuple(weight.shape), act
         return out
 
@@ -696,6 +718,11 @@ class _LinearActTN(torch.autograd.Function):
         x, w, out = ctx.saved_tensors
         if ctx.act == "relu":
             g = torch.ops.aten.threshold_backward(g, out, 0)
+        elif ctx.act == "ssp":                     # d/dv (softplus(v) - ln2) = sigmoid(v) = 1 - exp(-(out + ln2))
+            g = g.contiguous()
+            dpre = torch.empty_like(g)
+            check(lib().mdl_ssp_bwd(ptr(g), ptr(out), ptr(dpre), g.numel(), dtype_code(g), stream()), "mdl_ssp_bwd")
+            g = dpre
         dx, dw, db = _linear_tn_grads(ctx, g.contiguous(), x, w)
         return dx, dw, db, None, None, None
 
@@ -714,9 +741,9 @@ class _LinearGatherAct(torch.autograd.Function):
         tabs += [None] * (3 - len(tabs))
         ids = list(idx) + [None] * (3 - len(idx))
         out = torch.empty((N, M), dtype=x.dtype, device=x.device)
-        check(lib().mdl_linear_gather_act(ptr(x), ptr(w), ptr(b), ptr(tabs[0]), ptr(ids[0]), ptr(tabs[1]), ptr(ids[1]),
-                                          ptr(tabs[2]), ptr(ids[2]), ptr(out), N, K, M, 1 if act == "relu" else 0,
-                                          dtype_code(x), stream()), "mdl_linear_gather_act")
+        check(_launch_timed("edge_linear", lambda: lib().mdl_linear_gather_act(
+            ptr(x), ptr(w), ptr(b), ptr(tabs[0]), ptr(ids[0]), ptr(tabs[1]), ptr(ids[1]), ptr(tabs[2]), ptr(ids[2]), ptr(out),
+            N, K, M, 1 if act == "relu" else 0, dtype_code(x), stream())), "mdl_linear_gather_act")
         ctx.save_for_backward(x, w, out if act == "relu" else None)
         ctx.idx, ctx.rows = ids, [None if t is None else t.shape[0] for t in tabs]
         ctx.wdtype, ctx.has_bias, ctx.shape, ctx.act, ctx.ntab = weight.dtype, bias is not None, tuple(weight.shape), act, len(tables)
@@ -753,20 +780,25 @@ def linear_gather_act(x, weight, bias, act, gathered):
 def linear_act(x, weight, bias, act, lowp=None):
     """getattr(F, act)(F.linear(x, weight, bias)) — fused forward for bf16 inputs with dense rows, even in <= 256,
     out <= 128 and act in (relu, none); anything else composes `linear` with the library activation."""
-    if (act in ("relu", None) and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
-            and x.shape[0] >= 1024 and weight.shape[0] <= 128 and 4 <= weight.shape[1] <= 256 and weight.shape[1] % 2 == 0
+    if (act in ("relu", "ssp", None) and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
+            and x.shape[0] >= 1024 and _hip_shape_ok(weight.shape[0], weight.shape[1])
             and x.data_ptr() % 16 == 0 and weight.requires_grad):
         w_lp, b_lp = (lowp if lowp is not None and lowp[0].dtype == x.dtype else (None, None))
         return _LinearActTN.apply(x, weight, bias, w_lp, b_lp, act)
     y = linear(x, weight, bias, lowp)
-    return y if act is None else getattr(torch.nn.functional, act)(y)
+    if act is None:
+        return y
+    if act == "ssp":
+        return torch.nn.functional.softplus(y) - 0.6931471805599453
+    return getattr(torch.nn.functional, act)(y)
 
 
 def linear(x, weight, bias, lowp=None):
     """F.linear in the dtype of x (fp32 master weights); bf16 inputs with many rows, out <= 128, in <= 256 take the
     HIP TN GEMM for dW, anything else the library autograd path.  `lowp` = (weight, bias) already cast to x.dtype."""
     if (x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] >= 1024
-            and weight.shape[0] <= 128 and weight.shape[1] <= 256 and weight.requires_grad):
+            and (weight.shape[0] <= 128 or _hip_shape_ok(weight.shape[0], weight.shape[1])) and weight.shape[1] <= 256
+            and weight.requires_grad):
         if lowp is not None and lowp[0].dtype == x.dtype:
             return _LinearTN.apply(x, weight, bias, lowp[0], lowp[1])
         return _LinearTN.apply(x, weight, bias)
@@ -779,10 +811,10 @@ def linear(x, weight, bias, lowp=None):
 def bn_supported(x):
     if not (x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)):
         return False
-    w = 8 if x.dtype == torch.bfloat16 else 4
     c = x.shape[1]
+    w = 8 if (x.dtype == torch.bfloat16 and c % 8 == 0) else 4          # 16-byte vectors, or 4 bf16 (C = 100, 150)
     # (N == 1 in training mode goes to the library path, which raises like torch does)
-    return x.shape[0] >= 2 and c % w == 0 and c <= 256 and 256 % (c // w) == 0 and x.data_ptr() % 16 == 0
+    return x.shape[0] >= 2 and c % 4 == 0 and 4 <= c <= 256 and x.data_ptr() % (w * x.element_size()) == 0
 
 
 # Static (padded) batches of the HIP-graph path: the tensors hold `capacity` rows, the first *n_rows (a device scalar)

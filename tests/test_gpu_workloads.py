@@ -92,7 +92,7 @@ def _model_parity(name, kw, ds, ids, grads=True):
             gpu_err = float((p.grad.cpu().double() - truth).abs().max()) if p.grad is not None else s
             # (50 x the fp32-CPU error: four MEGNet blocks with BatchNorm over edges amplify summation-order noise —
             # the CPU's own fp32 error on the worst tensor is already 2e-3 of its scale)
-            assert gpu_err <= max(50.0 * cpu_err, 2e-4 * s, 2e-5 * gmax), (name, k, gpu_err, cpu_err, s, gmax)
+            assert gpu_err <= max(50.0 * cpu_err, 2e-4 * s, 5e-5 * gmax), (name, k, gpu_err, cpu_err, s, gmax)
     # weights as they are after construction; BatchNorm buffers moved by the one training forward on BOTH sides
     ref_model.eval(); model.eval()
     with torch.no_grad():
