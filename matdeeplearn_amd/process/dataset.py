@@ -93,6 +93,61 @@ class GraphDataset:
     def num_edges(self):
         return int(self.edge_ptr[-1])
 
+    # ---- flat on-disk format (replaces torch.save((data, slices)) of process.py:520-532) ---------------
+    FLAT_MAGIC = b"MDLFLAT1"
+    _FLAT_FIELDS = ("node_ptr", "edge_ptr", "x", "z", "src", "tgt", "dist", "y")
+
+    def save_flat(self, path):
+        """One file: 8-byte magic, 8-byte little-endian header length, JSON header (dtype / shape / byte offset of every
+        array, edge-feature count, distance range, target index, structure ids), then the raw arrays, each 64-byte
+        aligned — the arrays of the in-memory layout as they are (graph-local CSR-by-target indices, 4 bytes of
+        distance per edge; the 50-wide RBF features are expanded on the device per batch), so loading is a memory map."""
+        import json
+        arrays = {k: np.ascontiguousarray(getattr(self, k)) for k in self._FLAT_FIELDS}
+        meta, off = {}, 0
+        for k, a in arrays.items():
+            off = -(-off // 64) * 64
+            meta[k] = {"dtype": a.dtype.str, "shape": list(a.shape), "offset": off}
+            off += a.nbytes
+        header = json.dumps({"arrays": meta, "num_edge_features": self.num_edge_features, "dist_range": list(self.dist_range),
+                             "target_index": int(self.target_index), "ids": [str(i) for i in self.ids]}).encode()
+        header += b" " * (-(16 + len(header)) % 64)
+        with open(path, "wb") as f:
+            f.write(self.FLAT_MAGIC)
+            f.write(len(header).to_bytes(8, "little"))
+            f.write(header)
+            base = f.tell()
+            for k, a in arrays.items():
+                f.seek(base + meta[k]["offset"])
+                f.write(a.tobytes())
+        return path
+
+    @classmethod
+    def load_flat(cls, path, mmap=True):
+        """Inverse of save_flat.  With mmap=True the arrays are read-only views of the file (pages fault in on first use;
+        .to(device) streams them to HBM); derived arrays (normalised distance, in-degree prefix) are recomputed."""
+        import json
+        with open(path, "rb") as f:
+            if f.read(8) != cls.FLAT_MAGIC:
+                raise ValueError("%s is not a matdeeplearn_amd flat dataset" % path)
+            hlen = int.from_bytes(f.read(8), "little")
+            hdr = json.loads(f.read(hlen).decode())
+            base = 16 + hlen
+        arr = {}
+        for k, m in hdr["arrays"].items():
+            shape = tuple(m["shape"])
+            if mmap:
+                arr[k] = np.memmap(path, dtype=np.dtype(m["dtype"]), mode="r", offset=base + m["offset"], shape=shape)
+            else:
+                with open(path, "rb") as f:
+                    f.seek(base + m["offset"])
+                    n = int(np.prod(shape)) if shape else 1
+                    arr[k] = np.fromfile(f, dtype=np.dtype(m["dtype"]), count=n).reshape(shape)
+        ds = cls(arr["node_ptr"], arr["edge_ptr"], arr["x"], arr["z"], arr["src"], arr["tgt"], arr["dist"], arr["y"],
+                 hdr["ids"], hdr["num_edge_features"], tuple(hdr["dist_range"]))
+        ds.target_index = hdr["target_index"]
+        return ds
+
     # ---- device residency -----------------------------------------------------------------------
     def to(self, device):
         device = torch.device(device)
