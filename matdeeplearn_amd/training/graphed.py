@@ -13,6 +13,11 @@ What makes a step capturable here:
   * every index structure is rebuilt inside the graph (ops.NO_INDEX_CACHE) and every scratch comes from static arenas;
   * the library never allocates or synchronises, so its launches land in the capturing stream like torch's own.
 A batch that does not fit the static capacity (or a ragged last batch) runs eagerly — same arithmetic, no padding.
+
+Scope: models whose operators walk the batch through `rowptr` only (CGCNN: K2 / K3 / K3c, BatchNorm, pooling).  SchNet,
+MEGNet, MPNN and GCN also build by-source permutations from the edge arrays themselves, and the unused tail of the padded
+arrays would enter those sorts (measured: hundreds of milliseconds per replay) — they run eagerly until the loader emits
+the by-source order per graph.
 """
 import torch
 import torch.nn.functional as F

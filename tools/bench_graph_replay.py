@@ -1,5 +1,5 @@
 import os, sys, time, torch, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from matdeeplearn_amd import models, ops
 from matdeeplearn_amd.process import synthetic_bulk
 from matdeeplearn_amd.training import GraphedStep, make_optimizer

@@ -1,6 +1,6 @@
 """Where does the HOST spend its time per training step once the loop has run for a while?  (cProfile over bench's step)"""
 import cProfile, pstats, io, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from matdeeplearn_amd import models, ops
 from matdeeplearn_amd.process import synthetic_bulk, DeviceLoader, split_data
