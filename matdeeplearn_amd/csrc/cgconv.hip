@@ -255,7 +255,9 @@ struct WaveCtx {
     bf16_t* oh_t;       // one-hot tables (bf16 kernels), see oh_update()
     bf16_t* oh_e;
     bf16_t* oh_w;
-    unsigned long long* touched;  // per-wave bitmap of window slots that received an edge
+    unsigned long long* touched;  // per-wave bitmap of window slots that received an edge (saved-gate kernel)
+    unsigned char* touched_b;     // the same as 64 bytes (one per window slot: plain idempotent byte writes, read back with a ballot)
+    int* dummy;                   // 64 dwords: where a lane's table writes go when it has nothing to write (branch-free updates)
     const T* wbase;     // packed weights (LDS or global)
 };
 
@@ -573,6 +575,8 @@ __device__ __forceinline__ void setup_wave(const CgParams& p, const D& dm, char*
     w.oh_t = reinterpret_cast<bf16_t*>(base + et_bytes + 32 + 128 + 32 + 16);
     w.oh_e = w.oh_t + 32 * OHS;
     w.oh_w = w.oh_e + 32 * OHS;
+    w.touched_b = reinterpret_cast<unsigned char*>(w.oh_w + 64 * OHS);
+    w.dummy = reinterpret_cast<int*>(w.touched_b + 64);
     w.wbase = w_lds ? reinterpret_cast<const T*>(smem) : static_cast<const T*>(p.wpack);
     if (w_lds) {
         const f32x4* g = reinterpret_cast<const f32x4*>(p.wpack);
@@ -1136,7 +1140,8 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             for (int r = 0; r < 16; ++r) dwe_acc[a][b][r] = 0.0f;
 
     float dbf_acc = 0.0f, dbs_acc = 0.0f;
-    int oh_ts = -1, oh_ss = -1;      // where this edge-slot lane currently has its 1.0 in the one-hot tables
+    int oh_a = -1;                   // where this lane currently has its 1.0 in the one-hot tables it keeps (bf16 path):
+                                     // lanes h = 0 keep the TARGET tables (oh_t, oh_e), lanes h = 1 the WINDOW table (oh_w)
     // Work distribution.  Static: one edge-balanced node range per wave (NodeRange).  Dynamic (p.ctr, large
     // problems): the waves of a slice take 32-node groups from a shared counter — equal tile counts do not mean equal
     // time (graphs wider than the source window fall back to atomics, CUs differ in memory latency), and the
@@ -1222,7 +1227,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { Wf[mt][r] = 0.0f; Ws[mt][r] = 0.0f; }
-        if (lane == 0) *w.touched = 0ull;
+        if constexpr (BF) w.touched_b[lane] = 0; else if (lane == 0) *w.touched = 0ull;
 
             TRESET();
         for (int eb = e0; eb < e1; eb += 32) {
@@ -1235,22 +1240,31 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             const bool oob = valid_i && !in_win;
             wave_lds_fence();
             if constexpr (ST) ew.commit(w.et, dm.EKS, lane); else stage_e_tile<T, EW>(p, dm, w, lane, eb, nv, cur.ep);
-            if (h == 0) {
+            if constexpr (BF) {
+                // Branch-free, and split over the two half-waves (both hold the indices of edge slot i): lanes h = 0 keep the
+                // target-side tables, lanes h = 1 the source-window side.  Every store is unconditional; a lane with nothing to
+                // write aims at its own dummy dword.  (As `if (h == 0) { if (changed) { if (old >= 0) ... } }` this was a chain
+                // of ~20 divergent skip branches per tile, each a v_cmp -> saveexec -> branch round trip, and one basic block
+                // boundary each for the scheduler.)
+                unsigned char* const dmb = reinterpret_cast<unsigned char*>(w.dummy + lane);
+                bf16_t* const dmh = reinterpret_cast<bf16_t*>(w.dummy + lane);
+                reinterpret_cast<unsigned char*>(h ? w.ssl : w.tsl)[i] =
+                    h ? (in_win ? (unsigned char)my_ss : (unsigned char)0xff) : (unsigned char)my_ts;
+                *(h ? (w.srcl + i) : (w.dummy + lane)) = oob ? cur.src : -1;
+                *((h && in_win) ? (w.touched_b + my_ss) : dmb) = 1;
+                const int nA = h ? (in_win ? (int)my_ss : -1) : (valid_i ? my_ts : -1);
+                bf16_t* const tabA = (h ? w.oh_w : w.oh_t) + oh_pos(i);
+                const bool chg = oh_a != nA, clr = chg && oh_a >= 0, set = chg && nA >= 0;
+                *(clr ? tabA + oh_a * OHS : dmh) = 0;
+                *(set ? tabA + nA * OHS : dmh) = 0x3F80;
+                *((clr && h == 0) ? w.oh_e + i * OHS + oh_a : dmh) = 0;
+                *((set && h == 0) ? w.oh_e + i * OHS + nA : dmh) = 0x3F80;
+                oh_a = nA;
+            } else if (h == 0) {
                 reinterpret_cast<unsigned char*>(w.tsl)[i] = (unsigned char)my_ts;
                 reinterpret_cast<unsigned char*>(w.ssl)[i] = in_win ? (unsigned char)my_ss : (unsigned char)0xff;
                 w.srcl[i] = oob ? cur.src : -1;
                 if (in_win) atomicOr(w.touched, 1ull << my_ss);
-                if constexpr (BF) {
-                    const int nts = valid_i ? my_ts : -1, nss = in_win ? (int)my_ss : -1;
-                    oh_update(w.oh_t, oh_ts, nts, oh_pos(i));
-                    oh_update(w.oh_w, oh_ss, nss, oh_pos(i));
-                    if (oh_ts != nts) {
-                        if (oh_ts >= 0) w.oh_e[i * OHS + oh_ts] = 0;
-                        if (nts >= 0) w.oh_e[i * OHS + nts] = 0x3F80;
-                    }
-                    oh_ts = nts;
-                    oh_ss = nss;
-                }
             }
             wave_lds_fence();
             TMARK(1);
@@ -1408,9 +1422,14 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
         {
             // (the mask is the same in every lane: SGPRs; d_row(r, h) = d_row(r, 0) + 4h: one per-lane shift, then constant
             // bit tests — per-row masks 1 << sl hoisted out of the group loop are the first thing hipcc spills)
-            const unsigned long long tmv = *w.touched;
-            const unsigned long long tm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(tmv >> 32)) << 32) |
-                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tmv);
+            unsigned long long tm;
+            if constexpr (BF) {
+                tm = __ballot(w.touched_b[lane] != 0);
+            } else {
+                const unsigned long long tmv = *w.touched;
+                tm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(tmv >> 32)) << 32) |
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tmv);
+            }
             const unsigned long long tmh = tm >> (4 * h);
             if (ch < dm.C) {
 #pragma unroll
@@ -1827,7 +1846,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
 
     const int et_bytes = (32 * d.EKS * (int)sizeof(T) + 15) & ~15;
     // e tile, tgt-slot bytes, source ids, src-slot bytes, bitmap, one-hot tables (32 + 32 + 64 rows)
-    p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16 + ((bwd && sizeof(T) == 2) ? 128 * OHS * 2 : 0);
+    p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16 + ((bwd && sizeof(T) == 2) ? 128 * OHS * 2 + 64 + 256 : 0);
     const int w_bytes = (p.w_elems * (int)sizeof(T) + 15) & ~15;
     const int waves = bwd ? 4 : MDL_FWD_THREADS / 64;
     // static fast shapes keep W in registers (no LDS copy); otherwise LDS if it fits, else global
