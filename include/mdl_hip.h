@@ -245,9 +245,17 @@ int mdl_linear_act(const void* x, const void* w, const void* bias, void* out, in
 int mdl_gemm_tn(const void* a, int64_t lda, int M, const void* b, int64_t ldb, int K, float* c, int64_t N, int dtype,
                 mdlStream_t stream);
 /* same, plus colsum[M] (fp32, caller zero-fills) += column sums of a — the bias gradient of that Linear
- * (`g.sum(0)` in the reference's autograd), out of the same pass.  Needs even M, K, lda, ldb and K <= 126. */
+ * (`g.sum(0)` in the reference's autograd), out of the same pass.  Needs even M, K, lda, ldb and K <= 158. */
 int mdl_gemm_tn_colsum(const void* a, int64_t lda, int M, const void* b, int64_t ldb, int K, float* c, float* colsum,
                        int64_t N, int dtype, mdlStream_t stream);
+/* same with a .* act'(y) in place of a: a = gradient w.r.t. the OUTPUT y[N, M] (leading dim ldy) of an activated Linear,
+ * act: 0 = none, 1 = ReLU (y > 0), 2 = shifted softplus (1 - exp(-(y + ln 2))); the factor is applied while the tile is
+ * staged, so `threshold_backward` / the softplus backward of the reference's autograd need no pass of their own when the
+ * Linear's input needs no gradient (first layer of SchNet's filter network, matdeeplearn/models/schnet.py:81 via
+ * torch_geometric.nn.models.schnet.InteractionBlock.mlp).  colsum (may be NULL) = column sums of a .* act'(y).
+ * Same shape limits as mdl_gemm_tn_colsum. */
+int mdl_gemm_tn_act(const void* a, int64_t lda, int M, const void* y, int64_t ldy, int act, const void* b, int64_t ldb,
+                    int K, float* c, float* colsum, int64_t N, int dtype, mdlStream_t stream);
 
 /* ---- generic gather / edge-weighted gather-reduce (SchNet CFConv, GCNConv, MEGNet, NNConv) ------
  * Replace the index_select + elementwise + torch_scatter sequence of PyG MessagePassing.propagate at

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "mdl_linear_gather_act": (_i32, [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_gemm_tn": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp]),
     "mdl_gemm_tn_colsum": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
+    "mdl_gemm_tn_act": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "mdl_gather_rows": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "mdl_gather_mul_reduce": (_i32, [_vp] * 7 + [_i64, _i64, _i32, _i32, _vp]),
     "mdl_edge_mul": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _vp]),

@@ -673,17 +673,34 @@ def _dx_hip(g, w):
     return g @ w
 
 
-def _linear_tn_grads(ctx, g, x, w):
-    """(dx, dW, db) of y = x W^T + b for a tall x: streaming HIP product (or library GEMM) for dx, one TN-GEMM launch for dW
-    and db."""
+def _tn_act_ok(ctx, g, x, y):
+    """mdl_gemm_tn_act can take the activation derivative into its staging: dx not wanted, streaming-kernel shapes."""
     M, K = ctx.shape
+    return (_TN_COLSUM and not ctx.needs_input_grad[0] and M % 2 == 0 and K % 2 == 0 and K <= 158 and (M <= 128 or K <= 160)
+            and g.dtype == torch.bfloat16 and x.stride(0) % 2 == 0 and g.stride(0) % 2 == 0 and y.stride(0) % 2 == 0
+            and x.data_ptr() % 4 == 0 and g.data_ptr() % 4 == 0 and y.data_ptr() % 4 == 0 and g.stride(1) == 1
+            and y.stride(1) == 1)
+
+
+def _linear_tn_grads(ctx, g, x, w, act_y=None):
+    """(dx, dW, db) of y = x W^T + b for a tall x: streaming HIP product (or library GEMM) for dx, one TN-GEMM launch for dW
+    and db.  act_y = (code, y): g is the gradient w.r.t. the ACTIVATED output y, dx is not wanted (_tn_act_ok), and the
+    activation derivative is applied inside the TN GEMM's staging (mdl_gemm_tn_act)."""
+    M, K = ctx.shape
+    if act_y is not None:
+        buf = torch.zeros(M * K + M, dtype=torch.float32, device=g.device)
+        dw, dbv = buf[:M * K].view(M, K), buf[M * K:]
+        check(lib().mdl_gemm_tn_act(ptr(g), g.stride(0), M, ptr(act_y[1]), act_y[1].stride(0), act_y[0], ptr(x), x.stride(0), K,
+                                    ptr(dw), ptr(dbv) if ctx.has_bias else None, g.shape[0], dtype_code(g), stream()),
+              "mdl_gemm_tn_act")
+        return None, dw.to(ctx.wdtype), (dbv.to(ctx.wdtype) if ctx.has_bias else None)
     dx = _dx_hip(g, w) if ctx.needs_input_grad[0] else None
     ga, Ma = g, M
     if M % 2:                               # the streaming kernel stages rows as dwords: pad an odd width (the model's
         ga, Ma = torch.nn.functional.pad(g, (0, 1)), M + 1             # 1-column output layer) with a zero column
     # db out of the same pass (mdl_gemm_tn_colsum: the column sums of g ride in a padding column of the B tile and are
     # flushed with one gathered atomic instruction per block); MDL_TN_COLSUM=0 falls back to the library reduction
-    fused_db = (_TN_COLSUM and ctx.has_bias and K % 2 == 0 and K <= 126 and x.stride(0) % 2 == 0
+    fused_db = (_TN_COLSUM and ctx.has_bias and K % 2 == 0 and K <= 158 and x.stride(0) % 2 == 0
                 and ga.stride(0) % 2 == 0 and x.data_ptr() % 4 == 0 and ga.data_ptr() % 4 == 0)
     buf = torch.zeros(Ma * K + Ma, dtype=torch.float32, device=g.device)          # dW | db in one zero fill
     dw, dbv = buf[:Ma * K].view(Ma, K), buf[Ma * K:]
@@ -716,6 +733,8 @@ class _LinearActTN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w, out = ctx.saved_tensors
+        if ctx.act in ("relu", "ssp") and _tn_act_ok(ctx, g, x, out):
+            return _linear_tn_grads(ctx, g, x, w, act_y=(1 if ctx.act == "relu" else 2, out)) + (None, None, None)
         if ctx.act == "relu":
             g = torch.ops.aten.threshold_backward(g, out, 0)
         elif ctx.act == "ssp":                     # d/dv (softplus(v) - ln2) = sigmoid(v) = 1 - exp(-(out + ln2))

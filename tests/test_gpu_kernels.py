@@ -493,7 +493,8 @@ def test_gather_rows_and_its_gradient(dtype):
 
 
 @pytest.mark.parametrize("N,M,K", [(1000, 64, 114), (129, 32, 50), (5000, 100, 200), (77, 128, 256), (1, 7, 3), (8192, 1, 64),
-                                   (8192, 64, 64), (3000, 2, 64), (700, 64, 126)])
+                                   (8192, 64, 64), (3000, 2, 64), (700, 64, 126), (2100, 150, 150), (3001, 150, 50),
+                                   (900, 64, 158), (1500, 100, 100), (640, 160, 32), (333, 32, 160)])
 def test_gemm_tn_matches_torch(N, M, K):
     """Tall-skinny weight-gradient GEMM (bf16 in, fp32 out) vs an fp32 matmul of the same rounded inputs."""
     from matdeeplearn_amd import _lib
@@ -505,7 +506,7 @@ def test_gemm_tn_matches_torch(N, M, K):
                                       _lib.MDL_BF16, _lib.stream()), "mdl_gemm_tn")
     ref = a.float().t() @ b.float()
     close(c, ref, 1e-4, 1e-5)
-    if M % 2 == 0 and K % 2 == 0 and K <= 126:          # same pass + column sums of a (the Linear's bias gradient)
+    if M % 2 == 0 and K % 2 == 0 and K <= 158:          # same pass + column sums of a (the Linear's bias gradient)
         c2, cs = torch.zeros(M, K, device=dev()), torch.zeros(M, device=dev())
         _lib.check(_lib.lib().mdl_gemm_tn_colsum(_lib.ptr(a), a.stride(0), M, _lib.ptr(b), b.stride(0), K, _lib.ptr(c2),
                                                  _lib.ptr(cs), N, _lib.MDL_BF16, _lib.stream()), "mdl_gemm_tn_colsum")
@@ -550,6 +551,49 @@ def test_linear_act_matches_torch(N, K, M, act, use_bias):
         close(xg.grad, xr.grad, 3e-2, 2e-2)
         if bp is not None:
             close(bp.grad, br.grad, 3e-2, 2e-2)
+
+
+@pytest.mark.parametrize("N,M,K,act", [(3001, 150, 50, 2), (2100, 150, 150, 2), (1000, 64, 114, 1), (777, 20, 50, 2),
+                                       (5000, 128, 64, 1)])
+def test_gemm_tn_act_matches_torch(N, M, K, act):
+    """TN GEMM with the activation derivative applied in its staging (mdl_gemm_tn_act) vs the two-step form: masked /
+    scaled gradient rounded to bf16 (what mdl_ssp_bwd / threshold_backward would have written), then an fp32 product."""
+    from matdeeplearn_amd import _lib
+    g = torch.Generator().manual_seed(N + M + act)
+    a = torch.randn(N, M, generator=g).to(torch.bfloat16).to(dev())
+    pre = torch.randn(N, M, generator=g) * 2
+    y = (torch.relu(pre) if act == 1 else torch.nn.functional.softplus(pre) - 0.6931471805599453).to(torch.bfloat16).to(dev())
+    b = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev())
+    c, cs = torch.zeros(M, K, device=dev()), torch.zeros(M, device=dev())
+    _lib.check(_lib.lib().mdl_gemm_tn_act(_lib.ptr(a), a.stride(0), M, _lib.ptr(y), y.stride(0), act, _lib.ptr(b), b.stride(0), K,
+                                          _lib.ptr(c), _lib.ptr(cs), N, _lib.MDL_BF16, _lib.stream()), "mdl_gemm_tn_act")
+    fac = (y.float() > 0).float() if act == 1 else 1.0 - torch.exp(-(y.float() + 0.6931471805599453))
+    am = (a.float() * fac).to(torch.bfloat16).float()
+    close(c, am.t() @ b.float(), 1e-4, 2e-5 * N ** 0.5)
+    close(cs, am.sum(0), 1e-4, 2e-5 * N ** 0.5)
+
+
+@pytest.mark.parametrize("act", ["relu", "ssp"])
+def test_linear_act_without_input_grad(act):
+    """A fused dense layer whose input needs no gradient (SchNet's filter network on the edge features): the backward
+    takes the activation derivative into the TN GEMM; weights / bias gradients vs fp32 torch."""
+    from matdeeplearn_amd import ops
+    N, K, M = 4000, 50, 150
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev())
+    w = (torch.randn(M, K, generator=g) / K ** 0.5).to(dev()).requires_grad_(True)
+    b = (torch.randn(M, generator=g) * 0.1).to(dev()).requires_grad_(True)
+    go = torch.randn(N, M, generator=g).to(dev())
+    y = ops.linear_act(x, w, b, act)
+    (y.float() * go).sum().backward()
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = b.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = torch.nn.functional.linear(x.float(), wr, br)
+    yr = torch.relu(yr) if act == "relu" else torch.nn.functional.softplus(yr) - 0.6931471805599453
+    (yr * go.to(torch.bfloat16).float()).sum().backward()
+    close(y, yr, 1e-2, 4e-3)
+    close(w.grad, wr.grad, 3e-2, 3e-2)
+    close(b.grad, br.grad, 3e-2, 3e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -1,0 +1,33 @@
+"""Event timing of the streaming dense kernels (TN GEMM, fused Linear) on the SchNet / MEGNet edge shapes.
+usage: python tools/bench_dense.py [rows ...]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from matdeeplearn_amd import _lib
+L = _lib.lib(); P = _lib.ptr; st = _lib.stream
+d = torch.device("cuda:0")
+
+
+def t(name, fn, bytes_, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    print("%-34s %8.1f us   %6.2f TB/s" % (name, us, bytes_ / us / 1e6))
+
+
+rows_list = [int(a) for a in sys.argv[1:]] or [1_498_398, 374_600]
+for rows in rows_list:
+    for (M, K) in ((150, 150), (150, 50), (100, 100), (64, 114)):
+        a = torch.randn(rows, M, device=d).to(torch.bfloat16); b = torch.randn(rows, K, device=d).to(torch.bfloat16)
+        c = torch.zeros(M, K, device=d); cs = torch.zeros(M, device=d)
+        t("gemm_tn %dx%d rows %d" % (M, K, rows), lambda: L.mdl_gemm_tn_colsum(P(a), a.stride(0), M, P(b), b.stride(0), K, P(c), P(cs), rows, _lib.MDL_BF16, st()),
+          rows * (M + K) * 2)
+    for (K, M, act) in ((50, 150, 2), (150, 150, 0), (100, 100, 1), (114, 64, 1)):
+        x = torch.randn(rows, K, device=d).to(torch.bfloat16); w = torch.randn(M, K, device=d).to(torch.bfloat16)
+        bb = torch.randn(M, device=d).to(torch.bfloat16); o = torch.empty(rows, M, device=d, dtype=torch.bfloat16)
+        t("linear %d->%d act %d rows %d" % (K, M, act, rows), lambda: L.mdl_linear_act(P(x), P(w), P(bb), P(o), rows, K, M, act, _lib.MDL_BF16, st()),
+          rows * (M + K) * 2)
