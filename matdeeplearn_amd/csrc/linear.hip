@@ -5,10 +5,11 @@
 // 12 us for the separate activation), while the layer is a stream: N*(K + M)*2 bytes, read / written once.
 //
 // Workgroup = 4 waves = 64 rows per step of a grid-stride loop.  W (all of it) sits in LDS for the whole kernel, rows
-// padded to an odd number of 16-byte slots.  The x tile is a CONTIGUOUS byte range (dense rows): it is fetched with
-// 16-byte buffer loads one tile ahead (range = the bytes left in the array, so the last tile needs no clamps and reads
-// zeros past the end) and scattered dword-wise into a padded LDS tile.  MFMA 32x32x16: A = x rows, B = W rows (both
-// row-wise ds_read_b128 fragments), K zero-padded to a multiple of 32 in LDS; bias + activation on the accumulators.
+// padded to an odd number of 16-byte slots.  The x tile is fetched one tile ahead with coalesced dword buffer loads
+// (wave = 16 rows, lane = dword of the row; range = the bytes left in the array, so the last tile needs no clamps and
+// reads zeros past the end) and written to a padded LDS tile.  MFMA 32x32x16: A = x rows, B = W rows (both row-wise
+// ds_read_b128 fragments), K zero-padded to a multiple of 32 in LDS; a wave owns one 32-row block row and every second
+// 32-column block, so an A fragment is read once per k-step for all of them; bias + activation on the accumulators.
 #include "mdl_common.h"
 
 namespace mdl {
@@ -26,116 +27,138 @@ struct GatherAdd {
     const int32_t* idx[3];     // row of table i for every row of x
 };
 
-template <int KP, int NT, bool GATHER = false>     // KP: K padded to {64, 128, 256}; NT: 32-column tiles of the output (M <= 32*NT)
+template <int KP, int NT, bool GATHER = false>     // KP: K padded to {64, 128, 160, 256}; NT: 32-column tiles of the output (M <= 32*NT)
 __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
-                                                            int64_t N, int K, int M, int act, unsigned inv_k2,
-                                                            GatherAdd ga) {
+                                                            int64_t N, int K, int M, int act, GatherAdd ga) {
     constexpr int TN = 64;
     constexpr int LD = KP + 8;                       // LDS row stride (bf16): odd number of 16-byte slots
-    constexpr int NLX = KP * 8 / 256;                // 16-byte chunks of the x tile per thread (tile = 64 rows x K, K <= KP)
-    constexpr int NB = (2 * NT + 3) / 4;             // (32-row, 32-col) output blocks per wave
+    constexpr int NB = (NT + 1) / 2;                 // output blocks per wave: block row wv & 1, block columns (wv >> 1) + 2j
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* wl = reinterpret_cast<bf16_t*>(smem);    // [32*NT][LD]
     bf16_t* xl = wl + 32 * NT * LD;                  // [TN][LD]
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k2 = K >> 1;                           // dwords per row
 
-    // W -> LDS (zero padded to [32*NT][KP]) and the zero padding of the x tile's columns K..KP-1 (never written again)
+    // W -> LDS, zero padded to [32*NT][KP]
     for (int q = tid; q < 32 * NT * (KP / 2); q += 256) {
         const int row = q / (KP / 2), d = q - row * (KP / 2);
         unsigned v = 0u;
         if (row < M && d < k2) v = *reinterpret_cast<const unsigned*>(w + (int64_t)row * K + 2 * d);
         *reinterpret_cast<unsigned*>(wl + row * LD + 2 * d) = v;
     }
-    for (int q = tid; q < TN * (KP / 2); q += 256) {
-        const int row = q / (KP / 2), d = q - row * (KP / 2);
-        if (d >= k2) *reinterpret_cast<unsigned*>(xl + row * LD + 2 * d) = 0u;
-    }
+    const int mt = wv & 1, ntb = wv >> 1;            // this wave's block row and first block column
     float bv[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int blk = wv + 4 * j, nt = blk % NT, col = nt * 32 + i;
+        const int col = (ntb + 2 * j) * 32 + i;
         bv[j] = (bias && col < M) ? bf2f(bias[col]) : 0.0f;
     }
 
+    // x tile staging (same map as gemm_tn.hip): wave wv stages rows 16*wv .. 16*wv+15; a padded row is DW = KP/2 dwords,
+    // dwords 0..64*Q-1 one load per 64 (lane = dword), the remaining R dwords for 64/R rows per load.  Row offsets are in
+    // the VGPR offset (range checked): rows past N and columns K..KP-1 read as zeros, so the padding columns of the LDS
+    // tile are rewritten with zeros by every tile and nothing needs a clamp.  (The previous version fetched the tile as
+    // flat 16-byte chunks and split every dword into (row, column) with a multiply-high: ~8 VALU per dword.)
+    constexpr int DW = KP / 2, Q = DW / 64, R = DW % 64, NR = R ? 16 * R / 64 : 0, NLX = 16 * Q + NR;
+    constexpr unsigned FAR = 0x40000000u;
+    const int w16 = 16 * wv;
+    const unsigned xrow = (unsigned)K * 2u;          // dense rows
     const int64_t n_tiles = (N + TN - 1) / TN;
-    const int tile_chunks = TN * K / 8;              // 16-byte chunks per full tile (K even -> 64*K*2 bytes, a multiple of 16)
-    u32x4_l xr[NLX];
+    unsigned xr[NLX];
     auto load_tile = [&](int64_t tile) {
-        const int64_t off = tile * TN * (int64_t)K;                      // elements
-        const int64_t rem = (N * (int64_t)K - off) * 2;                  // bytes left in the array
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<bf16_t*>(x + off), 0, (int)(rem < 0x7fffffffLL ? rem : 0x7fffffffLL), 0x00020000);
+        const int64_t nb = tile * TN;
+        const int64_t bytes = (N - nb) * (int64_t)K * 2, cap = (int64_t)TN * K * 2;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x + nb * (int64_t)K), 0,
+                                                                            (int)(bytes < cap ? bytes : cap), 0x00020000);
 #pragma unroll
-        for (int l = 0; l < NLX; ++l) xr[l] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16 + l * 4096, 0, 0);
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const int d = lane + 64 * j;
+                xr[r * Q + j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (d < k2) ? (unsigned)(w16 + r) * xrow + 4u * d : FAR, 0, 0);
+            }
+        if constexpr (R != 0) {
+            const int d = 64 * Q + lane % R, rr = lane / R;
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+                xr[16 * Q + k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (d < k2) ? (unsigned)(w16 + k * (64 / R) + rr) * xrow + 4u * d : FAR, 0, 0);
+        }
     };
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) load_tile(tile);
     for (; tile < n_tiles; tile += gridDim.x) {
         const int64_t nb = tile * TN;
-        __syncthreads();                                    // previous tile's fragments read; W / padding in place
+        __syncthreads();                                    // previous tile's fragments read; W in place
 #pragma unroll
-        for (int l = 0; l < NLX; ++l) {
-            const int c = l * 256 + tid;
-            if (c < tile_chunks) {
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned q = 4u * c + j;                       // dword of the tile -> (row, dword in row)
-                    const unsigned row = __umulhi(q, inv_k2);
-                    const unsigned d = q - row * (unsigned)k2;
-                    *reinterpret_cast<unsigned*>(xl + row * LD + 2 * d) = xr[l][j];
-                }
-            }
+            for (int j = 0; j < Q; ++j) *reinterpret_cast<unsigned*>(xl + (w16 + r) * LD + 2 * (lane + 64 * j)) = xr[r * Q + j];
+        if constexpr (R != 0) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+                *reinterpret_cast<unsigned*>(xl + (w16 + k * (64 / R) + lane / R) * LD + 2 * (64 * Q + lane % R)) = xr[16 * Q + k];
         }
         __syncthreads();
         if (tile + gridDim.x < n_tiles) load_tile(tile + gridDim.x);      // next tile's loads fly during the MFMAs
+        if (ntb < NT) {                                                    // (NT == 1: waves 2, 3 have no block)
+            // blocks (mt, ntb + 2j): one A fragment (x rows) per k-step feeds all of the wave's block columns
+            f32x16 acc[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int blk = wv + 4 * j;
-            if (blk < 2 * NT) {
-                const int mt = blk / NT, nt = blk - mt * NT;
-                f32x16 acc;
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = bv[j];
+                for (int r = 0; r < 16; ++r) acc[j][r] = bv[j];
 #pragma unroll
-                for (int kk = 0; kk < KP / 16; ++kk) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(xl + (mt * 32 + i) * LD + 16 * kk + 8 * h);
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + (nt * 32 + i) * LD + 16 * kk + 8 * h);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            for (int kk = 0; kk < KP / 16; ++kk) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(xl + (mt * 32 + i) * LD + 16 * kk + 8 * h);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int nt = min(ntb + 2 * j, NT - 1);              // (a block column past NT repeats the last one — no
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + (nt * 32 + i) * LD + 16 * kk + 8 * h);   // branch in the
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);                       // MFMA chain — and is not stored)
                 }
-                const int col = nt * 32 + i;
-                const int64_t remr = N - nb - mt * 32;                    // rows of this block that exist
-                if constexpr (GATHER) {
-                    // + the gathered projection rows (clamped row index: rows past N are computed on a valid row and then
-                    // dropped by the store's range check).  All index loads first, then all table loads: two round trips.
-                    const int colc = min(col, M - 1);
+            }
+            const int64_t remr = N - nb - mt * 32;                        // rows of this block row that exist
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        if (ga.p[t]) {
-                            int id[16];
+            for (int j = 0; j < NB; ++j) {
+                const int nt = ntb + 2 * j, col = nt * 32 + i;
+                if (nt < NT) {
+                    if constexpr (GATHER) {
+                        // + the gathered projection rows (clamped row index: rows past N are computed on a valid row and then
+                        // dropped by the store's range check).  All index loads first, then all table loads: two round trips.
+                        const int colc = min(col, M - 1);
 #pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                id[r] = ga.idx[t][min(nb + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, N - 1)];
-                            float v[16];
+                        for (int t = 0; t < 3; ++t) {
+                            if (ga.p[t]) {
+                                int id[16];
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) v[r] = bf2f(ga.p[t][(int64_t)id[r] * M + colc]);
+                                for (int r = 0; r < 16; ++r)
+                                    id[r] = ga.idx[t][min(nb + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, N - 1)];
+                                float v[16];
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[r] += v[r];
+                                for (int r = 0; r < 16; ++r) v[r] = bf2f(ga.p[t][(int64_t)id[r] * M + colc]);
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[j][r] += v[r];
+                            }
                         }
                     }
-                }
-                if (col < M && remr > 0) {
-                    const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
-                        out + (nb + mt * 32) * (int64_t)M, 0,
-                        (int)((remr * M * 2) < 0x7fffffffLL ? (remr * M * 2) : 0x7fffffffLL), 0x00020000);
-                    const int vo = (4 * h * M + col) * 2;
+                    if (col < M && remr > 0) {
+                        const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
+                            out + (nb + mt * 32) * (int64_t)M, 0,
+                            (int)((remr * M * 2) < 0x7fffffffLL ? (remr * M * 2) : 0x7fffffffLL), 0x00020000);
+                        const int vo = (4 * h * M + col) * 2;
+                        // (2-byte stores, 16 per block: pairing neighbouring lanes' columns into dword stores — half the store
+                        // instructions — measured no faster; these streams run at 4.2-4.9 TB/s of the ~6.3 TB/s a copy reaches)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[r];
-                        if (act == 1) v = v > 0.0f ? v : 0.0f;
-                        else if (act == 2) v = fmaxf(v, 0.0f) + __logf(1.0f + __expf(-fabsf(v))) - 0.6931471805599453f;   // shifted softplus
-                        __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(v), os, vo + ((r & 3) + 8 * (r >> 2)) * M * 2, 0, 0);
+                        for (int r = 0; r < 16; ++r) {
+                            float v = acc[j][r];
+                            if (act == 1) v = v > 0.0f ? v : 0.0f;
+                            else if (act == 2) {    // shifted softplus = max(v,0) + ln2 * (log2(1 + 2^(-|v| log2 e)) - 1): two transcendentals, 5 VALU
+                                const float l = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-LOG2E_F * fabsf(v)));
+                                v = fmaf(0.5f, v + fabsf(v), fmaf(LN2_F, l, -LN2_F));
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(v), os, vo + ((r & 3) + 8 * (r >> 2)) * M * 2, 0, 0);
+                        }
                     }
                 }
             }
@@ -170,8 +193,6 @@ extern "C" int mdl_linear_gather_act(const void* x, const void* w, const void* b
     const int nt = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 128 ? 4 : 5));
     int64_t grid = cdiv(N, 64);
     if (grid > 512) grid = 512;
-    const int k2 = K / 2;
-    const unsigned inv_k2 = (unsigned)((0x100000000ULL + k2 - 1) / k2);      // row = umulhi(q, inv) for q < 2^16 (k2 >= 2)
     const int lds = (32 * nt + 64) * (kp + 8) * 2;
 #define MDL_LIN(KP_, NT_)                                                                                            \
     do {                                                                                                             \
@@ -179,12 +200,12 @@ extern "C" int mdl_linear_gather_act(const void* x, const void* w, const void* b
             auto kf = linear_act_kernel<KP_, NT_, true>;                                                             \
             (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                       \
             hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,     \
-                               (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, inv_k2, ga);                         \
+                               (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, ga);                         \
         } else {                                                                                                     \
             auto kf = linear_act_kernel<KP_, NT_, false>;                                                            \
             (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                       \
             hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,     \
-                               (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, inv_k2, GatherAdd{});                \
+                               (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, GatherAdd{});                \
         }                                                                                                            \
     } while (0)
     if (kp == 64) { if (nt == 1) MDL_LIN(64, 1); else if (nt == 2) MDL_LIN(64, 2); else if (nt == 4) MDL_LIN(64, 4); else MDL_LIN(64, 5); }

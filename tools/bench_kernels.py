@@ -36,7 +36,7 @@ torch.cuda.synchronize()
 for k, v in ev.items():
     if v:
         t = [s.elapsed_time(e) * 1e3 for s, e in v]
-        print("%s: avg %.1f us  min %.1f us" % (k, sum(t) / len(t), min(t)))
+        print("%s: avg %.1f us  median %.1f us  min %.1f us" % (k, sum(t) / len(t), sorted(t)[len(t) // 2], min(t)))
 try:
     import ctypes
     L = _lib.lib()

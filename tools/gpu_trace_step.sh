@@ -2,7 +2,7 @@
 # kernel trace of a few bench steps, reduced to one line per launch (name, grid, duration) in launch order: gpurun_out/trace/step.txt
 OUT=$GRAFT_REPO_ROOT/gpurun_out/trace; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o t -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $OUT/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o t -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 "$@" > $OUT/prof.log 2>&1
 f=$(find $OUT/prof -name "*kernel_trace.csv" | head -1)
 python - "$f" > $OUT/step.txt <<'PY'
 import csv, sys
