@@ -135,6 +135,7 @@ struct CgParams {
     int GW;             // staging words per e row
     unsigned gw_inv;    // ceil(2^32 / GW)
     int n_groups;
+    int g_full;         // bwd, dynamic scheduling: group ids < g_full are 32-node groups, the rest 16-node half groups (tail)
     int w_elems;        // 2*Cp*WS
     int wave_lds_bytes; // per-wave LDS region
     int bias_col;       // 1: bias lives in K column G of wpack (e tile column G holds 1.0)
@@ -1152,9 +1153,12 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
     const int nend = dyn ? (int)p.N : R.nb;
     int gpend = 0;                                   // lane 0: group id returned by the counter (in flight)
     if (dyn && lane == 0) gpend = (int)atomicAdd(p.ctr + s, 1u);
-    int n0 = dyn ? 32 * __builtin_amdgcn_readfirstlane(gpend) : R.na;
+    // The last groups the counter hands out are HALF groups (16 nodes): a 32-node group is ~13 tiles = 45 us of a wave's
+    // ~550, and the kernel ends with the wave that drew the last one (measured spread of the waves' end times: 10 %).
+    auto group_start = [&](int g) { return g < p.g_full ? 32 * g : 32 * p.g_full + 16 * (g - p.g_full); };
+    int n0 = dyn ? group_start(__builtin_amdgcn_readfirstlane(gpend)) : R.na;
     while (n0 < nend) {
-        const int n1 = min(n0 + 32, nend);
+        const int n1 = min(n0 + ((dyn && n0 >= 32 * p.g_full) ? 16 : 32), nend);
         if (dyn && lane == 0) gpend = (int)atomicAdd(p.ctr + s, 1u);   // next group: issued now, read at the end of this one
         const int e0 = p.rowptr[n0];          // n0 is wave-uniform: scalar loads
         const int e1 = p.rowptr[n1];
@@ -1416,7 +1420,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 
         // the id of the next group (requested at the top of this one) is read BEFORE the flush: behind ~100 atomics and
         // stores, waiting for any returning operation means waiting for all of them
-        const int n0_dyn = dyn ? 32 * __builtin_amdgcn_readfirstlane(gpend) : 0;
+        const int n0_dyn = dyn ? group_start(__builtin_amdgcn_readfirstlane(gpend)) : 0;
         // flush the source window: one atomic row update per touched window node (instead of per edge)
         wave_lds_fence();
         {
@@ -1808,6 +1812,7 @@ struct CgEnv {
     int cb_fwd, cb_bwd;   // MDL_CG_CB / MDL_CG_CB_BWD: cooperative column-block kernels (-1 = compile-time default)
     int cb_wgs;           // MDL_CB_WGS: their workgroups per CU (0 = default)
     int ab_wgs;           // MDL_AB_WGS: workgroups per CU of the saved-gate backward (0 = default 1)
+    int no_half_groups;   // MDL_CG_NO_HALF=1: dynamic backward schedule without the half-group tail (A/B)
 };
 static const CgEnv& cg_env() {
     static const CgEnv e = [] {
@@ -1818,6 +1823,7 @@ static const CgEnv& cg_env() {
         v.cb_bwd = (s = getenv("MDL_CG_CB_BWD")) ? (atoi(s) != 0) : -1;
         v.cb_wgs = (s = getenv("MDL_CB_WGS")) ? atoi(s) : 0;
         v.ab_wgs = (s = getenv("MDL_AB_WGS")) ? atoi(s) : 0;
+        v.no_half_groups = (s = getenv("MDL_CG_NO_HALF")) ? (atoi(s) != 0) : 0;
         return v;
     }();
     return e;
@@ -1870,9 +1876,14 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     // total waves must be a multiple of NS so that every wave keeps one channel slice
     while ((grid * waves) % d.NS) ++grid;
     // dynamic group scheduling only pays when every wave gets several 32-node groups
+    p.g_full = p.n_groups;
     if (bwd && p.ctr) {
         if ((int64_t)p.n_groups * d.NS >= 4 * grid * waves && d.NS <= 16) {
             if (hipMemsetAsync(p.ctr, 0, 64, st) != hipSuccess) { set_error("%s: workspace memset failed", name); return MDL_E_LAUNCH; }
+            // the last two groups per wave of a slice are handed out as four half groups
+            const int64_t tail = 2 * (grid * waves / d.NS);
+            p.g_full = (int)std::max<int64_t>(0, (int64_t)p.n_groups - tail);
+            if (cg_env().no_half_groups) p.g_full = p.n_groups;
         } else {
             p.ctr = nullptr;
         }
