@@ -195,6 +195,21 @@ int mdl_nnconv_msg_bwd(const void* Y, const void* h, const void* dm, const int32
 int mdl_pad_batch_tail(const int64_t* noff, const int64_t* eoff, int B, int64_t n_cap, int32_t* rowptr, int64_t* batch,
                        mdlStream_t stream);
 
+/* CSR by SOURCE of the assembled batch from the dataset's per-graph by-source order (eperm_s [Et]: graph-local edge id at
+ * every by-source position, stable; lrowptr_s [Nt]: exclusive out-degree prefix inside the node's graph): rowptr_s [N+1]
+ * (n_cap+1 when padded), col_s / src_s / eid_s [E] = target, source and batch edge id per by-source slot.  This is the
+ * index PyG's MessagePassing backward (scatter of the message gradient to x_j) and `scatter_mean(e, edge_index[0])`
+ * (matdeeplearn/models/megnet.py:86,130) imply; taking it from the loader replaces one device sort per batch.
+ * n_cap >= 0: also close the tail of a padded static batch (rowptr_s[n] = E for the padding nodes). */
+int mdl_assemble_transposed(const int64_t* ids, const int64_t* noff, const int64_t* eoff, const int64_t* node_ptr,
+                            const int64_t* edge_ptr, const int32_t* src_l, const int32_t* tgt_l, const int32_t* eperm_s,
+                            const int32_t* lrowptr_s, int32_t* rowptr_s, int32_t* col_s, int32_t* eid_s, int32_t* src_s, int B,
+                            int64_t n_cap, mdlStream_t stream);
+/* Padded static batches: edge slots [E, e_cap) of src / tgt (and of the by-source arrays when given) point at the first
+ * padding node, whose rows carry zero gradients — per-edge kernels that run over all e_cap slots then add nothing. */
+int mdl_pad_edge_tail(const int64_t* noff, const int64_t* eoff, int B, int64_t n_cap, int64_t e_cap, int32_t* src, int32_t* tgt,
+                      int32_t* col_s, int32_t* eid_s, int32_t* src_s, mdlStream_t stream);
+
 /* ---- training-mode BatchNorm1d over rows, x: [N, C] row-major ------------------------------------
  * Replaces torch.nn.BatchNorm1d as applied after every conv layer (matdeeplearn/models/cgcnn.py:85-87,143)
  * and inside the MEGNet MLPs (megnet.py:47-48).  `sums` is an fp32 scratch of mdl_bn_sums_rows() x C floats the

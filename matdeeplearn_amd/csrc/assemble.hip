@@ -99,7 +99,75 @@ __global__ __launch_bounds__(256) void pad_tail_kernel(const int64_t* __restrict
     }
 }
 
+// CSR by SOURCE of the batch (the transposed index the by-source reductions walk: CFConv / GCNConv backward, MEGNet's
+// scatter at the source row, NNConv) from the dataset's per-graph by-source order, so that no batch needs a device sort:
+// the dataset keeps, per graph, eperm_s (local edge id at every by-source position; stable, i.e. by target inside a
+// source) and lrowptr_s (exclusive out-degree prefix).  One workgroup per graph; with n_cap >= 0 the tail of a padded
+// static batch is closed as well (rowptr_s = E for the padding nodes).
+__global__ __launch_bounds__(256) void assemble_transposed_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ noff,
+                                                                  const int64_t* __restrict__ eoff, const int64_t* __restrict__ node_ptr,
+                                                                  const int64_t* __restrict__ edge_ptr, const int32_t* __restrict__ src_l,
+                                                                  const int32_t* __restrict__ tgt_l, const int32_t* __restrict__ eperm_s,
+                                                                  const int32_t* __restrict__ lrowptr_s, int32_t* __restrict__ rowptr_s,
+                                                                  int32_t* __restrict__ col_s, int32_t* __restrict__ eid_s,
+                                                                  int32_t* __restrict__ src_s, int B, int64_t n_cap) {
+    const int g = blockIdx.x;
+    const int64_t gid = ids[g];
+    const int64_t n0s = node_ptr[gid], nn = node_ptr[gid + 1] - n0s;
+    const int64_t e0s = edge_ptr[gid], ne = edge_ptr[gid + 1] - e0s;
+    const int64_t no = noff[g], eo = eoff[g];
+    for (int64_t j = threadIdx.x; j < nn; j += blockDim.x) rowptr_s[no + j] = (int32_t)(eo + lrowptr_s[n0s + j]);
+    const int32_t shift = (int32_t)no;
+    for (int64_t k = threadIdx.x; k < ne; k += blockDim.x) {
+        const int32_t le = eperm_s[e0s + k];
+        eid_s[eo + k] = (int32_t)(eo + le);
+        col_s[eo + k] = tgt_l[e0s + le] + shift;
+        src_s[eo + k] = src_l[e0s + le] + shift;
+    }
+    const int64_t N = noff[B];
+    const int32_t E = (int32_t)eoff[B];
+    if (g == B - 1 && threadIdx.x == 0) rowptr_s[N] = E;
+    for (int64_t n = N + (int64_t)g * blockDim.x + threadIdx.x; n < n_cap; n += (int64_t)B * blockDim.x) rowptr_s[n + 1] = E;
+}
+
+// Edge slots past the batch's last edge (padded static batches) point at the first padding node: per-edge kernels that run
+// over all e_cap slots then read rows whose gradient is exactly zero, so the unused slots contribute nothing.
+__global__ __launch_bounds__(256) void pad_edge_tail_kernel(const int64_t* __restrict__ noff, const int64_t* __restrict__ eoff, int B,
+                                                            int64_t n_cap, int64_t e_cap, int32_t* __restrict__ src,
+                                                            int32_t* __restrict__ tgt, int32_t* __restrict__ col_s,
+                                                            int32_t* __restrict__ eid_s, int32_t* __restrict__ src_s) {
+    const int64_t N = noff[B], E = eoff[B];
+    const int32_t pad = (int32_t)(N < n_cap ? N : n_cap - 1);
+    for (int64_t e = E + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < e_cap; e += (int64_t)gridDim.x * blockDim.x) {
+        src[e] = pad;
+        tgt[e] = pad;
+        if (col_s) { col_s[e] = pad; src_s[e] = pad; eid_s[e] = (int32_t)e; }
+    }
+}
+
 }  // namespace mdl
+
+extern "C" int mdl_assemble_transposed(const int64_t* ids, const int64_t* noff, const int64_t* eoff, const int64_t* node_ptr,
+                                       const int64_t* edge_ptr, const int32_t* src_l, const int32_t* tgt_l,
+                                       const int32_t* eperm_s, const int32_t* lrowptr_s, int32_t* rowptr_s, int32_t* col_s,
+                                       int32_t* eid_s, int32_t* src_s, int B, int64_t n_cap, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(B >= 1 && ids && noff && eoff && node_ptr && edge_ptr && src_l && tgt_l && eperm_s && lrowptr_s && rowptr_s &&
+                    col_s && eid_s && src_s, MDL_E_ARG, "mdl_assemble_transposed: bad arguments");
+    hipLaunchKernelGGL(assemble_transposed_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, ids, noff, eoff, node_ptr,
+                       edge_ptr, src_l, tgt_l, eperm_s, lrowptr_s, rowptr_s, col_s, eid_s, src_s, B, n_cap);
+    return check_launch("mdl_assemble_transposed");
+}
+
+extern "C" int mdl_pad_edge_tail(const int64_t* noff, const int64_t* eoff, int B, int64_t n_cap, int64_t e_cap, int32_t* src,
+                                 int32_t* tgt, int32_t* col_s, int32_t* eid_s, int32_t* src_s, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(noff && eoff && src && tgt && B >= 1 && n_cap >= 1 && e_cap >= 0 && (!col_s || (eid_s && src_s)), MDL_E_ARG,
+                "mdl_pad_edge_tail: bad arguments");
+    hipLaunchKernelGGL(pad_edge_tail_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, noff, eoff, B, n_cap, e_cap, src, tgt,
+                       col_s, eid_s, src_s);
+    return check_launch("mdl_pad_edge_tail");
+}
 
 extern "C" int mdl_pad_batch_tail(const int64_t* noff, const int64_t* eoff, int B, int64_t n_cap, int32_t* rowptr,
                                   int64_t* batch, mdlStream_t stream) {

@@ -24,12 +24,36 @@ class EdgeCSR:
     """Edges sorted by target.  rowptr [N+1], src/tgt [E] int32, eperm [E] int32 or None when the
     caller's per-edge tensors are already in CSR order (the product loader guarantees that)."""
 
-    __slots__ = ("rowptr", "src", "tgt", "eperm", "N", "E", "_row", "_col", "_t", "_attr")
+    __slots__ = ("rowptr", "src", "tgt", "eperm", "N", "E", "_row", "_col", "_t", "_attr", "_tb", "partial")
 
     def __init__(self, rowptr, src, tgt, eperm, N, E, row=None, col=None):
         self.rowptr, self.src, self.tgt, self.eperm, self.N, self.E = rowptr, src, tgt, eperm, int(N), int(E)
         self._attr = None
-        self._row, self._col, self._t = row, col, None
+        self._row, self._col, self._t, self._tb = row, col, None, None
+        self.partial = False      # padded static batch: the arrays hold more rows than the rowptr ranges cover
+
+    def set_transposed(self, t):
+        """(rowptr_s, col_s, eid_s, src_sorted) supplied by the loader (static buffers of the HIP-graph path)."""
+        self._t = tuple(t)
+
+    def set_transposed_builder(self, fn):
+        """fn() -> (rowptr_s, col_s, eid_s, src_sorted): the loader's sort-free construction, run on first use."""
+        self._tb = fn
+
+    def seg_tgt(self):
+        """segment index of `col` (target per edge): what scatter(..., index=edge_index[1]) needs, without a sort"""
+        if self.eperm is not None:
+            return None
+        return make_seg_index(self.rowptr, self.tgt, partial=self.partial)
+
+    def seg_src(self):
+        """segment index of `row` (source per edge) from the by-source CSR"""
+        if self.eperm is not None:
+            return None
+        rowptr_s, _, eid_s, src_sorted = self.transposed()
+        si = make_seg_index(rowptr_s, src_sorted, partial=self.partial)
+        si.perm = eid_s
+        return si
 
     def sorted_attr(self, edge_attr):
         """edge_attr rows in CSR (target-sorted) order.  The static CGConv kernels stream the edge features
@@ -66,6 +90,8 @@ class EdgeCSR:
 
     def transposed(self):
         """CSR by SOURCE: (rowptr_s [N+1], col_s = target per slot, eid_s = caller's edge id per slot)."""
+        if self._t is None and self._tb is not None:
+            self._t = tuple(self._tb())
         if self._t is None:
             perm = torch.argsort(self.src, stable=True)
             src_sorted = self.src.index_select(0, perm)
@@ -179,10 +205,37 @@ def rbf_expand(dist, start=0.0, stop=1.0, resolution=50, width=0.2, out_dtype=to
 # K5 — scatter / pooling over a sorted (or sortable) index
 # ------------------------------------------------------------------------------------------------
 class _SegIndex:
-    __slots__ = ("rowptr", "seg", "perm", "N", "E")
+    __slots__ = ("rowptr", "seg", "perm", "N", "E", "partial")
 
 
 _SEG_CACHE = collections.OrderedDict()
+# index tensors whose segment index the loader already knows (edge_index rows of a product batch: no sort, and the only
+# correct index for the static buffers of the HIP-graph path, whose unused tail must stay outside every segment)
+_SEG_KNOWN = collections.OrderedDict()
+
+
+def register_seg_index(index, si, owner=None):
+    """`scatter(src, index, ...)` calls with this very memory (same address and length) use `si` — a segment index or a
+    callable that builds it on first use — for as long as `owner` (the tensor that owns the storage; default `index`)
+    is alive.  Only a weak reference is kept: when the owner dies its address may be recycled and the entry is dropped."""
+    import weakref
+    _SEG_KNOWN[(index.data_ptr(), index.numel(), index.device.index)] = [si, weakref.ref(index if owner is None else owner)]
+    while len(_SEG_KNOWN) > 256:
+        _SEG_KNOWN.popitem(last=False)
+
+
+def _known_seg_index(index, dim_size):
+    key = (index.data_ptr(), index.numel(), index.device.index)
+    ent = _SEG_KNOWN.get(key)
+    if ent is None:
+        return None
+    if ent[1]() is None:
+        del _SEG_KNOWN[key]
+        return None
+    if callable(ent[0]):
+        ent[0] = ent[0]()
+    si = ent[0]
+    return si if (si is not None and si.N == int(dim_size)) else None
 
 
 # Static buffers (HIP-graph path) are rewritten in place by kernels the version counter does not see: with NO_INDEX_CACHE
@@ -191,6 +244,9 @@ NO_INDEX_CACHE = False
 
 
 def _seg_index(index, dim_size, assume_sorted):
+    known = _known_seg_index(index, dim_size)
+    if known is not None:
+        return known
     if NO_INDEX_CACHE:
         return _seg_index_build(index, dim_size, assume_sorted)
     key = (index.data_ptr(), index._version, index.numel(), int(dim_size), bool(assume_sorted), index.device.index)
@@ -206,7 +262,7 @@ def _seg_index(index, dim_size, assume_sorted):
 
 def _seg_index_build(index, dim_size, assume_sorted):
     si = _SegIndex()
-    si.N, si.E = int(dim_size), index.numel()
+    si.N, si.E, si.partial = int(dim_size), index.numel(), False
     if assume_sorted:
         si.seg, si.perm = index.to(torch.int32).contiguous(), None
     else:
@@ -235,7 +291,9 @@ class _SegmentReduce(torch.autograd.Function):
         si, C = ctx.si, ctx.C
         g = g.contiguous()
         argmax = ctx.saved_tensors[0] if ctx.reduce == _lib.MDL_MAX else None
-        alloc = torch.zeros if ctx.reduce == _lib.MDL_MAX else torch.empty
+        # rows outside every segment (the unused tail of a padded static batch) must get exact zeros: they feed dense
+        # per-row kernels (weight-gradient GEMMs) that run over all rows
+        alloc = torch.zeros if (ctx.reduce == _lib.MDL_MAX or si.partial) else torch.empty
         gs = alloc(ctx.shape, dtype=g.dtype, device=g.device)
         check(lib().mdl_segment_reduce_bwd(ptr(g), ptr(si.rowptr), ptr(si.seg), ptr(si.perm), ptr(argmax), ptr(gs),
                                            si.N, si.E, C, ctx.reduce, dtype_code(g), stream()),
@@ -259,11 +317,12 @@ def scatter(src, index, dim=0, dim_size=None, reduce="sum", assume_sorted=False,
     return _SegmentReduce.apply(src, seg_index, _lib.REDUCE[reduce])
 
 
-def make_seg_index(rowptr_i32, seg_i32):
+def make_seg_index(rowptr_i32, seg_i32, partial=False):
     """Segment index over a SORTED segment id vector from its row pointers (rowptr [S+1] int32, seg [E] int32): what the
-    loaders know anyway (graph -> first node), so pooling needs neither a sort nor a search."""
+    loaders know anyway (graph -> first node), so pooling needs neither a sort nor a search.  partial: the rowptr ranges
+    do not cover all E rows (padded static batch)."""
     si = _SegIndex()
-    si.N, si.E = rowptr_i32.numel() - 1, seg_i32.numel()
+    si.N, si.E, si.partial = rowptr_i32.numel() - 1, seg_i32.numel(), bool(partial)
     si.rowptr, si.seg, si.perm = rowptr_i32, seg_i32, None
     return si
 
@@ -841,8 +900,20 @@ def bn_supported(x):
 _TRUE_ROWS = None
 
 
+def _true_rows_for(nrows):
+    """device row count for a tensor with `nrows` rows (None = all rows exist)"""
+    tr = _TRUE_ROWS
+    if tr is None:
+        return None
+    if isinstance(tr, dict):
+        return tr.get(int(nrows))
+    return tr
+
+
 class true_rows:
-    """`with ops.true_rows(n_dev):` — n_dev: int64 device tensor with one element, the number of node rows that exist."""
+    """`with ops.true_rows(n_dev):` — n_dev: int64 device tensor with one element, the number of rows that exist; or a dict
+    {rows of the padded tensor: device scalar} when node-, edge- and graph-level tensors are padded to different capacities
+    (a tensor whose row count is not in the dict is taken as complete)."""
 
     def __init__(self, n_dev):
         self.n_dev = n_dev
@@ -869,7 +940,7 @@ class _BatchNormTrain(torch.autograd.Function):
         gw = None if weight is None else weight.detach().float().contiguous()
         gb = None if bias is None else bias.detach().float().contiguous()
         y = torch.empty_like(x)
-        nd = _TRUE_ROWS
+        nd = _true_rows_for(N)
         check(lib().mdl_bn_stats_n(ptr(x), ptr(sums), N, C, ptr(nd), dt, stream()), "mdl_bn_stats")
         check(lib().mdl_bn_apply_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
                                    ptr(y), N, C, float(eps), float(momentum), ptr(nd), dt, stream()), "mdl_bn_apply")

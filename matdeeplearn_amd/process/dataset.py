@@ -37,6 +37,9 @@ class Batch:
         if self._edge_index is None:
             self._edge_index = torch.stack([self.csr.src.long(), self.csr.tgt.long()])
             ops.register_csr(self._edge_index, self.csr)
+            if self.csr.eperm is None and self._edge_index.is_cuda:       # scatter(..., edge_index[k]) without a sort
+                ops.register_seg_index(self._edge_index[0], self.csr.seg_src, owner=self._edge_index)
+                ops.register_seg_index(self._edge_index[1], self.csr.seg_tgt, owner=self._edge_index)
         return self._edge_index
 
     def to(self, device):
@@ -161,6 +164,22 @@ class GraphDataset:
         self.device = device
         return self
 
+    def by_source(self):
+        """Per-graph by-SOURCE order of the edges (device tensors, computed once): eperm_s [Et] = graph-local edge id at every
+        by-source position (stable: by target inside a source), lrowptr_s [Nt] = exclusive out-degree prefix inside the
+        node's graph.  The batch assembly turns them into the transposed CSR without a per-batch sort."""
+        if "eperm_s" not in self._dev:
+            epg = np.diff(self.edge_ptr)
+            gl_src = np.asarray(self.src, dtype=np.int64) + np.repeat(self.node_ptr[:-1], epg)
+            perm = np.argsort(gl_src, kind="stable")                        # keys are graph-monotone: blocks stay in place
+            eperm_s = (perm - np.repeat(self.edge_ptr[:-1], epg)).astype(np.int32)
+            out_deg = np.bincount(gl_src, minlength=len(self.z))
+            csum = np.concatenate([[0], np.cumsum(out_deg, dtype=np.int64)])
+            lrowptr_s = (csum[:-1] - np.repeat(csum[self.node_ptr[:-1]], np.diff(self.node_ptr))).astype(np.int32)
+            self._dev["eperm_s"] = torch.from_numpy(eperm_s).to(self.device)
+            self._dev["lrowptr_s"] = torch.from_numpy(lrowptr_s).to(self.device)
+        return self._dev["eperm_s"], self._dev["lrowptr_s"]
+
     def assemble_hip(self, ids, x_dtype=torch.float32):
         """K8: the whole batch assembly in ONE HIP launch (one workgroup per graph).  Prefix offsets are
         computed on the host from node_ptr/edge_ptr (B numbers) and uploaded with the ids in one copy."""
@@ -193,6 +212,18 @@ class GraphDataset:
             p(ew), p(dn), p(y), B, F, self.y.shape[1], int(self.target_index), _lib.dtype_code(x), _lib.stream()),
             "mdl_assemble_batch")
         csr = ops.EdgeCSR(rowptr, src, tgt, None, N, E)
+        # the by-source index comes from the dataset as well (built on first use by the operators that need it)
+        def transposed():
+            eperm_s, lrowptr_s = self.by_source()
+            rowptr_s = torch.empty(N + 1, dtype=torch.int32, device=dev)
+            col_s, eid_s, src_s = (torch.empty(E, dtype=torch.int32, device=dev) for _ in range(3))
+            _lib.check(_lib.lib().mdl_assemble_transposed(
+                p(ids_d), p(noff_d), p(eoff_d), p(d["node_ptr"]), p(d["edge_ptr"]), p(d["src"]), p(d["tgt"]), p(eperm_s),
+                p(lrowptr_s), p(rowptr_s), p(col_s), p(eid_s), p(src_s), B, -1, _lib.stream()), "mdl_assemble_transposed")
+            return rowptr_s, col_s, eid_s, src_s
+        csr.set_transposed_builder(transposed)
+        ops.register_seg_index(src, csr.seg_src)                  # scatter(..., csr.row / csr.col): no per-batch sort
+        ops.register_seg_index(tgt, csr.seg_tgt)
         return Batch(x=x, edge_attr=None, edge_weight=ew, batch=batch, y=y, u=torch.zeros(B, 3, device=dev),
                      num_graphs=B, csr=csr, num_nodes=N, num_edges=E,
                      structure_id=[self.ids[i] for i in ids]), dn
@@ -366,11 +397,29 @@ class StaticBatch:
         self.y = torch.zeros(B, dtype=torch.float32, device=dev)
         self.edge_attr = torch.zeros((self.e_cap, G), dtype=edge_dtype, device=dev)
         csr = ops.EdgeCSR(self.rowptr, self.src, self.tgt, None, self.n_cap, self.e_cap)
+        # by-source index (static buffers, filled inside the graph) and the int64 edge_index view some models read
+        self.rowptr_s = torch.zeros(self.n_cap + 1, dtype=torch.int32, device=dev)
+        self.col_s, self.eid_s, self.src_s = (torch.zeros(self.e_cap, dtype=torch.int32, device=dev) for _ in range(3))
+        csr.set_transposed((self.rowptr_s, self.col_s, self.eid_s, self.src_s))
+        csr.partial = True                                     # rows past n_dev / e_dev belong to no segment
+        self.edge_index = torch.zeros((2, self.e_cap), dtype=torch.int64, device=dev)
+        self.b_dev = torch.full((1,), B, dtype=torch.int64, device=dev)
+        ds.by_source()
         self.pool_rowptr = torch.zeros(B + 2, dtype=torch.int32, device=dev)
         self.pool_seg = torch.full((self.n_cap,), B, dtype=torch.int32, device=dev)
-        self.batch = Batch(pool_index=ops.make_seg_index(self.pool_rowptr, self.pool_seg), x=self.x, edge_attr=self.edge_attr, edge_weight=self.ew, batch=self.batch_idx, y=self.y,
+        self.batch = Batch(pool_index=ops.make_seg_index(self.pool_rowptr, self.pool_seg, partial=True), x=self.x,
+                           true_rows={self.n_cap: self.n_dev, self.e_cap: self.e_dev, B + 1: self.b_dev}, edge_attr=self.edge_attr, edge_weight=self.ew, batch=self.batch_idx, y=self.y,
                            u=torch.zeros(B + 1, 3, device=dev), num_graphs=B + 1, csr=csr, num_nodes=self.n_cap,
                            num_edges=self.e_cap, n_dev=self.n_dev, structure_id=None)
+        self.batch._edge_index = self.edge_index
+        ops.register_csr(self.edge_index, csr)
+        # every index tensor a model may hand to scatter() maps to the loader's segment index: no sorts inside the graph,
+        # and the unused tail of the buffers stays outside every segment
+        ops.register_seg_index(self.edge_index[0], csr.seg_src(), owner=self.edge_index)
+        ops.register_seg_index(self.edge_index[1], csr.seg_tgt(), owner=self.edge_index)
+        ops.register_seg_index(self.src, csr.seg_src())
+        ops.register_seg_index(self.tgt, csr.seg_tgt())
+        ops.register_seg_index(self.batch_idx, self.batch.pool_index)
         self._pinned = [torch.zeros(3 * B + 2, dtype=torch.int64).pin_memory() for _ in range(ring)]
         self._events = [None] * ring
         self._slot = 0
@@ -380,7 +429,7 @@ class StaticBatch:
         ids = np.asarray(ids, dtype=np.int64)
         n = int((self.ds.node_ptr[ids + 1] - self.ds.node_ptr[ids]).sum())
         e = int((self.ds.edge_ptr[ids + 1] - self.ds.edge_ptr[ids]).sum())
-        return len(ids) == self.B and n <= self.n_cap and e <= self.e_cap
+        return len(ids) == self.B and n < self.n_cap and e <= self.e_cap       # (one padding node always exists)
 
     def load(self, ids):
         """Host side of a step: ids + exclusive prefix sums -> the device `pack` (one async copy from a pinned ring)."""
@@ -388,7 +437,7 @@ class StaticBatch:
         ids = np.asarray(ids, dtype=np.int64)
         noff = np.concatenate([[0], np.cumsum(ds.node_ptr[ids + 1] - ds.node_ptr[ids])])
         eoff = np.concatenate([[0], np.cumsum(ds.edge_ptr[ids + 1] - ds.edge_ptr[ids])])
-        if len(ids) != self.B or noff[-1] > self.n_cap or eoff[-1] > self.e_cap:
+        if len(ids) != self.B or noff[-1] >= self.n_cap or eoff[-1] > self.e_cap:
             raise ops.MdlError("StaticBatch.load: batch (%d graphs, %d nodes, %d edges) exceeds the static capacity "
                                "(%d, %d, %d)" % (len(ids), noff[-1], eoff[-1], self.B, self.n_cap, self.e_cap))
         k = self._slot
@@ -416,6 +465,15 @@ class StaticBatch:
             int(ds.target_index), _lib.dtype_code(self.x), _lib.stream()), "mdl_assemble_batch")
         _lib.check(_lib.lib().mdl_pad_batch_tail(p(noff_d), p(eoff_d), B, self.n_cap, p(self.rowptr), p(self.batch_idx),
                                                  _lib.stream()), "mdl_pad_batch_tail")
+        eperm_s, lrowptr_s = ds.by_source()
+        _lib.check(_lib.lib().mdl_assemble_transposed(
+            p(ids_d), p(noff_d), p(eoff_d), p(d["node_ptr"]), p(d["edge_ptr"]), p(d["src"]), p(d["tgt"]), p(eperm_s),
+            p(lrowptr_s), p(self.rowptr_s), p(self.col_s), p(self.eid_s), p(self.src_s), B, self.n_cap, _lib.stream()),
+            "mdl_assemble_transposed")
+        _lib.check(_lib.lib().mdl_pad_edge_tail(p(noff_d), p(eoff_d), B, self.n_cap, self.e_cap, p(self.src), p(self.tgt),
+                                                p(self.col_s), p(self.eid_s), p(self.src_s), _lib.stream()), "mdl_pad_edge_tail")
+        self.edge_index[0].copy_(self.src)
+        self.edge_index[1].copy_(self.tgt)
         ops.rbf_expand(self.dn, 0.0, 1.0, ds.num_edge_features, 0.2, offsets=d["offsets"], out=self.edge_attr)
         # node -> graph pooling index straight from the prefix offsets.  The dummy graph B is EMPTY here (the padding rows
         # belong to no segment): as one segment of thousands of rows it would be walked by a single lane group

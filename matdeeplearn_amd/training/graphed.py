@@ -14,10 +14,12 @@ What makes a step capturable here:
   * the library never allocates or synchronises, so its launches land in the capturing stream like torch's own.
 A batch that does not fit the static capacity (or a ragged last batch) runs eagerly — same arithmetic, no padding.
 
-Scope: models whose operators walk the batch through `rowptr` only (CGCNN: K2 / K3 / K3c, BatchNorm, pooling).  SchNet,
-MEGNet, MPNN and GCN also build by-source permutations from the edge arrays themselves, and the unused tail of the padded
-arrays would enter those sorts (measured: hundreds of milliseconds per replay) — they run eagerly until the loader emits
-the by-source order per graph.
+The padded rows (nodes past n_dev, edge slots past e_dev, the dummy graph) obey one invariant: forward values are finite,
+gradients are EXACTLY zero.  Segment reductions leave them outside every segment (their backward writes zeros there),
+BatchNorm over node / edge / graph rows reads the matching device row count (ops.true_rows takes a map keyed by the padded
+row count), the unused edge slots point at the first padding node, and the by-source index comes from the loader
+(mdl_assemble_transposed) instead of a sort of the padded arrays — so per-row dense kernels (Linear layers, weight-gradient
+GEMMs over all e_cap rows) may run over the padding and add nothing.  With that, SchNet, MEGNet and GCN replay like CGCNN.
 """
 import torch
 import torch.nn.functional as F
@@ -51,7 +53,7 @@ class GraphedStep:
     def _body(self):
         sb = self.sb
         batch = sb.assemble()
-        with ops.true_rows(sb.n_dev), ops.zero_arena(self.dev):
+        with ops.true_rows(batch.true_rows), ops.zero_arena(self.dev):
             out = self.model(batch)
             loss = getattr(F, self.loss_name)(out[:self.B], sb.y)
             loss.backward()
