@@ -315,9 +315,6 @@ def main():
                  "ms_per_step_by_16": [round((b - a) / 16 * 1e3, 2) for a, b in zip([0.0] + marks[:-1], marks)]}
         res["sustained"] = {"eager": eager}
         try:
-            if args.model != "cgcnn":
-                raise RuntimeError("graph replay is wired for the CGCNN step only (SchNet / MEGNet build by-source indices "
-                                   "from the padded edge arrays)")
             opt_g = make_optimizer(model.parameters(), "AdamW", lr=0.002, capturable=True)
             gs = GraphedStep(ds, model, opt_g, B, compute_dtype=cdt, indices=tr_idx)
             for _ in range(3):
@@ -340,8 +337,6 @@ def main():
         res["ref_batch_100"] = {"eager": {"value": round(e_small / dt, 1), "ms_per_step": round(dt / n_small * 1e3, 4)},
                                 "edges_per_step": int(e_small / n_small)}
         try:
-            if args.model != "cgcnn":
-                raise RuntimeError("graph replay is wired for the CGCNN step only")
             opt_s = make_optimizer(model.parameters(), "AdamW", lr=0.002, capturable=True)
             gs_s = GraphedStep(ds, model, opt_s, rb, compute_dtype=cdt, indices=tr_idx)
             run_for(gs_s.step, rb_stream, n=10)

@@ -112,9 +112,16 @@ class _FusedMetaLayer(MetaLayer):
 
     def forward(self, x, edge_index, edge_attr=None, u=None, batch=None, idx=None):
         em = self.edge_model
-        if idx is not None and em is not None and hasattr(em, "forward_fused") and em.fused_ok(x, edge_attr):
-            row32, col32, be32 = idx
-            edge_attr = em.forward_fused(x, row32, col32, edge_attr, u, be32)
+        if idx is not None and em is not None and hasattr(em, "forward_fused"):
+            row32, col32, batch_n = idx
+            if em.fused_ok(x, edge_attr):
+                edge_attr = em.forward_fused(x, row32, col32, edge_attr, u, batch_n)
+            else:
+                # the reference's formulation with the loader's index tensors: u[batch[row]] as two gathers, so that every
+                # gather's backward is a scatter over an index whose segments the loader already knows (no sort; and in a
+                # padded static batch no segment made of the unused edge slots)
+                edge_attr = em.run(torch.cat([ops.gather(x, row32), ops.gather(x, col32), edge_attr,
+                                              ops.gather(ops.gather(u, batch_n), row32)], dim=1))
             if self.node_model is not None:
                 x = self.node_model(x, edge_index, edge_attr, u, batch)
             if self.global_model is not None:
@@ -146,9 +153,11 @@ class MEGNet(GraphModel):
         ei = data.edge_index
         nb = getattr(data, "num_graphs", None) or data.u.shape[0]
         idx = None
-        if cd == torch.bfloat16:                     # int32 gather indices of the fused edge block, once per batch
-            row, col = ei[0], ei[1]
-            idx = (row.to(torch.int32), col.to(torch.int32), data.batch)
+        csr = getattr(data, "csr", None)
+        if csr is not None and csr.eperm is None:    # product loader: the int32 source / target arrays ARE the gather indices
+            idx = (csr.row, csr.col, data.batch)
+        elif cd == torch.bfloat16:                   # int32 gather indices of the fused edge block, once per batch
+            idx = (ei[0].to(torch.int32), ei[1].to(torch.int32), data.batch)
         x = e = u = None
         for i, conv in enumerate(self.conv_list):
             e_t = _run_embed(self.e_embed_list[i], data.edge_attr.to(cd) if i == 0 else e)

