@@ -130,6 +130,21 @@ def test_batch_assembly_matches_per_graph_concatenation(small_ds):
     assert b.edge_index.shape == (2, b.num_edges) and b.edge_index.dtype == torch.int64
 
 
+def test_dataset_by_source_order_is_the_stable_per_graph_sort(small_ds):
+    """GraphDataset.by_source(): eperm_s = graph-local edge ids in stable by-source order, lrowptr_s = exclusive
+    out-degree prefix inside the graph — what mdl_assemble_transposed turns into the batch's by-source CSR."""
+    ds = small_ds
+    ds.to("cpu")
+    eperm_s, lrowptr_s = (a.numpy() for a in ds.by_source())
+    assert eperm_s.dtype == np.int32 and len(eperm_s) == len(ds.src) and len(lrowptr_s) == len(ds.z)
+    for g in range(len(ds)):
+        n0, n1, e0, e1 = ds.node_ptr[g], ds.node_ptr[g + 1], ds.edge_ptr[g], ds.edge_ptr[g + 1]
+        src = ds.src[e0:e1]
+        assert np.array_equal(eperm_s[e0:e1], np.argsort(src, kind="stable"))
+        out_deg = np.bincount(src, minlength=n1 - n0)
+        assert np.array_equal(lrowptr_s[n0:n1], np.concatenate([[0], np.cumsum(out_deg)[:-1]]))
+
+
 def test_device_loader_partitions_like_distributed_sampler(small_ds):
     from matdeeplearn_amd.process import DeviceLoader
     ds = small_ds
