@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
-from ..nn import BatchNorm1d, Set2Set
+from ..nn import BatchNorm1d, Set2Set, lowp_copies as _lowp
 
 
 def dense(lin, h):
@@ -29,15 +29,6 @@ def dense_act(lin, h, act):
     if h.dtype == lin.weight.dtype:
         return getattr(F, act)(lin(h))
     return ops.linear_act(h, lin.weight, lin.bias, act, _lowp(lin))
-
-
-def _lowp(lin):
-    """The layer's (weight, bias) in the compute dtype if GraphModel._cast_dense made them for the CURRENT parameter
-    values (version counters), else None."""
-    sh = getattr(lin, "_mdl_lowp", None)
-    if sh is None or sh[2] != lin.weight._version or (lin.bias is not None and sh[3] != lin.bias._version):
-        return None
-    return sh[0], sh[1]
 
 
 class GraphModel(nn.Module):
@@ -93,10 +84,15 @@ class GraphModel(nn.Module):
     def _cast_dense(self, dtype):
         """fp32 master weights of every dense layer -> compute dtype in ONE multi-tensor copy per forward (instead of two
         small launches per layer); the copies carry the parameters' version counters so stale ones are never used."""
-        lins = [m for m in list(self.pre_lin_list) + list(self.post_lin_list) + [self.lin_out] if isinstance(m, nn.Linear)]
+        lins = getattr(self, "_dense_layers", None)           # every nn.Linear of the model, conv blocks included
+        if lins is None:
+            lins = [m for m in self.modules() if isinstance(m, nn.Linear)]
+            object.__setattr__(self, "_dense_layers", lins)
         params = [p for lin in lins for p in (lin.weight, lin.bias) if p is not None]
         if not params or not params[0].is_cuda or params[0].dtype == dtype:
             return
+        # zero-filled home of this step's dense weight gradients (ops._zeros_grad): one fill instead of one per layer
+        ops.new_grad_arena(params[0].device, sum(p.numel() + 128 for p in params))
         cache = getattr(self, "_lowp_cache", None)
         if cache is None or len(cache) != len(params) or cache[0].dtype != dtype or cache[0].device != params[0].device:
             cache = [torch.empty_like(p, dtype=dtype) for p in params]

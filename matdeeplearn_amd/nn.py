@@ -53,6 +53,15 @@ import torch
 import torch.nn.functional as F
 
 
+def lowp_copies(lin):
+    """The layer's (weight, bias) in the compute dtype if the model's per-step multi-tensor cast (GraphModel._cast_dense)
+    made them for the CURRENT parameter values (version counters), else None."""
+    sh = getattr(lin, "_mdl_lowp", None)
+    if sh is None or sh[2] != lin.weight._version or (lin.bias is not None and sh[3] != lin.bias._version):
+        return None
+    return sh[0], sh[1]
+
+
 def _lin(lin, h, act=None):
     """nn.Linear (+ activation) applied in the dtype of h (fp32 master weights, bf16 activations): the streaming HIP dense
     layer for bf16 rows, the library otherwise."""
@@ -61,7 +70,7 @@ def _lin(lin, h, act=None):
         if act is None:
             return y
         return F.softplus(y) - math.log(2.0) if act == "ssp" else getattr(F, act)(y)
-    return ops.linear_act(h, lin.weight, lin.bias, act)
+    return ops.linear_act(h, lin.weight, lin.bias, act, lowp_copies(lin))
 
 
 def _seq(seq, h):

@@ -405,6 +405,28 @@ class ZeroArena:
 
 _ARENA = None
 
+# Weight-gradient accumulators of the dense layers (the TN GEMM adds into zero-filled [out, in] + [out] buffers): a model
+# with dozens of Linear layers would launch dozens of 3-us fills per step.  The model's forward opens ONE freshly
+# allocated, zero-filled buffer per step (new_grad_arena) and the backward passes carve their accumulators out of it.
+# Unlike the ZeroArena this memory is never reused: the slices become the parameters' .grad tensors and live as long as
+# autograd / the optimizer keeps them.
+_GRAD_ARENA = None
+
+
+def new_grad_arena(device, nfloats):
+    global _GRAD_ARENA
+    _GRAD_ARENA = [torch.zeros(int(nfloats), dtype=torch.float32, device=device), 0]
+
+
+def _zeros_grad(n, device):
+    a = _GRAD_ARENA
+    n_al = (int(n) + 63) & ~63
+    if a is not None and a[0].device == device and a[1] + n_al <= a[0].numel():
+        t = a[0][a[1]:a[1] + int(n)]
+        a[1] += n_al
+        return t
+    return torch.zeros(int(n), dtype=torch.float32, device=device)
+
 
 class zero_arena:
     def __init__(self, device, nbytes=4 << 20):
@@ -747,7 +769,7 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
     activation derivative is applied inside the TN GEMM's staging (mdl_gemm_tn_act)."""
     M, K = ctx.shape
     if act_y is not None:
-        buf = torch.zeros(M * K + M, dtype=torch.float32, device=g.device)
+        buf = _zeros_grad(M * K + M, g.device)
         dw, dbv = buf[:M * K].view(M, K), buf[M * K:]
         check(lib().mdl_gemm_tn_act(ptr(g), g.stride(0), M, ptr(act_y[1]), act_y[1].stride(0), act_y[0], ptr(x), x.stride(0), K,
                                     ptr(dw), ptr(dbv) if ctx.has_bias else None, g.shape[0], dtype_code(g), stream()),
@@ -761,7 +783,7 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
     # flushed with one gathered atomic instruction per block); MDL_TN_COLSUM=0 falls back to the library reduction
     fused_db = (_TN_COLSUM and ctx.has_bias and K % 2 == 0 and K <= 158 and x.stride(0) % 2 == 0
                 and ga.stride(0) % 2 == 0 and x.data_ptr() % 4 == 0 and ga.data_ptr() % 4 == 0)
-    buf = torch.zeros(Ma * K + Ma, dtype=torch.float32, device=g.device)          # dW | db in one zero fill
+    buf = _zeros_grad(Ma * K + Ma, g.device)                                       # dW | db: zero-filled (one fill per step)
     dw, dbv = buf[:Ma * K].view(Ma, K), buf[Ma * K:]
     check(lib().mdl_gemm_tn_colsum(ptr(ga), ga.stride(0), Ma, ptr(x), x.stride(0), K, ptr(dw), ptr(dbv) if fused_db else None,
                                    g.shape[0], dtype_code(g), stream()), "mdl_gemm_tn_colsum")
