@@ -171,7 +171,7 @@ def main():
             ops.KERNEL_EVENTS = ktimes if timed else None
             with ops.zero_arena(dev):               # one zero fill per step for the kernels' small accumulators
                 out = model(batch)
-                loss = torch.nn.functional.l1_loss(out, batch.y)
+                loss = ops.loss("l1_loss", out, batch.y)
                 loss.backward()
             ops.KERNEL_EVENTS = None
             if dp.reduce_grads_async(force=use_dist):

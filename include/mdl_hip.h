@@ -210,6 +210,12 @@ int mdl_assemble_transposed(const int64_t* ids, const int64_t* noff, const int64
 int mdl_pad_edge_tail(const int64_t* noff, const int64_t* eoff, int B, int64_t n_cap, int64_t e_cap, int32_t* src, int32_t* tgt,
                       int32_t* col_s, int32_t* eid_s, int32_t* src_s, mdlStream_t stream);
 
+/* ---- training loss + gradient in one launch ---------------------------------------------------
+ * loss[0] = mean over n elements of |pred - y| (kind 0, F.l1_loss: the reference default, config.yml:117) or (pred - y)^2
+ * (kind 1, F.mse_loss); grad[i] = d loss / d pred[i].  fp32.  Replaces the eight elementwise / reduction launches of
+ * `getattr(F, loss)(output, data.y)` + its autograd (matdeeplearn/training/training.py:44-47). */
+int mdl_loss_fwd_bwd(const float* pred, const float* y, int64_t n, int kind, float* loss, float* grad, mdlStream_t stream);
+
 /* ---- training-mode BatchNorm1d over rows, x: [N, C] row-major ------------------------------------
  * Replaces torch.nn.BatchNorm1d as applied after every conv layer (matdeeplearn/models/cgcnn.py:85-87,143)
  * and inside the MEGNet MLPs (megnet.py:47-48).  `sums` is an fp32 scratch of mdl_bn_sums_rows() x C floats the

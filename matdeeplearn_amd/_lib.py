@@ -39,6 +39,7 @@ PROTOTYPES = {
     "mdl_pad_batch_tail": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "mdl_assemble_transposed": (_i32, [_vp] * 13 + [_i32, _i64, _vp]),
     "mdl_pad_edge_tail": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mdl_loss_fwd_bwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "mdl_bn_sums_rows": (_i32, []),
     "mdl_bn_stats_n": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "mdl_bn_apply_n": (_i32, [_vp] * 8 + [_i64, _i32, _f32, _f32, _vp, _i32, _vp]),

@@ -906,6 +906,36 @@ def linear(x, weight, bias, lowp=None):
 
 
 # ------------------------------------------------------------------------------------------------
+# training loss: value and gradient in one launch
+# ------------------------------------------------------------------------------------------------
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, kind):
+        p = pred.contiguous()
+        y = target.contiguous()
+        out = torch.empty(1 + p.numel(), dtype=torch.float32, device=p.device)          # loss | gradient
+        check(lib().mdl_loss_fwd_bwd(ptr(p), ptr(y), p.numel(), kind, ptr(out), ptr(out[1:]), stream()), "mdl_loss_fwd_bwd")
+        ctx.save_for_backward(out)
+        ctx.shape = tuple(pred.shape)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return (out[1:] * g).view(ctx.shape), None, None
+
+
+def loss(name, pred, target):
+    """getattr(F, name)(pred, target) as the reference's train() evaluates it (training.py:44-47).  l1_loss / mse_loss on
+    fp32 HIP tensors of equal shape compute the value and d loss / d pred in one launch; anything else is torch's."""
+    kind = {"l1_loss": 0, "mse_loss": 1}.get(name)
+    if (kind is not None and pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32
+            and pred.shape == target.shape and pred.numel() >= 1 and not target.requires_grad):
+        return _FusedLoss.apply(pred, target, kind)
+    return getattr(torch.nn.functional, name)(pred, target)
+
+
+# ------------------------------------------------------------------------------------------------
 # training-mode BatchNorm1d over rows (HIP streams instead of four slow library passes)
 # ------------------------------------------------------------------------------------------------
 def bn_supported(x):

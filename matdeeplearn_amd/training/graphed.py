@@ -55,7 +55,7 @@ class GraphedStep:
         batch = sb.assemble()
         with ops.true_rows(batch.true_rows), ops.zero_arena(self.dev):
             out = self.model(batch)
-            loss = getattr(F, self.loss_name)(out[:self.B], sb.y)
+            loss = ops.loss(self.loss_name, out[:self.B], sb.y)
             loss.backward()
         self.loss_value.copy_(loss.detach())
         if self.opt_in_graph:
@@ -152,7 +152,7 @@ class GraphedStep:
         self._zero_grad()
         with ops.zero_arena(self.dev):
             out = self.model(batch)
-            loss = getattr(F, self.loss_name)(out, batch.y)
+            loss = ops.loss(self.loss_name, out, batch.y)
             loss.backward()
         self.loss_value.copy_(loss.detach())
         self._finish_eager()

@@ -16,6 +16,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .. import ops
+
 
 def make_optimizer(params, name="AdamW", lr=0.002, **optimizer_args):
     """getattr(torch.optim, name)(params, lr, **optimizer_args) — training.py:429-432.  `capturable=True` (Adam family)
@@ -57,7 +59,7 @@ def train(model, optimizer, loader, loss_method, rank=None, dp=None, stats=None)
             optimizer.zero_grad()
         with _step_arena(output_device(data)):
             output = model(data)
-            loss = getattr(F, loss_method)(output, data.y)
+            loss = ops.loss(loss_method, output, data.y)
             loss.backward()
         loss_all = loss_all + loss.detach() * output.size(0)
         if dp is not None:

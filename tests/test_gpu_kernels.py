@@ -644,3 +644,23 @@ def test_hip_batch_assembly_matches_tensor_op_assembly(x_dtype):
     assert (a.num_nodes, a.num_edges) == (b.num_nodes, b.num_edges)
     full = ds.collate(ids, edge_dtype=torch.float32)
     assert full.edge_attr.shape == (b.num_edges, 50)
+
+
+@pytest.mark.parametrize("name", ["l1_loss", "mse_loss"])
+@pytest.mark.parametrize("n", [1, 100, 8192, 20000])
+def test_fused_loss_matches_torch(name, n):
+    """ops.loss (value + gradient in one launch) vs F.l1_loss / F.mse_loss and their autograd, incl. exact ties (gradient 0)."""
+    from matdeeplearn_amd import ops
+    g = torch.Generator().manual_seed(n)
+    p = torch.randn(n, generator=g)
+    y = torch.randn(n, generator=g)
+    if n > 4:
+        y[3] = p[3]
+    pd = p.to(dev()).requires_grad_(True)
+    out = ops.loss(name, pd, y.to(dev()))
+    (out * 3.0).backward()
+    pr = p.clone().requires_grad_(True)
+    ref = getattr(torch.nn.functional, name)(pr, y)
+    (ref * 3.0).backward()
+    close(out, ref, 1e-5, 1e-6)
+    close(pd.grad, pr.grad, 1e-6, 1e-9)

@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 for m in "$@"; do
 OUT=$GRAFT_REPO_ROOT/gpurun_out/mprof_$m; mkdir -p $OUT
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o t -- python $GRAFT_REPO_ROOT/bench.py --model $m --no-cpu-baseline --no-extras --steps 5 --warmup 2 > $OUT/p.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o t -- python $GRAFT_REPO_ROOT/bench.py --model $m --no-cpu-baseline --no-extras --steps 5 --warmup 2 $EXTRA > $OUT/p.log 2>&1
 f=$(find $OUT/p -name "*kernel_stats.csv" | head -1)
 cp "$f" $OUT/kernel_stats.csv
 python - "$f" <<'PY'
