@@ -66,6 +66,7 @@ def parse():
                     help="headline only: skip sustained / fp32_mode / ref_batch_100 (used for the rocprofv3 pass, so that "
                          "the per-kernel averages of the trace are those of the measured workload)")
     ap.add_argument("--sustain-s", type=float, default=2.0)
+    ap.add_argument("--settle-s", type=float, default=1.0, help="seconds of untimed steps in front of the warm-up (0 = none)")
     ap.add_argument("--cpu-steps", type=int, default=1, help="timed oracle steps on the GPU run's own batches")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--dataset-cache", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "mdl_bench_data"),
@@ -192,6 +193,24 @@ def main():
         torch.cuda.synchronize()
 
     model.train()
+    # Settle phase (untimed, before the W warm-up steps): a fresh process sees a window of 100-200 ms, a few dozen steps
+    # after its first launches, in which every kernel runs 2-4x slower (measured with the dataset read from the cache, i.e.
+    # when the step loop starts within a second of process start: steps 20-40 took 10-12 ms instead of 3.8; with the 5 s
+    # dataset generation in front the window falls into the CPU phase).  Real steps are run until `--settle-s` seconds have
+    # passed on every rank, so the W + K steps that follow measure the steady state.
+    settle_steps = 0
+    if args.settle_s > 0:
+        t_s = time.perf_counter()
+        while True:
+            for _ in range(8):
+                step(next(stream), False)
+            settle_steps += 8
+            torch.cuda.synchronize()
+            el = torch.tensor([time.perf_counter() - t_s], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(el, op=dist.ReduceOp.MIN)
+            if float(el) >= args.settle_s:
+                break
     for i in range(args.warmup):
         step(step_ids[i], False)
     barrier()
@@ -270,7 +289,7 @@ def main():
                                % (wl_desc, " ".join("%s=%s" % kv for kv in sorted(mkw.items()) if kv[0].startswith(("dim", "gc", "post"))),
                                   args.dtype, gen_name, len(ds), B),
                    "batch_graphs_per_gpu": B, "edges_per_step_per_gpu": int(e_step), "nodes_per_step_per_gpu": int(n_step),
-                   "parallelism": "dp%d" % world, "dataset_load_s": round(gen_s, 1), "dataset_source": data_src,
+                   "parallelism": "dp%d" % world, "dataset_load_s": round(gen_s, 1), "dataset_source": data_src, "settle_steps": settle_steps,
                    "conv_kernel_share_of_step": round(sum(tot.values()) / elapsed, 3)},
     }
     if dom is not None:

@@ -140,6 +140,10 @@ size_t mdl_cgconv_workspace_bytes(int64_t N, int64_t E, int C, int G, int dtype)
  * C in {32, 64} (C == Cp); otherwise MDL_E_UNSUPP and the caller uses library GEMMs. */
 int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const void* r_tgt, const float* r_src,
                         const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype, mdlStream_t stream);
+/* same; zero_src != 0: r_src [N, 2*Cp] is handed back ZEROED (this kernel is its only reader), so a caller that keeps ONE
+ * r_src buffer for all layers and steps never fills it again — mdl_cgconv_bwd accumulates into it with atomics. */
+int mdl_cgconv_bwd_node_z(const void* x, const void* grad_out, const void* r_tgt, float* r_src, const void* wn_t, void* dx,
+                          float* dwn, int64_t N, int C, int dtype, int zero_src, mdlStream_t stream);
 
 /* Small layout helpers around the backward (replace the cat / transpose / cast / clone chain autograd would run):
  *   wn_t [C, 4Cp] (bf16) = Wn^T for mdl_cgconv_bwd_node from the two nn.Linear weights [C, 2C+G] (fp32);

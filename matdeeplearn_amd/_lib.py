@@ -31,6 +31,7 @@ PROTOTYPES = {
     "mdl_cgconv_fwd_save": (_i32, [_vp] * 9 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_cgconv_bwd_saved": (_i32, [_vp] * 10 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, ctypes.c_size_t, _vp]),
     "mdl_cgconv_bwd_node": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _vp]),
+    "mdl_cgconv_bwd_node_z": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "mdl_cgconv_pack_node_weights": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "mdl_cgconv_assemble_grads": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mdl_assemble_batch": (_i32, [_vp] * 20 + [_i32, _i32, _i32, _i32, _i32, _vp]),

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
                                                                     const bf16_t* __restrict__ r_tgt,
                                                                     const float* __restrict__ r_src,
                                                                     const bf16_t* __restrict__ wn_t, bf16_t* __restrict__ dx,
-                                                                    float* __restrict__ dwn, int64_t N) {
+                                                                    float* __restrict__ dwn, int64_t N, int zero_src) {
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     typedef __attribute__((address_space(3))) s16x4* lds4_t;
     constexpr int TN = 64;               // nodes per tile
@@ -114,6 +114,16 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
             const u32x2_t v = {pk_bf16(sreg[l][0], sreg[l][1]), pk_bf16(sreg[l][2], sreg[l][3])};
             *reinterpret_cast<u32x2_t*>(rl + (srow0 + l * SROWS) * LD + 2 * CP + 4 * scc) = v;
+        }
+        // zero_src: this kernel is the only reader of r_src, so it can hand the buffer back ZEROED for the next edge
+        // pass (which accumulates into it with atomics) — the rows are in registers at this point, the stores ride behind
+        // the loads, and the caller's 100-MB fill per layer disappears (mdl_cgconv_bwd_node_z)
+        if (zero_src) {
+            const int64_t rem = N - nb;
+            const __amdgpu_buffer_rsrc_t sz = rsrc(r_src + nb * (2 * CP), rem * (2 * CP * 4));
+#pragma unroll
+            for (int l = 0; l < NSL; ++l)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, sz, so + opaque(l * (SROWS * 2 * CP * 4)), 0, 0);
         }
 #pragma unroll
         for (int l = 0; l < NXL; ++l) {
@@ -237,6 +247,12 @@ extern "C" int mdl_cgconv_assemble_grads(const float* dwn, const float* dwe, con
 extern "C" int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const void* r_tgt, const float* r_src,
                                    const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype,
                                    mdlStream_t stream) {
+    return mdl_cgconv_bwd_node_z(x, grad_out, r_tgt, const_cast<float*>(r_src), wn_t, dx, dwn, N, C, dtype, 0, stream);
+}
+
+extern "C" int mdl_cgconv_bwd_node_z(const void* x, const void* grad_out, const void* r_tgt, float* r_src,
+                                     const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype, int zero_src,
+                                     mdlStream_t stream) {
     using namespace mdl;
     MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_cgconv_bwd_node: bf16 only (fp32 parity mode uses library GEMMs)");
     MDL_REQUIRE(C == 32 || C == 64, MDL_E_UNSUPP, "mdl_cgconv_bwd_node: C must be 32 or 64 (got %d)", C);
@@ -254,12 +270,12 @@ extern "C" int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const vo
         auto kf = cgconv_node_stream_kernel<64>;
         set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
         hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
-                           (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N);
+                           (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N, zero_src);
     } else {
         const int lds = (32 * (128 + 8) + 64 * (128 + 8) + 64 * (32 + 8)) * 2;
         auto kf = cgconv_node_stream_kernel<32>;
         hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
-                           (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N);
+                           (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N, zero_src);
     }
     return check_launch("mdl_cgconv_bwd_node");
 }

@@ -479,6 +479,23 @@ def _workspace(device, nbytes):
 _SAVE_GATE = os.environ.get("MDL_CG_SAVE_GATE", "0") == "1"
 
 
+# r_src (by-source sums of the CGConv backward: fp32 [N, 2*Cp], accumulated with atomics) must start at zero: 107 MB per
+# layer at the bench batch, i.e. a 15-22 us fill launch in front of every edge pass.  Its only reader, the node kernel,
+# can hand it back zeroed (mdl_cgconv_bwd_node_z), so eager steps keep ONE buffer per device and stream for all layers and
+# steps.  `dirty` covers an exception between the two launches; captured graphs keep their own zero-filled tensors.
+_RSRC = {}
+
+
+def _take_rsrc(nfloats, device):
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ent = _RSRC.get(key)
+    if ent is None or ent[0].numel() < nfloats or ent[1]:
+        ent = _RSRC[key] = [torch.zeros(int(nfloats), dtype=torch.float32, device=device), False]
+    return ent
+
+
 class _CGConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, edge_attr, w_f, b_f, w_s, b_s, csr, aggr):
@@ -536,7 +553,12 @@ class _CGConvFn(torch.autograd.Function):
         g = g.contiguous()
         dt = dtype_code(x)
         r_tgt = torch.empty((N, 2 * Cp), dtype=x.dtype, device=x.device)          # by-target sums, compute dtype
-        r_src = torch.zeros((N, 2 * Cp), dtype=torch.float32, device=x.device)
+        node_hip = dt == _lib.MDL_BF16 and C == Cp and C in (32, 64)          # K3c consumes r_tgt / r_src
+        keep = _take_rsrc(N * 2 * Cp, x.device) if node_hip else None
+        if keep is not None:
+            r_src, keep[1] = keep[0][:N * 2 * Cp].view(N, 2 * Cp), True
+        else:
+            r_src = torch.zeros((N, 2 * Cp), dtype=torch.float32, device=x.device)
         small = _zeros_step((2 * Cp * GP + 2 * Cp + 4 * Cp * C,), x.device)
         dwe = small[:2 * Cp * GP].view(2 * Cp, GP)
         db = small[2 * Cp * GP:2 * Cp * GP + 2 * Cp]
@@ -554,14 +576,16 @@ class _CGConvFn(torch.autograd.Function):
                 ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt,
                 ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd")
         # node-level dense part: rows of Wn / dWn = (f_tgt, s_tgt, f_src, s_src)
-        if dt == _lib.MDL_BF16 and C == Cp and C in (32, 64):
+        if node_hip:
             wn_t = torch.empty((C, 4 * Cp), dtype=torch.bfloat16, device=x.device)                 # Wn^T
             check(lib().mdl_cgconv_pack_node_weights(ptr(wf32), ptr(ws32), C, G, ptr(wn_t), dt, stream()),
                   "mdl_cgconv_pack_node_weights")
             dx = torch.empty_like(x)
-            check(_launch_timed("bwd_node", lambda: lib().mdl_cgconv_bwd_node(
-                ptr(x), ptr(g), ptr(r_tgt), ptr(r_src), ptr(wn_t), ptr(dx), ptr(dwn), N, C, dt, stream())),
-                "mdl_cgconv_bwd_node")
+            check(_launch_timed("bwd_node", lambda: lib().mdl_cgconv_bwd_node_z(
+                ptr(x), ptr(g), ptr(r_tgt), ptr(r_src), ptr(wn_t), ptr(dx), ptr(dwn), N, C, dt, 1 if keep is not None else 0,
+                stream())), "mdl_cgconv_bwd_node")
+            if keep is not None:
+                keep[1] = False                                                                     # handed back zeroed
             dW_f = torch.empty((C, 2 * C + G), dtype=torch.float32, device=x.device)
             dW_s = torch.empty_like(dW_f)
             db_f = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[0] else None

@@ -154,7 +154,13 @@ class GraphDataset:
     # ---- device residency -----------------------------------------------------------------------
     def to(self, device):
         device = torch.device(device)
-        f = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a)).to(device=device, dtype=dt)
+        # File-backed (memory-mapped) arrays go through an anonymous copy: the runtime pins the pages of a large pageable
+        # source for the upload, and pinned PAGE-CACHE pages (of a flat file written seconds ago: writeback, reclaim) later
+        # trigger MMU-notifier invalidations that evict the process's GPU queues — measured as a 100-200 ms window, 2-3 s
+        # after start, in which every kernel takes 2-4x longer (bench runs reading the dataset cache: 12 ms steps).
+        def f(a, dt=None):
+            a = np.array(a) if isinstance(a, np.memmap) else np.ascontiguousarray(a)
+            return torch.as_tensor(a).to(device=device, dtype=dt)
         self._dev = dict(node_ptr=f(self.node_ptr), edge_ptr=f(self.edge_ptr), x=f(self.x, torch.float32),
                          src=f(self.src, torch.int32), tgt=f(self.tgt, torch.int32),
                          dist=f(self.dist, torch.float32), dist_norm=f(self.dist_norm, torch.float32),
