@@ -664,3 +664,19 @@ def test_fused_loss_matches_torch(name, n):
     (ref * 3.0).backward()
     close(out, ref, 1e-5, 1e-6)
     close(pd.grad, pr.grad, 1e-6, 1e-9)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("E", [1, 127, 128, 129, 100003])
+def test_rbf_block_kernel_matches_oracle_on_ragged_sizes(dtype, E):
+    """K1's 128-edges-per-block kernel (G = 50) vs the oracle expansion: block tails, a single edge, many blocks."""
+    from matdeeplearn_amd import ops
+    g = torch.Generator().manual_seed(E)
+    d = torch.rand(E, generator=g)
+    ref = oops.rbf_expand(d, 0.0, 1.0, 50, 0.2)
+    out = ops.rbf_expand(d.to(dev()), 0.0, 1.0, 50, 0.2, out_dtype=dtype)
+    assert out.shape == (E, 50)
+    if dtype == torch.float32:
+        assert torch.allclose(out.cpu(), ref, rtol=1e-6, atol=1e-7)
+    else:
+        assert torch.allclose(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=1e-2, atol=1e-6)
