@@ -13,7 +13,7 @@ cd /tmp
 for m in cgcnn schnet megnet; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$m -o t -- python $GRAFT_REPO_ROOT/bench.py --model $m --no-cpu-baseline --no-extras > $OUT/prof_$m.log 2>&1
   f=$(find $OUT/prof_$m -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -45 "$f" > $OUT/kernel_stats_$m.csv
-  tail -1 $OUT/prof_$m.log | grep "^{" > $OUT/bench_${m}_under_rocprof.json
+  grep -h '^{"metric"' $OUT/prof_$m.log > $OUT/bench_${m}_under_rocprof.json
   rm -rf $OUT/prof_$m
 done
 head -6 $OUT/kernel_stats_cgcnn.csv | cut -c1-140
