@@ -47,6 +47,11 @@ WORKLOADS = {
                dict(dim1=100, dim2=100, dim3=150, cutoff=8, pre_fc_count=1, gc_count=4, post_fc_count=3), "cfg3 MOF_data SchNet_demo"),
     "megnet": ("MEGNet", "synthetic_bulk", 16384, 4096,
                dict(dim1=100, dim2=100, dim3=100, pre_fc_count=1, gc_count=4, gc_fc_count=1, post_fc_count=3), "cfg4 bulk_data MEGNet_demo"),
+    # the two remaining members of the cfg5 ensemble, on surface-like slabs (config.yml:141-161, 206-225)
+    "mpnn": ("MPNN", "synthetic_surface", 8192, 1024,
+             dict(dim1=100, dim2=100, dim3=100, pre_fc_count=1, gc_count=4, post_fc_count=3), "cfg5 surface_data MPNN_demo"),
+    "gcn": ("GCN", "synthetic_surface", 8192, 2048,
+            dict(dim1=100, dim2=150, pre_fc_count=1, gc_count=4, post_fc_count=3), "cfg5 surface_data GCN_demo"),
 }
 
 
@@ -159,7 +164,8 @@ def main():
     dp = FlatDataParallel(model)
     opt = make_optimizer(model.parameters(), "AdamW", lr=0.002 * world)   # lr x world_size, training.py:388-389
 
-    ktimes = {"cgcnn": {"fwd": [], "bwd": []}, "schnet": {"gmr_fwd": []}, "megnet": {"edge_linear": []}}[args.model]
+    ktimes = {"cgcnn": {"fwd": [], "bwd": []}, "schnet": {"gmr_fwd": []}, "megnet": {"edge_linear": []},
+              "gcn": {"gmr_fwd": []}, "mpnn": {"nnconv_fwd": []}}[args.model]
 
     def make_step(model, dp, opt, dtype):
         pending = {}                                 # ids (bytes) -> batch assembled during the previous step's all-reduce
@@ -250,6 +256,14 @@ def main():
         F_ = mkw["dim3"]
         ab = {"gmr_fwd": e_step * (2 * F_ * s + 8) + n_step * (F_ * s + 4)}
         kname = {"gmr_fwd": "mdl_gather_mul_reduce"}
+    elif args.model == "gcn":                        # K4a with a scalar edge weight: E(F s + 8) + N(F s + 4)
+        F_ = mkw["dim1"]
+        ab = {"gmr_fwd": e_step * (F_ * s + 8) + n_step * (F_ * s + 4)}
+        kname = {"gmr_fwd": "mdl_gather_mul_reduce"}
+    elif args.model == "mpnn":                       # K7: N C d3 s (Y, read once per source node) + E (d3 + C) s   (csrc/nnconv.hip)
+        C_, d3 = mkw["dim1"], mkw["dim3"]
+        ab = {"nnconv_fwd": n_step * C_ * d3 * s + e_step * (d3 + C_) * s}
+        kname = {"nnconv_fwd": "mdl_nnconv_msg_fwd"}
     else:                                            # K6: E(d s [e in] + d s [out] + 3 d s [gathered rows] + 12)
         d = mkw["dim3"]
         ab = {"edge_linear": e_step * (5 * d * s + 12)}
@@ -278,7 +292,8 @@ def main():
 
     value = edges_all / elapsed_max
     metric = {"cgcnn": "edges/sec training CGCNN on bulk_data", "schnet": "edges/sec training SchNet on MOF_data",
-              "megnet": "edges/sec training MEGNet on bulk_data"}[args.model]
+              "megnet": "edges/sec training MEGNet on bulk_data", "mpnn": "edges/sec training MPNN on surface_data",
+              "gcn": "edges/sec training GCN on surface_data"}[args.model]
     res = {
         "metric": metric,
         "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

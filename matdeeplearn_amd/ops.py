@@ -705,8 +705,8 @@ class _NNConvMsg(torch.autograd.Function):
         Y, h = Y.contiguous(), h.contiguous()
         rowptr_s, _, eid_s, _ = csr.transposed()
         m = torch.empty((csr.E, Co), dtype=Y.dtype, device=Y.device)
-        check(lib().mdl_nnconv_msg_fwd(ptr(Y), ptr(h), ptr(rowptr_s), ptr(eid_s), ptr(m), csr.N, Co, D3, dtype_code(Y),
-                                       stream()), "mdl_nnconv_msg_fwd")
+        check(_launch_timed("nnconv_fwd", lambda: lib().mdl_nnconv_msg_fwd(
+            ptr(Y), ptr(h), ptr(rowptr_s), ptr(eid_s), ptr(m), csr.N, Co, D3, dtype_code(Y), stream())), "mdl_nnconv_msg_fwd")
         ctx.csr, ctx.dims = csr, (Co, D3)
         ctx.save_for_backward(Y, h)
         return m
