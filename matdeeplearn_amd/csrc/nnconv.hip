@@ -118,6 +118,186 @@ __global__ __launch_bounds__(256) void nnconv_msg_bwd_kernel(const T* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16, Co <= 128, D3 <= 128 (the reference's sizes: 100 x 100): the same contraction on MFMA.  One workgroup (4 waves)
+// per source node; Y_j (Co x D3, 20 KB) is staged ONCE in LDS as a zero-padded [128][136] bf16 tile with coalesced dword
+// loads (wave = row, lane = dword), the node's out-edges are taken 32 at a time: their h (and dm) rows are gathered into
+// [32][136] tiles, and
+//   forward   m  [edges x Co] = H  . Y^T     A = H rows,  B = Y rows                      (wave w: output columns 32w..)
+//   backward  dh [edges x D3] = DM . Y       A = DM rows, B = Y read k-major (transpose read)
+//             dY [Co x D3]   += DM^T . H     both operands k-major over the EDGES (transpose reads), kept in registers
+// The scalar kernels above move 2 bytes per load while staging Y and keep 100 of 256 threads busy in the dot products:
+// 3.2 ms (forward) / 7.5 ms (backward) per layer on 6e4 nodes / 8e5 edges, 0.06 of the HBM roofline.
+constexpr int NM_KP = 128, NM_LD = NM_KP + 8;
+typedef __attribute__((ext_vector_type(4))) short nm_s16x4;
+typedef __attribute__((address_space(3))) nm_s16x4* nm_lds4_t;
+
+// fragment whose 8 K slots are ROWS 16*ks + 8*h + q of a row-major LDS tile, for column ct*32 + i  (see gemm_tn.hip)
+__device__ __forceinline__ bf16x8 nm_tr_frag(const bf16_t* tile, int ks, int ct, int i, int h) {
+    const int t = i & 15;
+    const bf16_t* p = tile + (16 * ks + 8 * h + (t >> 2)) * NM_LD + ct * 32 + (i & 16) + 4 * (t & 3);
+    const nm_s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((nm_lds4_t)p);
+    const nm_s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((nm_lds4_t)(p + 4 * NM_LD));
+    return bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+}
+// fragment whose 8 K slots are COLUMNS 16*ks + 8*h + q of row `row`
+__device__ __forceinline__ bf16x8 nm_row_frag(const bf16_t* tile, int row, int ks, int h) {
+    return *reinterpret_cast<const bf16x8*>(tile + row * NM_LD + 16 * ks + 8 * h);
+}
+// rows [0, rows) x `width` bf16 of a dense row-major matrix at `src` -> zero-padded LDS tile [nrows][NM_LD]
+// (wave wv takes rows wv, wv+4, ...; lane = dword of the row; rows >= rows and dwords >= width/2 become zeros)
+__device__ __forceinline__ void nm_stage_dense(const bf16_t* __restrict__ src, int rows, int width, bf16_t* tile, int nrows,
+                                               int wv, int lane) {
+    const int w2 = width >> 1;
+    for (int r0 = wv; r0 < nrows; r0 += 32) {
+        unsigned v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 4 * u;
+            const bool ok = r < rows && lane < w2;
+            v[u] = *reinterpret_cast<const unsigned*>(src + (int64_t)(ok ? r : 0) * width + 2 * (ok ? lane : 0));
+            if (!ok) v[u] = 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 4 * u;
+            if (r < nrows) *reinterpret_cast<unsigned*>(tile + r * NM_LD + 2 * lane) = v[u];
+        }
+    }
+}
+// gathered rows: row r of the tile = src[ids[r], 0:width] (ids[r] < 0: zeros); 32 rows, 8 per wave
+__device__ __forceinline__ void nm_stage_rows(const bf16_t* __restrict__ src, const int* ids, int width, bf16_t* tile, int wv,
+                                              int lane) {
+    const int w2 = width >> 1;
+    unsigned v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int id = ids[wv + 4 * u];
+        const bool ok = id >= 0 && lane < w2;
+        v[u] = *reinterpret_cast<const unsigned*>(src + (int64_t)(ok ? id : 0) * width + 2 * (ok ? lane : 0));
+        if (!ok) v[u] = 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *reinterpret_cast<unsigned*>(tile + (wv + 4 * u) * NM_LD + 2 * lane) = v[u];
+}
+
+__global__ __launch_bounds__(256, 2) void nnconv_msg_fwd_mfma_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ h,
+                                                                     const int32_t* __restrict__ rowptr_s,
+                                                                     const int32_t* __restrict__ eid_s, bf16_t* __restrict__ m,
+                                                                     int Co, int D3) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    bf16_t* Ys = reinterpret_cast<bf16_t*>(smem_c);          // [128][LD]
+    bf16_t* Hs = Ys + 128 * NM_LD;                            // [32][LD]
+    int* ids = reinterpret_cast<int*>(Hs + 32 * NM_LD);       // [32]
+    const int j = blockIdx.x;
+    const int b = rowptr_s[j], e = rowptr_s[j + 1];
+    if (b == e) return;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, hh = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    nm_stage_dense(Y + (int64_t)j * Co * D3, Co, D3, Ys, 128, wv, lane);
+    const int KS = (D3 + 15) >> 4;
+    for (int c0 = b; c0 < e; c0 += 32) {
+        const int cnt = min(32, e - c0);
+        if (tid < 32) ids[tid] = tid < cnt ? (eid_s ? eid_s[c0 + tid] : c0 + tid) : -1;
+        __syncthreads();                                      // ids visible (and, first trip, Ys complete)
+        nm_stage_rows(h, ids, D3, Hs, wv, lane);
+        __syncthreads();
+        if (wv * 32 < Co) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int ks = 0; ks < KS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nm_row_frag(Hs, i, ks, hh), nm_row_frag(Ys, wv * 32 + i, ks, hh), acc, 0, 0, 0);
+            const int col = wv * 32 + i;
+            if (col < Co) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int id = ids[(r & 3) + 8 * (r >> 2) + 4 * hh];
+                    if (id >= 0) m[(int64_t)id * Co + col] = f2bf(acc[r]);
+                }
+            }
+        }
+        __syncthreads();                                      // tile and ids are rewritten by the next chunk
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void nnconv_msg_bwd_mfma_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ h,
+                                                                     const bf16_t* __restrict__ dm,
+                                                                     const int32_t* __restrict__ rowptr_s,
+                                                                     const int32_t* __restrict__ eid_s, bf16_t* __restrict__ dh,
+                                                                     bf16_t* __restrict__ dY, int Co, int D3) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    bf16_t* Ys = reinterpret_cast<bf16_t*>(smem_c);          // [128][LD]
+    bf16_t* Hs = Ys + 128 * NM_LD;                            // [32][LD]
+    bf16_t* Ds = Hs + 32 * NM_LD;                             // [32][LD]  dm rows
+    int* ids = reinterpret_cast<int*>(Ds + 32 * NM_LD);
+    const int j = blockIdx.x;
+    const int b = rowptr_s[j], e = rowptr_s[j + 1];
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, hh = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    bf16_t* dYj = dY + (int64_t)j * Co * D3;
+    if (b == e) {                                             // node without out-edges: dY_j = 0
+        for (int q = tid; q < (Co * D3) / 2; q += 256) reinterpret_cast<unsigned*>(dYj)[q] = 0u;
+        return;
+    }
+    nm_stage_dense(Y + (int64_t)j * Co * D3, Co, D3, Ys, 128, wv, lane);
+    f32x16 accY[4];                                           // wave wv: rows o = 32 wv + ..., column tiles kt = 0..3
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accY[kt][r] = 0.0f;
+    const int OS = (Co + 15) >> 4;
+    for (int c0 = b; c0 < e; c0 += 32) {
+        const int cnt = min(32, e - c0);
+        if (tid < 32) ids[tid] = tid < cnt ? (eid_s ? eid_s[c0 + tid] : c0 + tid) : -1;
+        __syncthreads();
+        nm_stage_rows(h, ids, D3, Hs, wv, lane);
+        nm_stage_rows(dm, ids, Co, Ds, wv, lane);
+        __syncthreads();
+        if (wv * 32 < D3) {                                   // dh tile: columns k = 32 wv + i
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int os = 0; os < OS; ++os)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nm_row_frag(Ds, i, os, hh), nm_tr_frag(Ys, os, wv, i, hh), acc, 0, 0, 0);
+            const int col = wv * 32 + i;
+            if (col < D3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int id = ids[(r & 3) + 8 * (r >> 2) + 4 * hh];
+                    if (id >= 0) dh[(int64_t)id * D3 + col] = f2bf(acc[r]);
+                }
+            }
+        }
+        if (wv * 32 < Co) {                                   // dY rows o = 32 wv + ..: contraction over the chunk's edges
+#pragma unroll
+            for (int es = 0; es < 2; ++es) {
+                const bf16x8 a = nm_tr_frag(Ds, es, wv, i, hh);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    if (kt * 32 < D3) accY[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, nm_tr_frag(Hs, es, kt, i, hh), accY[kt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (wv * 32 < Co) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int k = kt * 32 + i;
+            if (k < D3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (o < Co) dYj[o * D3 + k] = f2bf(accY[kt][r]);
+                }
+            }
+        }
+    }
+}
+
+static bool nm_ok(int Co, int D3, int dtype, const void* a, const void* b) {
+    return dtype == MDL_BF16 && Co <= 128 && D3 <= 128 && Co >= 2 && D3 >= 2 && Co % 2 == 0 && D3 % 2 == 0 &&
+           reinterpret_cast<uintptr_t>(a) % 4 == 0 && reinterpret_cast<uintptr_t>(b) % 4 == 0;
+}
+
 static int nn_check(const char* name, int64_t N, int Co, int D3, int dtype) {
     MDL_REQUIRE(dtype == MDL_F32 || dtype == MDL_BF16, MDL_E_UNSUPP, "%s: unsupported dtype %d", name, dtype);
     MDL_REQUIRE(N >= 0 && N < (1ll << 31) && Co >= 1 && D3 >= 1, MDL_E_ARG, "%s: bad sizes", name);
@@ -135,8 +315,15 @@ extern "C" int mdl_nnconv_msg_fwd(const void* Y, const void* h, const int32_t* r
     if (rc) return rc;
     if (N == 0) return MDL_OK;
     MDL_REQUIRE(Y && h && rowptr_s && m, MDL_E_ARG, "mdl_nnconv_msg_fwd: null pointer");
-    const int lds = (Co * (D3 + 1) + D3) * 4;
     hipStream_t st = (hipStream_t)stream;
+    if (nm_ok(Co, D3, dtype, Y, h) && reinterpret_cast<uintptr_t>(m) % 2 == 0) {
+        const int lds_m = (128 + 32) * NM_LD * 2 + 32 * 4;
+        auto kf = nnconv_msg_fwd_mfma_kernel;
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds_m);
+        hipLaunchKernelGGL(kf, dim3((unsigned)N), dim3(256), lds_m, st, (const bf16_t*)Y, (const bf16_t*)h, rowptr_s, eid_s, (bf16_t*)m, Co, D3);
+        return check_launch("mdl_nnconv_msg_fwd");
+    }
+    const int lds = (Co * (D3 + 1) + D3) * 4;
     if (dtype == MDL_F32) {
         auto kf = nnconv_msg_fwd_kernel<float>;
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
@@ -157,8 +344,16 @@ extern "C" int mdl_nnconv_msg_bwd(const void* Y, const void* h, const void* dm, 
     if (rc) return rc;
     if (N == 0) return MDL_OK;
     MDL_REQUIRE(Y && h && dm && rowptr_s && dh && dY, MDL_E_ARG, "mdl_nnconv_msg_bwd: null pointer");
-    const int lds = (Co * (D3 + 1) + D3 + Co) * 4;
     hipStream_t st = (hipStream_t)stream;
+    if (nm_ok(Co, D3, dtype, Y, h) && reinterpret_cast<uintptr_t>(dm) % 4 == 0 && reinterpret_cast<uintptr_t>(dY) % 4 == 0) {
+        const int lds_m = (128 + 64) * NM_LD * 2 + 32 * 4;
+        auto kf = nnconv_msg_bwd_mfma_kernel;
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds_m);
+        hipLaunchKernelGGL(kf, dim3((unsigned)N), dim3(256), lds_m, st, (const bf16_t*)Y, (const bf16_t*)h, (const bf16_t*)dm, rowptr_s, eid_s,
+                           (bf16_t*)dh, (bf16_t*)dY, Co, D3);
+        return check_launch("mdl_nnconv_msg_bwd");
+    }
+    const int lds = (Co * (D3 + 1) + D3 + Co) * 4;
     if (dtype == MDL_F32) {
         auto kf = nnconv_msg_bwd_kernel<float>;
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);

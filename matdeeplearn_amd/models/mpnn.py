@@ -1,11 +1,29 @@
 """MPNN — /root/reference/matdeeplearn/models/mpnn.py:17-188: NNConv(gc_dim, gc_dim, nn=Seq(Linear(G,dim3),
 ReLU, Linear(dim3, gc_dim^2)), aggr="mean") (:83-88) -> BN -> act -> dropout -> one GRU step with
 h0 = pre-FC output (:141-161)."""
+import torch
 import torch.nn.functional as F
 from torch import nn
 
 from ..nn import NNConv
 from ._base import GraphModel
+
+
+def gru_step(gru, x, h):
+    """One step of a single-layer torch.nn.GRU (`out, h = gru(x[None], h[None])`, mpnn.py:160-161) written out: two dense
+    products in the dtype of x, the gate arithmetic in fp32 (torch's gate order r | z | n; n uses r * (W_hn h + b_hn)).
+    The library call goes through MIOpen's RNN path, which for sequence length 1 spends ~7 ms per layer on 6e4 rows in
+    fp32 GEMMs and tensor-op kernels — a third of the MPNN step; the parameters stay those of the nn.GRU module
+    (state_dict keys gru_list.{i}.weight_ih_l0, ...)."""
+    cd = x.dtype
+    gi = F.linear(x, gru.weight_ih_l0.to(cd), gru.bias_ih_l0.to(cd)).float()
+    gh = F.linear(h.to(cd), gru.weight_hh_l0.to(cd), gru.bias_hh_l0.to(cd)).float()
+    i_r, i_z, i_n = gi.chunk(3, dim=1)
+    h_r, h_z, h_n = gh.chunk(3, dim=1)
+    r = torch.sigmoid(i_r + h_r)
+    z = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    return n + z * (h - n)                                    # (1 - z) * n + z * h
 
 
 class MPNN(GraphModel):
@@ -26,11 +44,15 @@ class MPNN(GraphModel):
     def forward(self, data):
         x, edge_attr, csr = self._inputs(data)
         cd = self.compute_dtype
-        out = self._pre(x)                  # NNConv (K7) + BatchNorm in the compute dtype; the GRU (library) in fp32
-        h = out.float().unsqueeze(0)
+        out = self._pre(x)                  # NNConv (K7) + BatchNorm in the compute dtype; the GRU state in fp32
+        h = out.float()
         for i, conv in enumerate(self.conv_list):
             m = self._bn(i, conv(out, None, edge_attr, csr=csr))
             m = self._drop(getattr(F, self.act)(m))
-            out32, h = self.gru_list[i](m.float().unsqueeze(0), h)
-            out = out32.squeeze(0).to(cd)
+            gru = self.gru_list[i]
+            if gru.num_layers == 1 and not gru.bidirectional and gru.bias:
+                h = gru_step(gru, m, h)
+            else:
+                h = gru(m.float().unsqueeze(0), h.unsqueeze(0))[1].squeeze(0)
+            out = h.to(cd)
         return self._head(out, data)

@@ -275,13 +275,15 @@ def test_cgconv_saved_gate_pair_matches_recompute_through_the_c_abi(C):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("n,Ci,Co,D3", [(300, 100, 100, 100), (57, 24, 24, 16), (40, 20, 36, 50)])
+@pytest.mark.parametrize("n,Ci,Co,D3", [(300, 100, 100, 100), (57, 24, 24, 16), (40, 20, 36, 50), (64, 32, 128, 128), (33, 16, 30, 34)])
 def test_nnconv_contraction_matches_oracle(dtype, n, Ci, Co, D3):
     """K7 through nn.NNConv (Y = x W2r per node, per-edge mat-vec by source) against the oracle's NNConv, which builds the
     per-edge Ci x Co matrices like the reference does: output and every gradient (x, edge network, root weight, bias)."""
     from matdeeplearn_amd import nn as pnn
     g = torch.Generator().manual_seed(n + Ci)
     ei = rand_graph(n, n + Co, sort=False, empty_frac=0.15)
+    # a hub with 75 out-edges: the MFMA kernels take a node's out-edges 32 at a time (two full chunks + a ragged one)
+    ei = torch.cat([ei, torch.stack([torch.full((75,), 3, dtype=ei.dtype), torch.randint(0, n, (75,), generator=g).to(ei.dtype)])], dim=1)
     E = ei.shape[1]
     torch.manual_seed(n)
     mk = lambda: torch.nn.Sequential(torch.nn.Linear(50, D3), torch.nn.ReLU(), torch.nn.Linear(D3, Ci * Co))
