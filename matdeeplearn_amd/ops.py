@@ -24,7 +24,7 @@ class EdgeCSR:
     """Edges sorted by target.  rowptr [N+1], src/tgt [E] int32, eperm [E] int32 or None when the
     caller's per-edge tensors are already in CSR order (the product loader guarantees that)."""
 
-    __slots__ = ("rowptr", "src", "tgt", "eperm", "N", "E", "_row", "_col", "_t", "_attr", "_tb", "partial")
+    __slots__ = ("rowptr", "src", "tgt", "eperm", "N", "E", "_row", "_col", "_t", "_attr", "_tb", "partial", "__weakref__")
 
     def __init__(self, rowptr, src, tgt, eperm, N, E, row=None, col=None):
         self.rowptr, self.src, self.tgt, self.eperm, self.N, self.E = rowptr, src, tgt, eperm, int(N), int(E)
@@ -220,7 +220,7 @@ def register_seg_index(index, si, owner=None):
     is alive.  Only a weak reference is kept: when the owner dies its address may be recycled and the entry is dropped."""
     import weakref
     _SEG_KNOWN[(index.data_ptr(), index.numel(), index.device.index)] = [si, weakref.ref(index if owner is None else owner)]
-    while len(_SEG_KNOWN) > 256:
+    while len(_SEG_KNOWN) > 64:
         _SEG_KNOWN.popitem(last=False)
 
 

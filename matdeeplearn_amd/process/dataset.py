@@ -24,6 +24,18 @@ class GraphRecord:
         self.y, self.u = y, u
 
 
+def _weak_call(obj, method):
+    """obj.method() through a weak reference (None once obj is gone): what the segment-index registry may keep without
+    keeping a batch's index tensors alive."""
+    import weakref
+    ref = weakref.ref(obj)
+
+    def call():
+        o = ref()
+        return None if o is None else getattr(o, method)()
+    return call
+
+
 class Batch:
     """Batched graphs; `edge_index` ([2,E] int64, PyG convention) is materialised lazily because the
     product kernels consume `csr` (int32) directly."""
@@ -38,8 +50,8 @@ class Batch:
             self._edge_index = torch.stack([self.csr.src.long(), self.csr.tgt.long()])
             ops.register_csr(self._edge_index, self.csr)
             if self.csr.eperm is None and self._edge_index.is_cuda:       # scatter(..., edge_index[k]) without a sort
-                ops.register_seg_index(self._edge_index[0], self.csr.seg_src, owner=self._edge_index)
-                ops.register_seg_index(self._edge_index[1], self.csr.seg_tgt, owner=self._edge_index)
+                ops.register_seg_index(self._edge_index[0], _weak_call(self.csr, "seg_src"), owner=self._edge_index)
+                ops.register_seg_index(self._edge_index[1], _weak_call(self.csr, "seg_tgt"), owner=self._edge_index)
         return self._edge_index
 
     def to(self, device):
@@ -228,8 +240,8 @@ class GraphDataset:
                 p(lrowptr_s), p(rowptr_s), p(col_s), p(eid_s), p(src_s), B, -1, _lib.stream()), "mdl_assemble_transposed")
             return rowptr_s, col_s, eid_s, src_s
         csr.set_transposed_builder(transposed)
-        ops.register_seg_index(src, csr.seg_src)                  # scatter(..., csr.row / csr.col): no per-batch sort
-        ops.register_seg_index(tgt, csr.seg_tgt)
+        ops.register_seg_index(src, _weak_call(csr, "seg_src"))   # scatter(..., csr.row / csr.col): no per-batch sort
+        ops.register_seg_index(tgt, _weak_call(csr, "seg_tgt"))
         return Batch(x=x, edge_attr=None, edge_weight=ew, batch=batch, y=y, u=torch.zeros(B, 3, device=dev),
                      num_graphs=B, csr=csr, num_nodes=N, num_edges=E,
                      structure_id=[self.ids[i] for i in ids]), dn
