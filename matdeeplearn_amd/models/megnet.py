@@ -59,12 +59,12 @@ class Megnet_EdgeModel(_Mlp):
         d = lin.out_features
         cd = x.dtype
         wa, wb, wc, wd = (lin.weight[:, k * d:(k + 1) * d] for k in range(4))       # column blocks: src | dest | e | u
-        p_src = F.linear(x, wa.to(cd))                                              # [N, d] per-node projections
+        p_src = ops.linear(x, wa, None)                                             # [N, d] per-node projections (dW: TN GEMM)
         p_glb = F.linear(u, wd.to(cd), None if lin.bias is None else lin.bias.to(cd))  # [B, d] per graph (+ bias)
         # batch[row] == batch[col] (an edge stays inside its graph): the per-graph row is folded into the TARGET node's row, so
         # the kernel gathers two tables, and the per-graph gradient is a 25-row reduction over nodes instead of a
         # 325-row one over edges
-        p_dst = F.linear(x, wb.to(cd)) + ops.gather(p_glb, batch_n)
+        p_dst = ops.linear(x, wb, None) + ops.gather(p_glb, batch_n)
         out = ops.linear_gather_act(edge_attr, wc, None, self.act, [(p_src, row), (p_dst, col)])
         return self._tail(out, 0)
 

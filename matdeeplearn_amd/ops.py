@@ -758,6 +758,14 @@ class _LinearTN(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+def _tn_split_ok(x, weight):
+    """dW of a Linear with 256 < in <= 512 as two TN-GEMM halves (_linear_tn_grads): even widths, dword-aligned halves"""
+    M, K = weight.shape
+    kh = (K // 2 + 1) & ~1
+    return (K <= 512 and K % 2 == 0 and M % 2 == 0 and M <= 128 and x.stride(0) % 2 == 0 and x.data_ptr() % 4 == 0
+            and kh <= 256 and K - kh <= 256)
+
+
 def _hip_shape_ok(M, K):
     """(out, in) features the streaming dense kernels take: linear.hip forward and gemm_tn.hip weight gradient."""
     return 1 <= M <= 160 and 4 <= K <= 256 and K % 2 == 0 and (M <= 128 or (K <= 160 and M % 2 == 0))
@@ -800,6 +808,24 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
               "mdl_gemm_tn_act")
         return None, dw.to(ctx.wdtype), (dbv.to(ctx.wdtype) if ctx.has_bias else None)
     dx = _dx_hip(g, w) if ctx.needs_input_grad[0] else None
+    if K > 256:
+        # wide inputs (MEGNet's node block: [x | v_e | u[batch]] = 3d columns): the TN GEMM takes <= 256 input columns, so dW
+        # is two products over column halves of x (the library's (M x N)(N x K) form runs this K = N ~ 1e5 contraction on 9
+        # workgroups: 335 us for 100 x 300 x 1e5)
+        kh = (K // 2 + 1) & ~1
+        buf = _zeros_grad(M * K + M, g.device)
+        d1, d2, dbv = buf[:M * kh].view(M, kh), buf[M * kh:M * K].view(M, K - kh), buf[M * K:]
+        fused_db = ctx.has_bias and kh <= 158
+        check(lib().mdl_gemm_tn_colsum(ptr(g), g.stride(0), M, ptr(x), x.stride(0), kh, ptr(d1), ptr(dbv) if fused_db else None,
+                                       g.shape[0], dtype_code(g), stream()), "mdl_gemm_tn_colsum")
+        x2 = x[:, kh:]
+        check(lib().mdl_gemm_tn_colsum(ptr(g), g.stride(0), M, ptr(x2), x.stride(0), K - kh, ptr(d2), None, g.shape[0],
+                                       dtype_code(g), stream()), "mdl_gemm_tn_colsum")
+        dw = torch.cat([d1, d2], dim=1)
+        db = None
+        if ctx.has_bias:
+            db = dbv.to(ctx.wdtype) if fused_db else g.sum(dim=0, dtype=torch.float32).to(ctx.wdtype)
+        return dx, dw.to(ctx.wdtype), db
     ga, Ma = g, M
     if M % 2:                               # the streaming kernel stages rows as dwords: pad an odd width (the model's
         ga, Ma = torch.nn.functional.pad(g, (0, 1)), M + 1             # 1-column output layer) with a zero column
@@ -921,8 +947,8 @@ def linear(x, weight, bias, lowp=None):
     """F.linear in the dtype of x (fp32 master weights); bf16 inputs with many rows, out <= 128, in <= 256 take the
     HIP TN GEMM for dW, anything else the library autograd path.  `lowp` = (weight, bias) already cast to x.dtype."""
     if (x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] >= 1024
-            and (weight.shape[0] <= 128 or _hip_shape_ok(weight.shape[0], weight.shape[1])) and weight.shape[1] <= 256
-            and weight.requires_grad):
+            and (weight.shape[0] <= 128 or _hip_shape_ok(weight.shape[0], weight.shape[1]))
+            and (weight.shape[1] <= 256 or _tn_split_ok(x, weight)) and weight.requires_grad):
         if lowp is not None and lowp[0].dtype == x.dtype:
             return _LinearTN.apply(x, weight, bias, lowp[0], lowp[1])
         return _LinearTN.apply(x, weight, bias)

@@ -575,6 +575,30 @@ def test_gemm_tn_act_matches_torch(N, M, K, act):
     close(cs, am.sum(0), 1e-4, 2e-5 * N ** 0.5)
 
 
+@pytest.mark.parametrize("K", [300, 420])
+def test_wide_input_linear_takes_its_weight_gradient_from_two_tn_gemms(K):
+    """ops.linear with 256 < in <= 512 (MEGNet's node block: 3 x 100 concatenated columns): library forward, dW as two
+    TN-GEMM column halves (+ db from the first); vs fp32 torch on the same bf16-rounded operands."""
+    from matdeeplearn_amd import ops
+    N, M = 5000, 100
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev()).requires_grad_(True)
+    w = (torch.randn(M, K, generator=g) / K ** 0.5).to(dev()).requires_grad_(True)
+    b = (torch.randn(M, generator=g) * 0.1).to(dev()).requires_grad_(True)
+    go = torch.randn(N, M, generator=g).to(dev())
+    y = ops.linear(x, w, b)
+    (y.float() * go).sum().backward()
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = b.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr, wr, br)
+    (yr * go.to(torch.bfloat16).float()).sum().backward()
+    close(y, yr, 1e-2, 1e-2)
+    close(w.grad, wr.grad, 3e-2, 3e-2)
+    close(b.grad, br.grad, 3e-2, 3e-2)
+    close(x.grad, xr.grad, 3e-2, 2e-2)
+
+
 @pytest.mark.parametrize("act", ["relu", "ssp"])
 def test_linear_act_without_input_grad(act):
     """A fused dense layer whose input needs no gradient (SchNet's filter network on the edge features): the backward
