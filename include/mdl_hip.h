@@ -262,6 +262,12 @@ int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save, float* su
  * activation).  bf16 only, K even, 4 <= K <= 256, M <= 128 — or M <= 160 with K <= 160 (SchNet's 150-wide filters). */
 int mdl_linear_act(const void* x, const void* w, const void* bias, void* out, int64_t N, int K, int M, int act, int dtype,
                    mdlStream_t stream);
+/* same with x .* act'(y) in place of x: x = gradient w.r.t. the OUTPUT y[N, K] of an activated layer (xact 1: ReLU, y > 0;
+ * 2: shifted softplus, 1 - exp(-(y + ln 2)); 0: none), applied while the tile is staged — the dX product of a fused
+ * Linear + activation without a `threshold_backward` / softplus-backward pass (the reference's autograd runs one per
+ * activation, e.g. matdeeplearn/models/megnet.py:41-56). */
+int mdl_linear_act_in(const void* x, const void* y, int xact, const void* w, const void* bias, void* out, int64_t N, int K,
+                      int M, int act, int dtype, mdlStream_t stream);
 
 /* ---- tall-skinny TN GEMM: weight gradients of node-level Linear layers ---------------------------
  * c[M, K] (fp32, row-major, caller zero-fills) += a[N, M]^T . b[N, K]   a, b bf16 with leading dims lda, ldb.

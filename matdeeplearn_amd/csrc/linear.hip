@@ -27,10 +27,15 @@ struct GatherAdd {
     const int32_t* idx[3];     // row of table i for every row of x
 };
 
-template <int KP, int NT, bool GATHER = false>     // KP: K padded to {64, 128, 160, 256}; NT: 32-column tiles of the output (M <= 32*NT)
+// XACT (mdl_linear_act_in): the input rows are a gradient w.r.t. the OUTPUT y of an activated layer and the product wanted
+// is the one with x .* act'(y) (relu: y > 0, shifted softplus: 1 - exp(-(y + ln 2))) — the dX product of a fused
+// Linear + activation, with the activation derivative applied while the tile is staged, like gemm_tn.hip does for dW:
+// `threshold_backward` / the softplus backward never run as a pass over [N, K] of their own.
+template <int KP, int NT, bool GATHER = false, int XACT = 0>     // KP: K padded to {64, 128, 160, 256}; NT: 32-column tiles of the output (M <= 32*NT)
 __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
-                                                            int64_t N, int K, int M, int act, GatherAdd ga) {
+                                                            int64_t N, int K, int M, int act, GatherAdd ga,
+                                                            const bf16_t* __restrict__ xy) {
     constexpr int TN = 64;
     constexpr int LD = KP + 8;                       // LDS row stride (bf16): odd number of 16-byte slots
     constexpr int NB = (NT + 1) / 2;                 // output blocks per wave: block row wv & 1, block columns (wv >> 1) + 2j
@@ -65,24 +70,42 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
     const int w16 = 16 * wv;
     const unsigned xrow = (unsigned)K * 2u;          // dense rows
     const int64_t n_tiles = (N + TN - 1) / TN;
-    unsigned xr[NLX];
+    unsigned xr[NLX], yr[XACT ? NLX : 1];
     auto load_tile = [&](int64_t tile) {
         const int64_t nb = tile * TN;
         const int64_t bytes = (N - nb) * (int64_t)K * 2, cap = (int64_t)TN * K * 2;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x + nb * (int64_t)K), 0,
+                                                                            (int)(bytes < cap ? bytes : cap), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>((XACT ? xy : x) + nb * (int64_t)K), 0,
                                                                             (int)(bytes < cap ? bytes : cap), 0x00020000);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
             for (int j = 0; j < Q; ++j) {
                 const int d = lane + 64 * j;
-                xr[r * Q + j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (d < k2) ? (unsigned)(w16 + r) * xrow + 4u * d : FAR, 0, 0);
+                const unsigned off = (d < k2) ? (unsigned)(w16 + r) * xrow + 4u * d : FAR;
+                xr[r * Q + j] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+                if constexpr (XACT != 0) yr[r * Q + j] = __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0);
             }
         if constexpr (R != 0) {
             const int d = 64 * Q + lane % R, rr = lane / R;
 #pragma unroll
-            for (int k = 0; k < NR; ++k)
-                xr[16 * Q + k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (d < k2) ? (unsigned)(w16 + k * (64 / R) + rr) * xrow + 4u * d : FAR, 0, 0);
+            for (int k = 0; k < NR; ++k) {
+                const unsigned off = (d < k2) ? (unsigned)(w16 + k * (64 / R) + rr) * xrow + 4u * d : FAR;
+                xr[16 * Q + k] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+                if constexpr (XACT != 0) yr[16 * Q + k] = __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0);
+            }
+        }
+    };
+    auto xfix = [&](unsigned v, unsigned yv) -> unsigned {
+        if constexpr (XACT == 1) {
+            return (__uint_as_float(yv << 16) > 0.0f ? (v & 0xffffu) : 0u) | (__uint_as_float(yv & 0xffff0000u) > 0.0f ? (v & 0xffff0000u) : 0u);
+        } else if constexpr (XACT == 2) {                                 // same arithmetic as ssp_bwd_kernel (gather.hip)
+            const float s0 = 1.0f - __expf(-(__uint_as_float(yv << 16) + 0.6931471805599453f));
+            const float s1 = 1.0f - __expf(-(__uint_as_float(yv & 0xffff0000u) + 0.6931471805599453f));
+            return pk_bf16(__uint_as_float(v << 16) * s0, __uint_as_float(v & 0xffff0000u) * s1);
+        } else {
+            return v;
         }
     };
     int64_t tile = blockIdx.x;
@@ -93,11 +116,13 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int j = 0; j < Q; ++j) *reinterpret_cast<unsigned*>(xl + (w16 + r) * LD + 2 * (lane + 64 * j)) = xr[r * Q + j];
+            for (int j = 0; j < Q; ++j)
+                *reinterpret_cast<unsigned*>(xl + (w16 + r) * LD + 2 * (lane + 64 * j)) = xfix(xr[r * Q + j], yr[XACT ? r * Q + j : 0]);
         if constexpr (R != 0) {
 #pragma unroll
             for (int k = 0; k < NR; ++k)
-                *reinterpret_cast<unsigned*>(xl + (w16 + k * (64 / R) + lane / R) * LD + 2 * (64 * Q + lane % R)) = xr[16 * Q + k];
+                *reinterpret_cast<unsigned*>(xl + (w16 + k * (64 / R) + lane / R) * LD + 2 * (64 * Q + lane % R)) =
+                    xfix(xr[16 * Q + k], yr[XACT ? 16 * Q + k : 0]);
         }
         __syncthreads();
         if (tile + gridDim.x < n_tiles) load_tile(tile + gridDim.x);      // next tile's loads fly during the MFMAs
@@ -173,6 +198,24 @@ extern "C" int mdl_linear_act(const void* x, const void* w, const void* bias, vo
     return mdl_linear_gather_act(x, w, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out, N, K, M, act, dtype, stream);
 }
 
+static int linear_launch(const void* x, const void* xy, int xact, const void* w, const void* bias, const mdl::GatherAdd& ga,
+                         bool gather, void* out, int64_t N, int K, int M, int act, mdlStream_t stream);
+
+extern "C" int mdl_linear_act_in(const void* x, const void* y, int xact, const void* w, const void* bias, void* out, int64_t N,
+                                 int K, int M, int act, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_linear_act_in: bf16 only");
+    MDL_REQUIRE(xact >= 0 && xact <= 2 && (xact == 0 || (y && reinterpret_cast<uintptr_t>(y) % 4 == 0)), MDL_E_ARG,
+                "mdl_linear_act_in: xact must be 0, 1 (relu) or 2 (shifted softplus), with the activated output y for 1 / 2");
+    MDL_REQUIRE(K >= 4 && K <= 256 && K % 2 == 0 && M >= 1 && M <= 160 && (M <= 128 || K <= 160), MDL_E_UNSUPP,
+                "mdl_linear_act: need even 4<=K<=256 and 1<=M<=160 (K<=160 when M>128) (got K=%d M=%d)", K, M);
+    MDL_REQUIRE(act >= 0 && act <= 2, MDL_E_ARG, "mdl_linear_act: act must be 0 (none), 1 (relu) or 2 (shifted softplus)");
+    MDL_REQUIRE(N >= 0 && (N == 0 || (x && w && out)), MDL_E_ARG, "mdl_linear_act: bad arguments");
+    MDL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 4 == 0 && reinterpret_cast<uintptr_t>(w) % 4 == 0, MDL_E_ARG, "mdl_linear_act_in: misaligned pointer");
+    if (N == 0) return MDL_OK;
+    return linear_launch(x, y, xact, w, bias, GatherAdd{}, false, out, N, K, M, act, stream);
+}
+
 extern "C" int mdl_linear_gather_act(const void* x, const void* w, const void* bias, const void* p1, const int32_t* idx1,
                                      const void* p2, const int32_t* idx2, const void* p3, const int32_t* idx3, void* out,
                                      int64_t N, int K, int M, int act, int dtype, mdlStream_t stream) {
@@ -188,30 +231,37 @@ extern "C" int mdl_linear_gather_act(const void* x, const void* w, const void* b
     MDL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(w) % 4 == 0 &&
                 reinterpret_cast<uintptr_t>(out) % 2 == 0, MDL_E_ARG, "mdl_linear_act: misaligned pointer");
     if (N == 0) return MDL_OK;
+    return linear_launch(x, nullptr, 0, w, bias, ga, gather, out, N, K, M, act, stream);
+}
+
+static int linear_launch(const void* x, const void* xy, int xact, const void* w, const void* bias, const mdl::GatherAdd& ga,
+                         bool gather, void* out, int64_t N, int K, int M, int act, mdlStream_t stream) {
+    using namespace mdl;
     hipStream_t st = (hipStream_t)stream;
     const int kp = K <= 64 ? 64 : (K <= 128 ? 128 : (K <= 160 ? 160 : 256));
     const int nt = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 128 ? 4 : 5));
     int64_t grid = cdiv(N, 64);
     if (grid > 512) grid = 512;
     const int lds = (32 * nt + 64) * (kp + 8) * 2;
+#define MDL_LIN_K(KP_, NT_, G_, X_)                                                                                  \
+    do {                                                                                                             \
+        auto kf = linear_act_kernel<KP_, NT_, G_, X_>;                                                               \
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                           \
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
+                           (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, ga, (const bf16_t*)xy);                  \
+    } while (0)
 #define MDL_LIN(KP_, NT_)                                                                                            \
     do {                                                                                                             \
-        if (gather) {                                                                                                \
-            auto kf = linear_act_kernel<KP_, NT_, true>;                                                             \
-            (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                       \
-            hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,     \
-                               (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, ga);                         \
-        } else {                                                                                                     \
-            auto kf = linear_act_kernel<KP_, NT_, false>;                                                            \
-            (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                       \
-            hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,     \
-                               (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, GatherAdd{});                \
-        }                                                                                                            \
+        if (gather) MDL_LIN_K(KP_, NT_, true, 0);                                                                    \
+        else if (xact == 1) MDL_LIN_K(KP_, NT_, false, 1);                                                           \
+        else if (xact == 2) MDL_LIN_K(KP_, NT_, false, 2);                                                           \
+        else MDL_LIN_K(KP_, NT_, false, 0);                                                                          \
     } while (0)
     if (kp == 64) { if (nt == 1) MDL_LIN(64, 1); else if (nt == 2) MDL_LIN(64, 2); else if (nt == 4) MDL_LIN(64, 4); else MDL_LIN(64, 5); }
     else if (kp == 128) { if (nt == 1) MDL_LIN(128, 1); else if (nt == 2) MDL_LIN(128, 2); else if (nt == 4) MDL_LIN(128, 4); else MDL_LIN(128, 5); }
     else if (kp == 160) { if (nt == 1) MDL_LIN(160, 1); else if (nt == 2) MDL_LIN(160, 2); else if (nt == 4) MDL_LIN(160, 4); else MDL_LIN(160, 5); }
     else { if (nt == 1) MDL_LIN(256, 1); else if (nt == 2) MDL_LIN(256, 2); else MDL_LIN(256, 4); }
 #undef MDL_LIN
+#undef MDL_LIN_K
     return check_launch("mdl_linear_act");
 }

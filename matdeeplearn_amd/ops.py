@@ -771,25 +771,39 @@ def _hip_shape_ok(M, K):
     return 1 <= M <= 160 and 4 <= K <= 256 and K % 2 == 0 and (M <= 128 or (K <= 160 and M % 2 == 0))
 
 
-def _dx_hip(g, w):
+def _dx_hip_ok(g, w):
+    M, K = w.shape
+    return (g.dtype == torch.bfloat16 and g.is_cuda and g.shape[0] >= 1024 and g.is_contiguous() and g.data_ptr() % 16 == 0
+            and _hip_shape_ok(K, M) and M % 2 == 0)
+
+
+def _dx_hip(g, w, act_y=None):
     """dX = g W for a tall bf16 g through the streaming dense kernel (the 'weight' of that product is W^T): the library
     picks a 64x64x256 macro tile for [1.5e6, 150] x [150, 150] and runs it at 35 TFLOP/s (1.9 ms); as a stream it is
-    E*(M+K)*2 bytes."""
+    E*(M+K)*2 bytes.  act_y = (code, y): g is the gradient w.r.t. the activated output y; the activation derivative is
+    applied while the kernel stages its input (mdl_linear_act_in) — callers check _dx_hip_ok first."""
     M, K = w.shape
-    if (g.dtype == torch.bfloat16 and g.is_cuda and g.shape[0] >= 1024 and g.is_contiguous() and g.data_ptr() % 16 == 0
-            and _hip_shape_ok(K, M) and M % 2 == 0):
+    if _dx_hip_ok(g, w):
         wt = w.t().contiguous()
         dx = torch.empty((g.shape[0], K), dtype=g.dtype, device=g.device)
-        check(lib().mdl_linear_act(ptr(g), ptr(wt), None, ptr(dx), g.shape[0], M, K, 0, dtype_code(g), stream()),
-              "mdl_linear_act(dX)")
+        if act_y is not None:
+            check(lib().mdl_linear_act_in(ptr(g), ptr(act_y[1]), act_y[0], ptr(wt), None, ptr(dx), g.shape[0], M, K, 0,
+                                          dtype_code(g), stream()), "mdl_linear_act_in(dX)")
+        else:
+            check(lib().mdl_linear_act(ptr(g), ptr(wt), None, ptr(dx), g.shape[0], M, K, 0, dtype_code(g), stream()),
+                  "mdl_linear_act(dX)")
         return dx
+    assert act_y is None
     return g @ w
 
 
-def _tn_act_ok(ctx, g, x, y):
-    """mdl_gemm_tn_act can take the activation derivative into its staging: dx not wanted, streaming-kernel shapes."""
+def _tn_act_ok(ctx, g, x, y, w=None):
+    """The activation derivative can go into the staging of the backward products instead of a pass of its own: the TN
+    GEMM (dW, db) always, the dX product when it runs on the streaming kernel (or is not wanted)."""
     M, K = ctx.shape
-    return (_TN_COLSUM and not ctx.needs_input_grad[0] and M % 2 == 0 and K % 2 == 0 and K <= 158 and (M <= 128 or K <= 160)
+    if ctx.needs_input_grad[0] and not (w is not None and g.is_contiguous() and y.is_contiguous() and _dx_hip_ok(g, w)):
+        return False
+    return (_TN_COLSUM and M % 2 == 0 and K % 2 == 0 and K <= 158 and (M <= 128 or K <= 160)
             and g.dtype == torch.bfloat16 and x.stride(0) % 2 == 0 and g.stride(0) % 2 == 0 and y.stride(0) % 2 == 0
             and x.data_ptr() % 4 == 0 and g.data_ptr() % 4 == 0 and y.data_ptr() % 4 == 0 and g.stride(1) == 1
             and y.stride(1) == 1)
@@ -806,7 +820,8 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
         check(lib().mdl_gemm_tn_act(ptr(g), g.stride(0), M, ptr(act_y[1]), act_y[1].stride(0), act_y[0], ptr(x), x.stride(0), K,
                                     ptr(dw), ptr(dbv) if ctx.has_bias else None, g.shape[0], dtype_code(g), stream()),
               "mdl_gemm_tn_act")
-        return None, dw.to(ctx.wdtype), (dbv.to(ctx.wdtype) if ctx.has_bias else None)
+        dx = _dx_hip(g, w, act_y) if ctx.needs_input_grad[0] else None
+        return dx, dw.to(ctx.wdtype), (dbv.to(ctx.wdtype) if ctx.has_bias else None)
     dx = _dx_hip(g, w) if ctx.needs_input_grad[0] else None
     if K > 256:
         # wide inputs (MEGNet's node block: [x | v_e | u[batch]] = 3d columns): the TN GEMM takes <= 256 input columns, so dW
@@ -864,7 +879,7 @@ class _LinearActTN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w, out = ctx.saved_tensors
-        if ctx.act in ("relu", "ssp") and _tn_act_ok(ctx, g, x, out):
+        if ctx.act in ("relu", "ssp") and _tn_act_ok(ctx, g, x, out, w):
             return _linear_tn_grads(ctx, g, x, w, act_y=(1 if ctx.act == "relu" else 2, out)) + (None, None, None)
         if ctx.act == "relu":
             g = torch.ops.aten.threshold_backward(g, out, 0)
