@@ -10,7 +10,8 @@ python - "$f" <<'PY'
 import csv, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 tot=sum(float(r['TotalDurationNs']) for r in rows)
-print("total kernel time per step (7 steps): %.2f ms"%(tot/7/1e6))
+steps=max([int(r['Calls']) for r in rows if 'assemble_kernel' in r['Name']] + [1])      # one batch assembly per step (settle + warm-up + timed)
+print("total kernel time per step (%d steps): %.2f ms"%(steps, tot/steps/1e6))
 for r in rows[:16]:
     print("%6.2f%%  calls %5s  avg %9.1f us  %s"%(float(r['Percentage']), r['Calls'], float(r['AverageNs'])/1e3, r['Name'][:110]))
 PY
