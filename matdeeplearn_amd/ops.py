@@ -232,9 +232,7 @@ def _known_seg_index(index, dim_size):
     if ent[1]() is None:
         del _SEG_KNOWN[key]
         return None
-    if callable(ent[0]):
-        ent[0] = ent[0]()
-    si = ent[0]
+    si = ent[0]() if callable(ent[0]) else ent[0]     # (a callable is resolved per use: the registry must not pin a batch)
     return si if (si is not None and si.N == int(dim_size)) else None
 
 
