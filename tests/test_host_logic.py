@@ -559,3 +559,23 @@ def test_product_graph_builder_matches_loop_oracle_on_random_clouds():
         assert np.array_equal(pg.one_hot_degree(ei_o, n, k + 1), og.one_hot_degree(ei_o, n, k + 1))
 
     check()
+
+
+def test_written_out_gru_step_is_torch_gru():
+    """models.mpnn.gru_step (the one-step GRU the product MPNN runs instead of the library's RNN path, mpnn.py:160-161)
+    against torch.nn.GRU on the same parameters: output and every gradient, fp32 on the CPU."""
+    from matdeeplearn_amd.models.mpnn import gru_step
+    torch.manual_seed(0)
+    c, n = 12, 37
+    gru = torch.nn.GRU(c, c)
+    x = torch.randn(n, c, requires_grad=True)
+    h = torch.randn(n, c, requires_grad=True)
+    out_ref, h_ref = gru(x.unsqueeze(0), h.unsqueeze(0))
+    assert torch.equal(out_ref.squeeze(0), h_ref.squeeze(0))
+    w = torch.randn(n, c)
+    g_ref = torch.autograd.grad((h_ref.squeeze(0) * w).sum(), [x, h] + list(gru.parameters()))
+    out = gru_step(gru, x, h)
+    g = torch.autograd.grad((out * w).sum(), [x, h] + list(gru.parameters()))
+    assert torch.allclose(out, h_ref.squeeze(0), rtol=1e-5, atol=1e-6)
+    for a, b in zip(g, g_ref):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
