@@ -579,3 +579,31 @@ def test_written_out_gru_step_is_torch_gru():
     assert torch.allclose(out, h_ref.squeeze(0), rtol=1e-5, atol=1e-6)
     for a, b in zip(g, g_ref):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_static_capacity_covers_random_batches(small_ds):
+    """process.static_capacity: (n_cap, e_cap) of the padded static batch = mean + 6 sigma of a random batch, rounded up to
+    the quantum — every one of 200 random batches of the dataset fits."""
+    from matdeeplearn_amd.process import static_capacity
+    ds, B = small_ds, 16
+    n_cap, e_cap = static_capacity(ds, B, quantum=64)
+    assert n_cap % 64 == 0 and e_cap % 64 == 0
+    rng = np.random.default_rng(0)
+    nn, ne = np.diff(ds.node_ptr), np.diff(ds.edge_ptr)
+    for _ in range(200):
+        ids = rng.choice(len(ds), size=B, replace=False)
+        assert nn[ids].sum() < n_cap and ne[ids].sum() <= e_cap
+    assert n_cap < 4 * B * nn.mean() and e_cap < 4 * B * ne.mean()          # ... without being absurdly large
+
+
+def test_loss_and_shape_predicates_off_the_hip_path():
+    """ops.loss on CPU tensors is torch's loss; the shape predicates that route dense layers to the HIP kernels."""
+    from matdeeplearn_amd import ops
+    p, y = torch.randn(9, requires_grad=True), torch.randn(9)
+    assert torch.equal(ops.loss("l1_loss", p, y), torch.nn.functional.l1_loss(p, y))
+    assert torch.equal(ops.loss("smooth_l1_loss", p, y), torch.nn.functional.smooth_l1_loss(p, y))
+    assert ops._hip_shape_ok(150, 150) and ops._hip_shape_ok(100, 256) and not ops._hip_shape_ok(150, 256)
+    assert not ops._hip_shape_ok(161, 100) and not ops._hip_shape_ok(100, 51)
+    x = torch.zeros(4, 300)
+    assert ops._tn_split_ok(x, torch.zeros(100, 300)) and not ops._tn_split_ok(x, torch.zeros(130, 300))
+    assert not ops._tn_split_ok(torch.zeros(4, 600), torch.zeros(100, 600))
