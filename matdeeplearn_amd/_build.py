@@ -15,6 +15,10 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libmdl_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+# per-file extras: the edge-per-lane CGConv backward wants its MFMA results in VGPRs (see csrc/cgconv.hip)
+FILE_FLAGS = {"cgconv_ep.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# translation units that #include another .hip file
+FILE_DEPS = {"cgconv_ep.hip": ["cgconv.hip"]}
 
 
 def _hipcc():
@@ -50,9 +54,11 @@ def build(force=False, verbose=True):
     hdr_t = _deps_mtime()
 
     def compile_one(src):
-        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            cmd = [cc] + FLAGS + ["-c", src, "-o", obj]
+        base = os.path.basename(src)
+        obj = os.path.join(OBJDIR, base[:-4] + ".o")
+        src_t = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(CSRC, d)) for d in FILE_DEPS.get(base, [])])
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(src_t, hdr_t):
+            cmd = [cc] + FLAGS + FILE_FLAGS.get(base, []) + ["-c", src, "-o", obj]
             if verbose:
                 print("[mdl build]", " ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)

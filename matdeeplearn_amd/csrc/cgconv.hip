@@ -72,10 +72,18 @@
 #ifndef MDL_FWD_PRE_DEPTH
 #define MDL_FWD_PRE_DEPTH 3   // all-slices forward: pinned LDS-read / MFMA interleave in pre_tile, reads issued ahead (-6 %)
 #endif
+#ifndef MDL_BWD_DERIV2
+#define MDL_BWD_DERIV2 0  // 1: bf16 backward with the select-free gate derivative (Gate<true>::deriv2, 3 VALU fewer per element): measured +-0
+#endif
 #ifndef MDL_BWD_WAVES
 #define MDL_BWD_WAVES 1   // waves per SIMD the backward kernel is register-allocated for
 #endif
 
+#ifdef MDL_CG_EP_TU      // compiled a second time as cgconv_ep.hip (see the include of cgconv_ep.inc below): own debug symbols
+#define mdl_debug_life mdl_debug_life_ep
+#define mdl_debug_read mdl_debug_read_ep
+#define mdl_debug_reset mdl_debug_reset_ep
+#endif
 #ifdef MDL_CG_TIMING   // experiment builds only: per-phase cycle counters of wave 0 (kept in SGPRs, flushed at the end)
 __device__ long long g_cg_dbg[48];
 __device__ long long g_cg_life[2][4096][3];     // [fwd|bwd][wave] = wall start, wall end, tiles (last launch)
@@ -1311,7 +1319,11 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float sf, sp_u, ss;
+#if MDL_BWD_DERIV2
+                    if constexpr (BF) GT::deriv2(accf[r], accs[r], sf, sp_u, ss); else GT::deriv(accf[r], accs[r], sf, sp_u, ss);
+#else
                     GT::deriv(accf[r], accs[r], sf, sp_u, ss);
+#endif
                     const float t = dmv[r] * sf;
                     accf[r] = (t * GT::M_SCALE) * (1.0f - sf) * sp_u;
                     accs[r] = t * ss;
@@ -1764,6 +1776,34 @@ __global__ __launch_bounds__(256, 1) void cgconv_bwd_ab_kernel(CgParams p) {
 }
 
 #include "cgconv_cb.inc"   // namespace mdl::cb
+// The edge-per-lane backward (cgconv_ep.inc, namespace mdl::ep; opt-in, MDL_CG_EP=1) lives in its own translation
+// unit: cgconv_ep.hip defines MDL_CG_EP_TU and includes THIS file, so that it sees the shared tile machinery above, and is
+// compiled with -mllvm -amdgpu-mfma-vgpr-form=1 — its phase-A MFMA results then land in the VGPRs the gate arithmetic reads
+// (the default AGPR form costs one v_accvgpr_read per value, 96 per tile), while the per-wave kernels of this unit, which
+// live on 256 + 179 registers, need the AGPR form.
+#ifdef MDL_CG_EP_TU
+#include "cgconv_ep.inc"
+namespace ep {
+int launch(CgParams& p, hipStream_t st, int wgs, const char* name) {
+    typedef Cfg<64> F;
+    // one workgroup per CU; small problems: at least two rounds of tiles per workgroup
+    const int64_t eg = std::min<int64_t>(wgs > 0 ? wgs : 256, std::max<int64_t>(1, cdiv(p.E, 32 * F::NW * 2)));
+    auto kf = bwd_kernel<64>;
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), F::LDS);
+    if (e != hipSuccess) { set_error("%s: LDS attribute (%d B): %s", name, F::LDS, hipGetErrorString(e)); return MDL_E_LAUNCH; }
+    hipLaunchKernelGGL(kf, dim3((unsigned)eg), dim3(F::NT), F::LDS, st, p);
+    return check_launch(name);
+}
+}  // namespace ep
+}  // namespace mdl
+#else
+namespace ep {
+#ifndef MDL_EP_DEFAULT
+#define MDL_EP_DEFAULT 0      // 1: mdl_cgconv_bwd takes the edge-per-lane kernel for bf16, C = 64, G = 50 (MDL_CG_EP=0/1 overrides).
+                              // Off: parity-green but 15 % slower than the per-wave kernel on the bench batch
+#endif
+int launch(CgParams& p, hipStream_t st, int wgs, const char* name);
+}
 
 // ------------------------------------------------------------------------------------------
 // Weight packing: nn.Linear [C, 2C+G] (target|source|edge) -> [2Cp][WS] with K order [e|x_tgt|x_src]
@@ -1813,6 +1853,8 @@ struct CgEnv {
     int cb_wgs;           // MDL_CB_WGS: their workgroups per CU (0 = default)
     int ab_wgs;           // MDL_AB_WGS: workgroups per CU of the saved-gate backward (0 = default 1)
     int no_half_groups;   // MDL_CG_NO_HALF=1: dynamic backward schedule without the half-group tail (A/B)
+    int ep;               // MDL_CG_EP: edge-per-lane backward edge pass (cgconv_ep.inc); -1 = compile-time default
+    int ep_wgs;           // MDL_EP_WGS: its grid cap (0 = one workgroup per CU)
 };
 static const CgEnv& cg_env() {
     static const CgEnv e = [] {
@@ -1824,6 +1866,8 @@ static const CgEnv& cg_env() {
         v.cb_wgs = (s = getenv("MDL_CB_WGS")) ? atoi(s) : 0;
         v.ab_wgs = (s = getenv("MDL_AB_WGS")) ? atoi(s) : 0;
         v.no_half_groups = (s = getenv("MDL_CG_NO_HALF")) ? (atoi(s) != 0) : 0;
+        v.ep = (s = getenv("MDL_CG_EP")) ? (atoi(s) != 0) : -1;
+        v.ep_wgs = (s = getenv("MDL_EP_WGS")) ? atoi(s) : 0;
         return v;
     }();
     return e;
@@ -1873,6 +1917,11 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     if (grid > cap) grid = cap;
     const CgEnv& env = cg_env();
     if (env.grid_cap > 0 && grid > env.grid_cap) grid = env.grid_cap;   // experiments
+    // edge-per-lane backward (cgconv_ep.inc): bf16, C = 64, G = 50, target-sorted edge features
+    if constexpr (sizeof(T) == 2) {
+        const bool use_ep = env.ep >= 0 ? env.ep != 0 : (MDL_EP_DEFAULT != 0);
+        if (use_ep && bwd && fast && d.Cp == 64 && p.bias_col && p.E >= 64) return ep::launch(p, st, env.ep_wgs, name);
+    }
     // total waves must be a multiple of NS so that every wave keeps one channel slice
     while ((grid * waves) % d.NS) ++grid;
     // dynamic group scheduling only pays when every wave gets several 32-node groups
@@ -2138,3 +2187,4 @@ extern "C" int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_
     if (dtype == MDL_BF16) return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd");
     return cg_launch<float>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd");
 }
+#endif   // !MDL_CG_EP_TU

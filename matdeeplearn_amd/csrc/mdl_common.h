@@ -128,6 +128,7 @@ template <> struct Gate<false> {
         sf = sigmoid(f);
         softplus_sigmoid(sv, sp_u, ss);
     }
+    __device__ static __forceinline__ void deriv2(float f, float sv, float& sf, float& sp_u, float& ss) { deriv(f, sv, sf, sp_u, ss); }
 };
 template <> struct Gate<true> {
     static constexpr float W_SCALE = LOG2E_F;
@@ -169,6 +170,26 @@ template <> struct Gate<true> {
         const float rl = r * a1;
         sp_u = relu_plus(sv, __builtin_amdgcn_logf(l));
         ss = sv >= 0.0f ? rl : ea * rl;
+    }
+    // The same three values without a select, an |s| or a second add (edge-per-lane backward, where the gate arithmetic is
+    // the instruction count that bounds the kernel):
+    //   u = min(2^-f, 2^63), es = min(2^s, 2^63)      integer min on the bit patterns (both >= 0: same order); keeps the
+    //                                                  product (1 + u)(1 + es) finite
+    //   r = 1 / ((1 + u)(1 + es));  sf = r (1 + es) = sigmoid(f);  ss = es r (1 + u) = sigmoid(s)
+    //   sp_u = max(log2(1 + es), s) = log2(1 + 2^s): the max restores the exact value where es was capped; taken as a SIGNED
+    //          INTEGER max of the bit patterns (log2(1 + es) >= 0: a negative s is a negative integer, two non-negative floats
+    //          order like their patterns) — fmaxf costs a canonicalising second instruction
+    __device__ static __forceinline__ void deriv2(float f, float sv, float& sf, float& sp_u, float& ss) {
+        const unsigned ub = __float_as_uint(__builtin_amdgcn_exp2f(-f));
+        const unsigned eb = __float_as_uint(__builtin_amdgcn_exp2f(sv));
+        const float a1 = 1.0f + __uint_as_float(ub < 0x5f000000u ? ub : 0x5f000000u);
+        const float es = __uint_as_float(eb < 0x5f000000u ? eb : 0x5f000000u);
+        const float l = 1.0f + es;
+        const float r = __builtin_amdgcn_rcpf(a1 * l);
+        sf = r * l;
+        ss = es * (r * a1);
+        const int lg = (int)__float_as_uint(__builtin_amdgcn_logf(l)), si = (int)__float_as_uint(sv);
+        sp_u = __uint_as_float((unsigned)(lg > si ? lg : si));
     }
 };
 

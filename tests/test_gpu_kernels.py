@@ -153,6 +153,24 @@ def test_cgconv_cooperative_kernels_match_oracle(C, monkeypatch):
     _cgconv_case(90, C, 50, torch.bfloat16, True, seed=22, aggr="add")
 
 
+def test_cgconv_edge_per_lane_backward_matches_oracle():
+    """The opt-in edge-per-lane backward edge pass (cgconv_ep.inc, MDL_CG_EP=1; bf16, C = 64, G = 50) against the oracle:
+    several workgroups and rounds, partial tiles, isolated nodes (groups without edges), sources outside the 96-node
+    window (rand_graph's window of +-40 around the target spans it for 32-node groups), sum and mean aggregation.  Runs
+    in a fresh interpreter: the library reads its experiment switches once per process."""
+    import subprocess
+    import sys
+    code = ("import torch; import tests.test_gpu_kernels as t\n"
+            "t._cgconv_case(700, 64, 50, torch.bfloat16, True, seed=21, empty_frac=0.05)\n"
+            "t._cgconv_case(2500, 64, 50, torch.bfloat16, True, seed=23, empty_frac=0.3)\n"
+            "t._cgconv_case(90, 64, 50, torch.bfloat16, True, seed=22, aggr='add')\n"
+            "t._cgconv_case(200, 64, 50, torch.bfloat16, False, seed=24)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "MDL_CG_EP": "1"}, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_cgconv_c_abi_eperm_and_workspace_paths():
     """Straight through the C ABI: (a) unsorted edge features addressed through eperm (generic kernels) give the same
     forward as target-sorted features (static kernels); (b) the backward with and without the optional workspace

@@ -44,6 +44,10 @@ try:
         buf = (ctypes.c_longlong * 48)()
         L.mdl_debug_read(buf)
         v = list(buf)
+        if hasattr(L, "mdl_debug_read_ep") and os.environ.get("MDL_CG_EP", "0") != "0":   # the edge-per-lane backward keeps
+            buf2 = (ctypes.c_longlong * 48)()                                               # its counters in its own unit
+            L.mdl_debug_read_ep(buf2)
+            v[16:32] = list(buf2)[16:32]
         n = max(v[15], 1)
         if os.environ.get("MDL_CG_CB") == "1":
             cbn = ["data loads issue", "mfma chain", "gate+swaps", "reduce", "epilogue", "barrier", "commit (waits)", "idx issue"]
@@ -55,12 +59,14 @@ try:
             cbn = ["mfma chain", "dmv", "deriv+swaps", "reductions+dwe", "oob", "group flush", "commit+tables", "loads issue", "barrier"]
             print("cb bwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[30] / n), {cbn[k]: round(v[16 + k] / n) for k in range(9)})
         names = ["loop top", "commit+tables", "issue loads", "pre", "dmv", "gate deriv", "pack", "reduce tgt", "reduce win", "dwe+rest", "prologue: zero+window base", "group epilogue", "prologue: loads+wait+gB"]
+        if os.environ.get("MDL_CG_EP", "0") != "0":   # edge-per-lane kernel: cycles per ROUND of four tiles
+            names = ["walk (take)", "A commit+tables", "A issue loads", "A mfma pair0", "A mfma pair1 || gate0", "A gathers + gate1", "-", "barrier 1", "B rest", "barrier 2", "B header+flush", "B operand wait+mfma", "B out-of-window"]
         print("bwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[30] / n), {names[k]: round(v[16 + k] / n) for k in range(13)}, "sum", round(sum(v[16:29]) / n), "| shader clock %.2f GHz, wave-0 lifetime %.1f us/launch" % (v[30] / max(v[29], 1) * 0.1, v[29] / 100.0 / max(1, a.iters + 2)))
     if hasattr(L, "mdl_debug_life"):
         import numpy as np
         for which, nm in ((0, "fwd"), (1, "bwd")):
             buf = (ctypes.c_longlong * (4096 * 3))()
-            L.mdl_debug_life(buf, which)
+            (L.mdl_debug_life_ep if (which == 1 and hasattr(L, "mdl_debug_life_ep") and os.environ.get("MDL_CG_EP", "0") != "0") else L.mdl_debug_life)(buf, which)
             arr = np.array(list(buf), dtype=np.int64).reshape(4096, 3)
             arr = arr[arr[:, 1] > 0]
             if len(arr):
