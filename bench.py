@@ -73,6 +73,12 @@ def parse():
     ap.add_argument("--sustain-s", type=float, default=2.0)
     ap.add_argument("--settle-s", type=float, default=1.0, help="seconds of untimed steps in front of the warm-up (0 = none)")
     ap.add_argument("--cpu-steps", type=int, default=1, help="timed oracle steps on the GPU run's own batches")
+    ap.add_argument("--cpu-graphs", type=int, default=0,
+                    help="graphs of each timed batch the oracle steps on (0 = whole batch; MPNN defaults to 16: the oracle "
+                         "materialises the reference's E x C x C edge tensor)")
+    ap.add_argument("--no-other-models", action="store_true",
+                    help="skip the short schnet / megnet / gcn / mpnn legs the default cgcnn line carries (other_models)")
+    ap.add_argument("--strong-steps", type=int, default=10, help="N > 1: timed steps of the strong-scaling leg (global batch fixed)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--dataset-cache", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "mdl_bench_data"),
                     help="directory for the flat on-disk copy of the synthetic dataset ('' = always regenerate)")
@@ -125,6 +131,13 @@ def main():
     cls_name, gen_name, n_graphs, B, mkw, wl_desc = WORKLOADS[args.model]
     n_graphs = args.graphs or n_graphs
     B = args.batch or B
+    # weak scaling draws B graphs per GPU and step: every rank's partition of the train split (0.8 n / world) must hold at
+    # least one full batch, or a "batch" would be spliced from several epochs of the partition and contain duplicate graphs
+    # (at 8 x 8192 the reference-sized 46,744-graph recipe is too small).  The synthetic recipe is simply drawn longer.
+    need = int(np.ceil(B * world / 0.8 * 1.02)) + 8
+    grown = (not args.graphs) and n_graphs < need
+    if grown:
+        n_graphs = need
     if mkw is None:
         mkw = dict(dim1=args.dim, dim2=args.dim, pre_fc_count=1, gc_count=args.gc, post_fc_count=3)
     mkw = dict(mkw, pool="global_mean_pool", pool_order="early", batch_norm="True", batch_track_stats="True", act="relu",
@@ -152,7 +165,8 @@ def main():
     ds.to(dev)
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     tr_idx, va_idx, _ = split_data(len(ds), 0.8, 0.05, 0.15, seed=args.seed)
-    B = min(B, len(tr_idx))
+    B = min(B, len(tr_idx) // world)
+    assert B >= 1 and B * world <= len(tr_idx), "a per-rank partition of the train split must hold one full batch"
     loader = DeviceLoader(ds, tr_idx, B, shuffle=True, seed=args.seed, rank=rank, world_size=world)
     stream = batch_stream(loader, B)
     total_steps = args.warmup + args.steps
@@ -236,6 +250,28 @@ def main():
         dist.all_reduce(etot, op=dist.ReduceOp.SUM)
     elapsed_max, edges_all = float(tmax), float(etot)
 
+    # ---- strong scaling beside it (N > 1): the GLOBAL batch fixed at the one-GPU size, B / N graphs per GPU ----
+    strong = None
+    if world > 1 and args.strong_steps > 0:
+        Bs = max(1, B // world)
+        s_stream = batch_stream(DeviceLoader(ds, tr_idx, Bs, shuffle=True, seed=args.seed + 1, rank=rank, world_size=world), Bs)
+        s_ids = [next(s_stream) for _ in range(args.warmup + args.strong_steps)]
+        for i in range(args.warmup):
+            step(s_ids[i], False)
+        barrier()
+        t1 = time.perf_counter()
+        e_s = 0
+        for i in range(args.warmup, len(s_ids)):
+            e_s += step(s_ids[i], False, s_ids[i + 1] if i + 1 < len(s_ids) else None)[0]
+        barrier()
+        ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        es = torch.tensor([float(e_s)], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        dist.all_reduce(es, op=dist.ReduceOp.SUM)
+        strong = {"value": round(float(es) / float(ts), 1), "unit": "edges/s", "scaling": "strong", "steps": args.strong_steps,
+                  "ms_per_step": round(float(ts) / args.strong_steps * 1e3, 4), "global_batch_graphs": Bs * world,
+                  "batch_graphs_per_gpu": Bs}
+
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -273,9 +309,19 @@ def main():
 
     # HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes over tools/bench_kernels.py,
     # tools/gpu_pmc.sh -> profiles/hbm_traffic.json), scaled to this batch's edge count
-    traffic = {}
+    traffic, traffic_src = {}, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        import glob
+        import hashlib
+        hsh = hashlib.sha256()
+        for f in sorted(glob.glob(os.path.join(ROOT, "matdeeplearn_amd/csrc/cgconv*")) + glob.glob(os.path.join(ROOT, "matdeeplearn_amd/csrc/rbf.hip"))):
+            hsh.update(open(f, "rb").read())
+        traffic_src = {"file": "profiles/hbm_traffic.json", "measured_at_E": tj.get("E"),
+                       "kernel_sources_sha16": tj.get("kernel_sources_sha16"),
+                       "stale": tj.get("kernel_sources_sha16") != hsh.hexdigest()[:16],
+                       "note": "PMC pass over tools/bench_kernels.py (tools/gpu_pmc.sh), scaled to this batch's edge count; stale = the "
+                               "conv kernel sources changed since that pass"}
         if args.model == "cgcnn" and mkw["dim1"] == 64 and args.dtype == "bf16":
             for k in ("fwd", "bwd"):
                 if "mdl_cgconv_" + k in tj:
@@ -287,6 +333,7 @@ def main():
         ach = ab[k] / avg[k] / 1e9
         return {"kernel": kname[k], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(k),
+                "traffic_source": traffic_src if traffic.get(k) is not None else None,
                 "avg_launch_us": round(avg[k] * 1e6, 2), "launches": len(dur[k]),
                 "algorithmic_bytes_per_launch": int(ab[k])}
 
@@ -307,6 +354,11 @@ def main():
                    "parallelism": "dp%d" % world, "dataset_load_s": round(gen_s, 1), "dataset_source": data_src, "settle_steps": settle_steps,
                    "conv_kernel_share_of_step": round(sum(tot.values()) / elapsed, 3)},
     }
+    if strong is not None:
+        res["strong_scaling"] = strong
+    if grown:
+        res["config"]["dataset_note"] = ("the recipe was drawn to %d graphs (reference-sized: %d) so that every rank's partition "
+                                         "of the train split holds a full batch of distinct graphs" % (n_graphs, WORKLOADS[args.model][2]))
     if dom is not None:
         res["roofline"] = roof(dom)
         other = [k for k in have if k != dom]
@@ -404,12 +456,49 @@ def main():
             res["fp32_mode"] = {"value": round(e32 / dt, 1), "unit": "edges/s", "ms_per_step": round(dt / n32 * 1e3, 4), "steps": n32}
             del m32, dp32, opt32
 
+    # ---- the other BASELINE configurations as short legs of the same run (cfg3 SchNet_demo, cfg4 MEGNet_demo, the cfg5 members):
+    # one sub-process each, a dataset of two batches, a few timed steps, bf16 parity on a small held-out sample ----------
+    if world == 1 and args.model == "cgcnn" and not args.no_extras and not args.no_other_models:
+        res["other_models"] = other_models(args)
+
     # ---- CPU baseline: the oracle (pure-torch restatement of the reference path) on host cores ----
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args, ds, model, cls_name, mkw, step_ids[args.warmup:], va_idx)
     if use_dist:
         dist.destroy_process_group()
     print(json.dumps(res))
+
+
+def other_models(args):
+    """Short legs of the other workloads, each in its own process (fresh allocator, a failure cannot take the headline
+    down): {model: {ms_per_step, value [edges/s], edges_per_step, roofline kernel + frac, val_mae_delta_bf16, ...}}."""
+    import subprocess
+    out = {}
+    for name in ("schnet", "megnet", "gcn", "mpnn"):
+        B = WORKLOADS[name][3]
+        cmd = [sys.executable, os.path.abspath(__file__), "--model", name, "--steps", "6", "--warmup", "2", "--settle-s", "0.3",
+               "--no-extras", "--graphs", str(int(B * 1.25 / 0.8) + 64), "--cpu-steps", "0", "--dataset-cache", args.dataset_cache,
+               "--seed", str(args.seed)]
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+            if not line:
+                out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+                continue
+            j = json.loads(line[-1])
+            cb = j.get("cpu_baseline") or {}
+            out[name] = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                         "steps": j["steps"], "edges_per_step": j["config"]["edges_per_step_per_gpu"],
+                         "batch_graphs": j["config"]["batch_graphs_per_gpu"], "dtype": j["dtype"],
+                         "roofline_kernel": (j.get("roofline") or {}).get("kernel"), "roofline_frac": (j.get("roofline") or {}).get("frac"),
+                         "conv_kernel_share_of_step": j["config"].get("conv_kernel_share_of_step"),
+                         "val_mae_delta": cb.get("val_mae_delta"), "val_mae_delta_bf16": cb.get("val_mae_delta_bf16"),
+                         "pred_max_rel_delta_bf16": cb.get("pred_max_rel_delta_bf16"), "val_graphs": cb.get("val_graphs"),
+                         "wall_s": round(time.time() - t0, 1)}
+        except Exception as exc:                                  # report, never hide
+            out[name] = {"error": repr(exc)[:300]}
+    return out
 
 
 def cpu_baseline(args, ds, gpu_model, cls_name, mkw, timed_ids, va_idx):
@@ -423,6 +512,13 @@ def cpu_baseline(args, ds, gpu_model, cls_name, mkw, timed_ids, va_idx):
     from matdeeplearn_amd.training import make_optimizer
 
     cores = os.cpu_count() or 1
+    # the oracle NNConv materialises the reference's E x C x C edge tensor (40 KB per edge at C = 100): MPNN steps on 16 graphs
+    cap = args.cpu_graphs or {"MPNN": 16}.get(cls_name, 0)
+    if cap:
+        timed_ids = [ids[:cap] for ids in timed_ids]
+    val_cap = 1024 if not cap else 4 * cap
+    if args.cpu_steps <= 0:
+        val_cap = min(val_cap, 64 if cls_name != "MPNN" else 16)   # parity-only leg (other_models): a small held-out sample
     cds = copy.copy(ds)
     cds._dev = {}
     cds.to("cpu")
@@ -445,9 +541,10 @@ def cpu_baseline(args, ds, gpu_model, cls_name, mkw, timed_ids, va_idx):
 
     # thread-pool size: torch's intra-op pool degrades when the thread count far exceeds the useful parallelism of these
     # tensor sizes; pick the faster of two sizes on a small probe batch, then time the identical batches with it
-    probe = cds.collate(timed_ids[0][:512], rbf=rbf)
-    best_nt, best_t = None, None
-    for nt in sorted({min(cores, t) for t in (16, 64)}):
+    out = {}
+    probe = cds.collate(timed_ids[0][:512], rbf=rbf) if args.cpu_steps > 0 else None
+    best_nt, best_t = min(cores, 16), None
+    for nt in (sorted({min(cores, t) for t in (16, 64)}) if args.cpu_steps > 0 else []):
         torch.set_num_threads(nt)
         om = oracle()
         om.train()
@@ -457,24 +554,26 @@ def cpu_baseline(args, ds, gpu_model, cls_name, mkw, timed_ids, va_idx):
         if best_t is None or t < best_t:
             best_nt, best_t = nt, t
     torch.set_num_threads(best_nt)
-    om = oracle()
-    om.train()
-    opt = make_optimizer(om.parameters(), "AdamW", lr=0.002)
-    nsteps = max(1, min(args.cpu_steps, len(timed_ids) - 1))
-    batches = [cds.collate(timed_ids[i], rbf=rbf) for i in range(nsteps + 1)]
-    one_step(om, opt, batches[0])                                  # warm-up on the GPU run's first timed batch
-    edges, t_total = 0, 0.0
-    for b in batches[1:]:
-        t_total += one_step(om, opt, b)
-        edges += b.num_edges
-    out = {"value": round(edges / t_total, 1), "unit": "edges/s", "cores": best_nt, "host_cores": cores, "kind": "port",
-           "sample": "%d fp32 training step(s) of the oracle %s on the GPU run's own timed batch(es) (%d graphs, %d edges) "
-                     "after 1 warm-up step, %.1f s" % (nsteps, cls_name, len(timed_ids[1]), edges, t_total)}
+    if args.cpu_steps > 0:
+        om = oracle()
+        om.train()
+        opt = make_optimizer(om.parameters(), "AdamW", lr=0.002)
+        nsteps = max(1, min(args.cpu_steps, len(timed_ids) - 1))
+        batches = [cds.collate(timed_ids[i], rbf=rbf) for i in range(nsteps + 1)]
+        one_step(om, opt, batches[0])                                  # warm-up on the GPU run's first timed batch
+        edges, t_total = 0, 0.0
+        for b in batches[1:]:
+            t_total += one_step(om, opt, b)
+            edges += b.num_edges
+        out = {"value": round(edges / t_total, 1), "unit": "edges/s", "cores": best_nt, "host_cores": cores, "kind": "port",
+               "sample": "%d fp32 training step(s) of the oracle %s on %s of the GPU run's own timed batch(es) (%d graphs, %d edges) "
+                         "after 1 warm-up step, %.1f s" % (nsteps, cls_name, ("the first %d graphs" % cap) if cap else "all graphs",
+                                                           len(timed_ids[1]), edges, t_total)}
 
     # parity at the trained weights on held-out graphs: oracle (CPU fp32) vs HIP fp32 vs HIP bf16
     om = oracle()
     om.eval()
-    ids = np.asarray(va_idx[:1024])
+    ids = np.asarray(va_idx[:val_cap])
     with torch.no_grad():
         bc = cds.collate(ids, rbf=rbf)
         p_cpu = om(bc)

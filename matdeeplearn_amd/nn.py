@@ -153,7 +153,9 @@ class GCNConv(nn.Module):
         super().__init__()
         if add_self_loops:
             raise ops.MdlError("GCNConv(add_self_loops=True) is not on the reference path (gcn.py:81)")
-        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        # two glorot draws like PyG 2.0.1 (its Linear draws once in the ctor — without torch's default-init draw —, then
+        # GCNConv.__init__ ends with reset_parameters()): a third draw would shift every later layer's seeded weights
+        self.lin = torch.nn.utils.skip_init(nn.Linear, in_channels, out_channels, bias=False)
         nn.init.xavier_uniform_(self.lin.weight)
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         self.reset_parameters()

@@ -702,7 +702,10 @@ class _NNConvMsg(torch.autograd.Function):
             raise MdlError("nnconv_msg: Y (%s) and h (%s) must share a dtype" % (Y.dtype, h.dtype))
         Y, h = Y.contiguous(), h.contiguous()
         rowptr_s, _, eid_s, _ = csr.transposed()
-        m = torch.empty((csr.E, Co), dtype=Y.dtype, device=Y.device)
+        # padded static batch (HIP-graph replay): the unused edge slots belong to no by-source segment, so neither kernel
+        # writes their rows — they must read as zeros (finite forward values, exactly zero gradients on every padded row)
+        ctx.padded = _true_rows_for(h.shape[0]) is not None
+        m = (torch.zeros if ctx.padded else torch.empty)((csr.E, Co), dtype=Y.dtype, device=Y.device)
         check(_launch_timed("nnconv_fwd", lambda: lib().mdl_nnconv_msg_fwd(
             ptr(Y), ptr(h), ptr(rowptr_s), ptr(eid_s), ptr(m), csr.N, Co, D3, dtype_code(Y), stream())), "mdl_nnconv_msg_fwd")
         ctx.csr, ctx.dims = csr, (Co, D3)
@@ -715,7 +718,7 @@ class _NNConvMsg(torch.autograd.Function):
         Co, D3 = ctx.dims
         rowptr_s, _, eid_s, _ = ctx.csr.transposed()
         dm = dm.contiguous()
-        dh, dY = torch.empty_like(h), torch.empty_like(Y)
+        dh, dY = (torch.zeros_like(h) if ctx.padded else torch.empty_like(h)), torch.empty_like(Y)
         check(lib().mdl_nnconv_msg_bwd(ptr(Y), ptr(h), ptr(dm), ptr(rowptr_s), ptr(eid_s), ptr(dh), ptr(dY), ctx.csr.N, Co,
                                        D3, dtype_code(Y), stream()), "mdl_nnconv_msg_bwd")
         return dY, dh, None, None, None
@@ -943,8 +946,10 @@ def linear_gather_act(x, weight, bias, act, gathered):
 def linear_act(x, weight, bias, act, lowp=None):
     """getattr(F, act)(F.linear(x, weight, bias)) — fused forward for bf16 inputs with dense rows, even in <= 256,
     out <= 128 and act in (relu, none); anything else composes `linear` with the library activation."""
+    # (ssp: the one-pass softplus backward works on element PAIRS — an odd width would reach it with an odd element count)
     if (act in ("relu", "ssp", None) and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
             and x.shape[0] >= 1024 and _hip_shape_ok(weight.shape[0], weight.shape[1])
+            and (act != "ssp" or weight.shape[0] % 2 == 0)
             and x.data_ptr() % 16 == 0 and weight.requires_grad):
         w_lp, b_lp = (lowp if lowp is not None and lowp[0].dtype == x.dtype else (None, None))
         return _LinearActTN.apply(x, weight, bias, w_lp, b_lp, act)

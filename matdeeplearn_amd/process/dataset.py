@@ -423,6 +423,11 @@ class StaticBatch:
         self.edge_index = torch.zeros((2, self.e_cap), dtype=torch.int64, device=dev)
         self.b_dev = torch.full((1,), B, dtype=torch.int64, device=dev)
         ds.by_source()
+        # BatchNorm finds the true row count of a tensor by its PADDED row count (ops.true_rows): the three capacities must
+        # be pairwise distinct, or node-, edge- and graph-level tensors would be normalised over each other's row counts
+        if len({self.n_cap, self.e_cap, B + 1}) != 3:
+            raise ops.MdlError("StaticBatch: node capacity %d, edge capacity %d and graph rows %d must be pairwise distinct"
+                               % (self.n_cap, self.e_cap, B + 1))
         self.pool_rowptr = torch.zeros(B + 2, dtype=torch.int32, device=dev)
         self.pool_seg = torch.full((self.n_cap,), B, dtype=torch.int32, device=dev)
         self.batch = Batch(pool_index=ops.make_seg_index(self.pool_rowptr, self.pool_seg, partial=True), x=self.x,

@@ -168,6 +168,13 @@ def _gather_objects(obj, world_size):
     return bucket
 
 
+def _suffixed(path, tag):
+    """my_model.pth -> my_model<tag>.pth"""
+    import os
+    root, ext = os.path.splitext(path)
+    return root + tag + ext
+
+
 def train_repeat_replicas(rank, world_size, dataset, job, training, model_params, **kw):
     """Repeat mode sharded as REPLICAS (option 2): trial t runs entirely on rank t % world_size — a
     single-GPU training with no gradient exchange — and the error table is gathered at the end.  Same trials and same
@@ -180,7 +187,10 @@ def train_repeat_replicas(rank, world_size, dataset, job, training, model_params
     seeds = [resolve_seed(0) for _ in range(trials)]                     # agreed on all ranks
     mine = {}
     for t in range(r_id, trials, ws):
-        j = dict(job, seed=seeds[t], job_name="%s%d" % (job.get("job_name", "repeat"), t))
+        # every rank is the root of its own single-GPU training here: a checkpoint path shared by all trials (the default
+        # my_model.pth) would be written by several ranks at once — one file per trial instead
+        j = dict(job, seed=seeds[t], job_name="%s%d" % (job.get("job_name", "repeat"), t),
+                 model_path=_suffixed(job.get("model_path", "my_model.pth"), "_trial%d" % t))
         r = train_regular("cuda" if dataset.device is not None and dataset.device.type == "cuda" else "cpu", 1, dataset,
                           j, training, model_params, **kw)             # world_size 1: a local, independent training
         mine[t] = [r.get("train_error", np.nan), r.get("val_error", np.nan), r.get("test_error", np.nan)]
@@ -204,7 +214,8 @@ def train_ensemble_replicas(rank, world_size, dataset, job, training, models_par
     mine = {}
     for k in range(r_id, len(models_params), ws):
         r = train_regular("cuda" if dataset.device is not None and dataset.device.type == "cuda" else "cpu", 1, dataset,
-                          dict(job, seed=seed, job_name="%s_%d" % (job.get("job_name", "ens"), k)), training,
+                          dict(job, seed=seed, job_name="%s_%d" % (job.get("job_name", "ens"), k),
+                               model_path=_suffixed(job.get("model_path", "my_model.pth"), "_model%d" % k)), training,
                           models_params[k], splits=splits, **kw)
         mine[k] = (r.get("test_error", np.nan), r.get("test_rows"))
     allr = {}

@@ -42,6 +42,10 @@ class GraphedStep:
         if self.opt_in_graph and not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ops.MdlError("GraphedStep: the optimizer step is captured — build it with capturable=True "
                                "(training.make_optimizer(..., capturable=True))")
+        if self.opt_in_graph and not all(torch.is_tensor(g["lr"]) and g["lr"].is_cuda for g in optimizer.param_groups):
+            raise ops.MdlError("GraphedStep: the optimizer step is captured, so its learning rate must be a device tensor (a "
+                               "float would be frozen into the graph and every scheduler update ignored by the replays): "
+                               "training.make_optimizer(..., capturable=True) builds it that way")
         self.loss_value = torch.zeros((), dtype=torch.float32, device=self.dev)
         self.graph = None
         self.bn_layers = [m for m in model.modules() if isinstance(m, BatchNorm1d)]
@@ -86,7 +90,10 @@ class GraphedStep:
                     self._zero_grad()
                     self._body()
                     if not self.opt_in_graph:
-                        self._finish_eager()
+                        # no gradient exchange in the warm-up: its results are thrown away, and a rank whose first batch
+                        # takes the eager path instead issues ONE all-reduce for this step — the capture must issue exactly
+                        # one too (the replay below), or equal-sized collectives of different steps pair up across ranks
+                        self._finish_eager(comm=False)
             torch.cuda.current_stream(self.dev).wait_stream(side)
             torch.cuda.synchronize(self.dev)
             self._zero_grad()
@@ -121,8 +128,8 @@ class GraphedStep:
             if m.training and m.track_running_stats:
                 m._nbt_pending = getattr(m, "_nbt_pending", 0) + n
 
-    def _finish_eager(self):
-        if self.dp is not None:
+    def _finish_eager(self, comm=True):
+        if self.dp is not None and comm:
             self.dp.reduce_grads()
         self.opt.step()
 

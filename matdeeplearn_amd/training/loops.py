@@ -26,6 +26,11 @@ def make_optimizer(params, name="AdamW", lr=0.002, **optimizer_args):
     plist = list(params)
     if name in ("Adam", "AdamW") and plist and plist[0].is_cuda and "fused" not in kw and "foreach" not in kw:
         kw["fused"] = True   # one kernel for all parameters instead of one per tensor
+    if kw.get("capturable") and plist and plist[0].is_cuda and not torch.is_tensor(lr):
+        # a python-float lr is a kernel ARGUMENT of the fused step: captured into a HIP graph it is frozen, and a scheduler
+        # (the reference steps ReduceLROnPlateau every epoch, training.py:193) would be ignored by every replay.  As a
+        # device tensor it is read by the kernel at run time; torch's schedulers update tensor lrs in place.
+        lr = torch.tensor(float(lr), dtype=torch.float32, device=plist[0].device)
     return getattr(torch.optim, name)(plist, lr=lr, **kw)
 
 

@@ -248,8 +248,10 @@ class GCNConv(nn.Module):
     def __init__(self, in_channels, out_channels, improved=False, add_self_loops=True, bias=True):
         super().__init__()
         assert not add_self_loops, "the reference passes add_self_loops=False (gcn.py:81)"
-        self.lin = nn.Linear(in_channels, out_channels, bias=False)
-        nn.init.xavier_uniform_(self.lin.weight)            # PyG Linear(weight_initializer="glorot") draws in its ctor ...
+        # PyG's own Linear(weight_initializer="glorot") allocates its weight WITHOUT a draw and then draws glorot once in its
+        # ctor; torch's nn.Linear would consume one more (kaiming) draw and shift every later layer's seeded initialisation
+        self.lin = torch.nn.utils.skip_init(nn.Linear, in_channels, out_channels, bias=False)
+        nn.init.xavier_uniform_(self.lin.weight)            # ... the ctor's draw ...
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         self.reset_parameters()                             # ... and GCNConv.__init__ ends with reset_parameters()
 

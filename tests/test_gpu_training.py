@@ -41,7 +41,7 @@ def test_bf16_models_train_finite():
     from matdeeplearn_amd.process import synthetic_bulk
     ds = synthetic_bulk(64, seed=2).to("cuda")
     b = ds.collate(np.arange(48), edge_dtype=torch.bfloat16, x_dtype=torch.bfloat16)
-    for name, kw in [("CGCNN", {}), ("SchNet", dict(dim3=64)), ("GCN", {})]:
+    for name, kw in [("CGCNN", {}), ("SchNet", dict(dim3=64)), ("GCN", {}), ("MPNN", dict(dim3=32)), ("MEGNet", dict(dim3=64, gc_fc_count=1))]:
         torch.manual_seed(0)
         m = getattr(models, name)(ds, dim1=64, dim2=64, gc_count=2, post_fc_count=1, compute_dtype="bf16", **kw).to("cuda")
         out = m(b)
@@ -174,7 +174,7 @@ def test_loader_by_source_index_matches_the_sort():
             assert float((out - ref).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["SchNet", "MEGNet", "GCN"])
+@pytest.mark.parametrize("name", ["SchNet", "MEGNet", "GCN", "MPNN"])
 def test_graph_replay_of_the_other_models_matches_eager(name):
     """GraphedStep for the models that also walk the batch by SOURCE and run dense layers over all edge rows: the padded
     node rows / edge slots / dummy graph must be invisible (finite forward values, exactly zero gradients).  Before every
@@ -195,7 +195,8 @@ def test_graph_replay_of_the_other_models_matches_eager(name):
     batches = [batches[4], batches[0], batches[3], batches[1], batches[2]]          # large, small, large, small, medium
     kw = dict(SchNet=dict(dim1=32, dim2=32, dim3=48, gc_count=2, post_fc_count=2),
               MEGNet=dict(dim1=32, dim2=32, dim3=32, gc_count=2, gc_fc_count=1, post_fc_count=2),
-              GCN=dict(dim1=32, dim2=32, gc_count=2, post_fc_count=2))[name]
+              GCN=dict(dim1=32, dim2=32, gc_count=2, post_fc_count=2),
+              MPNN=dict(dim1=32, dim2=32, dim3=24, gc_count=2, post_fc_count=2))[name]
     for cd, dt, ltol, gtol, floor in (("fp32", torch.float32, 2e-5, 1e-3, 5e-5), ("bf16", torch.bfloat16, 2e-2, 6e-2, 1e-2)):
         if name == "MEGNet" and cd == "bf16":
             # single-ulp bf16 differences (BatchNorm sums over a different block partition) are amplified to several per
@@ -233,7 +234,7 @@ def test_graph_replay_of_the_other_models_matches_eager(name):
         assert len(bad) <= max(2, len(names) * len(batches) // 25), (name, cd, bad[:8])
 
 
-@pytest.mark.parametrize("name", ["CGCNN", "SchNet", "MEGNet", "GCN"])
+@pytest.mark.parametrize("name", ["CGCNN", "SchNet", "MEGNet", "GCN", "MPNN"])
 def test_padded_rows_never_reach_the_results(name):
     """The invariant behind GraphedStep: whatever the unused tail of the static buffers holds (node rows past n_dev, edge
     slots past e_dev, index entries) — zeros, stale rows of a larger earlier batch, or garbage — losses and gradients of a
@@ -255,7 +256,8 @@ def test_padded_rows_never_reach_the_results(name):
     kw = dict(CGCNN=dict(dim1=32, dim2=32, gc_count=2, post_fc_count=2),
               SchNet=dict(dim1=32, dim2=32, dim3=48, gc_count=2, post_fc_count=2),
               MEGNet=dict(dim1=32, dim2=32, dim3=32, gc_count=2, gc_fc_count=1, post_fc_count=2),
-              GCN=dict(dim1=32, dim2=32, gc_count=2, post_fc_count=2))[name]
+              GCN=dict(dim1=32, dim2=32, gc_count=2, post_fc_count=2),
+              MPNN=dict(dim1=32, dim2=32, dim3=24, gc_count=2, post_fc_count=2))[name]
     # (a leak of thousands of garbage rows moves a gradient by tens of per cent; rounding noise through ReLU kinks by 1e-4..1e-3)
     for cd, dt, gtol in (("fp32", torch.float32, 3e-3), ("bf16", torch.bfloat16, 3e-2)):
         torch.manual_seed(4)
@@ -286,3 +288,37 @@ def test_padded_rows_never_reach_the_results(name):
                 lim = gtol if name != "MEGNet" else (8e-2 if cd == "bf16" else 1e-2)
                 assert err <= lim * gmax, (name, cd, step, k, err / gmax)
         assert ga.replays == gb.replays == len(batches)
+
+
+def test_replayed_optimizer_step_follows_the_learning_rate():
+    """The captured fused AdamW step must read its learning rate at run time: make_optimizer(capturable=True) keeps it in a
+    device tensor, a scheduler updates that tensor in place, and a replay with lr = 0 leaves the weights untouched (a float
+    lr would have been frozen into the graph at capture time).  GraphedStep refuses an optimizer whose lr is a float."""
+    from matdeeplearn_amd import models, ops
+    from matdeeplearn_amd.process import synthetic_bulk
+    from matdeeplearn_amd.training import GraphedStep, make_optimizer, make_scheduler
+    dev = torch.device("cuda:0")
+    ds = synthetic_bulk(200, seed=3).to(dev)
+    torch.manual_seed(0)
+    m = models.CGCNN(ds, dim1=32, dim2=32, gc_count=2, post_fc_count=1).to(dev)
+    with pytest.raises(ops.MdlError):
+        GraphedStep(ds, m, torch.optim.AdamW(m.parameters(), lr=0.002, capturable=True), 32)
+    opt = make_optimizer(m.parameters(), "AdamW", lr=0.002, capturable=True)
+    lr_t = opt.param_groups[0]["lr"]
+    assert torch.is_tensor(lr_t) and lr_t.is_cuda
+    gs = GraphedStep(ds, m, opt, 32)
+    rng = np.random.default_rng(0)
+    gs.step(rng.choice(len(ds), 32, replace=False))
+    sch = make_scheduler(opt, "ReduceLROnPlateau", mode="min", factor=0.5, patience=0)
+    sch.step(1.0)
+    sch.step(2.0)                                                  # no improvement -> lr halves, in place
+    assert opt.param_groups[0]["lr"] is lr_t and abs(float(lr_t) - 0.001) < 1e-9
+    before = [p.detach().clone() for p in m.parameters()]
+    gs.step(rng.choice(len(ds), 32, replace=False))
+    moved = max(float((p.detach() - b).abs().max()) for p, b in zip(m.parameters(), before))
+    assert 0 < moved < 2.5e-3                                      # AdamW moves a weight by at most ~lr per step
+    lr_t.fill_(0.0)
+    before = [p.detach().clone() for p in m.parameters()]
+    gs.step(rng.choice(len(ds), 32, replace=False))
+    assert all(torch.equal(p.detach(), b) for p, b in zip(m.parameters(), before))
+    assert gs.replays == 3 and gs.eager_steps == 0

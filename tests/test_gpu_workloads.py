@@ -221,7 +221,130 @@ def test_cfg4_megnet_demo_on_bulk_like_graphs(bulk):
     _model_parity("MEGNet", kw, bulk, np.arange(256))
 
 
+def test_cfg4_megnet_bf16_training_tracks_fp32():
+    """cfg4's performance mode must TRAIN like the parity mode, not only evaluate like it at fixed weights: MEGNet_demo
+    (config.yml:184-205) on bulk-like graphs, the same seed / batches / AdamW settings in fp32 and in bf16 compute mode,
+    24 steps at batch 64.  Stated tolerances: (i) the bf16 loss curve stays within 20 % of the fp32 curve at every step and
+    within 5 % on average (observed: 12 % at one step, 2-3 % typically; every step draws a fresh 64-graph batch, so the
+    curve is the per-batch loss); (ii) at the bf16-TRAINED weights the bf16 and fp32 compute modes predict the same on
+    held-out graphs to 5 % of the prediction scale (observed 1 %); (iii) the held-out MAE of the two trained models agrees
+    to 10 %.  What is NOT asserted is equality of the two weight sets: AdamW turns rounding noise in near-zero gradients
+    (BatchNorm biases) into +-lr steps, so two trainings drift apart in those parameters — in fp32 against fp32 as well."""
+    from matdeeplearn_amd import models, ops
+    from matdeeplearn_amd.process import synthetic_bulk
+    from matdeeplearn_amd.training import make_optimizer
+    ds = _composition_targets(synthetic_bulk(512, seed=5)).to(DEV)
+    kw = dict(dim1=100, dim2=100, dim3=100, pre_fc_count=1, gc_count=4, gc_fc_count=1, post_fc_count=3)
+    rng = np.random.default_rng(0)
+    batches = [rng.choice(448, size=64, replace=False) for _ in range(24)]
+    held = np.arange(448, 512)
+    curves, trained = {}, {}
+    for cd, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        torch.manual_seed(0)
+        m = models.MEGNet(ds, compute_dtype=cd, **kw).to(DEV)
+        opt = make_optimizer(m.parameters(), "AdamW", lr=0.0005)
+        m.train()
+        losses = []
+        for ids in batches:
+            b = ds.collate(ids, edge_dtype=dt, x_dtype=dt)
+            opt.zero_grad(set_to_none=True)
+            with ops.zero_arena(torch.device(DEV)):
+                loss = torch.nn.functional.l1_loss(m(b), b.y)
+                loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        trained[cd] = m
+        curves[cd] = np.array(losses)
+    f, h = curves["fp32"], curves["bf16"]
+    assert np.isfinite(f).all() and np.isfinite(h).all(), (f, h)
+    rel = np.abs(h - f) / np.maximum(np.abs(f), 1e-6)
+    assert rel.max() < 0.20 and rel.mean() < 0.05, (rel.round(3).tolist(), f.round(3).tolist(), h.round(3).tolist())
+
+    def held_out(weights, cd):
+        dt = torch.bfloat16 if cd == "bf16" else torch.float32
+        m = models.MEGNet(ds, compute_dtype=cd, **kw).to(DEV)
+        m.load_state_dict(trained[weights].state_dict())
+        m.eval()
+        b = ds.collate(held, edge_dtype=dt, x_dtype=dt)
+        with torch.no_grad():
+            p = m(b).float()
+        return p.cpu(), float(torch.nn.functional.l1_loss(p, b.y.view_as(p)))
+
+    p_bb, mae_b = held_out("bf16", "bf16")
+    p_bf, _ = held_out("bf16", "fp32")
+    _, mae_f = held_out("fp32", "fp32")
+    _close(p_bb, p_bf, 5e-2, "bf16-trained weights: bf16 vs fp32 compute mode")
+    assert abs(mae_b - mae_f) < 0.10 * mae_f, (mae_b, mae_f)
+
+
+def test_cfg4_megnet_edge_block_with_batchnorm_bf16_gradients():
+    """Megnet_EdgeModel (K6 first layer + BatchNorm over the EDGE rows + second Linear -> ReLU -> BatchNorm, megnet.py:41-56)
+    in bf16 against the fp32 oracle block on bf16-rounded operands and weights: output and the gradients w.r.t. the node
+    state, the edge state, u and every parameter (the kernel-level bf16 gradient check of the chain the MEGNet bench leg
+    runs).  Tolerances: output 6e-2 of its scale (two bf16 Linear + two bf16 BatchNorm roundings on values of magnitude 5;
+    observed 4.9e-2), dx / de / du 5e-2 (observed <= 1e-2), parameter gradients 6e-2 of max(their own scale, 1e-1 of the
+    block's largest gradient) — a bias in front of a training-mode BatchNorm has an exactly zero true gradient when its
+    ReLU is active, so those tensors are compared against the floor, not against their own ~1e-3 scale (a sum of 2e4 cancelling
+    bf16-rounded terms: observed error 2e-3 of the largest gradient)."""
+    from matdeeplearn_amd.models.megnet import Megnet_EdgeModel
+    bulk = _composition_targets(__import__("matdeeplearn_amd.process", fromlist=["synthetic_bulk"]).synthetic_bulk(96, seed=9)).to(DEV)
+    bc, bg = _batches(bulk, np.arange(64), torch.bfloat16)
+    d = 64
+    torch.manual_seed(3)
+    oe = omodels.MegnetEdgeModel(d, "relu", "True", "True", 0.0, 1)
+    with torch.no_grad():
+        # biases of +2.5 on small weights keep (nearly) every ReLU unit active: a pre-activation within bf16 rounding of the kink
+        # flips its mask between the two sides and moves a gradient by a whole upstream value — not a kernel property
+        for k_, p_ in oe.named_parameters():
+            if "edge_mlp" in k_:
+                p_.copy_(((p_ * 0.3) if p_.dim() == 2 else torch.full_like(p_, 2.5) + 0.1 * torch.randn_like(p_)).to(torch.bfloat16).float())
+            else:
+                p_.copy_((p_ + 0.05 * torch.randn_like(p_)).to(torch.bfloat16).float())
+    pe = Megnet_EdgeModel(d, "relu", "True", "True", 0.0, 1)
+    pe.load_state_dict(oe.state_dict())
+    pe.to(DEV)
+    oe.train(); pe.train()
+    g = torch.Generator().manual_seed(11)
+    N, E, B = bc.x.shape[0], bc.edge_index.shape[1], int(bc.batch.max()) + 1
+    r16 = lambda t: t.to(torch.bfloat16).float()
+    x, e, u = r16(torch.randn(N, d, generator=g)), r16(torch.randn(E, d, generator=g)), r16(torch.randn(B, d, generator=g))
+    row, col = bc.edge_index[0], bc.edge_index[1]
+    xo, eo, uo = [t.clone().requires_grad_(True) for t in (x, e, u)]
+    ref = oe(xo[row], xo[col], eo, uo, bc.batch[row])
+    gout = torch.randn(E, d, generator=g)
+    (ref * gout).sum().backward()
+    xd, ed, ud = [t.to(DEV).to(torch.bfloat16).requires_grad_(True) for t in (x, e, u)]
+    row32, col32 = bg.csr.row, bg.csr.col
+    assert pe.fused_ok(xd, ed)
+    out = pe.forward_fused(xd, row32, col32, ed, ud, bg.batch)
+    assert out.dtype == torch.bfloat16
+    (out.float() * gout.to(DEV)).sum().backward()
+    _close(out, ref, 6e-2, "edge block out")
+    for a, r_, nm in ((xd, xo, "dx"), (ed, eo, "de"), (ud, uo, "du")):
+        _close(a.grad, r_.grad, 5e-2, nm)
+    og = dict(oe.named_parameters())
+    gmax = max(float(v.grad.abs().max()) for v in og.values())
+    for k, p_ in pe.named_parameters():
+        ref_g = og[k].grad
+        err = float((p_.grad.detach().float().cpu() - ref_g).abs().max())
+        assert err <= 6e-2 * max(float(ref_g.abs().max()), 1e-1 * gmax), (k, err, float(ref_g.abs().max()), gmax)
+
+
 # ------------------------------------------------------------------------------------------------ cfg5
+@pytest.fixture(scope="module")
+def slabs():
+    from matdeeplearn_amd.process import synthetic_surface
+    return _composition_targets(synthetic_surface(24, seed=8)).to(DEV)
+
+
+def test_cfg5_mpnn_demo_on_surface_like_slabs(slabs):
+    """MPNN_demo (config.yml:141-156: dims 100 / 100 / 100, 4 NNConv + GRU layers) on surface-like slabs, few enough that the
+    oracle's literal E x C x C edge tensor fits: fp32 prediction / gradients / val-MAE, then the bf16 compute mode (K7 on
+    MFMA, the written-out GRU step) against the same oracle prediction."""
+    kw = dict(dim1=100, dim2=100, dim3=100, pre_fc_count=1, gc_count=4, post_fc_count=3)
+    _model_parity("MPNN", kw, slabs, np.arange(12))
+
+
 def test_cfg5_five_model_ensemble_on_surface_like_slabs():
     """The Ensemble driver with all five models on the device (product kernels) against the same driver on the oracle:
     same seed -> same split, same initial weights, same batches; one epoch of fp32 training stays within 2e-3."""

@@ -607,3 +607,26 @@ def test_loss_and_shape_predicates_off_the_hip_path():
     x = torch.zeros(4, 300)
     assert ops._tn_split_ok(x, torch.zeros(100, 300)) and not ops._tn_split_ok(x, torch.zeros(130, 300))
     assert not ops._tn_split_ok(torch.zeros(4, 600), torch.zeros(100, 600))
+
+
+def test_gcnconv_consumes_two_glorot_draws_like_pyg():
+    """PyG 2.0.1's GCNConv builds its weight with PyG's own Linear (allocated without a draw, glorot once in the ctor) and ends
+    its constructor with reset_parameters() (glorot again): TWO draws.  One more (torch's nn.Linear default init) would shift
+    the seeded initial weights of every layer created after a GCNConv (gcn.py:77-87 creates conv_i, bn_i, ... in a loop)."""
+    from matdeeplearn_amd import nn as pnn
+    from oracle import ops as oops
+    for cls in (pnn.GCNConv, oops.GCNConv):
+        torch.manual_seed(5)
+        conv = cls(7, 5, improved=True, add_self_loops=False)
+        after = torch.rand(3)
+        torch.manual_seed(5)
+        w = torch.empty(5, 7)
+        torch.nn.init.xavier_uniform_(w)
+        torch.nn.init.xavier_uniform_(w)
+        assert torch.equal(conv.lin.weight.detach(), w) and torch.equal(after, torch.rand(3)), cls
+
+
+def test_replica_drivers_give_every_trial_its_own_checkpoint_path():
+    from matdeeplearn_amd.training import driver
+    assert driver._suffixed("my_model.pth", "_trial3") == "my_model_trial3.pth"
+    assert driver._suffixed("out/m", "_model0") == "out/m_model0"

@@ -11,7 +11,7 @@ ids = rng.choice(len(ds), size=B, replace=False)
 name = sys.argv[1]; cd = sys.argv[2]; dt = torch.bfloat16 if cd == "bf16" else torch.float32
 kw = dict(SchNet=dict(dim1=32, dim2=32, dim3=48, gc_count=2, post_fc_count=2), CGCNN=dict(dim1=32, dim2=32, gc_count=2, post_fc_count=2),
           MEGNet=dict(dim1=32, dim2=32, dim3=32, gc_count=2, gc_fc_count=1, post_fc_count=2),
-          GCN=dict(dim1=32, dim2=32, gc_count=2, post_fc_count=2))[name]
+          GCN=dict(dim1=32, dim2=32, gc_count=2, post_fc_count=2), MPNN=dict(dim1=32, dim2=32, dim3=24, gc_count=2, post_fc_count=2))[name]
 torch.manual_seed(4)
 m = getattr(models, name)(ds, compute_dtype=cd, **kw).to(dev); m.train()
 n_cap, e_cap = static_capacity(ds, B)

@@ -33,14 +33,20 @@ done 2>&1 | tee $OUT/summary.txt
 # HBM traffic per launch for bench.py's roofline.traffic (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports
 # half of the bytes of a wide coalesced read stream -> doubled; WRITE_SIZE taken as is; both are in KiB)
 python - $OUT/summary.txt $OUT/plain.log > $OUT/hbm_traffic.json <<'PY'
-import ast, json, re, sys
+import ast, glob, hashlib, json, os, re, sys
 vals = {}
 for line in open(sys.argv[1]):
     m = re.match(r"^(fwd|bwd|rbf|node) (\{.*\})\s*$", line)
     if m:
         vals.setdefault(m.group(1), {}).update(ast.literal_eval(m.group(2)))
 ne = re.search(r"N=(\d+) E=(\d+)", open(sys.argv[2]).read())
-out = {"N": int(ne.group(1)), "E": int(ne.group(2)), "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024; separate --pmc passes"}
+# fingerprint of the conv kernel sources the counters belong to: bench.py marks the traffic figure stale when it differs
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+hsh = hashlib.sha256()
+for f in sorted(glob.glob(os.path.join(root, "matdeeplearn_amd/csrc/cgconv*")) + glob.glob(os.path.join(root, "matdeeplearn_amd/csrc/rbf.hip"))):
+    hsh.update(open(f, "rb").read())
+out = {"N": int(ne.group(1)), "E": int(ne.group(2)), "kernel_sources_sha16": hsh.hexdigest()[:16],
+       "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024; separate --pmc passes"}
 for k, d in vals.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         out[{"rbf": "mdl_rbf_expand", "node": "mdl_cgconv_bwd_node"}.get(k, "mdl_cgconv_" + k)] = {
