@@ -138,6 +138,8 @@ struct CgParams {
     unsigned* ctr;      // bwd, optional: NS zeroed work counters (caller workspace) -> dynamic group scheduling
     void* ab;           // saved gate factors [E][Cp][2] bf16 (A | B per channel): written by the training forward, read by
                         // the saved-gate backward (cgconv_bwd_ab_kernel)
+    const void* pt;     // W-split kernels: per-node projections P_t = x [W_f,tgt ; W_s,tgt]^T and P_s = x [W_f,src ; W_s,src]^T,
+    const void* ps;     // [N, 2Cp] each in the compute dtype (columns f | s), scaled like the packed weights
     int64_t N, E;
     int C, G, Cp, KE, KT, WS, EKS, NS, GP, aggr;
     int GW;             // staging words per e row
@@ -239,7 +241,7 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const float* v) {
 // Problem dimensions: compile-time when the kernel is instantiated for a fixed (CP_, G_) — loops
 // unroll fully, so all loads of a tile are issued before the first MFMA that needs them — or
 // run-time (CP_ = 0 / G_ = 0) for the generic fallback.
-template <typename T, int CP_, int G_, int EW>
+template <typename T, int CP_, int G_, int EW, int WSP = 0>
 struct Dims {
     static constexpr bool STATIC = (CP_ != 0) && (G_ != 0);
     static constexpr int PADW = std::is_same<T, bf16_t>::value ? 8 : 1;
@@ -249,7 +251,7 @@ struct Dims {
         Cp = CP_ ? CP_ : p.Cp;
         G = G_ ? G_ : p.G;
         KE = G_ ? ((G_ + 15) / 16 * 16) : p.KE;
-        WS = KE + 2 * Cp + PADW;
+        WS = KE + (WSP ? 0 : 2 * Cp) + PADW;      // W-split: the packed weights hold the edge-feature part only
         EKS = KE + PADW;
         GW = G / EW;
     }
@@ -354,6 +356,69 @@ struct XFrags {
     }
 };
 
+// W-split: z W^T = e W_e^T + P_t[tgt] + P_s[src] with per-node projections
+// P = x [W_tgt | W_src]^T from ONE dense launch per layer, so that per edge only the K = 64 edge-feature product remains.
+// The gathered projection rows enter the accumulators through the matrix core: they ARE A fragments (lane = edge, eight
+// consecutive columns = 16 bytes, exactly like the x rows they replace) of a product with an IDENTITY B operand —
+// D[edge][ch] += sum_k P[edge][k] (k == ch) — two k-steps per 32-channel block instead of the K = 64 (four k-steps) of the
+// x part, no unpack / add VALU, no weight-fragment LDS reads.
+// Fragment f of a slice: column (f >> 1) * Cp + 32 * slice + 16 * (f & 1) of the [f | s] row, i.e. (part f / s, k-step).
+template <int CP_, int NSLF>
+struct PFrags {
+    bf16x8 t[4 * NSLF], s[4 * NSLF];
+    __device__ __forceinline__ void load(const void* pt, const void* ps, int my_tgt, int my_src, int h, int sl0) {
+        const bf16_t* a = static_cast<const bf16_t*>(pt) + (int64_t)my_tgt * (2 * CP_) + 8 * h + 32 * sl0;
+        const bf16_t* b = static_cast<const bf16_t*>(ps) + (int64_t)my_src * (2 * CP_) + 8 * h + 32 * sl0;
+#pragma unroll
+        for (int q = 0; q < 4 * NSLF; ++q) t[q] = *reinterpret_cast<const bf16x8*>(a + ((q >> 1) & 1) * CP_ + 32 * (q >> 2) + 16 * (q & 1));
+#pragma unroll
+        for (int q = 0; q < 4 * NSLF; ++q) s[q] = *reinterpret_cast<const bf16x8*>(b + ((q >> 1) & 1) * CP_ + 32 * (q >> 2) + 16 * (q & 1));
+    }
+};
+// identity B fragments of the 32 x 32 product in two k-steps: B[k][n] = (k == n), lane n, k = 16 ks + 8 h + q
+__device__ __forceinline__ void identity_frags(int i, int h, bf16x8 (&idf)[2]) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+    const bool mine = ((i >> 3) & 1) == h;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const unsigned one = (mine && (i >> 4) == ks) ? (0x3F80u << (16 * (i & 1))) : 0u;
+        const int d = (i & 7) >> 1;
+        const u4_t v = {d == 0 ? one : 0u, d == 1 ? one : 0u, d == 2 ? one : 0u, d == 3 ? one : 0u};
+        idf[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+// pre-activation tile of slice `sl` (global) whose projection fragments sit at local slice `sll` of pf
+template <int CP_, int NSLF, int DEPTH, typename D>
+__device__ __forceinline__ void pre_tile_wsp(const D& dm, const WaveCtx<bf16_t>& w, int lane, int sl, int sll,
+                                             const PFrags<CP_, NSLF>& pf, const bf16x8 (&idf)[2], f32x16& accf, f32x16& accs) {
+    const int i = lane & 31, h = lane >> 5;
+    const int rowf = sl * 32 + i, rows = dm.Cp + sl * 32 + i;
+#pragma unroll
+    for (int k0 = 0; k0 < dm.KE; k0 += 16) {
+        const bf16x8 a = ld_frag(w.et, i, dm.EKS, k0, h);
+        accf = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ld_frag(w.wbase, rowf, dm.WS, k0, h), accf, 0, 0, 0);
+        accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ld_frag(w.wbase, rows, dm.WS, k0, h), accs, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        accf = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf.t[4 * sll + ks], idf[ks], accf, 0, 0, 0);
+        accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf.t[4 * sll + 2 + ks], idf[ks], accs, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        accf = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf.s[4 * sll + ks], idf[ks], accf, 0, 0, 0);
+        accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf.s[4 * sll + 2 + ks], idf[ks], accs, 0, 0, 0);
+    }
+    if constexpr (DEPTH > 0) {      // weight-fragment reads of the edge-feature part a few deep ahead of the chain
+        __builtin_amdgcn_sched_group_barrier(0x100, DEPTH, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+}
+
 // Packed weights of this wave's channel slice held in registers for the whole kernel (static
 // shapes): the B fragments of all K steps, f rows and s rows.  Removes every per-tile LDS read of W.
 template <typename T, int NK>
@@ -421,6 +486,22 @@ __device__ __forceinline__ void pre_tile(const CgParams& p, const D& dm, const W
     }
     if constexpr (CP_ != 0) {
         constexpr int NF = XFrags<T, CP_, VEC>::NF;
+#ifdef MDL_ABL_WSPLIT_BOUND
+        // Upper bound of what the W-split (per-node projections P = x [W_tgt | W_src]^T added to the accumulators) can buy:
+        // the x part of the product as TWO MFMAs per gathered row and accumulator (what the identity-operand form of the
+        // split issues: K = 32 instead of 64) and WITHOUT their weight-fragment LDS reads; the gathers stay.  Results are
+        // wrong by construction — timing only.
+#pragma unroll
+        for (int f = 0; f < NF / 2; ++f) {
+            accf = M::mma(xf.t[f], xf.t[f + NF / 2], accf);
+            accs = M::mma(xf.t[f], xf.t[f + NF / 2], accs);
+        }
+#pragma unroll
+        for (int f = 0; f < NF / 2; ++f) {
+            accf = M::mma(xf.s[f], xf.s[f + NF / 2], accf);
+            accs = M::mma(xf.s[f], xf.s[f + NF / 2], accs);
+        }
+#else
 #pragma unroll
         for (int f = 0; f < NF; ++f) {      // target-node features (x_i)
             accf = M::mma(xf.t[f], ld_frag(w.wbase, rowf, dm.WS, dm.KE + f * M::KSTEP, h), accf);
@@ -431,11 +512,16 @@ __device__ __forceinline__ void pre_tile(const CgParams& p, const D& dm, const W
             accf = M::mma(xf.s[f], ld_frag(w.wbase, rowf, dm.WS, dm.KE + dm.Cp + f * M::KSTEP, h), accf);
             accs = M::mma(xf.s[f], ld_frag(w.wbase, rows, dm.WS, dm.KE + dm.Cp + f * M::KSTEP, h), accs);
         }
+#endif
         // Pin the schedule of the chain: DEPTH fragment reads up front, then one read behind every MFMA, so
         // that the LDS latency of a weight fragment hides under the MFMAs issued before it.  (Left alone, hipcc keeps
         // one or two reads in flight and every MFMA waits out a full LDS round trip.)
         if constexpr (DEPTH > 0 && std::is_same<T, bf16_t>::value) {
+#ifdef MDL_ABL_WSPLIT_BOUND
+            constexpr int NMMA = 2 * (D::STATIC ? ((50 + 15) / 16 + NF) : 0);
+#else
             constexpr int NMMA = 2 * (D::STATIC ? ((50 + 15) / 16 + 2 * NF) : 0);
+#endif
             __builtin_amdgcn_sched_group_barrier(0x100, DEPTH, 0);
 #pragma unroll
             for (int q = 0; q < NMMA; ++q) {
@@ -707,12 +793,12 @@ struct GroupInfo {
 #define MDL_FWD_THREADS 256     // workgroup size of the forward kernel (waves share one LDS copy of W)
 #define MDL_FWD_WAVES 2         // waves per SIMD it is register-allocated for
 #endif
-template <typename T, int CP_, int G_, int VEC, int EW, int WM, bool AB_ = false>   // WM: 0 global, 1 LDS, 2 registers
+template <typename T, int CP_, int G_, int VEC, int EW, int WM, bool AB_ = false, int WSP = 0>   // WM: 0 global, 1 LDS, 2 registers
 __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_kernel(CgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Mma<T> M;
     typedef Gate<M::FAST> GT;
-    typedef Dims<T, CP_, G_, EW> D;
+    typedef Dims<T, CP_, G_, EW, WSP> D;
     constexpr bool ST = D::STATIC;
     const D dm(p);
     WaveCtx<T> w;
@@ -754,7 +840,16 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
         GN = G;
         TileIdx cur, nxt;
         EWords<T, G_, EW> ew;
-        XFrags<T, CP_, VEC> xf;
+        XFrags<T, WSP ? 0 : CP_, VEC> xf;
+        // W-split: projection rows instead of x rows, ONE slice's fragments at a time (32 registers, like the x rows): the
+        // rows of slice sl + 1 — or of the next tile's slice 0 — are requested right after slice sl's MFMAs have consumed
+        // the registers, and arrive under that slice's gate arithmetic and aggregation
+        PFrags<CP_, 1> pf;
+        bf16x8 idf[2];
+        if constexpr (WSP != 0) identity_frags(i, h, idf);
+        auto load_rows = [&](int tg, int sr) {
+            if constexpr (WSP != 0) pf.load(p.pt, p.ps, tg, sr, h, 0); else xf.load(x, dm.C, tg, sr, h);
+        };
         bool primed = false;                                  // cur / ew / xf already hold the group's first tile
         while (true) {
             const bool hasN = G.n1 < R.nb;
@@ -808,7 +903,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
             if (!primed) {
                 cur.template load<false>(p, G.e0, G.e1, i, G.n0);
                 ew.prefetch(p, lane, G.e0, min(32, G.e1 - G.e0), cur.ep);
-                xf.load(x, dm.C, cur.tgt, cur.src, h);
+                load_rows(cur.tgt, cur.src);
             }
             nxt = cur;
             bool nextHasEdges = false;                        // evaluated at the last tile (GN arrives by then)
@@ -861,7 +956,12 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                     const float b1 = (BC || p.bias_col) ? 0.0f : p.bpack[dm.Cp + sl * 32 + i];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { accf[r] = b0; accs[r] = b1; }
-                    pre_tile<T, CP_, VEC, WM, NKW, MDL_FWD_PRE_DEPTH>(p, dm, w, lane, sl, cur.tgt, cur.src, xf, wr, accf, accs);
+                    if constexpr (WSP != 0) {
+                        pre_tile_wsp<CP_, 1, MDL_FWD_PRE_DEPTH>(dm, w, lane, sl, 0, pf, idf, accf, accs);
+                        pf.load(p.pt, p.ps, sl == NSL - 1 ? nxt.tgt : cur.tgt, sl == NSL - 1 ? nxt.src : cur.src, h, (sl + 1) % NSL);
+                    } else {
+                        pre_tile<T, CP_, VEC, WM, NKW, MDL_FWD_PRE_DEPTH>(p, dm, w, lane, sl, cur.tgt, cur.src, xf, wr, accf, accs);
+                    }
                     TPIN16(accf); TPIN16(accs);
                     TMARK(3 + 3 * sl);
                     if constexpr (AB_) {
@@ -876,7 +976,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
 #if MDL_FWD_XEARLY
                     // the x rows of the NEXT tile: requested as soon as the last slice's MFMAs have consumed this
                     // tile's fragments (same registers), so their latency hides under the gate / aggregation
-                    if (sl == NSL - 1) xf.load(x, dm.C, nxt.tgt, nxt.src, h);      // unconditional, like the loads above
+                    if constexpr (WSP == 0) { if (sl == NSL - 1) load_rows(nxt.tgt, nxt.src); }   // unconditional, like the loads above
 #endif
                     f32x16 m;
                     if constexpr (AB_) {
@@ -912,7 +1012,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                     __builtin_amdgcn_sched_barrier(0);      // keep the slices' register footprints apart
                 }
 #if !MDL_FWD_XEARLY
-                if (!last || nextHasEdges) xf.load(x, dm.C, nxt.tgt, nxt.src, h);
+                if (!last || nextHasEdges) load_rows(nxt.tgt, nxt.src);
 #endif
                 cur = nxt;
                 TTILE();
@@ -1109,12 +1209,12 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
 // ------------------------------------------------------------------------------------------
 // Backward edge pass
 // ------------------------------------------------------------------------------------------
-template <typename T, int CP_, int G_, int VEC, int EW, int WM>
+template <typename T, int CP_, int G_, int VEC, int EW, int WM, int WSP = 0>
 __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Mma<T> M;
     typedef Gate<M::FAST> GT;
-    typedef Dims<T, CP_, G_, EW> D;
+    typedef Dims<T, CP_, G_, EW, WSP> D;
     constexpr bool ST = D::STATIC;
     constexpr bool BF = std::is_same<T, bf16_t>::value;
     const D dm(p);
@@ -1204,14 +1304,18 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
         // (4) first tiles of the edge stream
         TileIdx cur, nxt, nn;
         EWords<T, G_, EW> ew;
-        XFrags<T, CP_, VEC> xf, xn;
+        XFrags<T, WSP ? 0 : CP_, VEC> xf, xn;
+        PFrags<CP_, 1> pf, pn;                      // W-split: the projection rows of this wave's slice instead of x rows
+        bf16x8 idf[2];
+        if constexpr (WSP != 0) identity_frags(i, h, idf);
         cur.template load<!ST>(p, e0, e1, i, n0);
         nxt = cur;
         if (e0 + 32 < e1) nxt.template load<!ST>(p, e0 + 32, e1, i, n0);
         nn = nxt;
         constexpr bool XDB = MDL_BWD_XDB != 0;
         if constexpr (ST) ew.prefetch(p, lane, e0, min(32, e1 - e0), cur.ep);
-        if constexpr (CP_ != 0 && XDB) xf.load(x, dm.C, cur.tgt, cur.src, h);
+        if constexpr (WSP != 0) pf.load(p.pt, p.ps, cur.tgt, cur.src, h, s);
+        else if constexpr (CP_ != 0 && XDB) xf.load(x, dm.C, cur.tgt, cur.src, h);
 
         const float invd = (p.aggr == MDL_MEAN) ? 1.0f / (float)max(dg1 - dg0, 1) : 1.0f;
         typename M::frag_t gB[NFg];
@@ -1281,11 +1385,12 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             wave_lds_fence();
             TMARK(1);
 
-            if constexpr (CP_ != 0 && !XDB) xf.load(x, dm.C, cur.tgt, cur.src, h);
+            if constexpr (CP_ != 0 && !XDB && WSP == 0) xf.load(x, dm.C, cur.tgt, cur.src, h);
             // Unconditional on purpose (indices are clamped, so the last tile of a group re-reads valid rows): a path
             // that skips these loads merges into the loop with "the x fragments are the newest loads in flight", and
             // the waits hipcc then puts in front of the MFMAs drain this tile's prefetches as well.
-            if constexpr (CP_ != 0 && XDB) xn.load(x, dm.C, nxt.tgt, nxt.src, h);
+            if constexpr (WSP != 0) pn.load(p.pt, p.ps, nxt.tgt, nxt.src, h, s);
+            else if constexpr (CP_ != 0 && XDB) xn.load(x, dm.C, nxt.tgt, nxt.src, h);
             nn.template load<!ST, false>(p, eb + 64, e1, i, n0);
             if constexpr (ST) ew.prefetch(p, lane, eb + 32, 32, nxt.ep);
 
@@ -1293,7 +1398,8 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             f32x16 accf, accs;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
-            pre_tile<T, CP_, VEC, WM, NKW>(p, dm, w, lane, s, cur.tgt, cur.src, xf, wr, accf, accs);
+            if constexpr (WSP != 0) pre_tile_wsp<CP_, 1, 0>(dm, w, lane, s, 0, pf, idf, accf, accs);
+            else pre_tile<T, CP_, VEC, WM, NKW>(p, dm, w, lane, s, cur.tgt, cur.src, xf, wr, accf, accs);
             TPIN16(accf); TPIN16(accs);
             TMARK(3);
 
@@ -1425,7 +1531,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             }
             cur = nxt;
             nxt = nn;
-            if constexpr (XDB) xf = xn;
+            if constexpr (WSP != 0) pf = pn; else if constexpr (XDB) xf = xn;
             TMARK(9);
             TTILE();
         }
@@ -1783,7 +1889,17 @@ __global__ __launch_bounds__(256, 1) void cgconv_bwd_ab_kernel(CgParams p) {
 // live on 256 + 179 registers, need the AGPR form.
 #ifdef MDL_CG_EP_TU
 #include "cgconv_ep.inc"
+#include "cgconv_ep2.inc"
 namespace ep {
+int launch2(CgParams& p, hipStream_t st, int wgs, const char* name) {
+    typedef Cfg2<64> F;
+    const int64_t eg = std::min<int64_t>(wgs > 0 ? wgs : 256, std::max<int64_t>(1, cdiv(p.E, 32 * F::NA * 2)));
+    auto kf = bwd2_kernel<64>;
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), F::LDS);
+    if (e != hipSuccess) { set_error("%s: LDS attribute (%d B): %s", name, F::LDS, hipGetErrorString(e)); return MDL_E_LAUNCH; }
+    hipLaunchKernelGGL(kf, dim3((unsigned)eg), dim3(F::NT), F::LDS, st, p);
+    return check_launch(name);
+}
 int launch(CgParams& p, hipStream_t st, int wgs, const char* name) {
     typedef Cfg<64> F;
     // one workgroup per CU; small problems: at least two rounds of tiles per workgroup
@@ -1802,7 +1918,8 @@ namespace ep {
 #define MDL_EP_DEFAULT 0      // 1: mdl_cgconv_bwd takes the edge-per-lane kernel for bf16, C = 64, G = 50 (MDL_CG_EP=0/1 overrides).
                               // Off: parity-green but 15 % slower than the per-wave kernel on the bench batch
 #endif
-int launch(CgParams& p, hipStream_t st, int wgs, const char* name);
+int launch(CgParams& p, hipStream_t st, int wgs, const char* name);      // cgconv_ep.inc: phases one after the other
+int launch2(CgParams& p, hipStream_t st, int wgs, const char* name);     // cgconv_ep2.inc: producer / reducer waves side by side
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1841,6 +1958,38 @@ __global__ __launch_bounds__(256) void cgconv_pack_kernel(const float* __restric
     }
 }
 
+// W-split packing: the edge-feature part [2Cp][KE + pad] (bias in column G) and the two projection weights
+// wproj[side][2Cp][Cp] (side 0 target, 1 source; rows f then s; the `w` operand [M = 2Cp, K = C] of mdl_linear_act),
+// everything scaled like the packed weights.
+__global__ __launch_bounds__(256) void cgconv_pack_split_kernel(const float* __restrict__ wf, const float* __restrict__ bfv,
+                                                                const float* __restrict__ ws, const float* __restrict__ bsv,
+                                                                int C, int G, int Cp, int KE, int WSe, bf16_t* __restrict__ wpe,
+                                                                bf16_t* __restrict__ wproj, float scale) {
+    const int ldw = 2 * C + G;
+    const int ne = 2 * Cp * WSe, np_ = 2 * 2 * Cp * Cp;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ne + np_; q += gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (q < ne) {
+            const int row = q / WSe, k = q - row * WSe;
+            const int part = row / Cp, c = row - part * Cp;
+            const float* W = part ? ws : wf;
+            if (c < C) {
+                if (k < G) v = W[c * ldw + 2 * C + k];
+                else if (k == G) { const float* b = part ? bsv : bfv; v = b ? b[c] : 0.0f; }
+            }
+            wpe[q] = f2bf(v * scale);
+        } else {
+            const int r = q - ne;
+            const int side = r / (2 * Cp * Cp), rr = r - side * (2 * Cp * Cp);
+            const int row = rr / Cp, k = rr - row * Cp;
+            const int part = row / Cp, c = row - part * Cp;
+            const float* W = part ? ws : wf;
+            if (c < C && k < C) v = W[c * ldw + side * C + k];
+            wproj[r] = f2bf(v * scale);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Host-side dispatch
 // ------------------------------------------------------------------------------------------
@@ -1866,7 +2015,7 @@ static const CgEnv& cg_env() {
         v.cb_wgs = (s = getenv("MDL_CB_WGS")) ? atoi(s) : 0;
         v.ab_wgs = (s = getenv("MDL_AB_WGS")) ? atoi(s) : 0;
         v.no_half_groups = (s = getenv("MDL_CG_NO_HALF")) ? (atoi(s) != 0) : 0;
-        v.ep = (s = getenv("MDL_CG_EP")) ? (atoi(s) != 0) : -1;
+        v.ep = (s = getenv("MDL_CG_EP")) ? atoi(s) : -1;      // 0 off, 1 cgconv_ep.inc, 2 cgconv_ep2.inc
         v.ep_wgs = (s = getenv("MDL_EP_WGS")) ? atoi(s) : 0;
         return v;
     }();
@@ -1878,6 +2027,8 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     const CgDims d = cg_dims(p.C, p.G, dtype);
     p.Cp = d.Cp; p.KE = d.KE; p.KT = d.KT; p.WS = d.WS; p.EKS = d.EKS; p.NS = d.NS; p.GP = d.GP;
     p.w_elems = 2 * d.Cp * d.WS;
+    const bool wsp = p.pt != nullptr;  // W-split entry points: packed weights = edge-feature part only
+    if (wsp) { p.WS = d.EKS; p.w_elems = 2 * d.Cp * d.EKS; }
     p.bias_col = (p.G % 16) != 0;      // a zero-padding K column is free to carry the bias
     p.n_groups = (int)cdiv(p.N, 32);
     if (p.n_groups == 0) return MDL_OK;
@@ -1920,7 +2071,8 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     // edge-per-lane backward (cgconv_ep.inc): bf16, C = 64, G = 50, target-sorted edge features
     if constexpr (sizeof(T) == 2) {
         const bool use_ep = env.ep >= 0 ? env.ep != 0 : (MDL_EP_DEFAULT != 0);
-        if (use_ep && bwd && fast && d.Cp == 64 && p.bias_col && p.E >= 64) return ep::launch(p, st, env.ep_wgs, name);
+        if (use_ep && bwd && fast && !wsp && d.Cp == 64 && p.bias_col && p.E >= 64)
+            return env.ep == 2 ? ep::launch2(p, st, env.ep_wgs, name) : ep::launch(p, st, env.ep_wgs, name);
     }
     // total waves must be a multiple of NS so that every wave keeps one channel slice
     while ((grid * waves) % d.NS) ++grid;
@@ -1961,7 +2113,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     // cooperative column-block kernels (cgconv_cb.inc): bf16 static shapes
     if constexpr (sizeof(T) == 2) {
         const bool use_cb = env.cb_fwd >= 0 ? env.cb_fwd != 0 : (MDL_CG_CB_DEFAULT != 0);
-        if (use_cb && fast && !bwd && p.E >= 64 && p.bias_col) {   // (E >= 64: the kernels' edge-feature window is 1024 dwords)
+        if (use_cb && fast && !wsp && !bwd && p.E >= 64 && p.bias_col) {   // (E >= 64: the kernels' edge-feature window is 1024 dwords)
             const int cb_wgs = env.cb_wgs > 0 ? env.cb_wgs : MDL_CB_FWD_WG_PER_CU;
             int64_t cb_grid = std::min<int64_t>(256 * cb_wgs, ranges);
             if (env.grid_cap > 0 && cb_grid > env.grid_cap) cb_grid = env.grid_cap;
@@ -1975,7 +2127,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
             return check_launch(name);
         }
         const bool use_cbb = env.cb_bwd >= 0 ? env.cb_bwd != 0 : (MDL_CG_CB_BWD_DEFAULT != 0);
-        if (use_cbb && fast && bwd && p.E >= 64 && p.bias_col) {
+        if (use_cbb && fast && !wsp && bwd && p.E >= 64 && p.bias_col) {
             const int cb_wgs = env.cb_wgs > 0 ? env.cb_wgs : MDL_CB_BWD_OCC;
             const int64_t cb_grid = std::min<int64_t>(256 * cb_wgs, ranges);
             if (d.Cp == 64) {
@@ -2003,6 +2155,35 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
 #define MDL_CG_BY_WL(VEC_, EW_) do { if (w_lds) MDL_CG_LAUNCH(0, 0, VEC_, EW_, 1); else MDL_CG_LAUNCH(0, 0, VEC_, EW_, 0); } while (0)
 #define MDL_CG_BY_EW(VEC_) do { if (EW == 2) MDL_CG_BY_WL(VEC_, 2); else MDL_CG_BY_WL(VEC_, 1); } while (0)
 
+    if (wsp) {
+        // W-split kernels: bf16, static shapes, W (edge part) in LDS
+        if constexpr (sizeof(T) == 2) {
+            if (!(fast && w_lds && p.bias_col && (bwd || all_slices))) {
+                set_error("%s: the W-split kernels support bf16, C in {32, 64}, G = 50, target-sorted edge features", name);
+                return MDL_E_UNSUPP;
+            }
+#define MDL_CG_LAUNCH_WSP(CP_)                                                                                         \
+            do {                                                                                                       \
+                hipError_t e;                                                                                          \
+                if (bwd) {                                                                                             \
+                    auto kf = cgconv_bwd_kernel<T, CP_, 50, 9, 2, 1, 1>;                                               \
+                    e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                   \
+                    if (e == hipSuccess) hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);   \
+                } else {                                                                                               \
+                    auto kf = cgconv_fwd_kernel<T, CP_, 50, 9, 2, 1, false, 1>;                                        \
+                    e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                   \
+                    if (e == hipSuccess) hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);   \
+                }                                                                                                      \
+                if (e != hipSuccess) { set_error("%s: LDS attribute (%d B): %s", name, lds, hipGetErrorString(e)); return MDL_E_LAUNCH; } \
+            } while (0)
+            if (d.Cp == 64) MDL_CG_LAUNCH_WSP(64); else MDL_CG_LAUNCH_WSP(32);
+#undef MDL_CG_LAUNCH_WSP
+            return check_launch(name);
+        } else {
+            set_error("%s: the W-split kernels are bf16 only", name);
+            return MDL_E_UNSUPP;
+        }
+    }
 #ifdef MDL_CG_FAST_ONLY   // compile-time experiments: only the bf16 C=64 G=50 instantiation
     if constexpr (sizeof(T) == 2) { if (fast && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 2, MDL_CG_WM); }
 #else
@@ -2167,6 +2348,64 @@ extern "C" int mdl_cgconv_bwd_saved(const void* edge_attr, const int32_t* rowptr
     p.r_tgt = r_tgt; p.r_src = r_src; p.dwe = dwe; p.db = db; p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr;
     p.ctr = (workspace && ws_bytes >= 64) ? static_cast<unsigned*>(workspace) : nullptr;
     return cg_launch_bwd_ab(p, (hipStream_t)stream, "mdl_cgconv_bwd_saved");
+}
+
+extern "C" size_t mdl_cgconv_wsplit_bytes(int C, int G, int dtype, int which) {
+    using namespace mdl;
+    if (dtype != MDL_BF16 || G != 50 || (C != 32 && C != 64)) return 0;
+    const CgDims d = cg_dims(C, G, dtype);
+    const size_t b = which == 0 ? (size_t)2 * d.Cp * d.EKS * 2 : (size_t)2 * 2 * d.Cp * d.Cp * 2;
+    return (b + 15) & ~(size_t)15;
+}
+
+extern "C" int mdl_cgconv_pack_weights_split(const float* w_f, const float* b_f, const float* w_s, const float* b_s, int C,
+                                             int G, void* wpack_e, void* wproj, float* bpack, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(w_f && w_s && wpack_e && wproj && bpack, MDL_E_ARG, "mdl_cgconv_pack_weights_split: null pointer");
+    MDL_REQUIRE(mdl_cgconv_wsplit_bytes(C, G, dtype, 0) != 0, MDL_E_UNSUPP,
+                "mdl_cgconv_pack_weights_split: unsupported C=%d G=%d dtype=%d (bf16, C in {32, 64}, G = 50)", C, G, dtype);
+    const CgDims d = cg_dims(C, G, dtype);
+    const int total = 2 * d.Cp * d.EKS + 4 * d.Cp * d.Cp;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cgconv_pack_split_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, w_f, b_f, w_s, b_s, C, G, d.Cp,
+                       d.KE, d.EKS, (bf16_t*)wpack_e, (bf16_t*)wproj, Gate<true>::W_SCALE);
+    if (hipMemsetAsync(bpack, 0, 2 * d.Cp * sizeof(float), st) != hipSuccess) { set_error("mdl_cgconv_pack_weights_split: memset failed"); return MDL_E_LAUNCH; }
+    return check_launch("mdl_cgconv_pack_weights_split");
+}
+
+extern "C" int mdl_cgconv_fwd_p(const void* x, const void* p_tgt, const void* p_src, const void* edge_attr, const int32_t* rowptr,
+                                const int32_t* src, const int32_t* tgt, const void* wpack_e, const float* bpack, void* out,
+                                int64_t N, int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    int rc = cg_check("mdl_cgconv_fwd_p", x, edge_attr, rowptr, src, tgt, wpack_e, bpack, N, E, C, G, aggr, dtype);
+    if (rc) return rc;
+    MDL_REQUIRE(N == 0 || (out && p_tgt && p_src), MDL_E_ARG, "mdl_cgconv_fwd_p: null pointer");
+    MDL_REQUIRE(reinterpret_cast<uintptr_t>(p_tgt) % 16 == 0 && reinterpret_cast<uintptr_t>(p_src) % 16 == 0, MDL_E_ARG,
+                "mdl_cgconv_fwd_p: the projections must be 16-byte aligned");
+    CgParams p = {};
+    p.x = x; p.pt = p_tgt; p.ps = p_src; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = nullptr;
+    p.wpack = wpack_e; p.bpack = bpack; p.out = out; p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr;
+    if (dtype != MDL_BF16) { set_error("mdl_cgconv_fwd_p: bf16 only"); return MDL_E_UNSUPP; }
+    return cg_launch<bf16_t>(false, p, dtype, (hipStream_t)stream, "mdl_cgconv_fwd_p");
+}
+
+extern "C" int mdl_cgconv_bwd_p(const void* p_tgt, const void* p_src, const void* edge_attr, const int32_t* rowptr,
+                                const int32_t* src, const int32_t* tgt, const void* wpack_e, const float* bpack,
+                                const void* grad_out, void* r_tgt, float* r_src, float* dwe, float* db, int64_t N, int64_t E,
+                                int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes, mdlStream_t stream) {
+    using namespace mdl;
+    int rc = cg_check("mdl_cgconv_bwd_p", p_tgt, edge_attr, rowptr, src, tgt, wpack_e, bpack, N, E, C, G, aggr, dtype);
+    if (rc) return rc;
+    MDL_REQUIRE(N == 0 || (grad_out && r_tgt && r_src && dwe && p_src), MDL_E_ARG, "mdl_cgconv_bwd_p: null pointer");
+    MDL_REQUIRE(reinterpret_cast<uintptr_t>(p_tgt) % 16 == 0 && reinterpret_cast<uintptr_t>(p_src) % 16 == 0, MDL_E_ARG,
+                "mdl_cgconv_bwd_p: the projections must be 16-byte aligned");
+    CgParams p = {};
+    p.x = p_tgt; p.pt = p_tgt; p.ps = p_src; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = nullptr;
+    p.wpack = wpack_e; p.bpack = bpack; p.gout = grad_out; p.r_tgt = r_tgt; p.r_src = r_src; p.dwe = dwe; p.db = db;
+    p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr;
+    p.ctr = (workspace && ws_bytes >= mdl_cgconv_workspace_bytes(N, E, C, G, dtype)) ? static_cast<unsigned*>(workspace) : nullptr;
+    if (dtype != MDL_BF16) { set_error("mdl_cgconv_bwd_p: bf16 only"); return MDL_E_UNSUPP; }
+    return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd_p");
 }
 
 extern "C" int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,

@@ -476,6 +476,10 @@ def _workspace(device, nbytes):
 # the default.
 _SAVE_GATE = os.environ.get("MDL_CG_SAVE_GATE", "0") == "1"
 
+# W-split CGConv pair (mdl_cgconv_fwd_p / mdl_cgconv_bwd_p: per-node projections P = x [W_tgt | W_src]^T from two dense launches,
+# per edge only the K = 64 edge-feature product): MDL_CG_WSPLIT=1.  DESIGN.md section 4 has the A/B.
+_WSPLIT = os.environ.get("MDL_CG_WSPLIT", "0") == "1"
+
 
 # r_src (by-source sums of the CGConv backward: fp32 [N, 2*Cp], accumulated with atomics) must start at zero: 107 MB per
 # layer at the bench batch, i.e. a 15-22 us fill launch in front of every edge pass.  Its only reader, the node kernel,
@@ -513,6 +517,32 @@ class _CGConvFn(torch.autograd.Function):
         wf32, ws32 = w_f.detach().float().contiguous(), w_s.detach().float().contiguous()
         bf32 = None if b_f is None else b_f.detach().float().contiguous()
         bs32 = None if b_s is None else b_s.detach().float().contiguous()
+        ctx.wsplit = None
+        if (_WSPLIT and L.mdl_cgconv_wsplit_bytes(C, G, dt, 0) and E > 0 and x.data_ptr() % 16 == 0
+                and edge_attr.data_ptr() % 4 == 0 and csr.eperm is None):
+            Cp = _rup(C, 32)
+            wpe = torch.empty(L.mdl_cgconv_wsplit_bytes(C, G, dt, 0), dtype=torch.uint8, device=x.device)
+            wproj = torch.empty((2, 2 * Cp, Cp), dtype=torch.bfloat16, device=x.device)
+            bpack = torch.empty(2 * Cp, dtype=torch.float32, device=x.device)
+            check(L.mdl_cgconv_pack_weights_split(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpe), ptr(wproj), ptr(bpack),
+                                                  dt, stream()), "mdl_cgconv_pack_weights_split")
+            pt = torch.empty((N, 2 * Cp), dtype=torch.bfloat16, device=x.device)
+            ps = torch.empty_like(pt)
+            out = torch.empty_like(x)
+
+            def launch():      # (timed as ONE forward: the two projection launches are part of the W-split's price)
+                rc = L.mdl_linear_act(ptr(x), ptr(wproj[0]), None, ptr(pt), N, C, 2 * Cp, 0, dt, stream())
+                rc = rc or L.mdl_linear_act(ptr(x), ptr(wproj[1]), None, ptr(ps), N, C, 2 * Cp, 0, dt, stream())
+                return rc or L.mdl_cgconv_fwd_p(
+                    ptr(x), ptr(pt), ptr(ps), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpe), ptr(bpack),
+                    ptr(out), N, E, C, G, aggr, dt, stream())
+            check(_launch_timed("fwd", launch), "mdl_cgconv_fwd_p")
+            ctx.gate = None
+            ctx.wsplit = (pt, ps)
+            ctx.save_for_backward(x, edge_attr, wf32, ws32, wpe, bpack)
+            ctx.csr, ctx.aggr, ctx.has_bias = csr, aggr, (b_f is not None, b_s is not None)
+            ctx.wdtypes = (w_f.dtype, w_s.dtype)
+            return out
         nbytes = L.mdl_cgconv_wpack_bytes(C, G, dt)
         if nbytes == 0:
             raise MdlError("cgconv: unsupported C=%d G=%d" % (C, G))
@@ -563,7 +593,14 @@ class _CGConvFn(torch.autograd.Function):
         dwn = small[2 * Cp * GP + 2 * Cp:].view(4 * Cp, C)
         ws = _workspace(x.device, lib().mdl_cgconv_workspace_bytes(N, E, C, G, dt))
         gate, ctx.gate = ctx.gate, None
-        if gate is not None:
+        wsp, ctx.wsplit = ctx.wsplit, None
+        if wsp is not None:
+            check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_p(
+                ptr(wsp[0]), ptr(wsp[1]), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(bpack),
+                ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, ptr(ws), ws.numel(), stream())),
+                "mdl_cgconv_bwd_p")
+            del wsp
+        elif gate is not None:
             check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_saved(
                 ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(gate), ptr(g), ptr(r_tgt), ptr(r_src),
                 ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd_saved")

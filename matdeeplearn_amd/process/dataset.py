@@ -198,6 +198,34 @@ class GraphDataset:
             self._dev["lrowptr_s"] = torch.from_numpy(lrowptr_s).to(self.device)
         return self._dev["eperm_s"], self._dev["lrowptr_s"]
 
+    def _upload(self, arr, dev, ring=8):
+        """host int64 array -> device tensor through a ring of pinned staging buffers (async; a slot is reused only after the
+        copy that read it has finished)"""
+        st = self.__dict__.setdefault("_pin", {"bufs": [None] * ring, "evs": [None] * ring, "k": 0})
+        k = st["k"]
+        st["k"] = (k + 1) % ring
+        n = int(arr.shape[0])
+        buf = st["bufs"][k]
+        if buf is None or buf.numel() < n:
+            buf = st["bufs"][k] = torch.empty(max(n, 1024), dtype=torch.int64).pin_memory()
+        elif st["evs"][k] is not None:
+            st["evs"][k].synchronize()
+        buf[:n].copy_(torch.from_numpy(arr))
+        out = torch.empty(n, dtype=torch.int64, device=dev)
+        out.copy_(buf[:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        st["evs"][k] = ev
+        return out
+
+    def _zero_u(self, B, dev):
+        """the reference's global state input: zeros [B, 3] (process.py:365) — constant, so one tensor per batch size"""
+        c = self.__dict__.setdefault("_u0", {})
+        t = c.get((B, str(dev)))
+        if t is None:
+            t = c[(B, str(dev))] = torch.zeros(B, 3, device=dev)
+        return t
+
     def assemble_hip(self, ids, x_dtype=torch.float32):
         """K8: the whole batch assembly in ONE HIP launch (one workgroup per graph).  Prefix offsets are
         computed on the host from node_ptr/edge_ptr (B numbers) and uploaded with the ids in one copy."""
@@ -211,8 +239,9 @@ class GraphDataset:
         eoff = np.concatenate([[0], np.cumsum(ecnt)])
         N, E = int(noff[-1]), int(eoff[-1])
         dev = self.device
-        host = torch.from_numpy(np.concatenate([ids, noff, eoff]).astype(np.int64))
-        pack = host.to(dev, non_blocking=True)
+        # one async copy from a ring of pinned buffers (a pageable source is staged through several blit kernels that sit
+        # in front of the assembly kernel on the stream: 4 x 4.8 us per step in the bench trace)
+        pack = self._upload(np.concatenate([ids, noff, eoff]).astype(np.int64), dev)
         ids_d, noff_d, eoff_d = pack[:B], pack[B:2 * B + 1], pack[2 * B + 1:]
         F = self.num_features
         x = torch.empty((N, F), dtype=x_dtype, device=dev)
@@ -242,7 +271,7 @@ class GraphDataset:
         csr.set_transposed_builder(transposed)
         ops.register_seg_index(src, _weak_call(csr, "seg_src"))   # scatter(..., csr.row / csr.col): no per-batch sort
         ops.register_seg_index(tgt, _weak_call(csr, "seg_tgt"))
-        return Batch(x=x, edge_attr=None, edge_weight=ew, batch=batch, y=y, u=torch.zeros(B, 3, device=dev),
+        return Batch(x=x, edge_attr=None, edge_weight=ew, batch=batch, y=y, u=self._zero_u(B, dev),
                      num_graphs=B, csr=csr, num_nodes=N, num_edges=E,
                      structure_id=[self.ids[i] for i in ids]), dn
 

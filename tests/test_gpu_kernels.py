@@ -96,10 +96,10 @@ def test_scatter_matches_oracle(reduce, dtype, sorted_idx, C):
     close(src_d.grad, src_o.grad, *tol)
 
 
-def _cgconv_case(n, C, G, dtype, sort, seed, aggr="mean", empty_frac=0.1):
+def _cgconv_case(n, C, G, dtype, sort, seed, aggr="mean", empty_frac=0.1, window=40):
     from matdeeplearn_amd import ops
     g = torch.Generator().manual_seed(seed)
-    ei = rand_graph(n, seed, sort=sort, empty_frac=empty_frac)
+    ei = rand_graph(n, seed, sort=sort, empty_frac=empty_frac, window=window)
     E = ei.shape[1]
     rnd = lambda *s: torch.randn(*s, generator=g)
     x = rnd(n, C).to(dtype).float()
@@ -153,8 +153,10 @@ def test_cgconv_cooperative_kernels_match_oracle(C, monkeypatch):
     _cgconv_case(90, C, 50, torch.bfloat16, True, seed=22, aggr="add")
 
 
-def test_cgconv_edge_per_lane_backward_matches_oracle():
-    """The opt-in edge-per-lane backward edge pass (cgconv_ep.inc, MDL_CG_EP=1; bf16, C = 64, G = 50) against the oracle:
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_cgconv_edge_per_lane_backward_matches_oracle(variant):
+    """The edge-per-lane backward edge passes (MDL_CG_EP=1: cgconv_ep.inc, phases one after the other; MDL_CG_EP=2:
+    cgconv_ep2.inc, producer and reducer waves side by side; bf16, C = 64, G = 50) against the oracle:
     several workgroups and rounds, partial tiles, isolated nodes (groups without edges), sources outside the 96-node
     window (rand_graph's window of +-40 around the target spans it for 32-node groups), sum and mean aggregation.  Runs
     in a fresh interpreter: the library reads its experiment switches once per process."""
@@ -164,9 +166,10 @@ def test_cgconv_edge_per_lane_backward_matches_oracle():
             "t._cgconv_case(700, 64, 50, torch.bfloat16, True, seed=21, empty_frac=0.05)\n"
             "t._cgconv_case(2500, 64, 50, torch.bfloat16, True, seed=23, empty_frac=0.3)\n"
             "t._cgconv_case(90, 64, 50, torch.bfloat16, True, seed=22, aggr='add')\n"
-            "t._cgconv_case(200, 64, 50, torch.bfloat16, False, seed=24)\n")
+            "t._cgconv_case(200, 64, 50, torch.bfloat16, False, seed=24)\n"
+            "t._cgconv_case(1500, 64, 50, torch.bfloat16, True, seed=25, empty_frac=0.0, window=400)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "MDL_CG_EP": "1"}, cwd=root,
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "MDL_CG_EP": variant}, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
@@ -724,3 +727,22 @@ def test_rbf_block_kernel_matches_oracle_on_ragged_sizes(dtype, E):
         assert torch.allclose(out.cpu(), ref, rtol=1e-6, atol=1e-7)
     else:
         assert torch.allclose(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=1e-2, atol=1e-6)
+
+
+def test_cgconv_w_split_pair_matches_oracle():
+    """The W-split CGConv pair (MDL_CG_WSPLIT=1: per-node projections from two dense launches, per edge only the K = 64
+    edge-feature product; mdl_cgconv_fwd_p / mdl_cgconv_bwd_p) against the oracle — forward and every gradient, bf16 tolerance
+    (the projections are rounded to bf16 once more than the fused product: 3e-2 of the tensor scale still holds).  Fresh
+    interpreter: the switch is read at import."""
+    import subprocess
+    import sys
+    code = ("import torch; import tests.test_gpu_kernels as t\n"
+            "t._cgconv_case(700, 64, 50, torch.bfloat16, True, seed=21, empty_frac=0.05)\n"
+            "t._cgconv_case(2500, 64, 50, torch.bfloat16, True, seed=23, empty_frac=0.3)\n"
+            "t._cgconv_case(90, 64, 50, torch.bfloat16, True, seed=22, aggr='add')\n"
+            "t._cgconv_case(77, 32, 50, torch.bfloat16, True, seed=26)\n"
+            "from matdeeplearn_amd import ops; assert ops._WSPLIT\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "MDL_CG_WSPLIT": "1"}, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

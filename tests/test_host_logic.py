@@ -457,10 +457,14 @@ def test_conv_kernels_register_budget():
         hits = [v for k, v in stats.items() if frag in k]
         assert hits, "kernel %s not found in the assembly" % frag
         return hits[0]
-    scratch, occ = find("cgconv_bwd_kernelItLi64ELi50")          # per-wave backward, bf16 C=64 G=50
+    scratch, occ = find("cgconv_bwd_kernelItLi64ELi50ELi9ELi2ELi1ELi0E")          # per-wave backward, bf16 C=64 G=50
     assert scratch == 0 and occ == 1
-    scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb0")          # all-slices forward
+    scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb0ELi0E")      # all-slices forward
     assert scratch == 0 and occ == 2
+    scratch, occ = find("cgconv_bwd_kernelItLi64ELi50ELi9ELi2ELi1ELi1E")          # opt-in W-split backward
+    assert scratch == 0 and occ == 1
+    scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb0ELi1E")      # opt-in W-split forward: a few dwords of
+    assert scratch <= 64 and occ == 2                                             # loop-invariant addresses spill
     scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb1")          # opt-in saved-gate forward: the 16 pending
     assert scratch <= 256 and occ == 2                                           # factor dwords spill at GROUP level only
     scratch, occ = find("cgconv_bwd_ab_kernelILi64")                              # opt-in saved-gate backward

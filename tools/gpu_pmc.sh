@@ -11,6 +11,7 @@ GRPS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
       "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS"
       "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum")
 [ "${PMC_ONLY:-}" = "traffic" ] && GRPS=("FETCH_SIZE" "WRITE_SIZE")
+[ "${PMC_ONLY:-}" = "sq" ] && GRPS=("${GRPS[0]}" "${GRPS[1]}")
 for grp in "${GRPS[@]}"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o p -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --iters 2 "$@" > $OUT/p$i.log 2>&1
@@ -20,7 +21,7 @@ import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    short = "bwd" if "cgconv_bwd_kernel" in k else "fwd" if ("cgconv_fwd_kernel" in k or "cb::fwd_kernel" in k) else \
+    short = "bwd" if ("cgconv_bwd_kernel" in k or "ep::bwd" in k or "bwd2_kernel" in k or "bwd_kernel" in k) else "fwd" if ("cgconv_fwd_kernel" in k or "cb::fwd_kernel" in k) else \
         "node" if "cgconv_node" in k else "rbf" if "rbf_" in k else None
     if short:
         agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
