@@ -120,6 +120,17 @@ int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, 
  * edge and layer for 24 of the 46 MFMAs, every transcendental and the x gathers of the recomputing pass. */
 size_t mdl_cgconv_gate_row_bytes(int C, int G, int dtype);
 
+/* mdl_cgconv_bwd with the by-source sums in bf16 (MDL_BF16, C in {32, 64}, G = 50, edge features in CSR order): r_src is a
+ * [N, 2Cp] bf16 array (zero-filled by the caller) accumulated with packed bf16 atomics — half the atomic operations and half
+ * the bytes of the fp32 form, and half the bytes its one consumer reads.  mdl_cgconv_bwd_node_h is that consumer:
+ * mdl_cgconv_bwd_node_z for a bf16 r_src (zero_src = 1 hands it back zeroed).  r_tgt, dwe, db as in mdl_cgconv_bwd. */
+int mdl_cgconv_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src, const int32_t* tgt,
+                     const void* wpack, const float* bpack, const void* grad_out, void* r_tgt, void* r_src, float* dwe,
+                     float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
+                     mdlStream_t stream);
+int mdl_cgconv_bwd_node_h(const void* x, const void* grad_out, const void* r_tgt, void* r_src, const void* wn_t, void* dx,
+                          float* dwn, int64_t N, int C, int dtype, int zero_src, mdlStream_t stream);
+
 /* W-split variant of the pair (dtype MDL_BF16, C in {32, 64}, G = 50, edge features in CSR order): the node parts of the two
  * Linear(2C+G, C) of PyG CGConv (cgcnn.py:80-83) leave the edge pass —
  *     z W^T = e W_e^T + P_t[i] + P_s[j],   P_t = x [W_f,tgt ; W_s,tgt]^T,   P_s = x [W_f,src ; W_s,src]^T   ([N, 2Cp] each)

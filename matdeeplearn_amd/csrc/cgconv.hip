@@ -138,6 +138,7 @@ struct CgParams {
     unsigned* ctr;      // bwd, optional: NS zeroed work counters (caller workspace) -> dynamic group scheduling
     void* ab;           // saved gate factors [E][Cp][2] bf16 (A | B per channel): written by the training forward, read by
                         // the saved-gate backward (cgconv_bwd_ab_kernel)
+    int rs16;           // bwd, bf16: r_src is a bf16 array accumulated with packed bf16 atomics (mdl_cgconv_bwd_h)
     const void* pt;     // W-split kernels: per-node projections P_t = x [W_f,tgt ; W_s,tgt]^T and P_s = x [W_f,src ; W_s,src]^T,
     const void* ps;     // [N, 2Cp] each in the compute dtype (columns f | s), scaled like the packed weights
     int64_t N, E;
@@ -1206,6 +1207,25 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
     }
 }
 
+// By-source sums in bf16 (p.rs16): two fp32 atomics per (row, lane) become ONE packed bf16 atomic per TWO rows.  A lane holds
+// column c of rows R (value va) and R + 1 (vb); neighbouring lanes hold neighbouring columns.  Even lanes take the pair
+// (c, c + 1) of row R, odd lanes the pair (c - 1, c) of row R + 1: each lane hands its partner (lane ^ 1) the value the partner
+// needs with one DPP quad permute, packs with one v_cvt_pk_bf16_f32 and issues global_atomic_pk_add_bf16 on a 4-byte
+// aligned column pair — half the atomic operations AND half the bytes of the fp32 form (atomic throughput at the L2 is what the
+// window flush costs: ablated, 45 of 585 us).  ca / cb: whether row R / R + 1 is to be added at all.
+__device__ __forceinline__ void rsrc16_add2(bf16_t* base_even_col, int64_t rowa_elems, int64_t rowb_elems, float va, float vb,
+                                            bool ca, bool cb, int odd) {
+    typedef __bf16 __attribute__((ext_vector_type(2))) bf2v;
+    typedef __attribute__((address_space(1))) bf2v* gptr_t;
+    const float send = odd ? va : vb;
+    const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));
+    const float lo = odd ? recv : va, hi = odd ? vb : recv;
+    if (odd ? cb : ca) {
+        const unsigned pk = pk_bf16(lo, hi);
+        __builtin_amdgcn_global_atomic_fadd_v2bf16((gptr_t)(base_even_col + (odd ? rowb_elems : rowa_elems)), __builtin_bit_cast(bf2v, pk));
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Backward edge pass
 // ------------------------------------------------------------------------------------------
@@ -1454,6 +1474,15 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sj[4 * q + k] = v[k];
                 }
+                if (BF && p.rs16) {
+                    bf16_t* const b16 = reinterpret_cast<bf16_t*>(p.r_src) + (ch & ~1);
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int64_t ra = (int64_t)max(sj[r], 0) * C2, rb = (int64_t)max(sj[r + 1], 0) * C2;
+                        rsrc16_add2(b16, ra, rb, accf[r], accf[r + 1], sj[r] >= 0, sj[r + 1] >= 0, i & 1);
+                        rsrc16_add2(b16 + dm.Cp, ra, rb, accs[r], accs[r + 1], sj[r] >= 0, sj[r + 1] >= 0, i & 1);
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (sj[r] >= 0) {
@@ -1461,6 +1490,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                         unsafeAtomicAdd(dst, accf[r]);
                         unsafeAtomicAdd(dst + dm.Cp, accs[r]);
                     }
+                }
                 }
             }
 
@@ -1553,7 +1583,22 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tmv);
             }
             const unsigned long long tmh = tm >> (4 * h);
-            if (ch < dm.C) {
+#ifdef MDL_ABL_NOWFLUSH
+            if (p.N < 0)
+#endif
+            if (BF && p.rs16) {
+                // (static bf16 shapes only: C == Cp, every lane owns a real column)
+                bf16_t* const b16 = reinterpret_cast<bf16_t*>(p.r_src) + (int64_t)(wb + 4 * h) * C2 + (ch & ~1);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int ra = 32 * mt + d_row(r, 0), rb = ra + 1;
+                        const bool ca = (tmh >> ra) & 1ull, cb = (tmh >> rb) & 1ull;
+                        rsrc16_add2(b16, (int64_t)ra * C2, (int64_t)rb * C2, Wf[mt][r], Wf[mt][r + 1], ca, cb, i & 1);
+                        rsrc16_add2(b16 + dm.Cp, (int64_t)ra * C2, (int64_t)rb * C2, Ws[mt][r], Ws[mt][r + 1], ca, cb, i & 1);
+                    }
+            } else if (ch < dm.C) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -2071,8 +2116,11 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     // edge-per-lane backward (cgconv_ep.inc): bf16, C = 64, G = 50, target-sorted edge features
     if constexpr (sizeof(T) == 2) {
         const bool use_ep = env.ep >= 0 ? env.ep != 0 : (MDL_EP_DEFAULT != 0);
-        if (use_ep && bwd && fast && !wsp && d.Cp == 64 && p.bias_col && p.E >= 64)
-            return env.ep == 2 ? ep::launch2(p, st, env.ep_wgs, name) : ep::launch(p, st, env.ep_wgs, name);
+        if (use_ep && bwd && fast && !wsp && d.Cp == 64 && p.bias_col && p.E >= 64) {
+            // cgconv_ep2.inc accumulates the by-source sums in bf16 (mdl_cgconv_bwd_h), cgconv_ep.inc in fp32 (mdl_cgconv_bwd)
+            if (env.ep == 2 && p.rs16) return ep::launch2(p, st, env.ep_wgs, name);
+            if (env.ep != 2 && !p.rs16) return ep::launch(p, st, env.ep_wgs, name);
+        }
     }
     // total waves must be a multiple of NS so that every wave keeps one channel slice
     while ((grid * waves) % d.NS) ++grid;
@@ -2127,7 +2175,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
             return check_launch(name);
         }
         const bool use_cbb = env.cb_bwd >= 0 ? env.cb_bwd != 0 : (MDL_CG_CB_BWD_DEFAULT != 0);
-        if (use_cbb && fast && !wsp && bwd && p.E >= 64 && p.bias_col) {
+        if (use_cbb && fast && !wsp && !p.rs16 && bwd && p.E >= 64 && p.bias_col) {
             const int cb_wgs = env.cb_wgs > 0 ? env.cb_wgs : MDL_CB_BWD_OCC;
             const int64_t cb_grid = std::min<int64_t>(256 * cb_wgs, ranges);
             if (d.Cp == 64) {
@@ -2406,6 +2454,26 @@ extern "C" int mdl_cgconv_bwd_p(const void* p_tgt, const void* p_src, const void
     p.ctr = (workspace && ws_bytes >= mdl_cgconv_workspace_bytes(N, E, C, G, dtype)) ? static_cast<unsigned*>(workspace) : nullptr;
     if (dtype != MDL_BF16) { set_error("mdl_cgconv_bwd_p: bf16 only"); return MDL_E_UNSUPP; }
     return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd_p");
+}
+
+extern "C" int mdl_cgconv_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
+                                const int32_t* tgt, const void* wpack, const float* bpack, const void* grad_out, void* r_tgt,
+                                void* r_src, float* dwe, float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype,
+                                void* workspace, size_t ws_bytes, mdlStream_t stream) {
+    using namespace mdl;
+    int rc = cg_check("mdl_cgconv_bwd_h", x, edge_attr, rowptr, src, tgt, wpack, bpack, N, E, C, G, aggr, dtype);
+    if (rc) return rc;
+    MDL_REQUIRE(mdl_cgconv_gate_row_bytes(C, G, dtype) != 0, MDL_E_UNSUPP,
+                "mdl_cgconv_bwd_h: unsupported C=%d G=%d dtype=%d (bf16, C in {32, 64}, G = 50)", C, G, dtype);
+    MDL_REQUIRE(N == 0 || (grad_out && r_tgt && r_src && dwe), MDL_E_ARG, "mdl_cgconv_bwd_h: null pointer");
+    MDL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(edge_attr) % 4 == 0 &&
+                    reinterpret_cast<uintptr_t>(r_src) % 4 == 0, MDL_E_ARG, "mdl_cgconv_bwd_h: x must be 16-byte, edge_attr / r_src 4-byte aligned");
+    CgParams p = {};
+    p.x = x; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = nullptr;
+    p.wpack = wpack; p.bpack = bpack; p.gout = grad_out; p.r_tgt = r_tgt; p.r_src = static_cast<float*>(r_src); p.dwe = dwe; p.db = db;
+    p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr; p.rs16 = 1;
+    p.ctr = (workspace && ws_bytes >= mdl_cgconv_workspace_bytes(N, E, C, G, dtype)) ? static_cast<unsigned*>(workspace) : nullptr;
+    return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd_h");
 }
 
 extern "C" int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,

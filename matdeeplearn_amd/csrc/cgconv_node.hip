@@ -33,7 +33,9 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 //     read ds_read_b64_tr_b16 — no strided global loads, no second pass over r_tgt/r_src.
 // Wave w: one (32-node, 32-feature) block of dx and MT*NT/4... of the (4Cp x C) dWn blocks (kept in registers over
 // the grid-stride loop, flushed once with fp32 atomics).
-template <int CP>
+// RS16: r_src arrives in bf16 as well (the edge pass accumulated it with packed bf16 atomics, mdl_cgconv_bwd_h): half the
+// bytes to read and to zero, no conversion.
+template <int CP, bool RS16 = false>
 __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gout,
                                                                     const bf16_t* __restrict__ r_tgt,
                                                                     const float* __restrict__ r_src,
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
     constexpr int TCH = 2 * CP / 8;      // 16-byte chunks per r_tgt row (8 bf16)
     constexpr int SCH = 2 * CP / 4;      // 16-byte chunks per r_src row (4 floats)
     constexpr int NTL = TN * TCH / 256;  // r_tgt chunks per thread: 4 (CP 64) / 2 (CP 32)
-    constexpr int NSL = TN * SCH / 256;  // r_src chunks per thread: 8 / 4
+    constexpr int NSL = RS16 ? NTL : TN * SCH / 256;  // r_src chunks per thread: 8 / 4 (fp32), like r_tgt when it is bf16
     constexpr int XCH = CP / 8;          // 16-byte chunks per x row
     constexpr int NXL = TN * XCH / 256;  // x chunks per thread: 2 / 1
     constexpr int MJ = (K4 / 32) * NT / 4;   // (32-row, 32-col) dWn blocks per wave: 4 / 1
@@ -92,13 +94,15 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
     auto load_tile = [&](int64_t tile) {
         const int64_t nb = tile * TN, rem = N - nb;
         const __amdgpu_buffer_rsrc_t tr = rsrc(r_tgt + nb * (2 * CP), rem * (2 * CP * 2));
-        const __amdgpu_buffer_rsrc_t sr = rsrc(r_src + nb * (2 * CP), rem * (2 * CP * 4));
+        const __amdgpu_buffer_rsrc_t sr = RS16 ? rsrc(reinterpret_cast<const bf16_t*>(r_src) + nb * (2 * CP), rem * (2 * CP * 2))
+                                               : rsrc(r_src + nb * (2 * CP), rem * (2 * CP * 4));
         const __amdgpu_buffer_rsrc_t xr = rsrc(x + nb * CP, rem * (CP * 2));
 #pragma unroll
         for (int l = 0; l < NTL; ++l) treg[l] = __builtin_amdgcn_raw_buffer_load_b128(tr, to + opaque(l * (TROWS * 2 * CP * 2)), 0, 0);
 #pragma unroll
         for (int l = 0; l < NSL; ++l)
-            sreg[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sr, so + opaque(l * (SROWS * 2 * CP * 4)), 0, 0));
+            sreg[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                sr, RS16 ? to + opaque(l * (TROWS * 2 * CP * 2)) : so + opaque(l * (SROWS * 2 * CP * 4)), 0, 0));
 #pragma unroll
         for (int l = 0; l < NXL; ++l) xreg[l] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo + opaque(l * (XROWS * CP * 2)), 0, 0);
     };
@@ -111,19 +115,25 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
         for (int l = 0; l < NTL; ++l) *reinterpret_cast<u32x4_t*>(rl + (trow0 + l * TROWS) * LD + 8 * tcc) = treg[l];
 #pragma unroll
         for (int l = 0; l < NSL; ++l) {
-            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-            const u32x2_t v = {pk_bf16(sreg[l][0], sreg[l][1]), pk_bf16(sreg[l][2], sreg[l][3])};
-            *reinterpret_cast<u32x2_t*>(rl + (srow0 + l * SROWS) * LD + 2 * CP + 4 * scc) = v;
+            if constexpr (RS16) {
+                *reinterpret_cast<u32x4_t*>(rl + (trow0 + l * TROWS) * LD + 2 * CP + 8 * tcc) = __builtin_bit_cast(u32x4_t, sreg[l]);
+            } else {
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                const u32x2_t v = {pk_bf16(sreg[l][0], sreg[l][1]), pk_bf16(sreg[l][2], sreg[l][3])};
+                *reinterpret_cast<u32x2_t*>(rl + (srow0 + l * SROWS) * LD + 2 * CP + 4 * scc) = v;
+            }
         }
         // zero_src: this kernel is the only reader of r_src, so it can hand the buffer back ZEROED for the next edge
         // pass (which accumulates into it with atomics) — the rows are in registers at this point, the stores ride behind
         // the loads, and the caller's 100-MB fill per layer disappears (mdl_cgconv_bwd_node_z)
         if (zero_src) {
             const int64_t rem = N - nb;
-            const __amdgpu_buffer_rsrc_t sz = rsrc(r_src + nb * (2 * CP), rem * (2 * CP * 4));
+            const __amdgpu_buffer_rsrc_t sz = RS16 ? rsrc(reinterpret_cast<const bf16_t*>(r_src) + nb * (2 * CP), rem * (2 * CP * 2))
+                                                   : rsrc(r_src + nb * (2 * CP), rem * (2 * CP * 4));
 #pragma unroll
             for (int l = 0; l < NSL; ++l)
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, sz, so + opaque(l * (SROWS * 2 * CP * 4)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, sz,
+                                                       RS16 ? to + opaque(l * (TROWS * 2 * CP * 2)) : so + opaque(l * (SROWS * 2 * CP * 4)), 0, 0);
         }
 #pragma unroll
         for (int l = 0; l < NXL; ++l) {
@@ -250,9 +260,22 @@ extern "C" int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const vo
     return mdl_cgconv_bwd_node_z(x, grad_out, r_tgt, const_cast<float*>(r_src), wn_t, dx, dwn, N, C, dtype, 0, stream);
 }
 
+static int bwd_node_launch(const void* x, const void* grad_out, const void* r_tgt, float* r_src, const void* wn_t, void* dx,
+                           float* dwn, int64_t N, int C, int dtype, int zero_src, bool rs16, mdlStream_t stream);
+
 extern "C" int mdl_cgconv_bwd_node_z(const void* x, const void* grad_out, const void* r_tgt, float* r_src,
                                      const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype, int zero_src,
                                      mdlStream_t stream) {
+    return bwd_node_launch(x, grad_out, r_tgt, r_src, wn_t, dx, dwn, N, C, dtype, zero_src, false, stream);
+}
+
+extern "C" int mdl_cgconv_bwd_node_h(const void* x, const void* grad_out, const void* r_tgt, void* r_src, const void* wn_t,
+                                     void* dx, float* dwn, int64_t N, int C, int dtype, int zero_src, mdlStream_t stream) {
+    return bwd_node_launch(x, grad_out, r_tgt, static_cast<float*>(r_src), wn_t, dx, dwn, N, C, dtype, zero_src, true, stream);
+}
+
+static int bwd_node_launch(const void* x, const void* grad_out, const void* r_tgt, float* r_src, const void* wn_t, void* dx,
+                           float* dwn, int64_t N, int C, int dtype, int zero_src, bool rs16, mdlStream_t stream) {
     using namespace mdl;
     MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_cgconv_bwd_node: bf16 only (fp32 parity mode uses library GEMMs)");
     MDL_REQUIRE(C == 32 || C == 64, MDL_E_UNSUPP, "mdl_cgconv_bwd_node: C must be 32 or 64 (got %d)", C);
@@ -267,13 +290,13 @@ extern "C" int mdl_cgconv_bwd_node_z(const void* x, const void* grad_out, const 
                                           // (measured 128 / 256 / 512 / 1024 blocks: 70 / 56 / 67 / 97 us)
     if (C == 64) {
         const int lds = (64 * (256 + 8) + 64 * (256 + 8) + 64 * (64 + 8)) * 2;
-        auto kf = cgconv_node_stream_kernel<64>;
+        auto kf = rs16 ? cgconv_node_stream_kernel<64, true> : cgconv_node_stream_kernel<64, false>;
         set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
         hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
                            (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N, zero_src);
     } else {
         const int lds = (32 * (128 + 8) + 64 * (128 + 8) + 64 * (32 + 8)) * 2;
-        auto kf = cgconv_node_stream_kernel<32>;
+        auto kf = rs16 ? cgconv_node_stream_kernel<32, true> : cgconv_node_stream_kernel<32, false>;
         hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
                            (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N, zero_src);
     }

@@ -480,6 +480,10 @@ _SAVE_GATE = os.environ.get("MDL_CG_SAVE_GATE", "0") == "1"
 # per edge only the K = 64 edge-feature product): MDL_CG_WSPLIT=1.  DESIGN.md section 4 has the A/B.
 _WSPLIT = os.environ.get("MDL_CG_WSPLIT", "0") == "1"
 
+# By-source sums of the CGConv backward in bf16, accumulated with packed bf16 atomics (mdl_cgconv_bwd_h / mdl_cgconv_bwd_node_h;
+# bf16 mode, C in {32, 64}, G = 50): half the atomic operations and bytes of the fp32 buffer.  MDL_CG_RSRC16=0 restores fp32.
+_RSRC16 = os.environ.get("MDL_CG_RSRC16", "1") == "1"
+
 
 # r_src (by-source sums of the CGConv backward: fp32 [N, 2*Cp], accumulated with atomics) must start at zero: 107 MB per
 # layer at the bench batch, i.e. a 15-22 us fill launch in front of every edge pass.  Its only reader, the node kernel,
@@ -582,11 +586,15 @@ class _CGConvFn(torch.autograd.Function):
         dt = dtype_code(x)
         r_tgt = torch.empty((N, 2 * Cp), dtype=x.dtype, device=x.device)          # by-target sums, compute dtype
         node_hip = dt == _lib.MDL_BF16 and C == Cp and C in (32, 64)          # K3c consumes r_tgt / r_src
-        keep = _take_rsrc(N * 2 * Cp, x.device) if node_hip else None
+        rs16 = (_RSRC16 and node_hip and G == 50 and ctx.gate is None and ctx.wsplit is None and E > 0
+                and x.data_ptr() % 16 == 0 and edge_attr.data_ptr() % 4 == 0)
+        nrs = N * 2 * Cp // 2 if rs16 else N * 2 * Cp                         # fp32 words of the by-source buffer
+        keep = _take_rsrc(nrs, x.device) if node_hip else None
         if keep is not None:
-            r_src, keep[1] = keep[0][:N * 2 * Cp].view(N, 2 * Cp), True
+            r_src, keep[1] = keep[0][:nrs], True
+            r_src = r_src.view(torch.bfloat16).view(N, 2 * Cp) if rs16 else r_src.view(N, 2 * Cp)
         else:
-            r_src = torch.zeros((N, 2 * Cp), dtype=torch.float32, device=x.device)
+            r_src = torch.zeros((N, 2 * Cp), dtype=torch.bfloat16 if rs16 else torch.float32, device=x.device)
         small = _zeros_step((2 * Cp * GP + 2 * Cp + 4 * Cp * C,), x.device)
         dwe = small[:2 * Cp * GP].view(2 * Cp, GP)
         db = small[2 * Cp * GP:2 * Cp * GP + 2 * Cp]
@@ -605,6 +613,11 @@ class _CGConvFn(torch.autograd.Function):
                 ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(gate), ptr(g), ptr(r_tgt), ptr(r_src),
                 ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd_saved")
             del gate
+        elif rs16:
+            check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_h(
+                ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(bpack), ptr(g),
+                ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, ptr(ws), ws.numel(), stream())),
+                "mdl_cgconv_bwd_h")
         else:
             check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd(
                 ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
@@ -616,7 +629,8 @@ class _CGConvFn(torch.autograd.Function):
             check(lib().mdl_cgconv_pack_node_weights(ptr(wf32), ptr(ws32), C, G, ptr(wn_t), dt, stream()),
                   "mdl_cgconv_pack_node_weights")
             dx = torch.empty_like(x)
-            check(_launch_timed("bwd_node", lambda: lib().mdl_cgconv_bwd_node_z(
+            node_fn = lib().mdl_cgconv_bwd_node_h if rs16 else lib().mdl_cgconv_bwd_node_z
+            check(_launch_timed("bwd_node", lambda: node_fn(
                 ptr(x), ptr(g), ptr(r_tgt), ptr(r_src), ptr(wn_t), ptr(dx), ptr(dwn), N, C, dt, 1 if keep is not None else 0,
                 stream())), "mdl_cgconv_bwd_node")
             if keep is not None:

@@ -169,7 +169,7 @@ def test_cgconv_edge_per_lane_backward_matches_oracle(variant):
             "t._cgconv_case(200, 64, 50, torch.bfloat16, False, seed=24)\n"
             "t._cgconv_case(1500, 64, 50, torch.bfloat16, True, seed=25, empty_frac=0.0, window=400)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "MDL_CG_EP": variant}, cwd=root,
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "MDL_CG_EP": variant, "MDL_CG_RSRC16": "1" if variant == "2" else "0"}, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
