@@ -1960,8 +1960,12 @@ int launch(CgParams& p, hipStream_t st, int wgs, const char* name) {
 #else
 namespace ep {
 #ifndef MDL_EP_DEFAULT
-#define MDL_EP_DEFAULT 0      // 1: mdl_cgconv_bwd takes the edge-per-lane kernel for bf16, C = 64, G = 50 (MDL_CG_EP=0/1 overrides).
-                              // Off: parity-green but 15 % slower than the per-wave kernel on the bench batch
+#define MDL_EP_DEFAULT 2      // edge-per-lane backward edge pass for bf16, C = 64, G = 50 (MDL_CG_EP = 0 / 1 / 2 overrides):
+                              // 2 = cgconv_ep2.inc where the by-source sums are bf16 (mdl_cgconv_bwd_h): 6-9 % faster than the
+                              // per-wave kernel on the bench batch; 1 = cgconv_ep.inc (fp32 sums; slower, kept for A/B); 0 = per-wave
+#endif
+#ifndef MDL_EP2_MIN_EDGES
+#define MDL_EP2_MIN_EDGES 400000   // default selection of kernel 2: at least ~12 rounds per workgroup (MDL_CG_EP=2 forces it)
 #endif
 int launch(CgParams& p, hipStream_t st, int wgs, const char* name);      // cgconv_ep.inc: phases one after the other
 int launch2(CgParams& p, hipStream_t st, int wgs, const char* name);     // cgconv_ep2.inc: producer / reducer waves side by side
@@ -2115,11 +2119,13 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     if (env.grid_cap > 0 && grid > env.grid_cap) grid = env.grid_cap;   // experiments
     // edge-per-lane backward (cgconv_ep.inc): bf16, C = 64, G = 50, target-sorted edge features
     if constexpr (sizeof(T) == 2) {
-        const bool use_ep = env.ep >= 0 ? env.ep != 0 : (MDL_EP_DEFAULT != 0);
-        if (use_ep && bwd && fast && !wsp && d.Cp == 64 && p.bias_col && p.E >= 64) {
+        const int ep_sel = env.ep >= 0 ? env.ep : MDL_EP_DEFAULT;
+        if (ep_sel != 0 && bwd && fast && !wsp && d.Cp == 64 && p.bias_col && p.E >= 64) {
             // cgconv_ep2.inc accumulates the by-source sums in bf16 (mdl_cgconv_bwd_h), cgconv_ep.inc in fp32 (mdl_cgconv_bwd)
-            if (env.ep == 2 && p.rs16) return ep::launch2(p, st, env.ep_wgs, name);
-            if (env.ep != 2 && !p.rs16) return ep::launch(p, st, env.ep_wgs, name);
+            // (a workgroup of kernel 2 stages 51 KB of weights and clears 112 KB of tile buffers before its first tile: below a few
+            // rounds per workgroup the per-wave kernel wins — 0.64 vs 0.71 ms per step at the reference's batch size 100)
+            if (ep_sel == 2 && p.rs16 && (env.ep == 2 || p.E >= MDL_EP2_MIN_EDGES)) return ep::launch2(p, st, env.ep_wgs, name);
+            if (ep_sel == 1 && !p.rs16) return ep::launch(p, st, env.ep_wgs, name);
         }
     }
     // total waves must be a multiple of NS so that every wave keeps one channel slice

@@ -153,13 +153,14 @@ def test_cgconv_cooperative_kernels_match_oracle(C, monkeypatch):
     _cgconv_case(90, C, 50, torch.bfloat16, True, seed=22, aggr="add")
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
 def test_cgconv_edge_per_lane_backward_matches_oracle(variant):
-    """The edge-per-lane backward edge passes (MDL_CG_EP=1: cgconv_ep.inc, phases one after the other; MDL_CG_EP=2:
-    cgconv_ep2.inc, producer and reducer waves side by side; bf16, C = 64, G = 50) against the oracle:
-    several workgroups and rounds, partial tiles, isolated nodes (groups without edges), sources outside the 96-node
-    window (rand_graph's window of +-40 around the target spans it for 32-node groups), sum and mean aggregation.  Runs
-    in a fresh interpreter: the library reads its experiment switches once per process."""
+    """Every backward edge pass for bf16, C = 64, G = 50 against the oracle — MDL_CG_EP=2: cgconv_ep2.inc (producer and
+    reducer waves side by side; the default), MDL_CG_EP=1: cgconv_ep.inc (phases one after the other), MDL_CG_EP=0: the
+    per-wave kernel (with bf16 by-source sums, as the default path uses it for C = 32): several workgroups and rounds,
+    partial tiles, isolated nodes (groups without edges), sources outside the by-source window (the last case spreads them
+    over +-400 nodes), sum and mean aggregation.  Runs in a fresh interpreter: the library reads its experiment switches
+    once per process."""
     import subprocess
     import sys
     code = ("import torch; import tests.test_gpu_kernels as t\n"
@@ -169,7 +170,7 @@ def test_cgconv_edge_per_lane_backward_matches_oracle(variant):
             "t._cgconv_case(200, 64, 50, torch.bfloat16, False, seed=24)\n"
             "t._cgconv_case(1500, 64, 50, torch.bfloat16, True, seed=25, empty_frac=0.0, window=400)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "MDL_CG_EP": variant, "MDL_CG_RSRC16": "1" if variant == "2" else "0"}, cwd=root,
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "MDL_CG_EP": variant, "MDL_CG_RSRC16": "0" if variant == "1" else "1"}, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 

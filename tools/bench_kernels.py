@@ -47,7 +47,7 @@ try:
         if hasattr(L, "mdl_debug_read_ep") and os.environ.get("MDL_CG_EP", "0") != "0":   # the edge-per-lane backward keeps
             buf2 = (ctypes.c_longlong * 48)()                                               # its counters in its own unit
             L.mdl_debug_read_ep(buf2)
-            v[16:32] = list(buf2)[16:32]
+            v[16:48] = list(buf2)[16:48]
         n = max(v[15], 1)
         if os.environ.get("MDL_CG_CB") == "1":
             cbn = ["data loads issue", "mfma chain", "gate+swaps", "reduce", "epilogue", "barrier", "commit (waits)", "idx issue"]
@@ -62,6 +62,11 @@ try:
         if os.environ.get("MDL_CG_EP", "0") != "0":   # edge-per-lane kernel: cycles per ROUND of four tiles
             names = ["walk (take)", "A commit+tables", "A issue loads", "A mfma pair0", "A mfma pair1 || gate0", "A gathers + gate1", "-", "barrier 1", "B rest", "barrier 2", "B header+flush", "B operand wait+mfma", "B out-of-window"]
         print("bwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[30] / n), {names[k]: round(v[16 + k] / n) for k in range(13)}, "sum", round(sum(v[16:29]) / n), "| shader clock %.2f GHz, wave-0 lifetime %.1f us/launch" % (v[30] / max(v[29], 1) * 0.1, v[29] / 100.0 / max(1, a.iters + 2)))
+        if os.environ.get("MDL_CG_EP", "0") == "2":   # kernel 2: producer wave 0 above (first five slots), reducer wave 4 here; per ROUND
+            n = max(v[47], 1)
+            names = ["meta + group test", "group change (flush, roll)", "operand reads + tf + R", "e reads + dwe", "window blocks", "round tail", "barrier"]
+            print("ep2 producer per-round cycles:", dict(zip(["wait top", "take+commit+slots", "issue ids/e", "mfma+gate+oow", "barrier"], [round(v[16 + k] / max(v[31], 1)) for k in range(5)])))
+            print("ep2 reducer per-round cycles (%d rounds, total %d):" % (n, v[46] / n), {names[k]: round(v[32 + k] / n) for k in range(7)})
     if hasattr(L, "mdl_debug_life"):
         import numpy as np
         for which, nm in ((0, "fwd"), (1, "bwd")):
@@ -76,6 +81,8 @@ try:
                 print("%s waves %d: start us min/med/max %.1f %.1f %.1f | end us min/med/max %.1f %.1f %.1f | life us min/med/max %.1f %.1f %.1f | tiles min/med/max %d %d %d" % (
                     nm, len(arr), st.min(), np.median(st), st.max(), en.min(), np.median(en), en.max(), life.min(), np.median(life), life.max(),
                     arr[:, 2].min(), np.median(arr[:, 2]), arr[:, 2].max()))
+                if os.environ.get("MDL_LIFE_DUMP"):
+                    np.save(os.path.join(os.environ["MDL_LIFE_DUMP"], "life_%s.npy" % nm), np.stack([st, en, arr[:, 2]], 1))
                 q = np.argsort(en)[-8:]
                 print("   slowest waves:", [(int(k), round(float(st[k]), 1), round(float(en[k]), 1), int(arr[k, 2])) for k in q])
 except Exception as e:
