@@ -51,10 +51,16 @@ class FlatDataParallel:
     the model keeps its own class/attributes, so `model(data)`, `state_dict()` keys and hooks are
     unchanged (the reference unwraps `model.module`; here there is nothing to unwrap)."""
 
-    def __init__(self, model, process_group=None, broadcast=True):
+    def __init__(self, model, process_group=None, broadcast=True, force=None, chunk_bytes=4 << 20):
         self.model = model
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force: run the exchange even at world size 1 (an initialised process group with one rank) — how the RCCL path is
+        # exercised on a one-GPU box (MDL_FORCE_DIST=1: bench.py, tests)
+        if force is None:
+            force = os.environ.get("MDL_FORCE_DIST", "0") == "1"
+        self.force = bool(force) and dist.is_initialized()
+        self.active = self.world_size > 1 or self.force
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("FlatDataParallel: model has no trainable parameters")
@@ -68,6 +74,20 @@ class FlatDataParallel:
                 raise ValueError("FlatDataParallel expects fp32 master parameters")
             self.views.append(self.flat_grad[off:off + p.numel()].view_as(p))
             off += p.numel()
+        # Two-chunk exchange for large payloads (MPNN: 17.5 MB): the parameters are split where the flat buffer reaches half its
+        # size; the SECOND half (the layers the forward runs last) has its gradients first in the backward, so its all-reduce
+        # starts from a hook as soon as the last of them is written and runs under the rest of the backward.  Small payloads
+        # (CGCNN: 0.45 MB, latency bound) keep the single collective.
+        self.split, self._late_left, self._late_work = None, 0, None
+        if self.active and chunk_bytes and total * 4 > chunk_bytes and len(self.params) > 1:
+            acc, k = 0, 0
+            while k < len(self.params) - 1 and acc + self.params[k].numel() <= total // 2:
+                acc += self.params[k].numel()
+                k += 1
+            k = max(k, 1)
+            self.split = (k, sum(p.numel() for p in self.params[:k]))
+            for p in self.params[k:]:
+                p.register_post_accumulate_grad_hook(self._late_hook)
         self.zero_grad()
         if broadcast and self.world_size > 1:
             self.broadcast_state()
@@ -90,10 +110,47 @@ class FlatDataParallel:
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+        if self.split is not None:
+            self._late_left = len(self.params) - self.split[0]
 
-    def _pack(self):
+    def single_collective(self):
+        """One all-reduce per step, always (training.GraphedStep: a rank that replays a captured step and a rank that runs the
+        same step eagerly must issue the same sequence of collectives)."""
+        self.split = None
+        return self
+
+    def _late_hook(self, _param):
+        if self.split is None:
+            return
+        self._late_left -= 1
+        if self._late_left == 0 and self._late_work is None and self.active:
+            # (not inside a stream capture: a captured step issues its collectives outside the graph)
+            if self.flat_grad.is_cuda and torch.cuda.is_current_stream_capturing():
+                return
+            self._late_work = self._launch(self.split[0], len(self.params))
+
+    def _launch(self, lo, hi):
+        """pack the gradients of params[lo:hi] into their slice of the flat buffer and start its all_reduce(SUM)"""
+        off0 = sum(p.numel() for p in self.params[:lo])
+        off1 = off0 + sum(p.numel() for p in self.params[lo:hi])
+        buf = self.flat_grad[off0:off1]
+        if self.flat_grad.is_cuda:
+            dev = self.flat_grad.device
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=dev)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                self._pack(lo, hi)
+                return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pack(lo, hi)
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _pack(self, lo=0, hi=None):
         srcs, dsts = [], []
-        for p, v in zip(self.params, self.views):
+        hi = len(self.params) if hi is None else hi
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             if p.grad is None:
                 v.zero_()                                   # parameter unused in this step
             elif p.grad.data_ptr() != v.data_ptr():
@@ -107,21 +164,12 @@ class FlatDataParallel:
         waits for the backward through an event, so whatever the caller enqueues next on the compute stream (the next
         batch's assembly and RBF expansion in bench.py / the training loop) overlaps with the collective; finish() makes
         the compute stream wait for it.  Returns False when there is nothing to exchange (one rank)."""
-        if not (self.world_size > 1 or (force and dist.is_initialized())):
+        if not (self.active or (force and dist.is_initialized())):
             return False
-        if self.flat_grad.is_cuda:
-            dev = self.flat_grad.device
-            if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream(device=dev)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(ev)
-                self._pack()
-                self._work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        else:
-            self._pack()
-            self._work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        lo = 0
+        if self._late_work is not None:
+            lo = self.split[0]            # the late half is already on its way (hook)
+        self._work = self._launch(0, lo if lo else len(self.params))
         return True
 
     def finish(self):
@@ -132,6 +180,9 @@ class FlatDataParallel:
             return
         work.wait()
         self._work = None
+        if self._late_work is not None:
+            self._late_work.wait()
+            self._late_work = None
         if self.flat_grad.is_cuda:
             torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
         self.flat_grad.mul_(1.0 / self.world_size)

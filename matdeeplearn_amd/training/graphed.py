@@ -37,7 +37,9 @@ class GraphedStep:
         n_cap, e_cap = capacity if capacity is not None else static_capacity(dataset, batch_size, indices)
         self.sb = StaticBatch(dataset, batch_size, n_cap, e_cap, x_dtype=compute_dtype, edge_dtype=compute_dtype)
         self.dev = dataset.device
-        distributed = dp is not None and dp.world_size > 1
+        distributed = dp is not None and (dp.world_size > 1 or getattr(dp, "active", False))
+        if dp is not None and hasattr(dp, "single_collective"):
+            dp.single_collective()
         self.opt_in_graph = (not distributed) if optimizer_in_graph is None else bool(optimizer_in_graph)
         if self.opt_in_graph and not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ops.MdlError("GraphedStep: the optimizer step is captured — build it with capturable=True "

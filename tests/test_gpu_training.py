@@ -72,6 +72,50 @@ for p, r in zip(m.parameters(), ref):
     assert p.grad.data_ptr() != r.data_ptr() and torch.equal(p.grad, r), "all-reduce at world size 1 must be the identity"
 assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(dp.params, dp.views))
 t = torch.ones(4, device=dev); dist.all_reduce(t); assert float(t.sum()) == 4.0
+# the small-batch combination: the captured step (assembly + forward + backward) replayed, then the flat all-reduce and the
+# optimizer step outside the graph (training.GraphedStep(dp=...)); at world size 1 it must equal the fully captured step
+import copy, numpy as np
+from matdeeplearn_amd import models
+from matdeeplearn_amd.process import synthetic_bulk
+from matdeeplearn_amd.training import GraphedStep, make_optimizer
+ds = synthetic_bulk(320, seed=11).to(dev)
+torch.manual_seed(3)
+m_a = models.CGCNN(ds, dim1=64, dim2=64, gc_count=2, post_fc_count=2).to(dev)
+m_b = copy.deepcopy(m_a)
+dp_a = FlatDataParallel(m_a, force=True, chunk_bytes=1024)
+assert dp_a.active and dp_a.split is not None
+o_a = make_optimizer(m_a.parameters(), "AdamW", lr=0.002)
+o_b = make_optimizer(m_b.parameters(), "AdamW", lr=0.002, capturable=True)
+g_a = GraphedStep(ds, m_a, o_a, 64, dp=dp_a)
+g_b = GraphedStep(ds, m_b, o_b, 64)
+assert not g_a.opt_in_graph and g_b.opt_in_graph and dp_a.split is None      # one collective per replayed step
+rng = np.random.default_rng(0)
+for _ in range(4):
+    ids = rng.choice(len(ds), size=64, replace=False)
+    g_a.step(ids); g_b.step(ids)
+torch.cuda.synchronize()
+assert g_a.replays == 4 and g_b.replays == 4
+assert abs(float(g_a.loss_value) - float(g_b.loss_value)) <= 2e-4 * max(1.0, abs(float(g_b.loss_value)))
+for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+    assert torch.allclose(a.float(), b.float(), rtol=2e-4, atol=2e-5), k
+# eager steps with the two-chunk exchange (hook-started all-reduce of the late half under the rest of the backward)
+m_c = copy.deepcopy(m_b); m_d = copy.deepcopy(m_b)
+dp_c = FlatDataParallel(m_c, force=True, chunk_bytes=1024)
+assert dp_c.split is not None
+from matdeeplearn_amd import ops
+batch = ds.collate(np.arange(48))
+for m, dp in ((m_c, dp_c), (m_d, None)):
+    m.train()
+    for p in m.parameters(): p.grad = None
+    if dp is not None: dp.zero_grad()
+    with ops.zero_arena(dev):
+        torch.nn.functional.l1_loss(m(batch), batch.y).backward()
+    if dp is not None:
+        assert dp._late_work is not None
+        dp.reduce_grads()
+torch.cuda.synchronize()
+for (k, a), (_, b) in zip(m_c.named_parameters(), m_d.named_parameters()):
+    assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7), k
 dist.barrier(); dist.destroy_process_group()
 print("RCCL_OK")
 """
@@ -79,7 +123,9 @@ print("RCCL_OK")
 
 def test_rccl_backend_executes_on_one_gpu():
     """The `nccl` (= RCCL) branch of the data-parallel engine on real hardware at world size 1: process-group init bound
-    to the device, flat broadcast, the side-stream pack + all-reduce, and bench.py's distributed path (MDL_FORCE_DIST=1)."""
+    to the device, flat broadcast, the side-stream pack + all-reduce, the replayed step with the exchange and the optimizer
+    outside the graph (GraphedStep(dp=...)), the two-chunk exchange started from a gradient hook, and bench.py's distributed
+    path (MDL_FORCE_DIST=1)."""
     import json
     import subprocess
     import sys

@@ -253,6 +253,37 @@ def _dp_worker(rank, world, port, tmp):
     p1 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     dist.all_gather(gathered, p1)
     assert torch.equal(gathered[0], gathered[1]), "ranks diverged after the optimizer step"
+    # two-chunk exchange (payloads above chunk_bytes): the half of the parameters the forward uses last is reduced from a
+    # hook while the backward still runs, the rest afterwards — same gradients, two collectives, the late one issued first
+    m2 = omodels.CGCNN(ds, dim1=16, dim2=16, gc_count=2, post_fc_count=1, batch_norm="False")
+    m2.load_state_dict(ref.state_dict())
+    dp2 = FlatDataParallel(m2, chunk_bytes=1024)
+    assert dp2.split is not None and 0 < dp2.split[0] < len(dp2.params)
+    calls = []
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        calls.append((t.data_ptr() - dp2.flat_grad.data_ptr()) // 4)
+        return real_all_reduce(t, *a, **k)
+    dist.all_reduce = counting_all_reduce
+    try:
+        for _ in range(2):                                # twice: the hook countdown re-arms in zero_grad()
+            calls.clear()
+            dp2.zero_grad()
+            (torch.nn.functional.l1_loss(m2(batch), batch.y, reduction="sum") / 8.0).backward()
+            assert calls == [dp2.split[1]], "the late half must be on its way when the backward returns"
+            dp2.reduce_grads()
+            assert calls == [dp2.split[1], 0]
+            for (k, p), (_, q) in zip(m2.named_parameters(), ref.named_parameters()):
+                assert torch.allclose(p.grad, q.grad / world, rtol=1e-4, atol=1e-6), k
+        dp2.single_collective()                           # what training.GraphedStep asks for: one collective per step
+        calls.clear()
+        dp2.zero_grad()
+        (torch.nn.functional.l1_loss(m2(batch), batch.y, reduction="sum") / 8.0).backward()
+        dp2.reduce_grads()
+        assert calls == [0]
+    finally:
+        dist.all_reduce = real_all_reduce
     if rank == 0:
         open(tmp, "w").write("ok %d" % dp.grad_bytes())
     ddp_cleanup()
