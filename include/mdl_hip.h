@@ -92,6 +92,10 @@ int mdl_segment_reduce_bwd(const void* grad_out, const int32_t* rowptr, const in
 size_t mdl_cgconv_wpack_bytes(int C, int G, int dtype);
 int mdl_cgconv_pack_weights(const float* w_f, const float* b_f, const float* w_s, const float* b_s, int C,
                             int G, void* wpack, float* bpack, int dtype, mdlStream_t stream);
+/* The same launch also writes the operand of the backward node kernel (mdl_cgconv_pack_node_weights: wn_t [C][4Cp] bf16), so a
+ * training step packs each layer's weights once (dtype MDL_BF16). */
+int mdl_cgconv_pack_weights_node(const float* w_f, const float* b_f, const float* w_s, const float* b_s, int C,
+                                 int G, void* wpack, float* bpack, void* wn_t, int dtype, mdlStream_t stream);
 
 /* x: [N, C]; edge_attr: [E, G] (leading dim G); out: [N, C]; all in `dtype`. */
 int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,

@@ -24,6 +24,7 @@ PROTOTYPES = {
     "mdl_segment_reduce_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
     "mdl_cgconv_wpack_bytes": (_sz, [_i32, _i32, _i32]),
     "mdl_cgconv_pack_weights": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "mdl_cgconv_pack_weights_node": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "mdl_cgconv_fwd": (_i32, [_vp] * 9 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_cgconv_bwd": (_i32, [_vp] * 13 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, ctypes.c_size_t, _vp]),
     "mdl_cgconv_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i32, _i32, _i32]),

@@ -1978,9 +1978,22 @@ template <typename T>
 __global__ __launch_bounds__(256) void cgconv_pack_kernel(const float* __restrict__ wf, const float* __restrict__ bfv,
                                                           const float* __restrict__ ws, const float* __restrict__ bsv,
                                                           int C, int G, CgDims d, T* __restrict__ wpack,
-                                                          float* __restrict__ bpack, float scale, int bias_col) {
+                                                          float* __restrict__ bpack, float scale, int bias_col,
+                                                          bf16_t* __restrict__ wn_t = nullptr) {
     const int total = 2 * d.Cp * d.WS;
     const int ldw = 2 * C + G;
+    if (wn_t) {
+        // (mdl_cgconv_pack_weights_node) the backward node kernel's operand in the same launch: wn_t [C][4Cp] = transpose of
+        // Wn = rows (f_tgt, s_tgt, f_src, s_src) of the two Linears' node columns, unscaled
+        const int tn = C * 4 * d.Cp;
+        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < tn; q += gridDim.x * blockDim.x) {
+            const int k = q / (4 * d.Cp), r = q - k * (4 * d.Cp);
+            const int blk = r / d.Cp, c = r - blk * d.Cp;
+            float v = 0.0f;
+            if (c < C) v = ((blk & 1) ? ws : wf)[c * ldw + (blk >> 1) * C + k];
+            wn_t[q] = f2bf(v);
+        }
+    }
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
         const int row = q / d.WS, k = q - row * d.WS;
         const int part = row / d.Cp, c = row - part * d.Cp;
@@ -2322,8 +2335,19 @@ extern "C" size_t mdl_cgconv_wpack_bytes(int C, int G, int dtype) {
     return (b + 15) & ~(size_t)15;
 }
 
+static int cg_pack_weights(const float* w_f, const float* b_f, const float* w_s, const float* b_s, int C, int G, void* wpack,
+                           float* bpack, void* wn_t, int dtype, mdlStream_t stream);
 extern "C" int mdl_cgconv_pack_weights(const float* w_f, const float* b_f, const float* w_s, const float* b_s, int C,
                                        int G, void* wpack, float* bpack, int dtype, mdlStream_t stream) {
+    return cg_pack_weights(w_f, b_f, w_s, b_s, C, G, wpack, bpack, nullptr, dtype, stream);
+}
+extern "C" int mdl_cgconv_pack_weights_node(const float* w_f, const float* b_f, const float* w_s, const float* b_s, int C,
+                                            int G, void* wpack, float* bpack, void* wn_t, int dtype, mdlStream_t stream) {
+    MDL_REQUIRE(wn_t && dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_cgconv_pack_weights_node: bf16 only, wn_t required");
+    return cg_pack_weights(w_f, b_f, w_s, b_s, C, G, wpack, bpack, wn_t, dtype, stream);
+}
+static int cg_pack_weights(const float* w_f, const float* b_f, const float* w_s, const float* b_s, int C, int G, void* wpack,
+                           float* bpack, void* wn_t, int dtype, mdlStream_t stream) {
     using namespace mdl;
     MDL_REQUIRE(w_f && w_s && wpack && bpack, MDL_E_ARG, "mdl_cgconv_pack_weights: null pointer");
     MDL_REQUIRE(C >= 1 && C <= 256 && G >= 1 && G <= 64, MDL_E_UNSUPP, "mdl_cgconv_pack_weights: unsupported C=%d G=%d", C, G);
@@ -2334,10 +2358,10 @@ extern "C" int mdl_cgconv_pack_weights(const float* w_f, const float* b_f, const
     const int bias_col = (G % 16) != 0;
     if (dtype == MDL_BF16)
         hipLaunchKernelGGL((cgconv_pack_kernel<bf16_t>), grid, block, 0, st, w_f, b_f, w_s, b_s, C, G, d, (bf16_t*)wpack, bpack,
-                           Gate<true>::W_SCALE, bias_col);
+                           Gate<true>::W_SCALE, bias_col, (bf16_t*)wn_t);
     else if (dtype == MDL_F32)
         hipLaunchKernelGGL((cgconv_pack_kernel<float>), grid, block, 0, st, w_f, b_f, w_s, b_s, C, G, d, (float*)wpack, bpack,
-                           Gate<false>::W_SCALE, bias_col);
+                           Gate<false>::W_SCALE, bias_col, (bf16_t*)nullptr);
     else {
         set_error("mdl_cgconv_pack_weights: unsupported dtype %d", dtype);
         return MDL_E_UNSUPP;

@@ -91,8 +91,6 @@ class GraphModel(nn.Module):
         params = [p for lin in lins for p in (lin.weight, lin.bias) if p is not None]
         if not params or not params[0].is_cuda or params[0].dtype == dtype:
             return
-        # zero-filled home of this step's dense weight gradients (ops._zeros_grad): one fill instead of one per layer
-        ops.new_grad_arena(params[0].device, sum(p.numel() + 128 for p in params))
         cache = getattr(self, "_lowp_cache", None)
         if cache is None or len(cache) != len(params) or cache[0].dtype != dtype or cache[0].device != params[0].device:
             cache = [torch.empty_like(p, dtype=dtype) for p in params]
@@ -107,7 +105,21 @@ class GraphModel(nn.Module):
                 b = cache[k]; k += 1
             lin._mdl_lowp = (w, b, lin.weight._version, None if lin.bias is None else lin.bias._version)
 
+    def _open_grad_arena(self, device):
+        """Zero-filled home of this step's dense weight gradients and BatchNorm backward sums (ops._zeros_grad): one fill
+        instead of one per layer.  Opened by EVERY forward that may be followed by a backward, whatever the compute dtype — a
+        stale one (left by another model or an earlier step) would hand out slices that already hold sums."""
+        n = getattr(self, "_arena_floats", None)
+        if n is None:
+            R = ops.bn_sums_rows()
+            n = sum(p.numel() + 128 for m in self.modules() if isinstance(m, nn.Linear) for p in (m.weight, m.bias) if p is not None)
+            n += sum(R * m.num_features + 128 for m in self.modules() if isinstance(m, (BatchNorm1d, nn.BatchNorm1d)))
+            object.__setattr__(self, "_arena_floats", n)
+        ops.new_grad_arena(device, n)
+
     def _pre(self, out):
+        if torch.is_grad_enabled() and out.is_cuda:
+            self._open_grad_arena(out.device)
         if out.dtype == torch.bfloat16 and torch.is_grad_enabled():
             self._cast_dense(out.dtype)
         for lin in self.pre_lin_list:

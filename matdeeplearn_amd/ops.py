@@ -552,8 +552,16 @@ class _CGConvFn(torch.autograd.Function):
             raise MdlError("cgconv: unsupported C=%d G=%d" % (C, G))
         wpack = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         bpack = torch.empty(2 * _rup(C, 32), dtype=torch.float32, device=x.device)
-        check(L.mdl_cgconv_pack_weights(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpack), ptr(bpack), dt,
-                                        stream()), "mdl_cgconv_pack_weights")
+        # a training step on the K3c shapes packs the backward node kernel's operand in the same launch
+        wn_t = None
+        if dt == _lib.MDL_BF16 and C in (32, 64) and any(ctx.needs_input_grad):
+            wn_t = torch.empty((C, 4 * C), dtype=torch.bfloat16, device=x.device)
+            check(L.mdl_cgconv_pack_weights_node(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpack), ptr(bpack),
+                                                 ptr(wn_t), dt, stream()), "mdl_cgconv_pack_weights_node")
+        else:
+            check(L.mdl_cgconv_pack_weights(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpack), ptr(bpack), dt,
+                                            stream()), "mdl_cgconv_pack_weights")
+        ctx.wn_t = wn_t
         out = torch.empty_like(x)
         edge_attr = csr.sorted_attr(edge_attr)          # CSR order: the kernels never go through eperm
         # opt-in (MDL_CG_SAVE_GATE=1): training forward on the static bf16 shapes also stores the gate factors (4C bytes
@@ -625,9 +633,11 @@ class _CGConvFn(torch.autograd.Function):
                 ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd")
         # node-level dense part: rows of Wn / dWn = (f_tgt, s_tgt, f_src, s_src)
         if node_hip:
-            wn_t = torch.empty((C, 4 * Cp), dtype=torch.bfloat16, device=x.device)                 # Wn^T
-            check(lib().mdl_cgconv_pack_node_weights(ptr(wf32), ptr(ws32), C, G, ptr(wn_t), dt, stream()),
-                  "mdl_cgconv_pack_node_weights")
+            wn_t, ctx.wn_t = getattr(ctx, "wn_t", None), None                                      # Wn^T (packed by the forward)
+            if wn_t is None:
+                wn_t = torch.empty((C, 4 * Cp), dtype=torch.bfloat16, device=x.device)
+                check(lib().mdl_cgconv_pack_node_weights(ptr(wf32), ptr(ws32), C, G, ptr(wn_t), dt, stream()),
+                      "mdl_cgconv_pack_node_weights")
             dx = torch.empty_like(x)
             node_fn = lib().mdl_cgconv_bwd_node_h if rs16 else lib().mdl_cgconv_bwd_node_z
             check(_launch_timed("bwd_node", lambda: node_fn(
@@ -1100,6 +1110,11 @@ class true_rows:
         return False
 
 
+def bn_sums_rows():
+    """rows of the BatchNorm kernels' sums buffer (replicas + totals)"""
+    return int(lib().mdl_bn_sums_rows())
+
+
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
@@ -1128,8 +1143,8 @@ class _BatchNormTrain(torch.autograd.Function):
         dy = dy.contiguous()
         dt = dtype_code(x)
         R = lib().mdl_bn_sums_rows()
-        sums = torch.zeros((R, C), dtype=torch.float32, device=x.device)     # (not from the step arena: its totals rows are
-        dx = torch.empty_like(x)                                              # returned as parameter gradients)
+        sums = _zeros_grad(R * C, x.device).view(R, C)                       # (the step's GRADIENT arena, never reused: the totals
+        dx = torch.empty_like(x)                                              # rows are returned as parameter gradients)
         nd = ctx.n_dev
         check(lib().mdl_bn_bwd_stats_n(ptr(dy), ptr(x), ptr(save), ptr(sums), N, C, ptr(nd), dt, stream()), "mdl_bn_bwd_stats")
         check(lib().mdl_bn_bwd_apply_n(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, ptr(nd), dt, stream()),

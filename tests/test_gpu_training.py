@@ -183,9 +183,11 @@ def test_graph_replayed_step_matches_the_eager_step():
         sd_e, sd_g = m_e.state_dict(), m_g.state_dict()
         for k in sd_e:
             a, b = sd_g[k].float(), sd_e[k].float()
-            # fp32: rounding only.  bf16: Adam divides by sqrt(v), so bf16 noise in a small gradient moves a parameter
-            # by a sizeable fraction of lr (0.002) per step: six steps -> an absolute bound of a few lr
-            bound = tol * (float(b.abs().max()) + 1e-3) * 5 if cd == "fp32" else 6 * 0.002
+            # fp32: rounding only.  bf16: Adam divides by sqrt(v), so for a gradient entry near zero the bf16 / atomic-order
+            # noise decides its SIGN and the two runs move that parameter by lr (0.002) in opposite directions: 2 lr per step
+            # is the worst case, six steps -> 12 lr (seen: up to 7.5 lr on single entries); the losses above and the fp32 leg
+            # are the tight checks
+            bound = tol * (float(b.abs().max()) + 1e-3) * 5 if cd == "fp32" else 12 * 0.002
             assert float((a - b).abs().max()) <= bound, (cd, k)
         assert int(sd_g["bn_list.0.num_batches_tracked"]) == int(sd_e["bn_list.0.num_batches_tracked"])
         # a batch that does not fit the static capacity takes the eager path with the same optimizer state
