@@ -147,7 +147,9 @@ struct CgParams {
     unsigned gw_inv;    // ceil(2^32 / GW)
     int n_groups;
     int g_full;         // bwd, dynamic scheduling: group ids < g_full are 32-node groups, the rest 16-node half groups (tail)
-    int w_elems;        // 2*Cp*WS
+    int w_elems;        // 2*Cp*WS (w_slice: 64*WS)
+    int w_slice;        // 1: the workgroup's LDS copy of W holds only the 64 rows of its channel slice (all its waves share the
+                        // slice) — wide layers whose packed weights do not fit 160 KB (C = 100: 168 KB) still read them from LDS
     int wave_lds_bytes; // per-wave LDS region
     int bias_col;       // 1: bias lives in K column G of wpack (e tile column G holds 1.0)
 };
@@ -441,7 +443,7 @@ __device__ __forceinline__ void pre_tile(const CgParams& p, const D& dm, const W
                                          const WRegs<T, NKW>& wr, f32x16& accf, f32x16& accs) {
     typedef Mma<T> M;
     const int i = lane & 31, h = lane >> 5;
-    const int rowf = s * 32 + i, rows = dm.Cp + s * 32 + i;
+    const int rowf = (p.w_slice ? 0 : s * 32) + i, rows = (p.w_slice ? 32 : dm.Cp + s * 32) + i;
     if constexpr (CP_ != 0 && (WM == 2 || WM == 3)) {
         // static shapes.  WM 2: all B fragments live in registers.  WM 3: the x-part of W lives in
         // registers, the e-part is read from the LDS copy (those reads depend on nothing and are
@@ -674,7 +676,18 @@ __device__ __forceinline__ void setup_wave(const CgParams& p, const D& dm, char*
     w.touched_b = reinterpret_cast<unsigned char*>(w.oh_w + 64 * OHS);
     w.dummy = reinterpret_cast<int*>(w.touched_b + 64);
     w.wbase = w_lds ? reinterpret_cast<const T*>(smem) : static_cast<const T*>(p.wpack);
-    if (w_lds) {
+    if (w_lds && p.w_slice) {
+        // rows [32 s, +32) of the f part and of the s part -> LDS rows [0, 32) and [32, 64)   (WS * sizeof(T) % 16 == 0)
+        const int sl = (int)blockIdx.x % p.NS;
+        const int row16 = dm.WS * (int)sizeof(T) / 16;
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.wpack);
+        f32x4* l = reinterpret_cast<f32x4*>(smem);
+        for (int q = threadIdx.x; q < 64 * row16; q += blockDim.x) {
+            const int r = q / row16, c = q - r * row16;
+            const int gr = (r < 32 ? 32 * sl + r : dm.Cp + 32 * sl + (r - 32));
+            l[q] = g[(int64_t)gr * row16 + c];
+        }
+    } else if (w_lds) {
         const f32x4* g = reinterpret_cast<const f32x4*>(p.wpack);
         f32x4* l = reinterpret_cast<f32x4*>(smem);
         const int n16 = w_bytes / 16;
@@ -809,8 +822,10 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int total_waves = gridDim.x * (blockDim.x >> 6);
-    const int s = gw % p.NS;
+    // channel slice of this wave and its index among the waves of that slice (w_slice: a workgroup's waves share the slice)
+    const int s = p.w_slice ? (int)blockIdx.x % p.NS : gw % p.NS;
     const int gstride = total_waves / p.NS;
+    const int gidx = p.w_slice ? ((int)blockIdx.x / p.NS) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6) : gw / p.NS;
     // with a bias column the bias rides in the GEMM (K column G); otherwise it seeds the accumulators
     constexpr bool BC = G_ != 0 && (G_ % 16) != 0;   // bias column known at compile time
     const float bf = (BC || p.bias_col) ? 0.0f : p.bpack[s * 32 + i];
@@ -824,7 +839,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
     const int ch = s * 32 + i;
 
 #if MDL_FWD_ALLSLICES
-    if constexpr (ST && WM == 1) {
+    if constexpr (ST && WM == 1 && CP_ <= 64) {     // (wider static shapes: one slice per wave, the workgroup keeps that slice of W in LDS)
         // One wave handles ALL channel slices of its group.  Staging the tile (edge-feature stream, index
         // loads, x gathers, one-hot table) is slice independent: doing it once per tile instead of once per
         // (tile, slice) removes the duplicated per-tile overhead; the pre-GEMM / gate / aggregation then
@@ -1064,7 +1079,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
     // the load pipeline never drains.  A group's epilogue (residual add, mean, store) needs no
     // dependent loads: the in-degree comes out of the one-hot MFMA (cnt) and the residual rows are
     // requested at the top of the group's last tile.
-    const NodeRange R(p, __builtin_amdgcn_readfirstlane(gw / p.NS), gstride, lane);
+    const NodeRange R(p, __builtin_amdgcn_readfirstlane(gidx), gstride, lane);
     if (R.na >= R.nb) return;
     GroupInfo G, GN;
     G.load(p, R.na, R.nb);
@@ -1245,8 +1260,10 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int total_waves = gridDim.x * (blockDim.x >> 6);
-    const int s = gw % p.NS;
+    // channel slice of this wave and its index among the waves of that slice (w_slice: a workgroup's waves share the slice)
+    const int s = p.w_slice ? (int)blockIdx.x % p.NS : gw % p.NS;
     const int gstride = total_waves / p.NS;
+    const int gidx = p.w_slice ? ((int)blockIdx.x / p.NS) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6) : gw / p.NS;
     const int ch = s * 32 + i;
     constexpr bool BC = G_ != 0 && (G_ % 16) != 0;
     const float bf = (BC || p.bias_col) ? 0.0f : p.bpack[ch], bs = (BC || p.bias_col) ? 0.0f : p.bpack[dm.Cp + ch];
@@ -1277,7 +1294,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
     // kernel ends with its slowest wave.  The next group id is requested at the top of the current group.
     const bool dyn = p.ctr != nullptr;
     NodeRange R{0, 0};
-    if (!dyn) R = NodeRange(p, __builtin_amdgcn_readfirstlane(gw / p.NS), gstride, lane);
+    if (!dyn) R = NodeRange(p, __builtin_amdgcn_readfirstlane(gidx), gstride, lane);
     const int nend = dyn ? (int)p.N : R.nb;
     int gpend = 0;                                   // lane 0: group id returned by the counter (in flight)
     if (dyn && lane == 0) gpend = (int)atomicAdd(p.ctr + s, 1u);
@@ -2064,6 +2081,8 @@ struct CgEnv {
     int cb_wgs;           // MDL_CB_WGS: their workgroups per CU (0 = default)
     int ab_wgs;           // MDL_AB_WGS: workgroups per CU of the saved-gate backward (0 = default 1)
     int no_half_groups;   // MDL_CG_NO_HALF=1: dynamic backward schedule without the half-group tail (A/B)
+    int no_fast128;       // MDL_CG_NO_FAST128=1: 128-channel layers take the generic kernels (A/B)
+    int no_w_slice;       // MDL_CG_NO_WSLICE=1: wide layers read the packed weights from global memory as before (A/B)
     int ep;               // MDL_CG_EP: edge-per-lane backward edge pass (cgconv_ep.inc); -1 = compile-time default
     int ep_wgs;           // MDL_EP_WGS: its grid cap (0 = one workgroup per CU)
 };
@@ -2077,6 +2096,8 @@ static const CgEnv& cg_env() {
         v.cb_wgs = (s = getenv("MDL_CB_WGS")) ? atoi(s) : 0;
         v.ab_wgs = (s = getenv("MDL_AB_WGS")) ? atoi(s) : 0;
         v.no_half_groups = (s = getenv("MDL_CG_NO_HALF")) ? (atoi(s) != 0) : 0;
+        v.no_w_slice = (s = getenv("MDL_CG_NO_WSLICE")) ? (atoi(s) != 0) : 0;
+        v.no_fast128 = (s = getenv("MDL_CG_NO_FAST128")) ? (atoi(s) != 0) : 0;
         v.ep = (s = getenv("MDL_CG_EP")) ? atoi(s) : -1;      // 0 off, 1 cgconv_ep.inc, 2 cgconv_ep2.inc
         v.ep_wgs = (s = getenv("MDL_EP_WGS")) ? atoi(s) : 0;
         return v;
@@ -2116,8 +2137,23 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     const bool fast = !p.eperm && p.G == 50 && p.C == d.Cp && (d.Cp == 32 || d.Cp == 64) &&
                       (sizeof(T) == 2 ? (vec == 8 && EW == 2) : d.Cp == 64) &&
                       (bwd || (reinterpret_cast<uintptr_t>(p.out) % 16 == 0 && reinterpret_cast<uintptr_t>(p.x) % 16 == 0));
-    const bool w_lds = (!fast || MDL_CG_WM != 2) && w_bytes + waves * p.wave_lds_bytes <= LDS_CAP;
-    const int lds = (w_lds ? w_bytes : 0) + waves * p.wave_lds_bytes;
+    // 128 channels (the reference's default width 100, padded by the caller): the same static code, one channel slice per
+    // wave, the workgroup's slice of W in LDS (w_slice below) — the whole W is 168 KB
+    const bool fast128 = sizeof(T) == 2 && !wsp && !p.ab && !p.eperm && p.G == 50 && p.C == 128 && d.Cp == 128 && vec == 8 && EW == 2 &&
+                         p.bias_col && reinterpret_cast<uintptr_t>(p.x) % 16 == 0 &&
+                         (bwd ? reinterpret_cast<uintptr_t>(p.gout) % 16 == 0 : reinterpret_cast<uintptr_t>(p.out) % 16 == 0) &&
+                         !cg_env().no_fast128;
+    bool w_lds = (!fast || MDL_CG_WM != 2) && w_bytes + waves * p.wave_lds_bytes <= LDS_CAP;
+    int lds = (w_lds ? w_bytes : 0) + waves * p.wave_lds_bytes;
+    // packed weights that do not fit (C = 100 -> Cp = 128: 168 KB): every workgroup keeps the 64 rows of ONE channel slice
+    p.w_slice = 0;
+    if (!w_lds && !fast && !wsp && d.NS > 1 && (d.WS * (int)sizeof(T)) % 16 == 0 &&
+        64 * d.WS * (int)sizeof(T) + waves * p.wave_lds_bytes <= LDS_CAP && !cg_env().no_w_slice) {
+        p.w_slice = 1;
+        p.w_elems = 64 * d.WS;
+        w_lds = true;
+        lds = 64 * d.WS * (int)sizeof(T) + waves * p.wave_lds_bytes;
+    }
     const int wg_per_cu = lds * 2 <= LDS_CAP ? 2 : 1;
 
     const bool all_slices = !bwd && fast && MDL_FWD_ALLSLICES && MDL_CG_WM == 1 && (sizeof(T) == 2 || w_lds);
@@ -2141,8 +2177,9 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
             if (ep_sel == 1 && !p.rs16) return ep::launch(p, st, env.ep_wgs, name);
         }
     }
-    // total waves must be a multiple of NS so that every wave keeps one channel slice
+    // total waves must be a multiple of NS so that every wave keeps one channel slice (w_slice: whole workgroups)
     while ((grid * waves) % d.NS) ++grid;
+    if (p.w_slice) while (grid % d.NS) ++grid;
     // dynamic group scheduling only pays when every wave gets several 32-node groups
     p.g_full = p.n_groups;
     if (bwd && p.ctr) {
@@ -2257,6 +2294,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     if constexpr (sizeof(T) == 2) {
         if (fast && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 2, MDL_CG_WM);
         else if (fast && d.Cp == 32) MDL_CG_LAUNCH(32, 50, 9, 2, MDL_CG_WM);
+        else if (fast128 && p.w_slice) MDL_CG_LAUNCH(128, 50, 9, 2, 1);
         else if (vec == 8) MDL_CG_BY_EW(8);
         else if (vec == 4) MDL_CG_BY_EW(4);
         else MDL_CG_BY_EW(1);

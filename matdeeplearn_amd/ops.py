@@ -482,6 +482,7 @@ _WSPLIT = os.environ.get("MDL_CG_WSPLIT", "0") == "1"
 
 # By-source sums of the CGConv backward in bf16, accumulated with packed bf16 atomics (mdl_cgconv_bwd_h / mdl_cgconv_bwd_node_h;
 # bf16 mode, C in {32, 64}, G = 50): half the atomic operations and bytes of the fp32 buffer.  MDL_CG_RSRC16=0 restores fp32.
+_PAD128 = os.environ.get("MDL_CG_PAD128", "1") != "0"      # C in (96, 128): static 128-channel kernels on zero-padded rows
 _RSRC16 = os.environ.get("MDL_CG_RSRC16", "1") == "1"
 
 
@@ -550,6 +551,13 @@ class _CGConvFn(torch.autograd.Function):
         nbytes = L.mdl_cgconv_wpack_bytes(C, G, dt)
         if nbytes == 0:
             raise MdlError("cgconv: unsupported C=%d G=%d" % (C, G))
+        # widths between 97 and 127 (the reference's default dim1 = 100, config.yml:123) run the static 128-channel kernels on
+        # zero-padded rows: the packed weights already have that layout (rows / K columns past C are zeros), so the padded
+        # output columns hold the constant sigmoid(0) * softplus(0) and are cut off again; their gradients are zeros
+        Ck = C
+        if _PAD128 and dt == _lib.MDL_BF16 and G == 50 and 96 < C < 128 and csr.eperm is None and E > 0:
+            Ck = 128
+            x = torch.nn.functional.pad(x, (0, Ck - C))
         wpack = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         bpack = torch.empty(2 * _rup(C, 32), dtype=torch.float32, device=x.device)
         # a training step on the K3c shapes packs the backward node kernel's operand in the same launch
@@ -576,22 +584,28 @@ class _CGConvFn(torch.autograd.Function):
         else:
             check(_launch_timed("fwd", lambda: L.mdl_cgconv_fwd(
                 ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
-                ptr(bpack), ptr(out), N, E, C, G, aggr, dt, stream())), "mdl_cgconv_fwd")
+                ptr(bpack), ptr(out), N, E, Ck, G, aggr, dt, stream())), "mdl_cgconv_fwd")
         ctx.gate = gate
         ctx.save_for_backward(x, edge_attr, wf32, ws32, wpack, bpack)
         ctx.csr, ctx.aggr, ctx.has_bias = csr, aggr, (b_f is not None, b_s is not None)
         ctx.wdtypes = (w_f.dtype, w_s.dtype)
-        return out
+        ctx.C = C
+        return out if Ck == C else out[:, :C].contiguous()
 
     @staticmethod
     def backward(ctx, g):
         x, edge_attr, wf32, ws32, wpack, bpack = ctx.saved_tensors
         csr = ctx.csr
-        N, C = x.shape
+        N, Ck = x.shape                                   # Ck: the width the kernels ran at (128 for a padded layer)
+        C = getattr(ctx, "C", Ck)
         E, G = edge_attr.shape
         Cp, GP = _rup(C, 32), _rup(G, 64)
         g = g.contiguous()
         dt = dtype_code(x)
+        xk, gk = x, g
+        if Ck != C:
+            gk = torch.nn.functional.pad(g, (0, Ck - C))
+            x = x[:, :C]                                  # (the node-level part below works on the true width)
         r_tgt = torch.empty((N, 2 * Cp), dtype=x.dtype, device=x.device)          # by-target sums, compute dtype
         node_hip = dt == _lib.MDL_BF16 and C == Cp and C in (32, 64)          # K3c consumes r_tgt / r_src
         rs16 = (_RSRC16 and node_hip and G == 50 and ctx.gate is None and ctx.wsplit is None and E > 0
@@ -628,8 +642,8 @@ class _CGConvFn(torch.autograd.Function):
                 "mdl_cgconv_bwd_h")
         else:
             check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd(
-                ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
-                ptr(bpack), ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt,
+                ptr(xk), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
+                ptr(bpack), ptr(gk), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, Ck, G, ctx.aggr, dt,
                 ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd")
         # node-level dense part: rows of Wn / dWn = (f_tgt, s_tgt, f_src, s_src)
         if node_hip:

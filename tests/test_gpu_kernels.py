@@ -131,7 +131,7 @@ def _cgconv_case(n, C, G, dtype, sort, seed, aggr="mean", empty_frac=0.1, window
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("n,C,G,sort", [(200, 64, 50, True), (200, 64, 50, False), (77, 32, 50, True),
-                                         (130, 100, 50, False), (65, 128, 50, True), (50, 64, 41, True),
+                                         (130, 100, 50, False), (65, 128, 50, True), (900, 100, 50, True), (50, 64, 41, True),
                                          (33, 20, 7, False), (1, 64, 50, True)])
 def test_cgconv_matches_oracle(dtype, n, C, G, sort):
     _cgconv_case(n, C, G, dtype, sort, seed=n + C + G)
