@@ -474,11 +474,14 @@ def other_models(args):
     down): {model: {ms_per_step, value [edges/s], edges_per_step, roofline kernel + frac, val_mae_delta_bf16, ...}}."""
     import subprocess
     out = {}
-    for name in ("schnet", "megnet", "gcn", "mpnn"):
-        B = WORKLOADS[name][3]
-        cmd = [sys.executable, os.path.abspath(__file__), "--model", name, "--steps", "6", "--warmup", "2", "--settle-s", "0.3",
+    # cgcnn_dim100: the headline model at the reference's DEFAULT width (config.yml:123 dim1 = 100; the CGCNN member of cfg1 /
+    # cfg5) on the headline batch — static 128-channel kernels on zero-padded rows
+    for name in ("schnet", "megnet", "gcn", "mpnn", "cgcnn_dim100"):
+        model, extra = (("cgcnn", ["--dim", "100"]) if name == "cgcnn_dim100" else (name, []))
+        B = WORKLOADS[model][3]
+        cmd = [sys.executable, os.path.abspath(__file__), "--model", model, "--steps", "6", "--warmup", "2", "--settle-s", "0.3",
                "--no-extras", "--graphs", str(int(B * 1.25 / 0.8) + 64), "--cpu-steps", "0", "--dataset-cache", args.dataset_cache,
-               "--seed", str(args.seed)]
+               "--seed", str(args.seed), "--no-other-models"] + extra
         t0 = time.time()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)

@@ -666,6 +666,30 @@ class _CGConvFn(torch.autograd.Function):
             check(lib().mdl_cgconv_assemble_grads(ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s),
                                                   stream()), "mdl_cgconv_assemble_grads")
             return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None
+        if dt == _lib.MDL_BF16 and Cp == 128 and C % 2 == 0 and N > 0:
+            # wide layers (C = 100 / 128): the same products on the streaming kernels.  r_tgt / r_src keep their padded
+            # [N, 2 Cp] layout (padded columns are exact zeros), so  dx = g + r_tgt Wn_t + r_src Wn_s  is two library GEMMs on
+            # zero-padded weights (no gather / cat of the four column blocks) and  dWn = [r_tgt | r_src]^T x  four TN-GEMM
+            # launches (128 rows each) into the [4 Cp, C] layout mdl_cgconv_assemble_grads reads — the library's
+            # (4C x N)(N x C) form of that contraction ran 531 us per layer on a 64x64x256 macro tile
+            rs_b = r_src.to(torch.bfloat16)
+            wt = torch.zeros((2 * Cp, C), dtype=torch.float32, device=x.device)
+            wsrc = torch.zeros_like(wt)
+            wt[:C], wt[Cp:Cp + C] = wf32[:, :C], ws32[:, :C]
+            wsrc[:C], wsrc[Cp:Cp + C] = wf32[:, C:2 * C], ws32[:, C:2 * C]
+            dx = torch.addmm(g, r_tgt, wt.to(torch.bfloat16))
+            dx.addmm_(rs_b, wsrc.to(torch.bfloat16))
+            xc = x.contiguous()
+            for blk, r in enumerate((r_tgt[:, :Cp], r_tgt[:, Cp:], rs_b[:, :Cp], rs_b[:, Cp:])):
+                check(lib().mdl_gemm_tn(ptr(r), r.stride(0), Cp, ptr(xc), xc.stride(0), C, ptr(dwn[blk * Cp:(blk + 1) * Cp]), N,
+                                        dt, stream()), "mdl_gemm_tn")
+            dW_f = torch.empty((C, 2 * C + G), dtype=torch.float32, device=x.device)
+            dW_s = torch.empty_like(dW_f)
+            db_f = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[0] else None
+            db_s = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[1] else None
+            check(lib().mdl_cgconv_assemble_grads(ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s),
+                                                  stream()), "mdl_cgconv_assemble_grads")
+            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None
         Wn = torch.cat([wf32[:, :C], ws32[:, :C], wf32[:, C:2 * C], ws32[:, C:2 * C]], dim=0)      # [4C, C]
         rt = r_tgt.view(N, 2, Cp)[:, :, :C]                                                        # library GEMMs
         rs = r_src.view(N, 2, Cp)[:, :, :C]
