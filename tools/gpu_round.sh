@@ -16,5 +16,10 @@ for m in cgcnn schnet megnet; do
   grep -h '^{"metric"' $OUT/prof_$m.log > $OUT/bench_${m}_under_rocprof.json
   rm -rf $OUT/prof_$m
 done
+# the headline model at the reference's default width (config.yml:123): static 128-channel kernels on padded rows
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_dim100 -o t -- python $GRAFT_REPO_ROOT/bench.py --dim 100 --no-cpu-baseline --no-extras --no-other-models > $OUT/prof_dim100.log 2>&1
+f=$(find $OUT/prof_dim100 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -45 "$f" > $OUT/kernel_stats_cgcnn_dim100.csv
+grep -h '^{"metric"' $OUT/prof_dim100.log > $OUT/bench_cgcnn_dim100_under_rocprof.json
+rm -rf $OUT/prof_dim100
 head -6 $OUT/kernel_stats_cgcnn.csv | cut -c1-140
 cd $GRAFT_REPO_ROOT && PMC_ONLY=traffic bash tools/gpu_pmc.sh $TAG/pmc > $OUT/pmc.log 2>&1; cat $OUT/pmc/hbm_traffic.json 2>/dev/null | head -30
