@@ -338,6 +338,14 @@ int mdl_gather_rows(const void* src, const int32_t* idx, void* out, int64_t E, i
 int mdl_gather_mul_reduce(const void* h, const void* w, const float* scale, const int32_t* rowptr,
                           const int32_t* col, const int32_t* eid, void* out, int64_t N, int64_t F, int reduce,
                           int dtype, mdlStream_t stream);
+/* Backward of mdl_gather_mul_reduce (reduce = sum) in ONE walk over the transposed CSR (rowptr_s / col_s = target of the
+ * slot / eid_s = edge id of the slot): dh[j,:] = sum_{k: src_k = j} g[tgt_k,:] * w[k,:] * scale[k] and, from the same operands,
+ * dw[k,:] = g[tgt_k,:] * h[src_k,:] * scale[k] (the filter gradient of CFConv, schnet.py:134-143) — replaces the pair
+ * mdl_gather_mul_reduce(transposed) + mdl_edge_mul.  bf16, even F <= 512.  Rows of dw whose edge belongs to no by-source
+ * segment (unused slots of a padded static batch) are not written. */
+int mdl_gather_mul_reduce_dw(const void* g, const void* w, const float* scale, const int32_t* rowptr_s,
+                             const int32_t* col_s, const int32_t* eid_s, void* dh, const void* h, void* dw,
+                             int64_t N, int64_t F, int dtype, mdlStream_t stream);
 /* out[e, :] = a[ia[e], :] * b[ib[e], :] * scale[e]   (gradient w.r.t. the per-edge filter w) */
 int mdl_edge_mul(const void* a, const int32_t* ia, const void* b, const int32_t* ib, const float* scale, void* out,
                  int64_t E, int64_t F, int dtype, mdlStream_t stream);

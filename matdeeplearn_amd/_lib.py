@@ -66,6 +66,7 @@ PROTOTYPES = {
     "mdl_gemm_tn_act": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "mdl_gather_rows": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "mdl_gather_mul_reduce": (_i32, [_vp] * 7 + [_i64, _i64, _i32, _i32, _vp]),
+    "mdl_gather_mul_reduce_dw": (_i32, [_vp] * 9 + [_i64, _i64, _i32, _vp]),
     "mdl_edge_mul": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _vp]),
 }
 

@@ -443,7 +443,8 @@ __device__ __forceinline__ void pre_tile(const CgParams& p, const D& dm, const W
                                          const WRegs<T, NKW>& wr, f32x16& accf, f32x16& accs) {
     typedef Mma<T> M;
     const int i = lane & 31, h = lane >> 5;
-    const int rowf = (p.w_slice ? 0 : s * 32) + i, rows = (p.w_slice ? 32 : dm.Cp + s * 32) + i;
+    const bool wsl = (CP_ == 0 || CP_ > 64) && p.w_slice;    // (never for the static shapes whose W fits LDS: folds away there)
+    const int rowf = (wsl ? 0 : s * 32) + i, rows = (wsl ? 32 : dm.Cp + s * 32) + i;
     if constexpr (CP_ != 0 && (WM == 2 || WM == 3)) {
         // static shapes.  WM 2: all B fragments live in registers.  WM 3: the x-part of W lives in
         // registers, the e-part is read from the LDS copy (those reads depend on nothing and are
@@ -823,9 +824,10 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int total_waves = gridDim.x * (blockDim.x >> 6);
     // channel slice of this wave and its index among the waves of that slice (w_slice: a workgroup's waves share the slice)
-    const int s = p.w_slice ? (int)blockIdx.x % p.NS : gw % p.NS;
+    const bool wsl = (CP_ == 0 || CP_ > 64) && p.w_slice;
+    const int s = wsl ? (int)blockIdx.x % p.NS : gw % p.NS;
     const int gstride = total_waves / p.NS;
-    const int gidx = p.w_slice ? ((int)blockIdx.x / p.NS) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6) : gw / p.NS;
+    const int gidx = wsl ? ((int)blockIdx.x / p.NS) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6) : gw / p.NS;
     // with a bias column the bias rides in the GEMM (K column G); otherwise it seeds the accumulators
     constexpr bool BC = G_ != 0 && (G_ % 16) != 0;   // bias column known at compile time
     const float bf = (BC || p.bias_col) ? 0.0f : p.bpack[s * 32 + i];
@@ -1261,9 +1263,10 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int total_waves = gridDim.x * (blockDim.x >> 6);
     // channel slice of this wave and its index among the waves of that slice (w_slice: a workgroup's waves share the slice)
-    const int s = p.w_slice ? (int)blockIdx.x % p.NS : gw % p.NS;
+    const bool wsl = (CP_ == 0 || CP_ > 64) && p.w_slice;
+    const int s = wsl ? (int)blockIdx.x % p.NS : gw % p.NS;
     const int gstride = total_waves / p.NS;
-    const int gidx = p.w_slice ? ((int)blockIdx.x / p.NS) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6) : gw / p.NS;
+    const int gidx = wsl ? ((int)blockIdx.x / p.NS) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6) : gw / p.NS;
     const int ch = s * 32 + i;
     constexpr bool BC = G_ != 0 && (G_ % 16) != 0;
     const float bf = (BC || p.bias_col) ? 0.0f : p.bpack[ch], bs = (BC || p.bias_col) ? 0.0f : p.bpack[dm.Cp + ch];
@@ -2289,7 +2292,10 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
         }
     }
 #ifdef MDL_CG_FAST_ONLY   // compile-time experiments: only the bf16 C=64 G=50 instantiation
-    if constexpr (sizeof(T) == 2) { if (fast && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 2, MDL_CG_WM); }
+    if constexpr (sizeof(T) == 2) {
+        if (fast && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 2, MDL_CG_WM);
+        else if (fast128 && p.w_slice) MDL_CG_LAUNCH(128, 50, 9, 2, 1);
+    }
 #else
     if constexpr (sizeof(T) == 2) {
         if (fast && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 2, MDL_CG_WM);

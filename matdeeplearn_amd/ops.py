@@ -482,6 +482,7 @@ _WSPLIT = os.environ.get("MDL_CG_WSPLIT", "0") == "1"
 
 # By-source sums of the CGConv backward in bf16, accumulated with packed bf16 atomics (mdl_cgconv_bwd_h / mdl_cgconv_bwd_node_h;
 # bf16 mode, C in {32, 64}, G = 50): half the atomic operations and bytes of the fp32 buffer.  MDL_CG_RSRC16=0 restores fp32.
+_GMR_DW = os.environ.get("MDL_GMR_DW", "1") != "0"          # CFConv backward: dh and dw from one walk over the by-source CSR
 _PAD128 = os.environ.get("MDL_CG_PAD128", "1") != "0"      # C in (96, 128): static 128-channel kernels on zero-padded rows
 _RSRC16 = os.environ.get("MDL_CG_RSRC16", "1") == "1"
 
@@ -772,6 +773,16 @@ class _GatherMulReduce(torch.autograd.Function):
             deg = (csr.rowptr[1:] - csr.rowptr[:-1]).clamp(min=1).to(g.dtype)
             g = g / deg.unsqueeze(1)
         dh = dw = None
+        if (w is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _GMR_DW and h.dtype == torch.bfloat16
+                and h.shape[1] % 2 == 0 and h.shape[1] <= 512 and scale is not None):
+            # one walk over the by-source CSR gives both gradients (no mdl_edge_mul pass)
+            rowptr_s, col_s, eid_s, _ = csr.transposed()
+            dh = torch.empty_like(h)
+            # (unused edge slots of a padded static batch belong to no by-source segment: their dw rows must read as zeros)
+            dw = (torch.zeros_like if _true_rows_for(w.shape[0]) is not None else torch.empty_like)(w)
+            check(lib().mdl_gather_mul_reduce_dw(ptr(g), ptr(w), ptr(scale), ptr(rowptr_s), ptr(col_s), ptr(eid_s), ptr(dh), ptr(h),
+                                                 ptr(dw), csr.N, h.shape[1], dtype_code(h), stream()), "mdl_gather_mul_reduce_dw")
+            return dh, dw, None, None, None
         if ctx.needs_input_grad[0]:
             rowptr_s, col_s, eid_s, _ = csr.transposed()
             dh = torch.empty_like(h)

@@ -492,6 +492,10 @@ def test_conv_kernels_register_budget():
     assert scratch == 0 and occ == 1
     scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb0ELi0E")      # all-slices forward
     assert scratch == 0 and occ == 2
+    scratch, occ = find("cgconv_fwd_kernelItLi128ELi50ELi9ELi2ELi1ELb0ELi0E")     # 128-channel forward (padded C = 100): one
+    assert scratch == 0 and occ == 2                                              # slice per wave
+    scratch, occ = find("cgconv_bwd_kernelItLi128ELi50ELi9ELi2ELi1ELi0E")         # 128-channel backward: a few loop-invariant
+    assert scratch <= 64 and occ == 1                                             # dwords spill
     scratch, occ = find("cgconv_bwd_kernelItLi64ELi50ELi9ELi2ELi1ELi1E")          # opt-in W-split backward
     assert scratch == 0 and occ == 1
     scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb0ELi1E")      # opt-in W-split forward: a few dwords of
