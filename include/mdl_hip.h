@@ -304,6 +304,13 @@ int mdl_linear_act(const void* x, const void* w, const void* bias, void* out, in
 int mdl_linear_act_in(const void* x, const void* y, int xact, const void* w, const void* bias, void* out, int64_t N, int K,
                       int M, int act, int dtype, mdlStream_t stream);
 
+/* Two chained dense layers in one pass: h[N, M1] = act1(x[N, K] w1[M1, K]^T + b1), y[N, M2] = act2(h w2[M2, M1]^T + b2); both
+ * results are written (the backward of the pair needs h), the rows of h reach the second product through LDS.  The filter
+ * network of CFConv — Linear(num_gaussians, F) -> ShiftedSoftplus -> Linear(F, F) over the edges (matdeeplearn/models/
+ * schnet.py:81 via torch_geometric.nn.models.schnet.InteractionBlock.mlp).  bf16; even K <= 64, even M1 <= 160, M2 <= 160. */
+int mdl_mlp2(const void* x, const void* w1, const void* b1, int act1, const void* w2, const void* b2, int act2, void* h,
+             void* y, int64_t N, int K, int M1, int M2, int dtype, mdlStream_t stream);
+
 /* ---- tall-skinny TN GEMM: weight gradients of node-level Linear layers ---------------------------
  * c[M, K] (fp32, row-major, caller zero-fills) += a[N, M]^T . b[N, K]   a, b bf16 with leading dims lda, ldb.
  * Replaces the (out x N)(N x in) product autograd forms for dW of the reference's node-level Linears

@@ -970,19 +970,37 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
     return dx, dw.to(ctx.wdtype), db
 
 
+_MLP2_NEXT = {}        # (input ptr, weight ptr, act) -> output of a dense layer already computed by the previous layer's launch
+_MLP2 = os.environ.get("MDL_MLP2", "0") == "1"       # opt-in: measured slower than the two streaming layers
+
+
 class _LinearActTN(torch.autograd.Function):
     """act(x W^T + b) with the forward as ONE streaming HIP kernel (GEMM + bias + activation) and the backward of
     _LinearTN (library dX, TN GEMM for dW and db); the ReLU mask comes from the saved output."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w_lp, b_lp, act):
+    def forward(ctx, x, weight, bias, w_lp, b_lp, act, nxt=None):
         w = weight.to(x.dtype) if w_lp is None else w_lp
         b = None if bias is None else (bias.to(x.dtype) if b_lp is None else b_lp)
         N, K = x.shape
         M = weight.shape[0]
         out = torch.empty((N, M), dtype=x.dtype, device=x.device)
-        check(lib().mdl_linear_act(ptr(x), ptr(w), ptr(b), ptr(out), N, K, M, {"relu": 1, "ssp": 2}.get(act, 0), dtype_code(x),
-                                   stream()), "mdl_linear_act")
+        pre = _MLP2_NEXT.pop((x.data_ptr(), w.data_ptr(), act), None) if _MLP2_NEXT else None
+        if pre is not None and tuple(pre[0].shape) == (N, M) and pre[1].shape == x.shape:
+            out = pre[0]                                   # computed by the previous layer's launch (mdl_mlp2)
+        elif nxt is not None:
+            # the NEXT dense layer of the chain in the same launch (mdl_mlp2): its output waits in _MLP2_NEXT for that layer's
+            # own autograd Function, which then launches nothing — both keep their backward passes
+            w2, b2, act2 = nxt
+            y2 = torch.empty((N, w2.shape[0]), dtype=x.dtype, device=x.device)
+            codes = {"relu": 1, "ssp": 2}
+            check(lib().mdl_mlp2(ptr(x), ptr(w), ptr(b), codes.get(act, 0), ptr(w2), ptr(b2), codes.get(act2, 0), ptr(out), ptr(y2),
+                                 N, K, M, w2.shape[0], dtype_code(x), stream()), "mdl_mlp2")
+            _MLP2_NEXT.clear()
+            _MLP2_NEXT[(out.data_ptr(), w2.data_ptr(), act2)] = (y2, out)     # (holds `out`: its memory cannot be reused meanwhile)
+        else:
+            check(lib().mdl_linear_act(ptr(x), ptr(w), ptr(b), ptr(out), N, K, M, {"relu": 1, "ssp": 2}.get(act, 0), dtype_code(x),
+                                       stream()), "mdl_linear_act")
         ctx.save_for_backward(x, w, out if act in ("relu", "ssp") else None)
         ctx.wdtype, ctx.has_bias, ctx.shape, ctx.act = weight.dtype, bias is not None, tuple(weight.shape), act
         return out
@@ -991,7 +1009,7 @@ class _LinearActTN(torch.autograd.Function):
     def backward(ctx, g):
         x, w, out = ctx.saved_tensors
         if ctx.act in ("relu", "ssp") and _tn_act_ok(ctx, g, x, out, w):
-            return _linear_tn_grads(ctx, g, x, w, act_y=(1 if ctx.act == "relu" else 2, out)) + (None, None, None)
+            return _linear_tn_grads(ctx, g, x, w, act_y=(1 if ctx.act == "relu" else 2, out)) + (None, None, None, None)
         if ctx.act == "relu":
             g = torch.ops.aten.threshold_backward(g, out, 0)
         elif ctx.act == "ssp":                     # d/dv (softplus(v) - ln2) = sigmoid(v) = 1 - exp(-(out + ln2))
@@ -1000,7 +1018,7 @@ class _LinearActTN(torch.autograd.Function):
             check(lib().mdl_ssp_bwd(ptr(g), ptr(out), ptr(dpre), g.numel(), dtype_code(g), stream()), "mdl_ssp_bwd")
             g = dpre
         dx, dw, db = _linear_tn_grads(ctx, g.contiguous(), x, w)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _LinearGatherAct(torch.autograd.Function):
@@ -1053,7 +1071,7 @@ def linear_gather_act(x, weight, bias, act, gathered):
     return _LinearGatherAct.apply(x, weight, bias, act, idx, *[t.to(x.dtype) for t, _ in gathered])
 
 
-def linear_act(x, weight, bias, act, lowp=None):
+def linear_act(x, weight, bias, act, lowp=None, nxt=None):
     """getattr(F, act)(F.linear(x, weight, bias)) — fused forward for bf16 inputs with dense rows, even in <= 256,
     out <= 128 and act in (relu, none); anything else composes `linear` with the library activation."""
     # (ssp: the one-pass softplus backward works on element PAIRS — an odd width would reach it with an odd element count)
@@ -1062,6 +1080,14 @@ def linear_act(x, weight, bias, act, lowp=None):
             and (act != "ssp" or weight.shape[0] % 2 == 0)
             and x.data_ptr() % 16 == 0 and weight.requires_grad):
         w_lp, b_lp = (lowp if lowp is not None and lowp[0].dtype == x.dtype else (None, None))
+        # nxt = (weight2, bias2, act2, lowp2): the following dense layer of a chain; both layers in one launch (mdl_mlp2) when
+        # the shapes fit — the caller still applies the second layer, whose Function then finds its output ready
+        if (nxt is not None and _MLP2 and weight.shape[1] <= 64 and weight.shape[0] % 2 == 0 and weight.shape[0] <= 160
+                and nxt[0].shape[0] <= 160 and nxt[0].shape[1] == weight.shape[0] and nxt[2] in ("relu", "ssp", None)
+                and (nxt[2] != "ssp" or nxt[0].shape[0] % 2 == 0) and nxt[0].requires_grad
+                and _hip_shape_ok(nxt[0].shape[0], nxt[0].shape[1]) and nxt[3] is not None and nxt[3][0].dtype == x.dtype
+                and (nxt[1] is None) == (nxt[3][1] is None)):
+            return _LinearActTN.apply(x, weight, bias, w_lp, b_lp, act, (nxt[3][0], nxt[3][1], nxt[2]))
         return _LinearActTN.apply(x, weight, bias, w_lp, b_lp, act)
     y = linear(x, weight, bias, lowp)
     if act is None:
