@@ -132,6 +132,16 @@ int mdl_cgconv_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr
                      const void* wpack, const float* bpack, const void* grad_out, void* r_tgt, void* r_src, float* dwe,
                      float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
                      mdlStream_t stream);
+/* Work balance of the edge-per-lane backward: cost[0] = 0, cost[n + 1] = cost of node n in quarter units (4 per edge and node,
+ * + 3 per edge whose source is 48 or more rows away from its target).  The caller turns it into an inclusive prefix sum
+ * (int32, [N + 1]) and hands it to mdl_cgconv_bwd_hb, whose workgroups then take node ranges of equal COST instead of equal
+ * edge + node counts (graphs wider than the by-source window make their tiles dearer; topology only: one prefix per batch
+ * serves every layer).  NULL balance = mdl_cgconv_bwd_h. */
+int mdl_cgconv_balance(const int32_t* rowptr, const int32_t* src, int64_t N, int32_t* cost, mdlStream_t stream);
+int mdl_cgconv_bwd_hb(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src, const int32_t* tgt,
+                      const void* wpack, const float* bpack, const void* grad_out, void* r_tgt, void* r_src, float* dwe,
+                      float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
+                      const int32_t* balance, mdlStream_t stream);
 int mdl_cgconv_bwd_node_h(const void* x, const void* grad_out, const void* r_tgt, void* r_src, const void* wn_t, void* dx,
                           float* dwn, int64_t N, int C, int dtype, int zero_src, mdlStream_t stream);
 

@@ -30,6 +30,8 @@ PROTOTYPES = {
     "mdl_cgconv_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i32, _i32, _i32]),
     "mdl_cgconv_gate_row_bytes": (_sz, [_i32, _i32, _i32]),
     "mdl_cgconv_bwd_h": (_i32, [_vp] * 12 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "mdl_cgconv_bwd_hb": (_i32, [_vp] * 12 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp, _vp]),
+    "mdl_cgconv_balance": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "mdl_cgconv_bwd_node_h": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "mdl_cgconv_wsplit_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "mdl_cgconv_pack_weights_split": (_i32, [_vp] * 4 + [_i32, _i32, _vp, _vp, _vp, _i32, _vp]),

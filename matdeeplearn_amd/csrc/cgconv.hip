@@ -138,6 +138,8 @@ struct CgParams {
     unsigned* ctr;      // bwd, optional: NS zeroed work counters (caller workspace) -> dynamic group scheduling
     void* ab;           // saved gate factors [E][Cp][2] bf16 (A | B per channel): written by the training forward, read by
                         // the saved-gate backward (cgconv_bwd_ab_kernel)
+    const int32_t* balance;   // bwd, optional: [N + 1] non-decreasing cost prefix the workgroups' node ranges are balanced on
+                              // (mdl_cgconv_balance); null: edges + nodes in front of a node
     int rs16;           // bwd, bf16: r_src is a bf16 array accumulated with packed bf16 atomics (mdl_cgconv_bwd_h)
     const void* pt;     // W-split kernels: per-node projections P_t = x [W_f,tgt ; W_s,tgt]^T and P_s = x [W_f,src ; W_s,src]^T,
     const void* ps;     // [N, 2Cp] each in the compute dtype (columns f | s), scaled like the packed weights
@@ -774,6 +776,21 @@ __device__ __forceinline__ int wave_lower_bound(const int32_t* __restrict__ rowp
         const int n = min(lo + lane * step, hi);
         const unsigned long long ge = __ballot((int64_t)rowptr[n] + n >= b);   // monotone in lane
         if (ge == 0ull) { lo = min(lo + 63 * step, hi) + 1; continue; }   // all probes below b
+        const int fl = __builtin_ctzll(ge);
+        if (fl == 0) { hi = lo; break; }
+        hi = min(lo + fl * step, hi);
+        lo = lo + (fl - 1) * step + 1;
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
+}
+// the same search on an explicit non-decreasing key array key[0..N]
+__device__ __forceinline__ int wave_lower_bound_key(const int32_t* __restrict__ key, int N, int64_t b, int lane) {
+    int lo = 0, hi = N;
+    while (lo < hi) {
+        const int step = (hi - lo + 63) >> 6;
+        const int n = min(lo + lane * step, hi);
+        const unsigned long long ge = __ballot((int64_t)key[n] >= b);
+        if (ge == 0ull) { lo = min(lo + 63 * step, hi) + 1; continue; }
         const int fl = __builtin_ctzll(ge);
         if (fl == 0) { hi = lo; break; }
         hi = min(lo + fl * step, hi);
@@ -1956,12 +1973,19 @@ __global__ __launch_bounds__(256, 1) void cgconv_bwd_ab_kernel(CgParams p) {
 #include "cgconv_ep.inc"
 #include "cgconv_ep2.inc"
 namespace ep {
+static bool cg_env_ep2_static() {          // MDL_EP2_STATIC=1: kernel 2 without the dynamic tail (A/B)
+    static const bool v = [] { const char* s = getenv("MDL_EP2_STATIC"); return s && atoi(s) != 0; }();
+    return v;
+}
 int launch2(CgParams& p, hipStream_t st, int wgs, const char* name) {
     typedef Cfg2<64> F;
     const int64_t eg = std::min<int64_t>(wgs > 0 ? wgs : 256, std::max<int64_t>(1, cdiv(p.E, 32 * F::NA * 2)));
     auto kf = bwd2_kernel<64>;
     hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), F::LDS);
     if (e != hipSuccess) { set_error("%s: LDS attribute (%d B): %s", name, F::LDS, hipGetErrorString(e)); return MDL_E_LAUNCH; }
+    // optional caller workspace: the chunk counter of the dynamic tail, zeroed on the stream
+    if (MDL_EP2_TAIL == 0 || cg_env_ep2_static()) p.ctr = nullptr;
+    if (p.ctr && hipMemsetAsync(p.ctr, 0, 64, st) != hipSuccess) p.ctr = nullptr;
     hipLaunchKernelGGL(kf, dim3((unsigned)eg), dim3(F::NT), F::LDS, st, p);
     return check_launch(name);
 }
@@ -2530,10 +2554,58 @@ extern "C" int mdl_cgconv_bwd_p(const void* p_tgt, const void* p_src, const void
     return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd_p");
 }
 
+namespace mdl {
+// per-node cost of the backward edge pass in quarter units: 4 per edge and node, + 5 per edge whose source lies 48 or more
+// rows away from its target (such edges land in far blocks of the by-source window or outside it: +0.8 of an edge's time in the fit,
+// fitted on per-workgroup end times of the bench batch — DESIGN.md section 4)
+__global__ __launch_bounds__(256) void cgconv_balance_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+                                                             int64_t N, int32_t* __restrict__ cost, int far_w, int far_t) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) cost[0] = 0;
+    if (n >= N) return;
+    const int b = rowptr[n], e = rowptr[n + 1];
+    int far = 0;
+    for (int k = b; k < e; ++k) {
+        const int d = src[k] - (int)n;
+        far += (d >= far_t || d <= -far_t) ? 1 : 0;
+    }
+    cost[n + 1] = 4 * (e - b + 1) + far_w * far;
+}
+}  // namespace mdl
+
+extern "C" int mdl_cgconv_balance(const int32_t* rowptr, const int32_t* src, int64_t N, int32_t* cost, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(N >= 0 && (N == 0 || (rowptr && src && cost)), MDL_E_ARG, "mdl_cgconv_balance: bad arguments");
+    // (MDL_BAL_W / MDL_BAL_T: weight in quarter units and distance threshold of a far edge, for experiments)
+    static const int far_w = [] { const char* s = getenv("MDL_BAL_W"); return s ? atoi(s) : 5; }();
+    static const int far_t = [] { const char* s = getenv("MDL_BAL_T"); return s ? atoi(s) : 48; }();
+    hipLaunchKernelGGL(cgconv_balance_kernel, dim3((unsigned)cdiv(N + 1, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, src, N, cost,
+                       far_w, far_t);
+    return check_launch("mdl_cgconv_balance");
+}
+
+static int cg_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
+                    const int32_t* tgt, const void* wpack, const float* bpack, const void* grad_out, void* r_tgt,
+                    void* r_src, float* dwe, float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype,
+                    void* workspace, size_t ws_bytes, const int32_t* balance, mdlStream_t stream);
+extern "C" int mdl_cgconv_bwd_hb(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
+                                 const int32_t* tgt, const void* wpack, const float* bpack, const void* grad_out, void* r_tgt,
+                                 void* r_src, float* dwe, float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype,
+                                 void* workspace, size_t ws_bytes, const int32_t* balance, mdlStream_t stream) {
+    return cg_bwd_h(x, edge_attr, rowptr, src, tgt, wpack, bpack, grad_out, r_tgt, r_src, dwe, db, N, E, C, G, aggr, dtype, workspace,
+                    ws_bytes, balance, stream);
+}
 extern "C" int mdl_cgconv_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
                                 const int32_t* tgt, const void* wpack, const float* bpack, const void* grad_out, void* r_tgt,
                                 void* r_src, float* dwe, float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype,
                                 void* workspace, size_t ws_bytes, mdlStream_t stream) {
+    return cg_bwd_h(x, edge_attr, rowptr, src, tgt, wpack, bpack, grad_out, r_tgt, r_src, dwe, db, N, E, C, G, aggr, dtype, workspace,
+                    ws_bytes, nullptr, stream);
+}
+static int cg_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
+                    const int32_t* tgt, const void* wpack, const float* bpack, const void* grad_out, void* r_tgt,
+                    void* r_src, float* dwe, float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype,
+                    void* workspace, size_t ws_bytes, const int32_t* balance, mdlStream_t stream) {
     using namespace mdl;
     int rc = cg_check("mdl_cgconv_bwd_h", x, edge_attr, rowptr, src, tgt, wpack, bpack, N, E, C, G, aggr, dtype);
     if (rc) return rc;
@@ -2545,7 +2617,7 @@ extern "C" int mdl_cgconv_bwd_h(const void* x, const void* edge_attr, const int3
     CgParams p = {};
     p.x = x; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = nullptr;
     p.wpack = wpack; p.bpack = bpack; p.gout = grad_out; p.r_tgt = r_tgt; p.r_src = static_cast<float*>(r_src); p.dwe = dwe; p.db = db;
-    p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr; p.rs16 = 1;
+    p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr; p.rs16 = 1; p.balance = balance;
     p.ctr = (workspace && ws_bytes >= mdl_cgconv_workspace_bytes(N, E, C, G, dtype)) ? static_cast<unsigned*>(workspace) : nullptr;
     return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd_h");
 }

@@ -11,6 +11,7 @@
 // ds_read_b128 fragments), K zero-padded to a multiple of 32 in LDS; a wave owns one 32-row block row and every second
 // 32-column block, so an A fragment is read once per k-step for all of them; bias + activation on the accumulators.
 #include "mdl_common.h"
+#include <type_traits>
 
 namespace mdl {
 
@@ -263,13 +264,19 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(const bf16_t* __restrict__
             }
         }
     };
-    auto activate = [](float v, int act) -> float {
-        if (act == 1) return v > 0.0f ? v : 0.0f;
-        if (act == 2) {
+    // (the activation code is a compile-time constant of each epilogue instance: a run-time test per element turns the
+    // epilogue into one basic block per value)
+    auto activate = [](float v, auto ACT) -> float {
+        if constexpr (decltype(ACT)::value == 1) return v > 0.0f ? v : 0.0f;
+        else if constexpr (decltype(ACT)::value == 2) {
             const float l = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-LOG2E_F * fabsf(v)));
             return fmaf(0.5f, v + fabsf(v), fmaf(LN2_F, l, -LN2_F));
-        }
-        return v;
+        } else return v;
+    };
+    auto by_act = [](int act, auto&& f) {
+        if (act == 2) f(std::integral_constant<int, 2>{});
+        else if (act == 1) f(std::integral_constant<int, 1>{});
+        else f(std::integral_constant<int, 0>{});
     };
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) load_tile(tile);
@@ -306,6 +313,7 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(const bf16_t* __restrict__
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
                 }
             }
+            by_act(act1, [&](auto ACT) {
 #pragma unroll
             for (int j = 0; j < NB1; ++j) {
                 const int nt = ntb + 2 * j, col = nt * 32 + i;
@@ -318,13 +326,14 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(const bf16_t* __restrict__
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2);
-                        const bf16_t hv = f2bf(activate(acc[j][r], act1));
+                        const bf16_t hv = f2bf(activate(acc[j][r], ACT));
                         // columns M1 .. 32*NT1-1 hold act1(0 + 0): they meet zero weight columns in the second layer
                         hl[(mt * 32 + 4 * h + row) * LD2 + col] = hv;
                         if (st) __builtin_amdgcn_raw_buffer_store_b16((short)hv, os, vo + row * M1 * 2, 0, 0);
                     }
                 }
             }
+            });
         }
         __syncthreads();
         // ---- layer 2
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(const bf16_t* __restrict__
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
                 }
             }
+            by_act(act2, [&](auto ACT) {
 #pragma unroll
             for (int j = 0; j < NB2; ++j) {
                 const int nt = ntb + 2 * j, col = nt * 32 + i;
@@ -354,10 +364,11 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(const bf16_t* __restrict__
                     const int vo = (4 * h * M2 + col) * 2;
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(activate(acc[j][r], act2)), os,
+                        __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(activate(acc[j][r], ACT)), os,
                                                               vo + ((r & 3) + 8 * (r >> 2)) * M2 * 2, 0, 0);
                 }
             }
+            });
         }
     }
 }

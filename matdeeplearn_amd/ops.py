@@ -24,11 +24,12 @@ class EdgeCSR:
     """Edges sorted by target.  rowptr [N+1], src/tgt [E] int32, eperm [E] int32 or None when the
     caller's per-edge tensors are already in CSR order (the product loader guarantees that)."""
 
-    __slots__ = ("rowptr", "src", "tgt", "eperm", "N", "E", "_row", "_col", "_t", "_attr", "_tb", "partial", "__weakref__")
+    __slots__ = ("rowptr", "src", "tgt", "eperm", "N", "E", "_row", "_col", "_t", "_attr", "_tb", "_bal", "partial", "__weakref__")
 
     def __init__(self, rowptr, src, tgt, eperm, N, E, row=None, col=None):
         self.rowptr, self.src, self.tgt, self.eperm, self.N, self.E = rowptr, src, tgt, eperm, int(N), int(E)
         self._attr = None
+        self._bal = None
         self._row, self._col, self._t, self._tb = row, col, None, None
         self.partial = False      # padded static batch: the arrays hold more rows than the rowptr ranges cover
 
@@ -39,6 +40,26 @@ class EdgeCSR:
     def set_transposed_builder(self, fn):
         """fn() -> (rowptr_s, col_s, eid_s, src_sorted): the loader's sort-free construction, run on first use."""
         self._tb = fn
+
+    def balance(self):
+        """[N + 1] int32 cost prefix for the work distribution of the edge-per-lane CGConv backward (mdl_cgconv_balance + one
+        cumsum): topology only, so it is built once per batch and serves every layer."""
+        if self._bal is None:
+            cost = torch.empty(self.N + 1, dtype=torch.int32, device=self.rowptr.device)
+            check(lib().mdl_cgconv_balance(ptr(self.rowptr), ptr(self.src), self.N, ptr(cost), stream()), "mdl_cgconv_balance")
+            self._bal = torch.cumsum(cost, 0, dtype=torch.int32)
+        return self._bal
+
+    def refresh_balance(self):
+        """A CSR over static buffers (HIP-graph path) is rewritten in place with every batch: its prefix is rebuilt into the
+        SAME tensor by the batch assembly, inside the captured graph."""
+        if not (_BALANCE and self.E >= 400000 and self.eperm is None):
+            return
+        if self._bal is None:
+            self._bal = torch.zeros(self.N + 1, dtype=torch.int32, device=self.rowptr.device)
+        cost = torch.empty(self.N + 1, dtype=torch.int32, device=self.rowptr.device)
+        check(lib().mdl_cgconv_balance(ptr(self.rowptr), ptr(self.src), self.N, ptr(cost), stream()), "mdl_cgconv_balance")
+        torch.cumsum(cost, 0, dtype=torch.int32, out=self._bal)
 
     def seg_tgt(self):
         """segment index of `col` (target per edge): what scatter(..., index=edge_index[1]) needs, without a sort"""
@@ -483,6 +504,7 @@ _WSPLIT = os.environ.get("MDL_CG_WSPLIT", "0") == "1"
 # By-source sums of the CGConv backward in bf16, accumulated with packed bf16 atomics (mdl_cgconv_bwd_h / mdl_cgconv_bwd_node_h;
 # bf16 mode, C in {32, 64}, G = 50): half the atomic operations and bytes of the fp32 buffer.  MDL_CG_RSRC16=0 restores fp32.
 _GMR_DW = os.environ.get("MDL_GMR_DW", "1") != "0"          # CFConv backward: dh and dw from one walk over the by-source CSR
+_BALANCE = os.environ.get("MDL_CG_BALANCE", "1") != "0"     # cost-balanced node ranges for the edge-per-lane backward
 _PAD128 = os.environ.get("MDL_CG_PAD128", "1") != "0"      # C in (96, 128): static 128-channel kernels on zero-padded rows
 _RSRC16 = os.environ.get("MDL_CG_RSRC16", "1") == "1"
 
@@ -637,9 +659,11 @@ class _CGConvFn(torch.autograd.Function):
                 ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd_saved")
             del gate
         elif rs16:
-            check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_h(
+            # node ranges of equal COST (far sources make a tile dearer): one prefix per batch, shared by all layers
+            bal = csr.balance() if (_BALANCE and E >= 400000) else None
+            check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_hb(
                 ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(bpack), ptr(g),
-                ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, ptr(ws), ws.numel(), stream())),
+                ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, ptr(ws), ws.numel(), ptr(bal), stream())),
                 "mdl_cgconv_bwd_h")
         else:
             check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd(

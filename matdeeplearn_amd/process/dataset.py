@@ -531,6 +531,8 @@ class StaticBatch:
         # belong to no segment): as one segment of thousands of rows it would be walked by a single lane group
         self.pool_rowptr.copy_(torch.cat([noff_d, noff_d[-1:]]))
         self.pool_seg.copy_(self.batch_idx)
+        # the static CSR outlives the batch: its work-balance prefix (CGConv backward) is rebuilt with the batch, in place
+        self.batch.csr.refresh_balance()
         return self.batch
 
 
