@@ -52,6 +52,9 @@
 #define MDL_BWD_XDB 1
 #endif
 #ifndef MDL_FWD_ALLSLICES
+#ifndef MDL_FWD_AGE_SKEW
+#define MDL_FWD_AGE_SKEW 60     // all-slices forward at two workgroups per CU: per mille of extra work for the older half
+#endif
 #define MDL_FWD_ALLSLICES 1   // static shapes: one forward wave handles all channel slices of its group
 #endif
 #ifndef MDL_FWD_XEARLY
@@ -865,7 +868,25 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
         // run per 32-channel slice on the same staged operands.
         constexpr int NSL = CP_ / 32;
         const int nw_total = gridDim.x * (blockDim.x >> 6);
-        const NodeRange R(p, __builtin_amdgcn_readfirstlane(gw), nw_total, lane);
+        // Two workgroups share a CU and its SIMDs arbitrate by age: the waves of the workgroup dispatched first (block index
+        // below half the grid) run 14 % faster than their younger co-residents (measured wave lifetimes 161 vs 184 us), which
+        // then finish alone at half occupancy.  The older half takes MDL_FWD_AGE_SKEW per mille more of the work.
+        NodeRange R(0, 0);
+        {
+            const int half = nw_total >> 1, gwu = __builtin_amdgcn_readfirstlane(gw);
+            if (MDL_FWD_AGE_SKEW == 0 || (nw_total & 1) || gridDim.x < 512) {
+                R = NodeRange(p, gwu, nw_total, lane);
+            } else {
+                const int64_t Et = (int64_t)p.rowptr[p.N] + p.N;
+                const int64_t wa = 1000 + MDL_FWD_AGE_SKEW, wb = 1000 - MDL_FWD_AGE_SKEW;        // weights of the two halves
+                auto cut = [&](int k) -> int64_t {                                               // work in front of wave k
+                    const int64_t units = k <= half ? wa * k : wa * half + wb * (k - half);
+                    return Et * units / (1000 * (int64_t)nw_total);
+                };
+                R.na = gwu == 0 ? 0 : wave_lower_bound(p.rowptr, (int)p.N, cut(gwu), lane);
+                R.nb = gwu == nw_total - 1 ? (int)p.N : wave_lower_bound(p.rowptr, (int)p.N, cut(gwu + 1), lane);
+            }
+        }
         if (R.na >= R.nb) return;
         // The wave walks its groups as one continuous stream: the next group's row pointers are requested
         // at the top of the current group, and the indices / edge-feature words of the next group's first
