@@ -133,7 +133,8 @@ int mdl_cgconv_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr
                      float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
                      mdlStream_t stream);
 /* Work balance of the edge-per-lane backward: cost[0] = 0, cost[n + 1] = cost of node n in quarter units (4 per edge and node,
- * + 3 per edge whose source is 48 or more rows away from its target).  The caller turns it into an inclusive prefix sum
+ * + 5 per edge whose source is 48 or more rows away from its target, + 4 for a node without edges: 32 of them make an empty
+ * tile that costs a full tile's time).  The caller turns it into an inclusive prefix sum
  * (int32, [N + 1]) and hands it to mdl_cgconv_bwd_hb, whose workgroups then take node ranges of equal COST instead of equal
  * edge + node counts (graphs wider than the by-source window make their tiles dearer; topology only: one prefix per batch
  * serves every layer).  NULL balance = mdl_cgconv_bwd_h. */

@@ -2580,7 +2580,7 @@ namespace mdl {
 // rows away from its target (such edges land in far blocks of the by-source window or outside it: +0.8 of an edge's time in the fit,
 // fitted on per-workgroup end times of the bench batch — DESIGN.md section 4)
 __global__ __launch_bounds__(256) void cgconv_balance_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
-                                                             int64_t N, int32_t* __restrict__ cost, int far_w, int far_t) {
+                                                             int64_t N, int32_t* __restrict__ cost, int far_w, int far_t, int zero_w) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n == 0) cost[0] = 0;
     if (n >= N) return;
@@ -2590,7 +2590,9 @@ __global__ __launch_bounds__(256) void cgconv_balance_kernel(const int32_t* __re
         const int d = src[k] - (int)n;
         far += (d >= far_t || d <= -far_t) ? 1 : 0;
     }
-    cost[n + 1] = 4 * (e - b + 1) + far_w * far;
+    // (an edge-less node — the padding rows of a static batch come 32 to an empty tile that costs a full tile's time — is charged
+    // like the share of an average tile: without it the workgroup that holds the padding gets a fifth more rounds than the others)
+    cost[n + 1] = 4 * (e - b + 1) + far_w * far + (e == b ? zero_w : 0);
 }
 }  // namespace mdl
 
@@ -2600,8 +2602,9 @@ extern "C" int mdl_cgconv_balance(const int32_t* rowptr, const int32_t* src, int
     // (MDL_BAL_W / MDL_BAL_T: weight in quarter units and distance threshold of a far edge, for experiments)
     static const int far_w = [] { const char* s = getenv("MDL_BAL_W"); return s ? atoi(s) : 5; }();
     static const int far_t = [] { const char* s = getenv("MDL_BAL_T"); return s ? atoi(s) : 48; }();
+    static const int zero_w = [] { const char* s = getenv("MDL_BAL_Z"); return s ? atoi(s) : 4; }();
     hipLaunchKernelGGL(cgconv_balance_kernel, dim3((unsigned)cdiv(N + 1, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, src, N, cost,
-                       far_w, far_t);
+                       far_w, far_t, zero_w);
     return check_launch("mdl_cgconv_balance");
 }
 
