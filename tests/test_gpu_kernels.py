@@ -747,3 +747,114 @@ def test_cgconv_w_split_pair_matches_oracle():
     r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "MDL_CG_WSPLIT": "1"}, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_cgconv_balanced_ranges_through_the_c_abi():
+    """mdl_cgconv_balance against numpy (integer work: exact) and mdl_cgconv_bwd_hb — kernel 2 with node ranges of equal cost,
+    forced with MDL_CG_EP=2 in a fresh interpreter — against mdl_cgconv_bwd_h on the same operands: the partition changes
+    which workgroup sums what, not the sums (bf16 by-source sums: atomic order and window cuts differ)."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from matdeeplearn_amd import _lib, ops
+from tests.test_gpu_kernels import close
+d = torch.device("cuda:0")
+L, P, st = _lib.lib(), _lib.ptr, _lib.stream
+C, G, dt = 64, 50, _lib.MDL_BF16
+g = torch.Generator().manual_seed(5)
+n = 30000
+tgt = torch.arange(n).repeat_interleave(9)
+spread = torch.where(torch.arange(n) % 7 == 0, 150, 20).repeat_interleave(9)          # every seventh node: far sources
+src = (tgt + (torch.rand(tgt.numel(), generator=g) * 2 - 1) * spread).long().clamp_(0, n - 1)
+n_pad = n + 700                                                                        # edge-less rows at the end
+E = tgt.numel()
+csr = ops.build_csr(torch.stack([src, tgt]).to(d), n_pad, assume_sorted=True)
+cost = torch.empty(n_pad + 1, dtype=torch.int32, device=d)
+_lib.check(L.mdl_cgconv_balance(P(csr.rowptr), P(csr.src), n_pad, P(cost), st()), "balance")
+rp, s = csr.rowptr.cpu().numpy(), csr.src.cpu().numpy()
+ref = np.zeros(n_pad + 1, np.int64)
+for v in range(n_pad):
+    dd = np.abs(s[rp[v]:rp[v + 1]] - v)
+    ref[v + 1] = 4 * (rp[v + 1] - rp[v] + 1) + 5 * int((dd >= 48).sum()) + (4 if rp[v + 1] == rp[v] else 0)
+assert np.array_equal(cost.cpu().numpy(), ref), "mdl_cgconv_balance"
+assert torch.equal(csr.balance().cpu(), torch.from_numpy(np.cumsum(ref)).to(torch.int32))
+x = torch.randn(n_pad, C, generator=g).to(d).to(torch.bfloat16)
+ea = torch.rand(E, G, generator=g).to(d).to(torch.bfloat16)
+gout = torch.randn(n_pad, C, generator=g).to(d).to(torch.bfloat16)
+wf, ws = (torch.randn(C, 2 * C + G, generator=g) * 0.1).to(d), (torch.randn(C, 2 * C + G, generator=g) * 0.1).to(d)
+bf, bs = torch.zeros(C, device=d), torch.zeros(C, device=d)
+wpack = torch.empty(L.mdl_cgconv_wpack_bytes(C, G, dt), dtype=torch.uint8, device=d)
+bpack = torch.empty(2 * C, dtype=torch.float32, device=d)
+_lib.check(L.mdl_cgconv_pack_weights(P(wf), P(bf), P(ws), P(bs), C, G, P(wpack), P(bpack), dt, st()), "pack")
+res = []
+for bal in (None, csr.balance()):
+    r_tgt = torch.empty(n_pad, 2 * C, device=d, dtype=torch.bfloat16)
+    r_src = torch.zeros(n_pad, 2 * C, device=d, dtype=torch.bfloat16)
+    dwe, db = torch.zeros(2 * C, 64, device=d), torch.zeros(2 * C, device=d)
+    _lib.check(L.mdl_cgconv_bwd_hb(P(x), P(ea), P(csr.rowptr), P(csr.src), P(csr.tgt), P(wpack), P(bpack), P(gout), P(r_tgt),
+                                   P(r_src), P(dwe), P(db), n_pad, E, C, G, 1, dt, None, 0, P(bal), st()), "bwd_hb")
+    res.append((r_tgt, r_src, dwe, db))
+(rt0, rs0, dwe0, db0), (rt1, rs1, dwe1, db1) = res
+assert float(rt0[n:].abs().max()) == 0.0 and float(rt1[n:].abs().max()) == 0.0       # rows of the edge-less tail
+close(rt0, rt1, 8e-3, 1e-3)
+close(dwe0, dwe1, 2e-3, 1e-4)
+close(db0, db1, 2e-3, 1e-4)
+close(rs0, rs1, 2e-2, 2e-2)
+print("BALANCE_OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "MDL_CG_EP": "2"}, cwd=root, capture_output=True, text=True,
+                       timeout=600)
+    assert "BALANCE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_cfconv_backward_in_one_walk_matches_the_pair():
+    """mdl_gather_mul_reduce_dw (gradient w.r.t. the gathered rows AND the filter gradient from one walk over the by-source
+    CSR) against mdl_gather_mul_reduce on the transposed CSR + mdl_edge_mul: same arithmetic per element."""
+    from matdeeplearn_amd import _lib, ops
+    d = dev()
+    L, P, st = _lib.lib(), _lib.ptr, _lib.stream
+    g = torch.Generator().manual_seed(11)
+    n, F, dt = 3000, 150, _lib.MDL_BF16
+    ei = rand_graph(n, 13, sort=True, empty_frac=0.1)
+    E = ei.shape[1]
+    csr = ops.build_csr(ei.to(d), n, assume_sorted=True)
+    h = torch.randn(n, F, generator=g).to(d).to(torch.bfloat16)
+    w = torch.randn(E, F, generator=g).to(d).to(torch.bfloat16)
+    go = torch.randn(n, F, generator=g).to(d).to(torch.bfloat16)
+    c = torch.rand(E, generator=g).to(d)
+    rowptr_s, col_s, eid_s, _ = csr.transposed()
+    dh0, dw0 = torch.empty_like(h), torch.empty_like(w)
+    _lib.check(L.mdl_gather_mul_reduce(P(go), P(w), P(c), P(rowptr_s), P(col_s), P(eid_s), P(dh0), n, F, _lib.MDL_SUM, dt, st()), "gmr T")
+    _lib.check(L.mdl_edge_mul(P(h), P(csr.row), P(go), P(csr.col), P(c), P(dw0), E, F, dt, st()), "edge_mul")
+    dh1, dw1 = torch.empty_like(h), torch.full_like(w, float("nan"))
+    _lib.check(L.mdl_gather_mul_reduce_dw(P(go), P(w), P(c), P(rowptr_s), P(col_s), P(eid_s), P(dh1), P(h), P(dw1), n, F, dt, st()),
+               "gmr dw")
+    assert torch.equal(dh0, dh1)
+    close(dw1, dw0, 1e-2, 1e-3)          # (a * b) * c against (a * c) * b before the bf16 rounding
+
+
+def test_two_layer_dense_kernel_matches_two_launches():
+    """mdl_mlp2 (Linear -> activation -> Linear [-> activation] with the intermediate tile in LDS) against two mdl_linear_act
+    launches: the hidden rows bit-identical, the outputs equal to the rounding of the bf16 hidden rows they are computed from;
+    ragged row count, SchNet's filter-network shape and a relu / relu pair."""
+    from matdeeplearn_amd import _lib
+    d = dev()
+    L, P, st = _lib.lib(), _lib.ptr, _lib.stream
+    g = torch.Generator().manual_seed(2)
+    dt = _lib.MDL_BF16
+    for (N, K, M1, M2, a1, a2) in ((5000 + 37, 50, 150, 150, 2, 0), (3000, 64, 100, 100, 1, 1), (130, 10, 32, 8, 2, 2)):
+        x = torch.randn(N, K, generator=g).to(d).to(torch.bfloat16)
+        w1 = (torch.randn(M1, K, generator=g) * 0.2).to(d).to(torch.bfloat16)
+        w2 = (torch.randn(M2, M1, generator=g) * 0.1).to(d).to(torch.bfloat16)
+        b1 = (torch.randn(M1, generator=g) * 0.1).to(d).to(torch.bfloat16)
+        b2 = (torch.randn(M2, generator=g) * 0.1).to(d).to(torch.bfloat16)
+        h0, y0 = torch.empty(N, M1, device=d, dtype=torch.bfloat16), torch.empty(N, M2, device=d, dtype=torch.bfloat16)
+        _lib.check(L.mdl_linear_act(P(x), P(w1), P(b1), P(h0), N, K, M1, a1, dt, st()), "l1")
+        _lib.check(L.mdl_linear_act(P(h0), P(w2), P(b2), P(y0), N, M1, M2, a2, dt, st()), "l2")
+        h1 = torch.full_like(h0, float("nan"))
+        y1 = torch.full_like(y0, float("nan"))
+        _lib.check(L.mdl_mlp2(P(x), P(w1), P(b1), a1, P(w2), P(b2), a2, P(h1), P(y1), N, K, M1, M2, dt, st()), "mlp2")
+        assert torch.equal(h0, h1), (N, K, M1, M2)
+        close(y1, y0, 1e-2, 1e-3)
