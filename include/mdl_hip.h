@@ -315,6 +315,11 @@ int mdl_linear_act(const void* x, const void* w, const void* bias, void* out, in
 int mdl_linear_act_in(const void* x, const void* y, int xact, const void* w, const void* bias, void* out, int64_t N, int K,
                       int M, int act, int dtype, mdlStream_t stream);
 
+/* out[N, M] = x[N, K] w[M, K]^T for a wide output (M in the thousands; bf16, even K <= 160): NNConv's per-node operand
+ * Y = x W2r of the re-associated message (matdeeplearn/models/mpnn.py:83-88 — C_out * d3 = 10^4 columns), a write stream of
+ * N * M * 2 bytes that the library ran as a 256x256x32 macro-tile GEMM (771 us for 6.1e4 x 100 x 1e4). */
+int mdl_linear_wide(const void* x, const void* w, void* out, int64_t N, int K, int64_t M, int dtype, mdlStream_t stream);
+
 /* Two chained dense layers in one pass: h[N, M1] = act1(x[N, K] w1[M1, K]^T + b1), y[N, M2] = act2(h w2[M2, M1]^T + b2); both
  * results are written (the backward of the pair needs h), the rows of h reach the second product through LDS.  The filter
  * network of CFConv — Linear(num_gaussians, F) -> ShiftedSoftplus -> Linear(F, F) over the edges (matdeeplearn/models/

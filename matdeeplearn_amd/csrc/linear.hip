@@ -36,7 +36,17 @@ template <int KP, int NT, bool GATHER = false, int XACT = 0>     // KP: K padded
 __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
                                                             int64_t N, int K, int M, int act, GatherAdd ga,
-                                                            const bf16_t* __restrict__ xy) {
+                                                            const bf16_t* __restrict__ xy, int ldo = 0) {
+    // mdl_linear_wide: blockIdx.y = block of 32*NT output columns of a wider layer (ldo = its full width, the leading dimension
+    // of `out`); every other caller has gridDim.y = 1 and ldo = M
+    if (gridDim.y > 1) {
+        const int c0 = (int)blockIdx.y * 32 * NT;
+        w += (int64_t)c0 * K;
+        if (bias) bias += c0;
+        out += c0;
+        M = min(M - c0, 32 * NT);
+    }
+    if (ldo == 0) ldo = M;
     constexpr int TN = 64;
     constexpr int LD = KP + 8;                       // LDS row stride (bf16): odd number of 16-byte slots
     constexpr int NB = (NT + 1) / 2;                 // output blocks per wave: block row wv & 1, block columns (wv >> 1) + 2j
@@ -169,10 +179,12 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
                         }
                     }
                     if (col < M && remr > 0) {
+                        // (range = up to the end of this block row's last existing row; with column blocks the rows are ldo wide)
+                        const int64_t rbytes = ((remr - 1) * (int64_t)ldo + M) * 2;
                         const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
-                            out + (nb + mt * 32) * (int64_t)M, 0,
-                            (int)((remr * M * 2) < 0x7fffffffLL ? (remr * M * 2) : 0x7fffffffLL), 0x00020000);
-                        const int vo = (4 * h * M + col) * 2;
+                            out + (nb + mt * 32) * (int64_t)ldo, 0,
+                            (int)(rbytes < 0x7fffffffLL ? rbytes : 0x7fffffffLL), 0x00020000);
+                        const int vo = (4 * h * ldo + col) * 2;
                         // (2-byte stores, 16 per block: pairing neighbouring lanes' columns into dword stores — half the store
                         // instructions — measured no faster; these streams run at 4.2-4.9 TB/s of the ~6.3 TB/s a copy reaches)
 #pragma unroll
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
                                 const float l = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-LOG2E_F * fabsf(v)));
                                 v = fmaf(0.5f, v + fabsf(v), fmaf(LN2_F, l, -LN2_F));
                             }
-                            __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(v), os, vo + ((r & 3) + 8 * (r >> 2)) * M * 2, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(v), os, vo + ((r & 3) + 8 * (r >> 2)) * ldo * 2, 0, 0);
                         }
                     }
                 }
@@ -430,7 +442,7 @@ static int linear_launch(const void* x, const void* xy, int xact, const void* w,
         auto kf = linear_act_kernel<KP_, NT_, G_, X_>;                                                               \
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                           \
         hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
-                           (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, ga, (const bf16_t*)xy);                  \
+                           (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, ga, (const bf16_t*)xy, 0);               \
     } while (0)
 #define MDL_LIN(KP_, NT_)                                                                                            \
     do {                                                                                                             \
@@ -468,4 +480,35 @@ extern "C" int mdl_mlp2(const void* x, const void* w1, const void* b1, int act1,
     hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w1,
                        (const bf16_t*)b1, (const bf16_t*)w2, (const bf16_t*)b2, (bf16_t*)h, (bf16_t*)y, N, K, M1, M2, act1, act2);
     return check_launch("mdl_mlp2");
+}
+
+// out[N, M] = x[N, K] w[M, K]^T for a WIDE output (M in the thousands: NNConv's Y = x W2r, mpnn.py:83-88 — C_out * d3 = 10^4
+// columns per node): the layer is a write stream of N * M * 2 bytes; column blocks of 160 run as the second grid dimension of
+// the streaming kernel, each workgroup keeping its block of w in LDS for ~1/64 of the rows.
+extern "C" int mdl_linear_wide(const void* x, const void* w, void* out, int64_t N, int K, int64_t M, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_linear_wide: bf16 only");
+    MDL_REQUIRE(K >= 4 && K <= 160 && K % 2 == 0 && M >= 1 && M <= 160 * 65535LL && M * 2 * 64 < 0x7fffffffLL, MDL_E_UNSUPP,
+                "mdl_linear_wide: need even 4<=K<=160 (got K=%d M=%lld)", K, (long long)M);
+    MDL_REQUIRE(N >= 0 && (N == 0 || (x && w && out)), MDL_E_ARG, "mdl_linear_wide: bad arguments");
+    MDL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(w) % 4 == 0 &&
+                reinterpret_cast<uintptr_t>(out) % 2 == 0, MDL_E_ARG, "mdl_linear_wide: misaligned pointer");
+    if (N == 0) return MDL_OK;
+    const int kp = K <= 64 ? 64 : (K <= 128 ? 128 : 160);
+    const unsigned gy = (unsigned)((M + 159) / 160);
+    int64_t gx = cdiv(N, 64);
+    if (gx > 64) gx = 64;
+    const int lds = (32 * 5 + 64) * (kp + 8) * 2;
+    const GatherAdd ga{};
+#define MDL_WIDE(KP_)                                                                                                 \
+    do {                                                                                                              \
+        auto kf = linear_act_kernel<KP_, 5, false, 0>;                                                                \
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                            \
+        hipLaunchKernelGGL(kf, dim3((unsigned)gx, gy), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x,         \
+                           (const bf16_t*)w, (const bf16_t*)nullptr, (bf16_t*)out, N, K, (int)M, 0, ga,               \
+                           (const bf16_t*)nullptr, (int)M);                                                           \
+    } while (0)
+    if (kp == 64) MDL_WIDE(64); else if (kp == 128) MDL_WIDE(128); else MDL_WIDE(160);
+#undef MDL_WIDE
+    return check_launch("mdl_linear_wide");
 }

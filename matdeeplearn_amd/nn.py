@@ -235,7 +235,7 @@ class NNConv(nn.Module):
             hdn = _seq(list(self.nn)[:-1], edge_attr)
             d3 = last.in_features
             w2 = last.weight.view(ci, co * d3).to(x.dtype)
-            Y = x @ w2                                                    # [N, C_out*d3]: the only large dense product
+            Y = ops.matmul_wide(x, w2)                                    # [N, C_out*d3]: the only large dense product
             m = ops.nnconv_msg(Y, hdn.to(x.dtype), csr, co)
             if last.bias is not None:
                 m = m + ops.gather(x @ last.bias.view(ci, co).to(x.dtype), csr.row)

@@ -994,6 +994,7 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
     return dx, dw.to(ctx.wdtype), db
 
 
+_LINEAR_WIDE = os.environ.get("MDL_LINEAR_WIDE", "1") != "0"   # NNConv's Y = x W2r on the streaming kernel
 _MLP2_NEXT = {}        # (input ptr, weight ptr, act) -> output of a dense layer already computed by the previous layer's launch
 _MLP2 = os.environ.get("MDL_MLP2", "0") == "1"       # opt-in: measured slower than the two streaming layers
 
@@ -1093,6 +1094,37 @@ def linear_gather_act(x, weight, bias, act, gathered):
         return y if act is None else getattr(torch.nn.functional, act)(y)
     idx = [ix if ix.dtype == torch.int32 else ix.to(torch.int32) for _, ix in gathered]
     return _LinearGatherAct.apply(x, weight, bias, act, idx, *[t.to(x.dtype) for t, _ in gathered])
+
+
+class _LinearWide(torch.autograd.Function):
+    """y = x @ w for a wide w [K, M] (M in the thousands): forward as a streaming HIP kernel over 160-column blocks
+    (mdl_linear_wide), backward = the two library products autograd would form."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        N, K = x.shape
+        M = w.shape[1]
+        wt = w.t().contiguous()                                        # [M, K] rows for the kernel (2 MB for NNConv's W2r)
+        out = torch.empty((N, M), dtype=x.dtype, device=x.device)
+        check(lib().mdl_linear_wide(ptr(x), ptr(wt), ptr(out), N, K, M, dtype_code(x), stream()), "mdl_linear_wide")
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        dx = g @ w.t() if ctx.needs_input_grad[0] else None
+        dw = x.t() @ g if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def matmul_wide(x, w):
+    """x @ w; bf16 tall x (even K <= 160) with a wide w take the streaming kernel for the forward product."""
+    if (_LINEAR_WIDE and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
+            and x.shape[0] >= 1024 and x.shape[1] % 2 == 0 and 4 <= x.shape[1] <= 160 and w.shape[1] >= 640
+            and x.data_ptr() % 16 == 0):
+        return _LinearWide.apply(x, w)
+    return x @ w
 
 
 def linear_act(x, weight, bias, act, lowp=None, nxt=None):
