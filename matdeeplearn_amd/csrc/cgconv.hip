@@ -2633,8 +2633,8 @@ static int cg_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr,
     using namespace mdl;
     int rc = cg_check("mdl_cgconv_bwd_h", x, edge_attr, rowptr, src, tgt, wpack, bpack, N, E, C, G, aggr, dtype);
     if (rc) return rc;
-    MDL_REQUIRE(mdl_cgconv_gate_row_bytes(C, G, dtype) != 0, MDL_E_UNSUPP,
-                "mdl_cgconv_bwd_h: unsupported C=%d G=%d dtype=%d (bf16, C in {32, 64}, G = 50)", C, G, dtype);
+    MDL_REQUIRE(dtype == MDL_BF16 && G == 50 && (C == 32 || C == 64 || C == 128), MDL_E_UNSUPP,
+                "mdl_cgconv_bwd_h: unsupported C=%d G=%d dtype=%d (bf16, C in {32, 64, 128}, G = 50)", C, G, dtype);
     MDL_REQUIRE(N == 0 || (grad_out && r_tgt && r_src && dwe), MDL_E_ARG, "mdl_cgconv_bwd_h: null pointer");
     MDL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(edge_attr) % 4 == 0 &&
                     reinterpret_cast<uintptr_t>(r_src) % 4 == 0, MDL_E_ARG, "mdl_cgconv_bwd_h: x must be 16-byte, edge_attr / r_src 4-byte aligned");

@@ -631,7 +631,7 @@ class _CGConvFn(torch.autograd.Function):
             x = x[:, :C]                                  # (the node-level part below works on the true width)
         r_tgt = torch.empty((N, 2 * Cp), dtype=x.dtype, device=x.device)          # by-target sums, compute dtype
         node_hip = dt == _lib.MDL_BF16 and C == Cp and C in (32, 64)          # K3c consumes r_tgt / r_src
-        rs16 = (_RSRC16 and node_hip and G == 50 and ctx.gate is None and ctx.wsplit is None and E > 0
+        rs16 = (_RSRC16 and (node_hip or (Ck == 128 and dt == _lib.MDL_BF16)) and G == 50 and ctx.gate is None and ctx.wsplit is None and E > 0
                 and x.data_ptr() % 16 == 0 and edge_attr.data_ptr() % 4 == 0)
         nrs = N * 2 * Cp // 2 if rs16 else N * 2 * Cp                         # fp32 words of the by-source buffer
         keep = _take_rsrc(nrs, x.device) if node_hip else None
@@ -662,8 +662,8 @@ class _CGConvFn(torch.autograd.Function):
             # node ranges of equal COST (far sources make a tile dearer): one prefix per batch, shared by all layers
             bal = csr.balance() if (_BALANCE and E >= 400000) else None
             check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_hb(
-                ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(bpack), ptr(g),
-                ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, ptr(ws), ws.numel(), ptr(bal), stream())),
+                ptr(xk), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(bpack), ptr(gk),
+                ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, Ck, G, ctx.aggr, dt, ptr(ws), ws.numel(), ptr(bal), stream())),
                 "mdl_cgconv_bwd_h")
         else:
             check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd(
