@@ -669,3 +669,33 @@ def test_replica_drivers_give_every_trial_its_own_checkpoint_path():
     from matdeeplearn_amd.training import driver
     assert driver._suffixed("my_model.pth", "_trial3") == "my_model_trial3.pth"
     assert driver._suffixed("out/m", "_model0") == "out/m_model0"
+
+
+def test_sequential_chains_hand_the_next_dense_layer_over(monkeypatch):
+    """nn._seq: in a Linear -> activation -> Linear [-> activation] chain the first layer is told about the second (so that
+    ops.linear_act may compute both in one launch, mdl_mlp2); a lone layer or a Linear -> Linear pair is not."""
+    from matdeeplearn_amd import nn as mnn
+    calls = []
+
+    def fake_linear_act(h, weight, bias, act, lowp=None, nxt=None):
+        calls.append((tuple(weight.shape), act, None if nxt is None else (tuple(nxt[0].shape), nxt[2])))
+        return torch.zeros(h.shape[0], weight.shape[0], dtype=h.dtype)
+    monkeypatch.setattr(mnn.ops, "linear_act", fake_linear_act)
+    h = torch.zeros(4, 6, dtype=torch.bfloat16)                       # bf16 rows, fp32 master weights: the ops path
+    seq = torch.nn.Sequential(torch.nn.Linear(6, 10), mnn.ShiftedSoftplus(), torch.nn.Linear(10, 8))
+    mnn._seq(seq, h)
+    assert calls == [((10, 6), "ssp", ((8, 10), None)), ((8, 10), None, None)]
+    calls.clear()
+    seq = torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.ReLU(), torch.nn.Linear(10, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    mnn._seq(seq, h)
+    assert calls == [((10, 6), "relu", ((8, 10), "relu")), ((8, 10), "relu", ((3, 8), None)), ((3, 8), None, None)]
+    calls.clear()
+    mnn._seq(torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.Linear(10, 8)), h)
+    assert calls == [((10, 6), None, None), ((8, 10), None, None)]
+
+
+def test_wide_matmul_falls_back_to_the_library_off_device():
+    """ops.matmul_wide only takes the streaming kernel for bf16 rows on a HIP device; anything else is `x @ w`."""
+    from matdeeplearn_amd import ops
+    x, w = torch.randn(5, 6), torch.randn(6, 700)
+    assert torch.equal(ops.matmul_wide(x, w), x @ w)
