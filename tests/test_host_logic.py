@@ -699,3 +699,41 @@ def test_wide_matmul_falls_back_to_the_library_off_device():
     from matdeeplearn_amd import ops
     x, w = torch.randn(5, 6), torch.randn(6, 700)
     assert torch.equal(ops.matmul_wide(x, w), x @ w)
+
+
+def test_two_chunk_exchange_split_and_hook_rearm_in_process(tmp_path):
+    """FlatDataParallel at world size 1 (gloo, forced): the split sits where the flat buffer reaches half its size, the late
+    half's all-reduce is started by the gradient hook of its LAST-written parameter, zero_grad() re-arms it, parameters that
+    get no gradient fall back to the single exchange, and every .grad ends as a view of the flat buffer."""
+    import torch.distributed as dist
+    from matdeeplearn_amd.training import FlatDataParallel
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this interpreter")
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "pg"), rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Linear(8, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+        dp = FlatDataParallel(m, force=True, chunk_bytes=256)
+        sizes = [p.numel() for p in dp.params]
+        k, off = dp.split
+        assert off == sum(sizes[:k]) and off <= sum(sizes) // 2 < off + sizes[k]
+        x = torch.randn(16, 8)
+        for _ in range(2):
+            dp.zero_grad()
+            assert dp._late_left == len(sizes) - k and dp._late_work is None
+            m(x).sum().backward()
+            assert dp._late_work is not None                       # started from the hook, before reduce_grads()
+            ref = [p.grad.clone() for p in m.parameters()]
+            dp.reduce_grads()
+            assert dp._late_work is None
+            for p, r, v in zip(dp.params, ref, dp.views):
+                assert torch.equal(p.grad, r) and p.grad.data_ptr() == v.data_ptr()
+        # a parameter of the late half without a gradient: the hook count never reaches zero -> one exchange of everything
+        dp.zero_grad()
+        h = m[2](torch.relu(m[0](x)))
+        h.sum().backward()                                          # m[4] unused
+        assert dp._late_work is None
+        dp.reduce_grads()
+        assert all(float(v.abs().sum()) == 0.0 for p, v in zip(dp.params, dp.views) if p is m[4].weight or p is m[4].bias)
+    finally:
+        dist.destroy_process_group()
