@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--no-other-models", action="store_true",
                     help="skip the short schnet / megnet / gcn / mpnn legs the default cgcnn line carries (other_models)")
     ap.add_argument("--strong-steps", type=int, default=10, help="N > 1: timed steps of the strong-scaling leg (global batch fixed)")
+    ap.add_argument("--force-strong", action="store_true",
+                    help="run the strong-scaling leg at world size 1 too, as if the global batch were shared by two ranks (B / 2 "
+                         "graphs per step): executes the N > 1 code path on a one-GPU box (tests)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--dataset-cache", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "mdl_bench_data"),
                     help="directory for the flat on-disk copy of the synthetic dataset ('' = always regenerate)")
@@ -252,8 +255,9 @@ def main():
 
     # ---- strong scaling beside it (N > 1): the GLOBAL batch fixed at the one-GPU size, B / N graphs per GPU ----
     strong = None
-    if world > 1 and args.strong_steps > 0:
-        Bs = max(1, B // world)
+    if (world > 1 or args.force_strong) and args.strong_steps > 0:
+        div = world if world > 1 else 2
+        Bs = max(1, B // div)
         s_stream = batch_stream(DeviceLoader(ds, tr_idx, Bs, shuffle=True, seed=args.seed + 1, rank=rank, world_size=world), Bs)
         s_ids = [next(s_stream) for _ in range(args.warmup + args.strong_steps)]
         for i in range(args.warmup):
@@ -266,8 +270,9 @@ def main():
         barrier()
         ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         es = torch.tensor([float(e_s)], dtype=torch.float64, device=dev)
-        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-        dist.all_reduce(es, op=dist.ReduceOp.SUM)
+        if use_dist:
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            dist.all_reduce(es, op=dist.ReduceOp.SUM)
         strong = {"value": round(float(es) / float(ts), 1), "unit": "edges/s", "scaling": "strong", "steps": args.strong_steps,
                   "ms_per_step": round(float(ts) / args.strong_steps * 1e3, 4), "global_batch_graphs": Bs * world,
                   "batch_graphs_per_gpu": Bs}

@@ -44,10 +44,30 @@ enum {
     MDL_E_LAUNCH = -3   /* hipGetLastError() after a launch             */
 };
 
+/* Execution flags: OR-ed into the `dtype` argument of the entry points that say so.  The library keeps no mode state and
+ * reads no environment variable; what a caller (or a test) wants, it passes with the call.
+ *   MDL_DETERMINISTIC  run-to-run bit-reproducible results.  By default the gradient reductions combine per-workgroup
+ *                      partial sums with floating-point atomics (r_src / dwe / db of the CGConv backward, dWn, the TN
+ *                      GEMM, the BatchNorm sums, the fused head): the fastest form, but the order of the adds, hence the
+ *                      last bits, varies between runs.  With this flag such a kernel is launched in a shape in which every
+ *                      sum receives its terms from ONE wave in program order (one workgroup for the streaming kernels,
+ *                      one wave per channel slice for the CGConv edge pass).  A few hundred times slower: meant for
+ *                      HIP-vs-HIP regression checks (graph replay vs eager, padded rows, data-parallel exchange).
+ *   MDL_K3_PER_WAVE /  mdl_cgconv_bwd_h / _hb only: force the per-wave kernel / the edge-per-lane kernel 2 instead of
+ *   MDL_K3_EDGE_LANE   the edge-count heuristic (kernel 2 from 4e5 edges). */
+#define MDL_DTYPE_MASK 0xff
+#define MDL_DETERMINISTIC 0x100
+#define MDL_K3_PER_WAVE 0x200
+#define MDL_K3_EDGE_LANE 0x400
+
 typedef void* mdlStream_t; /* hipStream_t */
 
 int mdl_version(void);
 const char* mdl_last_error_string(void);
+/* Which backward edge pass the last mdl_cgconv_bwd* call of this thread launched (thread-local, like the error string):
+ * 0 none yet, 1 per-wave kernel, 2 edge-per-lane kernel 2, 3 per-wave kernel in its deterministic shape.  For tests that must
+ * know that the kernel they mean to check is the one that ran. */
+int mdl_debug_last_k3(void);
 
 /* ---- K1: Gaussian RBF edge expansion ------------------------------------------------------
  * Replaces GaussianSmearing.forward, matdeeplearn/process/process.py:588-590 (instantiated
@@ -110,19 +130,11 @@ int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_t* rowptr, 
  * from which the caller forms (dense, node level): dx = g + r_tgt W_tgt + r_src W_src, dW_tgt = r_tgt^T x,
  * dW_src = r_src^T x — by library GEMMs or by mdl_cgconv_bwd_node.  The gate pre-activations are
  * recomputed, not stored. */
+/* `dtype` may carry MDL_DETERMINISTIC (one wave per channel slice: r_src / dwe / db bit-reproducible). */
 int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
                    const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
                    const void* grad_out, void* r_tgt, float* r_src, float* dwe, float* db, int64_t N,
                    int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes, mdlStream_t stream);
-
-/* Saved-gate variant of the pair above (dtype MDL_BF16, C in {32, 64}, G = 50, edge features in CSR order; row bytes 0 =
- * unsupported).  The training forward also writes, per edge and channel, the two factors the backward needs
- *     A = d m / d pre_f = sigmoid'(pre_f) softplus(pre_s),   B = d m / d pre_s = sigmoid(pre_f) sigmoid(pre_s)
- * as one packed bf16 pair: gate [E, C, 2] = mdl_cgconv_gate_row_bytes(C, G, dtype) (= 4C) bytes per edge, caller-owned.
- * mdl_cgconv_bwd_saved then produces the SAME r_tgt / r_src / dwe / db as mdl_cgconv_bwd from grad_out, the indices,
- * the edge features and `gate` alone — no x, no weights, no recompute of the gate: it trades 8C bytes of HBM traffic per
- * edge and layer for 24 of the 46 MFMAs, every transcendental and the x gathers of the recomputing pass. */
-size_t mdl_cgconv_gate_row_bytes(int C, int G, int dtype);
 
 /* mdl_cgconv_bwd with the by-source sums in bf16 (MDL_BF16, C in {32, 64}, G = 50, edge features in CSR order): r_src is a
  * [N, 2Cp] bf16 array (zero-filled by the caller) accumulated with packed bf16 atomics — half the atomic operations and half
@@ -137,7 +149,8 @@ int mdl_cgconv_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr
  * tile that costs a full tile's time).  The caller turns it into an inclusive prefix sum
  * (int32, [N + 1]) and hands it to mdl_cgconv_bwd_hb, whose workgroups then take node ranges of equal COST instead of equal
  * edge + node counts (graphs wider than the by-source window make their tiles dearer; topology only: one prefix per batch
- * serves every layer).  NULL balance = mdl_cgconv_bwd_h. */
+ * serves every layer).  NULL balance = mdl_cgconv_bwd_h.  `dtype` of mdl_cgconv_bwd_h / _hb may carry MDL_DETERMINISTIC,
+ * MDL_K3_PER_WAVE or MDL_K3_EDGE_LANE; mdl_cgconv_bwd_node* and the flag-aware dense kernels below take MDL_DETERMINISTIC. */
 int mdl_cgconv_balance(const int32_t* rowptr, const int32_t* src, int64_t N, int32_t* cost, mdlStream_t stream);
 int mdl_cgconv_bwd_hb(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src, const int32_t* tgt,
                       const void* wpack, const float* bpack, const void* grad_out, void* r_tgt, void* r_src, float* dwe,
@@ -145,33 +158,6 @@ int mdl_cgconv_bwd_hb(const void* x, const void* edge_attr, const int32_t* rowpt
                       const int32_t* balance, mdlStream_t stream);
 int mdl_cgconv_bwd_node_h(const void* x, const void* grad_out, const void* r_tgt, void* r_src, const void* wn_t, void* dx,
                           float* dwn, int64_t N, int C, int dtype, int zero_src, mdlStream_t stream);
-
-/* W-split variant of the pair (dtype MDL_BF16, C in {32, 64}, G = 50, edge features in CSR order): the node parts of the two
- * Linear(2C+G, C) of PyG CGConv (cgcnn.py:80-83) leave the edge pass —
- *     z W^T = e W_e^T + P_t[i] + P_s[j],   P_t = x [W_f,tgt ; W_s,tgt]^T,   P_s = x [W_f,src ; W_s,src]^T   ([N, 2Cp] each)
- * — so that per edge only the K = 64 edge-feature product remains (4C G instead of 4C(2C+G) FLOP per edge).
- * mdl_cgconv_pack_weights_split fills wpack_e (mdl_cgconv_wsplit_bytes(.., 0) bytes: edge part + bias column) and wproj
- * (mdl_cgconv_wsplit_bytes(.., 1) bytes: two [2Cp, Cp] matrices, target then source, the `w` operand of mdl_linear_act with
- * M = 2Cp, K = C), both scaled like mdl_cgconv_pack_weights; the caller forms P_t / P_s with two mdl_linear_act launches.
- * mdl_cgconv_bwd_p produces the same r_tgt / r_src / dwe / db as mdl_cgconv_bwd: r_tgt = dL/dP_t and r_src = dL/dP_s are what
- * mdl_cgconv_bwd_node turns into dx and the node-weight gradients, unchanged. */
-size_t mdl_cgconv_wsplit_bytes(int C, int G, int dtype, int which);
-int mdl_cgconv_pack_weights_split(const float* w_f, const float* b_f, const float* w_s, const float* b_s, int C, int G,
-                                  void* wpack_e, void* wproj, float* bpack, int dtype, mdlStream_t stream);
-int mdl_cgconv_fwd_p(const void* x, const void* p_tgt, const void* p_src, const void* edge_attr, const int32_t* rowptr,
-                     const int32_t* src, const int32_t* tgt, const void* wpack_e, const float* bpack, void* out,
-                     int64_t N, int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream);
-int mdl_cgconv_bwd_p(const void* p_tgt, const void* p_src, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
-                     const int32_t* tgt, const void* wpack_e, const float* bpack, const void* grad_out, void* r_tgt,
-                     float* r_src, float* dwe, float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype,
-                     void* workspace, size_t ws_bytes, mdlStream_t stream);
-int mdl_cgconv_fwd_save(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
-                        const int32_t* tgt, const void* wpack, const float* bpack, void* out, void* gate,
-                        int64_t N, int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream);
-int mdl_cgconv_bwd_saved(const void* edge_attr, const int32_t* rowptr, const int32_t* src, const int32_t* tgt,
-                         const void* gate, const void* grad_out, void* r_tgt, float* r_src, float* dwe, float* db,
-                         int64_t N, int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
-                         mdlStream_t stream);
 
 /* Optional scratch for mdl_cgconv_bwd (caller-owned device memory, contents ignored; the library zeroes what it
  * uses, on the stream).  With it the backward hands 32-node groups to its waves dynamically (large problems);
@@ -331,13 +317,6 @@ int mdl_mlp_head_bwd(const void* x, const void* const* w, const void* const* h, 
  * Y = x W2r of the re-associated message (matdeeplearn/models/mpnn.py:83-88 — C_out * d3 = 10^4 columns), a write stream of
  * N * M * 2 bytes that the library ran as a 256x256x32 macro-tile GEMM (771 us for 6.1e4 x 100 x 1e4). */
 int mdl_linear_wide(const void* x, const void* w, void* out, int64_t N, int K, int64_t M, int dtype, mdlStream_t stream);
-
-/* Two chained dense layers in one pass: h[N, M1] = act1(x[N, K] w1[M1, K]^T + b1), y[N, M2] = act2(h w2[M2, M1]^T + b2); both
- * results are written (the backward of the pair needs h), the rows of h reach the second product through LDS.  The filter
- * network of CFConv — Linear(num_gaussians, F) -> ShiftedSoftplus -> Linear(F, F) over the edges (matdeeplearn/models/
- * schnet.py:81 via torch_geometric.nn.models.schnet.InteractionBlock.mlp).  bf16; even K <= 64, even M1 <= 160, M2 <= 160. */
-int mdl_mlp2(const void* x, const void* w1, const void* b1, int act1, const void* w2, const void* b2, int act2, void* h,
-             void* y, int64_t N, int K, int M1, int M2, int dtype, mdlStream_t stream);
 
 /* ---- tall-skinny TN GEMM: weight gradients of node-level Linear layers ---------------------------
  * c[M, K] (fp32, row-major, caller zero-fills) += a[N, M]^T . b[N, K]   a, b bf16 with leading dims lda, ldb.

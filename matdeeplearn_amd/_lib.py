@@ -10,6 +10,8 @@ LIB_PATH = os.environ.get("MDL_HIP_LIB") or os.path.join(HERE, "lib", "libmdl_hi
 
 MDL_F32, MDL_BF16 = 0, 1
 MDL_SUM, MDL_MEAN, MDL_MAX = 0, 1, 2
+# execution flags OR-ed into the `dtype` argument (include/mdl_hip.h)
+MDL_DTYPE_MASK, MDL_DETERMINISTIC, MDL_K3_PER_WAVE, MDL_K3_EDGE_LANE = 0xFF, 0x100, 0x200, 0x400
 REDUCE = {"sum": MDL_SUM, "add": MDL_SUM, "mean": MDL_MEAN, "max": MDL_MAX}
 
 _vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -18,6 +20,7 @@ _vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctyp
 PROTOTYPES = {
     "mdl_version": (_i32, []),
     "mdl_last_error_string": (ctypes.c_char_p, []),
+    "mdl_debug_last_k3": (_i32, []),
     "mdl_rbf_expand": (_i32, [_vp, _vp, _f32, _vp, _i64, _i32, _i64, _i32, _vp]),
     "mdl_csr_rowptr": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "mdl_segment_reduce_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
@@ -28,17 +31,10 @@ PROTOTYPES = {
     "mdl_cgconv_fwd": (_i32, [_vp] * 9 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_cgconv_bwd": (_i32, [_vp] * 13 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, ctypes.c_size_t, _vp]),
     "mdl_cgconv_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i32, _i32, _i32]),
-    "mdl_cgconv_gate_row_bytes": (_sz, [_i32, _i32, _i32]),
     "mdl_cgconv_bwd_h": (_i32, [_vp] * 12 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "mdl_cgconv_bwd_hb": (_i32, [_vp] * 12 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp, _vp]),
     "mdl_cgconv_balance": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "mdl_cgconv_bwd_node_h": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
-    "mdl_cgconv_wsplit_bytes": (_sz, [_i32, _i32, _i32, _i32]),
-    "mdl_cgconv_pack_weights_split": (_i32, [_vp] * 4 + [_i32, _i32, _vp, _vp, _vp, _i32, _vp]),
-    "mdl_cgconv_fwd_p": (_i32, [_vp] * 10 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
-    "mdl_cgconv_bwd_p": (_i32, [_vp] * 13 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
-    "mdl_cgconv_fwd_save": (_i32, [_vp] * 9 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
-    "mdl_cgconv_bwd_saved": (_i32, [_vp] * 10 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, ctypes.c_size_t, _vp]),
     "mdl_cgconv_bwd_node": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _vp]),
     "mdl_cgconv_bwd_node_z": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "mdl_cgconv_pack_node_weights": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp]),
@@ -63,7 +59,6 @@ PROTOTYPES = {
     "mdl_linear_act_in": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_ssp_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "mdl_linear_gather_act": (_i32, [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp]),
-    "mdl_mlp2": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_linear_wide": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp]),
     "mdl_mlp_head_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "mdl_mlp_head_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),

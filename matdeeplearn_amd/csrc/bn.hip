@@ -239,7 +239,8 @@ static int bn_check(const char* name, int64_t N, int C, int dtype, const void* p
     return MDL_OK;
 }
 
-static unsigned bn_grid(int64_t N, int C, int W) {
+static unsigned bn_grid(int64_t N, int C, int W, bool det) {
+    if (det) return 1;            // MDL_DETERMINISTIC: one workgroup, one add per sum
     const int rows = 256 / (C / W);
     int64_t g = cdiv(N, (int64_t)rows * 8);
     if (g > 1024) g = 1024;       // every block ends with 2C atomics, spread over BN_R copies of the sums
@@ -255,13 +256,15 @@ extern "C" int mdl_bn_stats(const void* x, float* sums, int64_t N, int C, int dt
 }
 extern "C" int mdl_bn_stats_n(const void* x, float* sums, int64_t N, int C, const int64_t* n_dev, int dtype, mdlStream_t stream) {
     using namespace mdl;
+    const bool det = (dtype & MDL_DETERMINISTIC) != 0;
+    dtype &= MDL_DTYPE_MASK;
     int rc = bn_check("mdl_bn_stats", N, C, dtype, x);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int W = bn_width(C, dtype);
-    if (dtype == MDL_BF16 && W == 8) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0, 8>), dim3(bn_grid(N, C, W)), dim3(bn_threads(C, 8)), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
-    else if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0, 4>), dim3(bn_grid(N, C, W)), dim3(bn_threads(C, 4)), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
-    else hipLaunchKernelGGL((bn_reduce_kernel<float, 0, 4>), dim3(bn_grid(N, C, W)), dim3(bn_threads(C, 4)), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
+    if (dtype == MDL_BF16 && W == 8) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0, 8>), dim3(bn_grid(N, C, W, det)), dim3(bn_threads(C, 8)), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
+    else if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0, 4>), dim3(bn_grid(N, C, W, det)), dim3(bn_threads(C, 4)), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
+    else hipLaunchKernelGGL((bn_reduce_kernel<float, 0, 4>), dim3(bn_grid(N, C, W, det)), dim3(bn_threads(C, 4)), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, sums, N, C, n_dev);
     return check_launch("mdl_bn_stats");
 }
 
@@ -274,6 +277,7 @@ extern "C" int mdl_bn_apply_n(const void* x, float* sums, const float* gamma, co
                               float* running_mean, float* running_var, void* y, int64_t N, int C, float eps, float momentum,
                               const int64_t* n_dev, int dtype, mdlStream_t stream) {
     using namespace mdl;
+    dtype &= MDL_DTYPE_MASK;
     int rc = bn_check("mdl_bn_apply", N, C, dtype, x);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -294,13 +298,15 @@ extern "C" int mdl_bn_bwd_stats(const void* dy, const void* x, const float* save
 extern "C" int mdl_bn_bwd_stats_n(const void* dy, const void* x, const float* save, float* sums, int64_t N, int C,
                                   const int64_t* n_dev, int dtype, mdlStream_t stream) {
     using namespace mdl;
+    const bool det = (dtype & MDL_DETERMINISTIC) != 0;
+    dtype &= MDL_DTYPE_MASK;
     int rc = bn_check("mdl_bn_bwd_stats", N, C, dtype, x);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int W = bn_width(C, dtype);
-    if (dtype == MDL_BF16 && W == 8) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1, 8>), dim3(bn_grid(N, C, W)), dim3(bn_threads(C, 8)), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, N, C, n_dev);
-    else if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1, 4>), dim3(bn_grid(N, C, W)), dim3(bn_threads(C, 4)), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, N, C, n_dev);
-    else hipLaunchKernelGGL((bn_reduce_kernel<float, 1, 4>), dim3(bn_grid(N, C, W)), dim3(bn_threads(C, 4)), 0, st, (const float*)dy, (const float*)x, save, sums, N, C, n_dev);
+    if (dtype == MDL_BF16 && W == 8) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1, 8>), dim3(bn_grid(N, C, W, det)), dim3(bn_threads(C, 8)), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, N, C, n_dev);
+    else if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1, 4>), dim3(bn_grid(N, C, W, det)), dim3(bn_threads(C, 4)), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, N, C, n_dev);
+    else hipLaunchKernelGGL((bn_reduce_kernel<float, 1, 4>), dim3(bn_grid(N, C, W, det)), dim3(bn_threads(C, 4)), 0, st, (const float*)dy, (const float*)x, save, sums, N, C, n_dev);
     return check_launch("mdl_bn_bwd_stats");
 }
 
@@ -311,6 +317,7 @@ extern "C" int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save
 extern "C" int mdl_bn_bwd_apply_n(const void* dy, const void* x, const float* save, float* sums, const float* gamma,
                                   void* dx, int64_t N, int C, const int64_t* n_dev, int dtype, mdlStream_t stream) {
     using namespace mdl;
+    dtype &= MDL_DTYPE_MASK;
     int rc = bn_check("mdl_bn_bwd_apply", N, C, dtype, x);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;

@@ -42,6 +42,10 @@
 
 #include "mdl_common.h"
 
+#ifndef MDL_EXPERIMENTS
+#define MDL_EXPERIMENTS 0   // 1: the experiments build (experiments/build.py): measured-negative kernel variants and their
+                            // environment switches are compiled in; libmdl_hip.so itself never reads the environment
+#endif
 #ifndef MDL_CG_WM
 #define MDL_CG_WM 1       // where the static bf16 kernels keep W: 1 LDS, 2 registers, 3 x-part registers + e-part LDS
 #endif
@@ -144,6 +148,7 @@ struct CgParams {
     const int32_t* balance;   // bwd, optional: [N + 1] non-decreasing cost prefix the workgroups' node ranges are balanced on
                               // (mdl_cgconv_balance); null: edges + nodes in front of a node
     int rs16;           // bwd, bf16: r_src is a bf16 array accumulated with packed bf16 atomics (mdl_cgconv_bwd_h)
+    int flags;          // host side: MDL_DETERMINISTIC / MDL_K3_* bits the caller OR-ed into `dtype`
     const void* pt;     // W-split kernels: per-node projections P_t = x [W_f,tgt ; W_s,tgt]^T and P_s = x [W_f,src ; W_s,src]^T,
     const void* ps;     // [N, 2Cp] each in the compute dtype (columns f | s), scaled like the packed weights
     int64_t N, E;
@@ -1710,293 +1715,29 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Backward edge pass from SAVED gate factors (static bf16 shapes).
-// The training forward stores, per (edge, channel), A = dm/dpre_f and B = dm/dpre_s as one packed dword (256 B per
-// edge at C = 64).  This pass then needs neither x, nor the weights, nor any transcendental: per 32-edge tile it
-// streams the tile's A|B rows (coalesced 128-byte row segments straight into D-layout registers) and its edge
-// features (LDS tile, for dwe), expands grad_out/deg to the edges with the one-hot MFMA, multiplies, and reduces
-// dpre the same three ways as cgconv_bwd_kernel (r_tgt by target, r_src by source window + atomics, dwe = dpre^T e).
-// It trades 2 x 4Cp bytes of HBM traffic per edge and layer for the whole recompute (24 of 46 MFMAs, ~90 VALU
-// cycles per element of gate derivative, the x gathers and their registers): on a part with 8 TB/s that is the
-// better side of the trade — the recomputing kernel sat at 0.24 of the HBM roofline, compute/latency bound.
-// Work distribution, group prologue, one-hot tables, window and flushes are those of cgconv_bwd_kernel.
-// ------------------------------------------------------------------------------------------
-template <int CP_>
-struct ABWords {
-    static constexpr int ROWB = 4 * CP_;
-    unsigned w[16];
-    // rows eb .. eb+31 of the saved factors, this lane's channel of slice s; rows past E read as zeros
-    __device__ __forceinline__ void prefetch(const CgParams& p, int eb, int s, int i, int h) {
-        const char* tb = static_cast<const char*>(p.ab) + (int64_t)eb * ROWB;
-        const int64_t rem = (p.E - (int64_t)eb) * ROWB;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(tb), 0, (int)(rem < 0 ? 0 : (rem < 0x7fffffffLL ? rem : 0x7fffffffLL)), 0x00020000);
-        const int vo0 = 4 * h * ROWB + s * 128 + i * 4, vo1 = vo0 + 16 * ROWB;     // + immediate < 4096: range-checked
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            w[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (r < 8 ? vo0 : vo1) + ((r & 3) + 8 * ((r >> 2) & 1)) * ROWB, 0, 0);
-    }
-};
-
-template <int CP_, int G_>
-__global__ __launch_bounds__(256, 1) void cgconv_bwd_ab_kernel(CgParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef bf16_t T;
-    constexpr int EW = 2;
-    typedef Dims<T, CP_, G_, EW> D;
-    const D dm(p);
-    WaveCtx<T> w;
-    setup_wave<T>(p, dm, smem, false, w);
-
-    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-    const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int total_waves = gridDim.x * (blockDim.x >> 6);
-    constexpr int NS = CP_ / 32;
-    const int s = gw % NS;
-    const int gstride = total_waves / NS;
-    const int ch = s * 32 + i;
-    const T* go = static_cast<const T*>(p.gout);
-    constexpr int C2 = 2 * CP_;
-
-    constexpr int GNT = (G_ + 31) / 32;
-    f32x16 dwe_acc[2][GNT];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < GNT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dwe_acc[a][b][r] = 0.0f;
-
-    float dbf_acc = 0.0f, dbs_acc = 0.0f;
-    int oh_ts = -1, oh_ss = -1;
-    const bool dyn = p.ctr != nullptr;
-    NodeRange R{0, 0};
-    if (!dyn) R = NodeRange(p, __builtin_amdgcn_readfirstlane(gw / NS), gstride, lane);
-    const int nend = dyn ? (int)p.N : R.nb;
-    int gpend = 0;
-    if (dyn && lane == 0) gpend = (int)atomicAdd(p.ctr + s, 1u);
-    int n0 = dyn ? 32 * __builtin_amdgcn_readfirstlane(gpend) : R.na;
-    while (n0 < nend) {
-        const int n1 = min(n0 + 32, nend);
-        if (dyn && lane == 0) gpend = (int)atomicAdd(p.ctr + s, 1u);
-        const int e0 = p.rowptr[n0];
-        const int e1 = p.rowptr[n1];
-
-        // ---- group prologue: every load unconditional on a clamped index, all issued before the first use
-        const int nd = min(n0 + i, n1 - 1);
-        const int dg0 = p.rowptr[nd], dg1 = p.rowptr[nd + 1];
-        float graw[2][8];
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                graw[f][q] = Elem<T>::ld(go + (int64_t)min(n0 + 16 * f + 8 * h + q, n1 - 1) * CP_ + ch);
-        int wb = 0x7fffffff;
-        for (int eb = e0; eb < e1; eb += 8 * WAVE) {
-            int sv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) sv[u] = p.src[min(eb + u * WAVE + lane, e1 - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) wb = min(wb, sv[u]);
-        }
-        TileIdx cur, nxt, nn;
-        EWords<T, G_, EW> ew;
-        ABWords<CP_> ab, abn;
-        cur.template load<false>(p, e0, e1, i, n0);
-        nxt = cur;
-        if (e0 + 32 < e1) nxt.template load<false>(p, e0 + 32, e1, i, n0);
-        nn = nxt;
-        ew.prefetch(p, lane, e0, 32, 0);
-        ab.prefetch(p, e0, s, i, h);
-
-        const float invd = (p.aggr == MDL_MEAN) ? 1.0f / (float)max(dg1 - dg0, 1) : 1.0f;
-        bf16x8 gB[2];
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            float v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int ns = 16 * f + 8 * h + q;
-                const float sc = __shfl(invd, ns);
-                v[q] = (n0 + ns < n1) ? graw[f][q] * sc : 0.0f;
-            }
-            gB[f] = pack_bf16x8(v);
-        }
-
-        f32x16 Rf, Rs;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { Rf[r] = 0.0f; Rs[r] = 0.0f; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) wb = min(wb, __shfl_xor(wb, o));
-        wb = __builtin_amdgcn_readfirstlane(wb);
-        f32x16 Wf[2], Ws[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { Wf[mt][r] = 0.0f; Ws[mt][r] = 0.0f; }
-        if (lane == 0) *w.touched = 0ull;
-
-        for (int eb = e0; eb < e1; eb += 32) {
-            const int nv = min(32, e1 - eb);
-            const bool valid_i = i < nv;
-            const int my_ts = valid_i ? (cur.tgt - n0) : 0xff;
-            const unsigned my_ss = (unsigned)(cur.src - wb);
-            const bool in_win = valid_i && my_ss < 64u;
-            const bool oob = valid_i && !in_win;
-            wave_lds_fence();
-            ew.commit(w.et, dm.EKS, lane);
-            if (h == 0) {
-                w.srcl[i] = oob ? cur.src : -1;
-                if (in_win) atomicOr(w.touched, 1ull << my_ss);
-                const int nts = valid_i ? my_ts : -1, nss = in_win ? (int)my_ss : -1;
-                oh_update(w.oh_t, oh_ts, nts, oh_pos(i));
-                oh_update(w.oh_w, oh_ss, nss, oh_pos(i));
-                if (oh_ts != nts) {
-                    if (oh_ts >= 0) w.oh_e[i * OHS + oh_ts] = 0;
-                    if (nts >= 0) w.oh_e[i * OHS + nts] = 0x3F80;
-                }
-                oh_ts = nts;
-                oh_ss = nss;
-            }
-            wave_lds_fence();
-
-            // next tile's loads, unconditional (clamped indices / range-checked buffer loads)
-            nn.template load<false, false>(p, eb + 64, e1, i, n0);
-            ew.prefetch(p, lane, eb + 32, 32, 0);
-            abn.prefetch(p, eb + 32, s, i, h);
-
-            // dmv[edge slot][ch] = grad_out[tgt(edge)][ch] / deg : one-hot(edge -> node slot) x gB
-            f32x16 dmv;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dmv[r] = 0.0f;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                dmv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh_frag(w.oh_e, i, ks, h), gB[ks], dmv, 0, 0, 0);
-
-            // dpre = dmv * (A | B).  dmv is an exact 0 for edge slots >= nv (empty one-hot row), so whatever the rows
-            // past the group's end hold (the next group's factors, finite) contributes exact zeros.
-            f32x16 accf, accs;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                accf[r] = dmv[r] * __uint_as_float(ab.w[r] << 16);
-                accs[r] = dmv[r] * __uint_as_float(ab.w[r] & 0xffff0000u);
-            }
-
-            if (__any(oob)) {
-                typedef __attribute__((ext_vector_type(4))) int i32x4;
-                int sj[16];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const i32x4 v = *reinterpret_cast<const i32x4*>(w.srcl + 8 * q + 4 * h);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) sj[4 * q + k] = v[k];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (sj[r] >= 0) {
-                        float* dst = p.r_src + (int64_t)sj[r] * C2 + ch;
-                        unsafeAtomicAdd(dst, accf[r]);
-                        unsafeAtomicAdd(dst + CP_, accs[r]);
-                    }
-                }
-            }
-
-            DFrags<T> dp;
-            dp.pack(accf, accs);
-            seg_reduce2_tab(dp, w.oh_t, i, h, Rf, Rs);                                          // by target -> r_tgt
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) seg_reduce2_tab(dp, w.oh_w, i + 32 * mt, h, Wf[mt], Ws[mt]);   // by source window
-
-            // dwe[ch][gcol] += sum_slot dpre[slot][ch] * e[slot][gcol]   (B = e-tile columns via the LDS transpose read)
-#pragma unroll
-            for (int nt = 0; nt < GNT; ++nt) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    typedef __attribute__((ext_vector_type(4))) short s16x4;
-                    typedef __attribute__((address_space(3))) s16x4* lds4_t;
-                    const int t = i & 15;
-                    const bf16_t* base = w.et + (16 * ks + 4 * h + (t >> 2)) * dm.EKS + nt * 32 + (i & 16) + 4 * (t & 3);
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(base));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(base + 8 * dm.EKS));
-                    const bf16x8 b = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    dwe_acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp.f[ks], b, dwe_acc[0][nt], 0, 0, 0);
-                    dwe_acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp.s[ks], b, dwe_acc[1][nt], 0, 0, 0);
-                }
-            }
-            cur = nxt;
-            nxt = nn;
-            ab = abn;
-        }
-
-        const int n0_dyn = dyn ? 32 * __builtin_amdgcn_readfirstlane(gpend) : 0;
-        wave_lds_fence();
-        {
-            const unsigned long long tmv = *w.touched;
-            const unsigned long long tm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(tmv >> 32)) << 32) |
-                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tmv);
-            const unsigned long long tmh = tm >> (4 * h);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int sl = 32 * mt + d_row(r, h);
-                    if ((tmh >> (32 * mt + d_row(r, 0))) & 1ull) {
-                        float* dst = p.r_src + (int64_t)(wb + sl) * C2 + ch;
-                        unsafeAtomicAdd(dst, Wf[mt][r]);
-                        unsafeAtomicAdd(dst + CP_, Ws[mt][r]);
-                    }
-                }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dbf_acc += Rf[r]; dbs_acc += Rs[r]; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + d_row(r, h);
-            if (n < n1) {
-                T* dst = static_cast<T*>(p.r_tgt) + (int64_t)n * C2 + ch;
-                Elem<T>::st(dst, Rf[r]);
-                Elem<T>::st(dst + CP_, Rs[r]);
-            }
-        }
-        n0 = dyn ? n0_dyn : n1;
-    }
-
-    if (p.db) {
-        dbf_acc += __shfl_xor(dbf_acc, 32);
-        dbs_acc += __shfl_xor(dbs_acc, 32);
-        if (h == 0) {
-            unsafeAtomicAdd(p.db + ch, dbf_acc);
-            unsafeAtomicAdd(p.db + CP_ + ch, dbs_acc);
-        }
-    }
-#pragma unroll
-    for (int nt = 0; nt < GNT; ++nt) {
-        const int gcol = nt * 32 + i;
-        if (gcol < G_) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = s * 32 + d_row(r, h);
-                unsafeAtomicAdd(p.dwe + (int64_t)c * p.GP + gcol, dwe_acc[0][nt][r]);
-                unsafeAtomicAdd(p.dwe + (int64_t)(CP_ + c) * p.GP + gcol, dwe_acc[1][nt][r]);
-            }
-        }
-    }
-}
-
-#include "cgconv_cb.inc"   // namespace mdl::cb
+#if MDL_EXPERIMENTS
+#include "../../experiments/csrc/cgconv_ab.inc"   // saved-gate backward edge pass: net zero against the recomputing pass
+#include "../../experiments/csrc/cgconv_cb.inc"   // namespace mdl::cb (cooperative weight-stationary kernels: measured slower)
+#endif
 // The edge-per-lane backward (cgconv_ep.inc, namespace mdl::ep; opt-in, MDL_CG_EP=1) lives in its own translation
 // unit: cgconv_ep.hip defines MDL_CG_EP_TU and includes THIS file, so that it sees the shared tile machinery above, and is
 // compiled with -mllvm -amdgpu-mfma-vgpr-form=1 — its phase-A MFMA results then land in the VGPRs the gate arithmetic reads
 // (the default AGPR form costs one v_accvgpr_read per value, 96 per tile), while the per-wave kernels of this unit, which
 // live on 256 + 179 registers, need the AGPR form.
 #ifdef MDL_CG_EP_TU
-#include "cgconv_ep.inc"
+#include "cgconv_ep_common.inc"
+#if MDL_EXPERIMENTS
+#include "../../experiments/csrc/cgconv_ep.inc"   // phases one after the other: measured slower than the per-wave kernel
+#endif
 #include "cgconv_ep2.inc"
 namespace ep {
-static bool cg_env_ep2_static() {          // MDL_EP2_STATIC=1: kernel 2 without the dynamic tail (A/B)
+static bool cg_env_ep2_static() {          // experiments build, MDL_EP2_STATIC=1: kernel 2 without the dynamic tail (A/B)
+#if MDL_EXPERIMENTS
     static const bool v = [] { const char* s = getenv("MDL_EP2_STATIC"); return s && atoi(s) != 0; }();
     return v;
+#else
+    return true;
+#endif
 }
 int launch2(CgParams& p, hipStream_t st, int wgs, const char* name) {
     typedef Cfg2<64> F;
@@ -2005,11 +1746,12 @@ int launch2(CgParams& p, hipStream_t st, int wgs, const char* name) {
     hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), F::LDS);
     if (e != hipSuccess) { set_error("%s: LDS attribute (%d B): %s", name, F::LDS, hipGetErrorString(e)); return MDL_E_LAUNCH; }
     // optional caller workspace: the chunk counter of the dynamic tail, zeroed on the stream
-    if (MDL_EP2_TAIL == 0 || cg_env_ep2_static()) p.ctr = nullptr;
+    if (MDL_EP2_TAIL == 0 || cg_env_ep2_static()) p.ctr = nullptr;      // (the dynamic tail: experiments build with -DMDL_EP2_TAIL=25)
     if (p.ctr && hipMemsetAsync(p.ctr, 0, 64, st) != hipSuccess) p.ctr = nullptr;
     hipLaunchKernelGGL(kf, dim3((unsigned)eg), dim3(F::NT), F::LDS, st, p);
     return check_launch(name);
 }
+#if MDL_EXPERIMENTS
 int launch(CgParams& p, hipStream_t st, int wgs, const char* name) {
     typedef Cfg<64> F;
     // one workgroup per CU; small problems: at least two rounds of tiles per workgroup
@@ -2020,19 +1762,22 @@ int launch(CgParams& p, hipStream_t st, int wgs, const char* name) {
     hipLaunchKernelGGL(kf, dim3((unsigned)eg), dim3(F::NT), F::LDS, st, p);
     return check_launch(name);
 }
+#endif
 }  // namespace ep
 }  // namespace mdl
 #else
 namespace ep {
 #ifndef MDL_EP_DEFAULT
-#define MDL_EP_DEFAULT 2      // edge-per-lane backward edge pass for bf16, C = 64, G = 50 (MDL_CG_EP = 0 / 1 / 2 overrides):
-                              // 2 = cgconv_ep2.inc where the by-source sums are bf16 (mdl_cgconv_bwd_h): 6-9 % faster than the
-                              // per-wave kernel on the bench batch; 1 = cgconv_ep.inc (fp32 sums; slower, kept for A/B); 0 = per-wave
+#define MDL_EP_DEFAULT 2      // edge-per-lane backward edge pass for bf16, C = 64, G = 50: 2 = cgconv_ep2.inc where the by-source
+                              // sums are bf16 (mdl_cgconv_bwd_h): 6-9 % faster than the per-wave kernel on the bench batch; 0 = the
+                              // per-wave kernel always.  Callers override per launch with MDL_K3_PER_WAVE / MDL_K3_EDGE_LANE.
 #endif
 #ifndef MDL_EP2_MIN_EDGES
-#define MDL_EP2_MIN_EDGES 400000   // default selection of kernel 2: at least ~12 rounds per workgroup (MDL_CG_EP=2 forces it)
+#define MDL_EP2_MIN_EDGES 400000   // default selection of kernel 2: at least ~12 rounds per workgroup (MDL_K3_EDGE_LANE forces it)
 #endif
-int launch(CgParams& p, hipStream_t st, int wgs, const char* name);      // cgconv_ep.inc: phases one after the other
+#if MDL_EXPERIMENTS
+int launch(CgParams& p, hipStream_t st, int wgs, const char* name);      // experiments/csrc/cgconv_ep.inc: phases one after the other
+#endif
 int launch2(CgParams& p, hipStream_t st, int wgs, const char* name);     // cgconv_ep2.inc: producer / reducer waves side by side
 }
 
@@ -2085,6 +1830,7 @@ __global__ __launch_bounds__(256) void cgconv_pack_kernel(const float* __restric
     }
 }
 
+#if MDL_EXPERIMENTS
 // W-split packing: the edge-feature part [2Cp][KE + pad] (bias in column G) and the two projection weights
 // wproj[side][2Cp][Cp] (side 0 target, 1 source; rows f then s; the `w` operand [M = 2Cp, K = C] of mdl_linear_act),
 // everything scaled like the packed weights.
@@ -2116,13 +1862,16 @@ __global__ __launch_bounds__(256) void cgconv_pack_split_kernel(const float* __r
         }
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Host-side dispatch
 // ------------------------------------------------------------------------------------------
 static constexpr int LDS_CAP = 160 * 1024;
 
-// Experiment switches from the environment, read ONCE (first launch) — the launch path itself is stateless.
+// Experiment switches.  libmdl_hip.so never reads the environment: variants a caller or a test wants are explicit flag bits
+// in the `dtype` argument (MDL_DETERMINISTIC, MDL_K3_PER_WAVE, MDL_K3_EDGE_LANE).  The experiments build (experiments/build.py,
+// -DMDL_EXPERIMENTS=1) reads them from the environment ONCE (first launch).
 struct CgEnv {
     int64_t grid_cap;     // MDL_GRID_CAP: upper bound on the grid (0 = none)
     int cb_fwd, cb_bwd;   // MDL_CG_CB / MDL_CG_CB_BWD: cooperative column-block kernels (-1 = compile-time default)
@@ -2131,10 +1880,11 @@ struct CgEnv {
     int no_half_groups;   // MDL_CG_NO_HALF=1: dynamic backward schedule without the half-group tail (A/B)
     int no_fast128;       // MDL_CG_NO_FAST128=1: 128-channel layers take the generic kernels (A/B)
     int no_w_slice;       // MDL_CG_NO_WSLICE=1: wide layers read the packed weights from global memory as before (A/B)
-    int ep;               // MDL_CG_EP: edge-per-lane backward edge pass (cgconv_ep.inc); -1 = compile-time default
+    int ep;               // MDL_CG_EP: edge-per-lane backward edge pass; -1 = compile-time default
     int ep_wgs;           // MDL_EP_WGS: its grid cap (0 = one workgroup per CU)
 };
 static const CgEnv& cg_env() {
+#if MDL_EXPERIMENTS
     static const CgEnv e = [] {
         CgEnv v;
         const char* s;
@@ -2150,8 +1900,15 @@ static const CgEnv& cg_env() {
         v.ep_wgs = (s = getenv("MDL_EP_WGS")) ? atoi(s) : 0;
         return v;
     }();
+#else
+    static const CgEnv e = {0, -1, -1, 0, 0, 0, 0, 0, -1, 0};
+#endif
     return e;
 }
+
+// which backward edge pass the last mdl_cgconv_bwd* call of this thread launched (mdl_debug_last_k3: tests assert that the
+// kernel they mean to check is the one that ran): 1 per-wave, 2 edge-per-lane kernel 2, 3 per-wave in deterministic shape
+static thread_local int g_last_k3 = 0;
 
 template <typename T>
 static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const char* name) {
@@ -2180,7 +1937,11 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     // e tile, tgt-slot bytes, source ids, src-slot bytes, bitmap, one-hot tables (32 + 32 + 64 rows)
     p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16 + ((bwd && sizeof(T) == 2) ? 128 * OHS * 2 + 64 + 256 : 0);
     const int w_bytes = (p.w_elems * (int)sizeof(T) + 15) & ~15;
-    const int waves = bwd ? 4 : MDL_FWD_THREADS / 64;
+    // MDL_DETERMINISTIC (backward): ONE wave per channel slice walks the whole batch — every sum this kernel forms with atomics
+    // (r_src rows, dwe, db) then receives its terms from a single wave in program order, i.e. the same bits on every run.
+    // For HIP-vs-HIP tests (graph replay vs eager, padded rows, data-parallel exchange); ~1/500 of the throughput.
+    const bool det = bwd && (p.flags & MDL_DETERMINISTIC) != 0;
+    const int waves = det ? 1 : (bwd ? 4 : MDL_FWD_THREADS / 64);
     // static fast shapes keep W in registers (no LDS copy); otherwise LDS if it fits, else global
     const bool fast = !p.eperm && p.G == 50 && p.C == d.Cp && (d.Cp == 32 || d.Cp == 64) &&
                       (sizeof(T) == 2 ? (vec == 8 && EW == 2) : d.Cp == 64) &&
@@ -2213,18 +1974,24 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     const int64_t cap = 256 * ((bwd && MDL_BWD_WAVES == 1) ? 1 : wg_per_cu);
     if (grid > cap) grid = cap;
     const CgEnv& env = cg_env();
-    if (env.grid_cap > 0 && grid > env.grid_cap) grid = env.grid_cap;   // experiments
-    // edge-per-lane backward (cgconv_ep.inc): bf16, C = 64, G = 50, target-sorted edge features
+    if (env.grid_cap > 0 && grid > env.grid_cap) grid = env.grid_cap;   // experiments build
+    if (det) { grid = d.NS; p.ctr = nullptr; }
+    // edge-per-lane backward (cgconv_ep2.inc): bf16, C = 64, G = 50, target-sorted edge features, bf16 by-source sums
     if constexpr (sizeof(T) == 2) {
-        const int ep_sel = env.ep >= 0 ? env.ep : MDL_EP_DEFAULT;
-        if (ep_sel != 0 && bwd && fast && !wsp && d.Cp == 64 && p.bias_col && p.E >= 64) {
-            // cgconv_ep2.inc accumulates the by-source sums in bf16 (mdl_cgconv_bwd_h), cgconv_ep.inc in fp32 (mdl_cgconv_bwd)
+        int ep_sel = env.ep >= 0 ? env.ep : MDL_EP_DEFAULT;
+        if (p.flags & MDL_K3_PER_WAVE) ep_sel = 0;
+        const bool force2 = env.ep == 2 || (p.flags & MDL_K3_EDGE_LANE) != 0;
+        if (force2) ep_sel = 2;
+        if (ep_sel != 0 && !det && bwd && fast && !wsp && d.Cp == 64 && p.bias_col && p.E >= 64) {
             // (a workgroup of kernel 2 stages 51 KB of weights and clears 112 KB of tile buffers before its first tile: below a few
             // rounds per workgroup the per-wave kernel wins — 0.64 vs 0.71 ms per step at the reference's batch size 100)
-            if (ep_sel == 2 && p.rs16 && (env.ep == 2 || p.E >= MDL_EP2_MIN_EDGES)) return ep::launch2(p, st, env.ep_wgs, name);
-            if (ep_sel == 1 && !p.rs16) return ep::launch(p, st, env.ep_wgs, name);
+            if (ep_sel == 2 && p.rs16 && (force2 || p.E >= MDL_EP2_MIN_EDGES)) { g_last_k3 = 2; return ep::launch2(p, st, env.ep_wgs, name); }
+#if MDL_EXPERIMENTS
+            if (ep_sel == 1 && !p.rs16) return ep::launch(p, st, env.ep_wgs, name);      // fp32 by-source sums (mdl_cgconv_bwd)
+#endif
         }
     }
+    if (bwd) g_last_k3 = det ? 3 : 1;
     // total waves must be a multiple of NS so that every wave keeps one channel slice (w_slice: whole workgroups)
     while ((grid * waves) % d.NS) ++grid;
     if (p.w_slice) while (grid % d.NS) ++grid;
@@ -2236,12 +2003,13 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
             // the last two groups per wave of a slice are handed out as four half groups
             const int64_t tail = 2 * (grid * waves / d.NS);
             p.g_full = (int)std::max<int64_t>(0, (int64_t)p.n_groups - tail);
-            if (cg_env().no_half_groups) p.g_full = p.n_groups;
+            if (env.no_half_groups) p.g_full = p.n_groups;
         } else {
             p.ctr = nullptr;
         }
     }
 
+#if MDL_EXPERIMENTS
     // training forward that also stores the gate factors for cgconv_bwd_ab_kernel (static bf16 shapes only)
     if constexpr (sizeof(T) == 2) {
         if (!bwd && p.ab) {
@@ -2297,6 +2065,8 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
         }
     }
 
+#endif
+
 #define MDL_CG_LAUNCH(CP_, G_, VEC_, EW_, WM_)                                                               \
     do {                                                                                                     \
         auto kf = bwd ? cgconv_bwd_kernel<T, CP_, G_, VEC_, EW_, WM_> : cgconv_fwd_kernel<T, CP_, G_, VEC_, EW_, WM_>; \
@@ -2307,6 +2077,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
 #define MDL_CG_BY_WL(VEC_, EW_) do { if (w_lds) MDL_CG_LAUNCH(0, 0, VEC_, EW_, 1); else MDL_CG_LAUNCH(0, 0, VEC_, EW_, 0); } while (0)
 #define MDL_CG_BY_EW(VEC_) do { if (EW == 2) MDL_CG_BY_WL(VEC_, 2); else MDL_CG_BY_WL(VEC_, 1); } while (0)
 
+#if MDL_EXPERIMENTS
     if (wsp) {
         // W-split kernels: bf16, static shapes, W (edge part) in LDS
         if constexpr (sizeof(T) == 2) {
@@ -2336,6 +2107,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
             return MDL_E_UNSUPP;
         }
     }
+#endif
 #ifdef MDL_CG_FAST_ONLY   // compile-time experiments: only the bf16 C=64 G=50 instantiation
     if constexpr (sizeof(T) == 2) {
         if (fast && d.Cp == 64) MDL_CG_LAUNCH(64, 50, 9, 2, MDL_CG_WM);
@@ -2360,6 +2132,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     return check_launch(name);
 }
 
+#if MDL_EXPERIMENTS
 // saved-gate backward (cgconv_bwd_ab_kernel): bf16, C in {32, 64}, G = 50, target-sorted edge features
 static int cg_launch_bwd_ab(CgParams& p, hipStream_t st, const char* name) {
     const CgDims d = cg_dims(p.C, p.G, MDL_BF16);
@@ -2398,6 +2171,7 @@ static int cg_launch_bwd_ab(CgParams& p, hipStream_t st, const char* name) {
     }
     return check_launch(name);
 }
+#endif
 
 static int cg_check(const char* name, const void* x, const void* ea, const int32_t* rowptr, const int32_t* src,
                     const int32_t* tgt, const void* wpack, const float* bpack, int64_t N, int64_t E, int C, int G,
@@ -2474,6 +2248,7 @@ extern "C" int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_
 
 extern "C" size_t mdl_cgconv_workspace_bytes(int64_t, int64_t, int, int, int) { return 64; }
 
+#if MDL_EXPERIMENTS   // saved-gate pair, W-split pair (declared in experiments/mdl_hip_experiments.h)
 extern "C" size_t mdl_cgconv_gate_row_bytes(int C, int G, int dtype) {
     return (dtype == MDL_BF16 && G == 50 && (C == 32 || C == 64)) ? (size_t)4 * C : 0;
 }
@@ -2574,6 +2349,7 @@ extern "C" int mdl_cgconv_bwd_p(const void* p_tgt, const void* p_src, const void
     if (dtype != MDL_BF16) { set_error("mdl_cgconv_bwd_p: bf16 only"); return MDL_E_UNSUPP; }
     return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd_p");
 }
+#endif
 
 namespace mdl {
 // per-node cost of the backward edge pass in quarter units: 4 per edge and node, + 5 per edge whose source lies 48 or more
@@ -2599,10 +2375,14 @@ __global__ __launch_bounds__(256) void cgconv_balance_kernel(const int32_t* __re
 extern "C" int mdl_cgconv_balance(const int32_t* rowptr, const int32_t* src, int64_t N, int32_t* cost, mdlStream_t stream) {
     using namespace mdl;
     MDL_REQUIRE(N >= 0 && (N == 0 || (rowptr && src && cost)), MDL_E_ARG, "mdl_cgconv_balance: bad arguments");
-    // (MDL_BAL_W / MDL_BAL_T: weight in quarter units and distance threshold of a far edge, for experiments)
+#if MDL_EXPERIMENTS
+    // (MDL_BAL_W / MDL_BAL_T: weight in quarter units and distance threshold of a far edge — tools/fit_balance.py)
     static const int far_w = [] { const char* s = getenv("MDL_BAL_W"); return s ? atoi(s) : 5; }();
     static const int far_t = [] { const char* s = getenv("MDL_BAL_T"); return s ? atoi(s) : 48; }();
     static const int zero_w = [] { const char* s = getenv("MDL_BAL_Z"); return s ? atoi(s) : 4; }();
+#else
+    constexpr int far_w = 5, far_t = 48, zero_w = 4;
+#endif
     hipLaunchKernelGGL(cgconv_balance_kernel, dim3((unsigned)cdiv(N + 1, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, src, N, cost,
                        far_w, far_t, zero_w);
     return check_launch("mdl_cgconv_balance");
@@ -2631,6 +2411,8 @@ static int cg_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr,
                     void* r_src, float* dwe, float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype,
                     void* workspace, size_t ws_bytes, const int32_t* balance, mdlStream_t stream) {
     using namespace mdl;
+    const int flags = dtype & ~MDL_DTYPE_MASK;
+    dtype &= MDL_DTYPE_MASK;
     int rc = cg_check("mdl_cgconv_bwd_h", x, edge_attr, rowptr, src, tgt, wpack, bpack, N, E, C, G, aggr, dtype);
     if (rc) return rc;
     MDL_REQUIRE(dtype == MDL_BF16 && G == 50 && (C == 32 || C == 64 || C == 128), MDL_E_UNSUPP,
@@ -2641,7 +2423,7 @@ static int cg_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr,
     CgParams p = {};
     p.x = x; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = nullptr;
     p.wpack = wpack; p.bpack = bpack; p.gout = grad_out; p.r_tgt = r_tgt; p.r_src = static_cast<float*>(r_src); p.dwe = dwe; p.db = db;
-    p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr; p.rs16 = 1; p.balance = balance;
+    p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr; p.rs16 = 1; p.balance = balance; p.flags = flags;
     p.ctr = (workspace && ws_bytes >= mdl_cgconv_workspace_bytes(N, E, C, G, dtype)) ? static_cast<unsigned*>(workspace) : nullptr;
     return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd_h");
 }
@@ -2652,10 +2434,13 @@ extern "C" int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_
                               int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
                               mdlStream_t stream) {
     using namespace mdl;
+    const int flags = dtype & ~MDL_DTYPE_MASK;
+    dtype &= MDL_DTYPE_MASK;
     int rc = cg_check("mdl_cgconv_bwd", x, edge_attr, rowptr, src, tgt, wpack, bpack, N, E, C, G, aggr, dtype);
     if (rc) return rc;
     MDL_REQUIRE(N == 0 || (grad_out && r_tgt && r_src && dwe), MDL_E_ARG, "mdl_cgconv_bwd: null pointer");
     CgParams p = {};
+    p.flags = flags;
     p.x = x; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = eperm;
     p.wpack = wpack; p.bpack = bpack; p.gout = grad_out; p.r_tgt = r_tgt; p.r_src = r_src; p.dwe = dwe; p.db = db;
     p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr;
@@ -2664,4 +2449,6 @@ extern "C" int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_
     if (dtype == MDL_BF16) return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd");
     return cg_launch<float>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd");
 }
+
+extern "C" int mdl_debug_last_k3(void) { return mdl::g_last_k3; }
 #endif   // !MDL_CG_EP_TU

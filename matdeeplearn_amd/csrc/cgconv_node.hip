@@ -277,6 +277,8 @@ extern "C" int mdl_cgconv_bwd_node_h(const void* x, const void* grad_out, const 
 static int bwd_node_launch(const void* x, const void* grad_out, const void* r_tgt, float* r_src, const void* wn_t, void* dx,
                            float* dwn, int64_t N, int C, int dtype, int zero_src, bool rs16, mdlStream_t stream) {
     using namespace mdl;
+    const bool det = (dtype & MDL_DETERMINISTIC) != 0;      // one workgroup: every dwn element gets one add from one wave
+    dtype &= MDL_DTYPE_MASK;
     MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_cgconv_bwd_node: bf16 only (fp32 parity mode uses library GEMMs)");
     MDL_REQUIRE(C == 32 || C == 64, MDL_E_UNSUPP, "mdl_cgconv_bwd_node: C must be 32 or 64 (got %d)", C);
     MDL_REQUIRE(N >= 0 && (N == 0 || (x && grad_out && r_tgt && r_src && wn_t && dx && dwn)), MDL_E_ARG,
@@ -286,6 +288,7 @@ static int bwd_node_launch(const void* x, const void* grad_out, const void* r_tg
     if (N == 0) return MDL_OK;
     hipStream_t st = (hipStream_t)stream;
     int64_t sgrid = cdiv(N, 64);
+    if (det) sgrid = 1;
     if (sgrid > 256) sgrid = 256;         // one block per CU: each flushes 4Cp*C atomics on the same addresses at the end
                                           // (measured 128 / 256 / 512 / 1024 blocks: 70 / 56 / 67 / 97 us)
     if (C == 64) {

@@ -302,6 +302,9 @@ extern "C" int mdl_gemm_tn_colsum(const void* a, int64_t lda, int M, const void*
 extern "C" int mdl_gemm_tn_act(const void* a, int64_t lda, int M, const void* y, int64_t ldy, int act, const void* b,
                                int64_t ldb, int K, float* c, float* colsum, int64_t N, int dtype, mdlStream_t stream) {
     using namespace mdl;
+    // MDL_DETERMINISTIC: one workgroup — every element of c / colsum then gets ONE add from one wave (no cross-block order)
+    const bool det = (dtype & MDL_DETERMINISTIC) != 0;
+    dtype &= MDL_DTYPE_MASK;
     MDL_REQUIRE(act >= 0 && act <= 2 && (act == 0 || (y && ldy >= M && ldy % 2 == 0 && reinterpret_cast<uintptr_t>(y) % 4 == 0)),
                 MDL_E_ARG, "mdl_gemm_tn_act: act must be 0, 1 (relu) or 2 (shifted softplus), with the saved output y for 1 / 2");
     MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_gemm_tn: bf16 only");
@@ -320,9 +323,8 @@ extern "C" int mdl_gemm_tn_act(const void* a, int64_t lda, int M, const void* y,
             // one block per CU: every block ends with M*K atomics on the same addresses — on 2e5 rows (64 x 114) the flush
             // costs ~10 us per 256 blocks (256 / 512 / 768 / 1024 blocks: 27 / 37 / 47 / 57 us); two per CU only where the
             // stream is long enough to pay for it (1.5e6 rows: 100 x 100 156 -> 134 us, 150 x 50 141 -> 128 us; the 5 x 5-tile
-            // shapes are register-allocated for one block per CU).  MDL_TN_GRID overrides (read once).
-            static const int grid_env = [] { const char* e = getenv("MDL_TN_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-            const int grid_cap = grid_env ? grid_env : ((N >= (1 << 20) && mt * nt < 25) ? 512 : 256);
+            // shapes are register-allocated for one block per CU).
+            const int grid_cap = det ? 1 : ((N >= (1 << 20) && mt * nt < 25) ? 512 : 256);
             int64_t sgrid = cdiv(N, 64);
             if (sgrid > grid_cap) sgrid = grid_cap;
 #define MDL_TNS(MT_, NT_)                                                                                                   \
@@ -346,6 +348,7 @@ extern "C" int mdl_gemm_tn_act(const void* a, int64_t lda, int M, const void* y,
     MDL_REQUIRE(!colsum, MDL_E_UNSUPP, "mdl_gemm_tn_colsum: the column sums need even M, K, lda, ldb, 4-byte aligned rows and K <= 158");
     int64_t grid = cdiv(N, 128);
     if (grid > 512) grid = 512;
+    if (det) grid = 1;
     const int mt = (M + 31) / 32, ntw = ((K + 31) / 32 + 3) / 4;
 #define MDL_TN(MT_, NTW_) hipLaunchKernelGGL((gemm_tn_kernel<MT_, NTW_>), dim3((unsigned)grid), dim3(256), 0, st, \
         (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, N)

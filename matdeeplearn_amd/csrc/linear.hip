@@ -11,6 +11,10 @@
 // ds_read_b128 fragments), K zero-padded to a multiple of 32 in LDS; a wave owns one 32-row block row and every second
 // 32-column block, so an A fragment is read once per k-step for all of them; bias + activation on the accumulators.
 #include "mdl_common.h"
+
+#ifndef MDL_EXPERIMENTS
+#define MDL_EXPERIMENTS 0
+#endif
 #include <type_traits>
 
 namespace mdl {
@@ -205,185 +209,9 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
 }
 
 
-// ---- two chained dense layers in one pass:  h = act1(x W1^T + b1),  y = act2(h W2^T + b2)  (mdl_mlp2) -----------------------
-// The filter network of SchNet's CFConv (Linear(G, F) -> shifted softplus -> Linear(F, F), schnet.py:81 via
-// torch_geometric InteractionBlock.mlp) runs over the EDGES: as two streaming layers the intermediate [E, F] rows are written
-// by the first and read back by the second (0.45 GB each way per layer at the bench batch).  Here the activated tile goes to
-// global memory (the backward needs it) AND to an LDS tile that is the A operand of the second product: one launch, the rows
-// of h move once.  Workgroup = 8 waves = 128 rows per step; both weight matrices sit in LDS for the whole kernel.
-template <int K1P, int K2P, int NT1, int NT2>      // K1P / K2P: padded input widths of the two layers (K2P >= 32 * NT1 rounded);
-__global__ __launch_bounds__(512, 1) void mlp2_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w1,
-                                                      const bf16_t* __restrict__ b1, const bf16_t* __restrict__ w2,
-                                                      const bf16_t* __restrict__ b2, bf16_t* __restrict__ hout,
-                                                      bf16_t* __restrict__ yout, int64_t N, int K1, int M1, int M2, int act1,
-                                                      int act2) {
-    constexpr int TN = 128;
-    constexpr int LD1 = K1P + 8, LD2 = K2P + 8;
-    constexpr int NB1 = (NT1 + 1) / 2, NB2 = (NT2 + 1) / 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* wl1 = reinterpret_cast<bf16_t*>(smem);          // [32*NT1][LD1]
-    bf16_t* wl2 = wl1 + 32 * NT1 * LD1;                     // [32*NT2][LD2]
-    bf16_t* xl = wl2 + 32 * NT2 * LD2;                      // [TN][LD1]
-    bf16_t* hl = xl + TN * LD1;                             // [TN][LD2]
-    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int k2 = K1 >> 1;
-    for (int q = tid; q < 32 * NT1 * (K1P / 2); q += 512) {
-        const int row = q / (K1P / 2), d = q - row * (K1P / 2);
-        unsigned v = 0u;
-        if (row < M1 && d < k2) v = *reinterpret_cast<const unsigned*>(w1 + (int64_t)row * K1 + 2 * d);
-        *reinterpret_cast<unsigned*>(wl1 + row * LD1 + 2 * d) = v;
-    }
-    for (int q = tid; q < 32 * NT2 * (K2P / 2); q += 512) {
-        const int row = q / (K2P / 2), d = q - row * (K2P / 2);
-        unsigned v = 0u;
-        if (row < M2 && d < (M1 >> 1)) v = *reinterpret_cast<const unsigned*>(w2 + (int64_t)row * M1 + 2 * d);
-        *reinterpret_cast<unsigned*>(wl2 + row * LD2 + 2 * d) = v;
-    }
-    // the padding columns [32*NT1 .. K2P) of the h tile are never written by the first layer: zero them once
-    for (int q = tid; q < TN * (LD2 / 2); q += 512) reinterpret_cast<unsigned*>(hl)[q] = 0u;
-    const int mt = wv & 3, ntb = wv >> 2;               // block row (of four) and first block column of this wave
-    float bv1[NB1], bv2[NB2];
-#pragma unroll
-    for (int j = 0; j < NB1; ++j) { const int col = (ntb + 2 * j) * 32 + i; bv1[j] = (b1 && col < M1) ? bf2f(b1[col]) : 0.0f; }
-#pragma unroll
-    for (int j = 0; j < NB2; ++j) { const int col = (ntb + 2 * j) * 32 + i; bv2[j] = (b2 && col < M2) ? bf2f(b2[col]) : 0.0f; }
-
-    constexpr int DW = K1P / 2, Q = DW / 64, R = DW % 64, NR = R ? 16 * R / 64 : 0, NLX = 16 * Q + NR;
-    constexpr unsigned FAR = 0x40000000u;
-    const int w16 = 16 * wv;
-    const unsigned xrow = (unsigned)K1 * 2u;
-    const int64_t n_tiles = (N + TN - 1) / TN;
-    unsigned xr[NLX];
-    auto load_tile = [&](int64_t tile) {
-        const int64_t nb = tile * TN;
-        const int64_t bytes = (N - nb) * (int64_t)K1 * 2, cap = (int64_t)TN * K1 * 2;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x + nb * (int64_t)K1), 0,
-                                                                            (int)(bytes < cap ? bytes : cap), 0x00020000);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int j = 0; j < Q; ++j) {
-                const int d = lane + 64 * j;
-                const unsigned off = (d < k2) ? (unsigned)(w16 + r) * xrow + 4u * d : FAR;
-                xr[r * Q + j] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
-            }
-        if constexpr (R != 0) {
-            const int d = 64 * Q + lane % R, rr = lane / R;
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                const unsigned off = (d < k2) ? (unsigned)(w16 + k * (64 / R) + rr) * xrow + 4u * d : FAR;
-                xr[16 * Q + k] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
-            }
-        }
-    };
-    // (the activation code is a compile-time constant of each epilogue instance: a run-time test per element turns the
-    // epilogue into one basic block per value)
-    auto activate = [](float v, auto ACT) -> float {
-        if constexpr (decltype(ACT)::value == 1) return v > 0.0f ? v : 0.0f;
-        else if constexpr (decltype(ACT)::value == 2) {
-            const float l = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-LOG2E_F * fabsf(v)));
-            return fmaf(0.5f, v + fabsf(v), fmaf(LN2_F, l, -LN2_F));
-        } else return v;
-    };
-    auto by_act = [](int act, auto&& f) {
-        if (act == 2) f(std::integral_constant<int, 2>{});
-        else if (act == 1) f(std::integral_constant<int, 1>{});
-        else f(std::integral_constant<int, 0>{});
-    };
-    int64_t tile = blockIdx.x;
-    if (tile < n_tiles) load_tile(tile);
-    for (; tile < n_tiles; tile += gridDim.x) {
-        const int64_t nb = tile * TN;
-        __syncthreads();                                    // previous tile's fragments (x and h tiles) read; weights in place
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int j = 0; j < Q; ++j)
-                *reinterpret_cast<unsigned*>(xl + (w16 + r) * LD1 + 2 * (lane + 64 * j)) = xr[r * Q + j];
-        if constexpr (R != 0) {
-#pragma unroll
-            for (int k = 0; k < NR; ++k)
-                *reinterpret_cast<unsigned*>(xl + (w16 + k * (64 / R) + lane / R) * LD1 + 2 * (64 * Q + lane % R)) = xr[16 * Q + k];
-        }
-        __syncthreads();
-        if (tile + gridDim.x < n_tiles) load_tile(tile + gridDim.x);
-        const int64_t remr = N - nb - mt * 32;
-        // ---- layer 1
-        if (ntb < NT1) {
-            f32x16 acc[NB1];
-#pragma unroll
-            for (int j = 0; j < NB1; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = bv1[j];
-#pragma unroll
-            for (int kk = 0; kk < K1P / 16; ++kk) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(xl + (mt * 32 + i) * LD1 + 16 * kk + 8 * h);
-#pragma unroll
-                for (int j = 0; j < NB1; ++j) {
-                    const int nt = min(ntb + 2 * j, NT1 - 1);
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl1 + (nt * 32 + i) * LD1 + 16 * kk + 8 * h);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-                }
-            }
-            by_act(act1, [&](auto ACT) {
-#pragma unroll
-            for (int j = 0; j < NB1; ++j) {
-                const int nt = ntb + 2 * j, col = nt * 32 + i;
-                if (nt < NT1) {
-                    const bool st = col < M1 && remr > 0;
-                    const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
-                        hout + (nb + mt * 32) * (int64_t)M1, 0,
-                        (int)(remr > 0 ? ((remr * M1 * 2) < 0x7fffffffLL ? (remr * M1 * 2) : 0x7fffffffLL) : 0), 0x00020000);
-                    const int vo = (4 * h * M1 + col) * 2;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2);
-                        const bf16_t hv = f2bf(activate(acc[j][r], ACT));
-                        // columns M1 .. 32*NT1-1 hold act1(0 + 0): they meet zero weight columns in the second layer
-                        hl[(mt * 32 + 4 * h + row) * LD2 + col] = hv;
-                        if (st) __builtin_amdgcn_raw_buffer_store_b16((short)hv, os, vo + row * M1 * 2, 0, 0);
-                    }
-                }
-            }
-            });
-        }
-        __syncthreads();
-        // ---- layer 2
-        if (ntb < NT2) {
-            f32x16 acc[NB2];
-#pragma unroll
-            for (int j = 0; j < NB2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = bv2[j];
-#pragma unroll
-            for (int kk = 0; kk < K2P / 16; ++kk) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(hl + (mt * 32 + i) * LD2 + 16 * kk + 8 * h);
-#pragma unroll
-                for (int j = 0; j < NB2; ++j) {
-                    const int nt = min(ntb + 2 * j, NT2 - 1);
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl2 + (nt * 32 + i) * LD2 + 16 * kk + 8 * h);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-                }
-            }
-            by_act(act2, [&](auto ACT) {
-#pragma unroll
-            for (int j = 0; j < NB2; ++j) {
-                const int nt = ntb + 2 * j, col = nt * 32 + i;
-                if (nt < NT2 && col < M2 && remr > 0) {
-                    const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
-                        yout + (nb + mt * 32) * (int64_t)M2, 0,
-                        (int)((remr * M2 * 2) < 0x7fffffffLL ? (remr * M2 * 2) : 0x7fffffffLL), 0x00020000);
-                    const int vo = (4 * h * M2 + col) * 2;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(activate(acc[j][r], ACT)), os,
-                                                              vo + ((r & 3) + 8 * (r >> 2)) * M2 * 2, 0, 0);
-                }
-            }
-            });
-        }
-    }
-}
+#if MDL_EXPERIMENTS
+#include "../../experiments/csrc/mlp2.inc"   // two chained dense layers in one launch: measured slower than two launches
+#endif
 
 }  // namespace mdl
 
@@ -460,6 +288,7 @@ static int linear_launch(const void* x, const void* xy, int xact, const void* w,
     return check_launch("mdl_linear_act");
 }
 
+#if MDL_EXPERIMENTS
 extern "C" int mdl_mlp2(const void* x, const void* w1, const void* b1, int act1, const void* w2, const void* b2, int act2,
                         void* h, void* y, int64_t N, int K, int M1, int M2, int dtype, mdlStream_t stream) {
     using namespace mdl;
@@ -481,6 +310,7 @@ extern "C" int mdl_mlp2(const void* x, const void* w1, const void* b1, int act1,
                        (const bf16_t*)b1, (const bf16_t*)w2, (const bf16_t*)b2, (bf16_t*)h, (bf16_t*)y, N, K, M1, M2, act1, act2);
     return check_launch("mdl_mlp2");
 }
+#endif
 
 // out[N, M] = x[N, K] w[M, K]^T for a WIDE output (M in the thousands: NNConv's Y = x W2r, mpnn.py:83-88 — C_out * d3 = 10^4
 // columns per node): the layer is a write stream of N * M * 2 bytes; column blocks of 160 run as the second grid dimension of

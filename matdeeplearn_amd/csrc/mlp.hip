@@ -246,6 +246,8 @@ extern "C" int mdl_mlp_head_bwd(const void* x, const void* const* w, const void*
         a.w[l] = (const bf16_t*)w[l]; a.M[l] = M[l]; a.dw[l] = dw[l]; a.db[l] = db[l];
         a.h[l] = l + 1 < NL ? (bf16_t*)const_cast<void*>(h[l]) : nullptr;
     }
+    const bool det = (dtype & MDL_DETERMINISTIC) != 0;      // one workgroup: one add per dw / db element
+    dtype &= MDL_DTYPE_MASK;
     int rc = mlp_check("mdl_mlp_head_bwd", a, dtype);
     if (rc) return rc;
     MDL_REQUIRE(N == 0 || (gy && reinterpret_cast<uintptr_t>(gy) % (M[NL - 1] % 2 ? 2 : 4) == 0), MDL_E_ARG,
@@ -260,6 +262,7 @@ extern "C" int mdl_mlp_head_bwd(const void* x, const void* const* w, const void*
     if (e != hipSuccess) { set_error("mdl_mlp_head_bwd: LDS attribute (%d B): %s", lds, hipGetErrorString(e)); return MDL_E_LAUNCH; }
     int64_t grid = cdiv(N, 64);
     if (grid > 256) grid = 256;
+    if (det) grid = 1;
     hipLaunchKernelGGL(mlp_head_bwd_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
     return check_launch("mdl_mlp_head_bwd");
 }

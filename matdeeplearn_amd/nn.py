@@ -62,17 +62,15 @@ def lowp_copies(lin):
     return sh[0], sh[1]
 
 
-def _lin(lin, h, act=None, nxt=None):
+def _lin(lin, h, act=None):
     """nn.Linear (+ activation) applied in the dtype of h (fp32 master weights, bf16 activations): the streaming HIP dense
-    layer for bf16 rows, the library otherwise.  nxt = (next Linear, its activation): the layer that follows in a chain."""
+    layer for bf16 rows, the library otherwise."""
     if h.dtype == lin.weight.dtype:
         y = lin(h)
         if act is None:
             return y
         return F.softplus(y) - math.log(2.0) if act == "ssp" else getattr(F, act)(y)
-    if nxt is not None:
-        nxt = (nxt[0].weight, nxt[0].bias, nxt[1], lowp_copies(nxt[0]))
-    return ops.linear_act(h, lin.weight, lin.bias, act, lowp_copies(lin), nxt)
+    return ops.linear_act(h, lin.weight, lin.bias, act, lowp_copies(lin))
 
 
 def _seq(seq, h):
@@ -86,11 +84,7 @@ def _seq(seq, h):
                 a = mods[j] if j < len(mods) else None
                 return "ssp" if isinstance(a, ShiftedSoftplus) else ("relu" if isinstance(a, nn.ReLU) else None)
             act = act_of(k + 1)
-            # the dense layer that follows (Linear -> activation -> Linear [-> activation]): handed to the first one, which
-            # computes both in one launch when the shapes allow it
-            j = k + (2 if act else 1)
-            follow = (mods[j], act_of(j + 1)) if j < len(mods) and isinstance(mods[j], nn.Linear) and act else None
-            h = _lin(m, h, act, follow)
+            h = _lin(m, h, act)
             k += 2 if act else 1
         else:
             h = m(h)

@@ -491,21 +491,57 @@ def _workspace(device, nbytes):
     return t
 
 
-# Saved-gate training pair (mdl_cgconv_fwd_save / mdl_cgconv_bwd_saved): opt-in.  Measured on the bench batch it moves
-# 110 us per layer from the backward (530 -> 420 us) into the forward (178 -> 300 us: the factor stores stall the
-# forward's load pipeline), i.e. no net gain, for 2.7 GB of saved activations per step — so the recomputing backward stays
-# the default.
-_SAVE_GATE = os.environ.get("MDL_CG_SAVE_GATE", "0") == "1"
+# Deterministic mode (include/mdl_hip.h, MDL_DETERMINISTIC): the kernels that combine per-workgroup partial sums with
+# floating-point atomics — the CGConv backward edge pass and node kernel, the TN GEMM, the BatchNorm sums, the fused head —
+# are launched in a shape in which every sum gets its terms from ONE wave in program order: bit-reproducible from run to run,
+# a few hundred times slower.  For HIP-vs-HIP regression checks (graph replay vs eager, padded rows, data-parallel exchange);
+# `with ops.deterministic():` or MDL_DETERMINISTIC=1 in the environment of the PYTHON process (the library reads none).
+_DET = os.environ.get("MDL_DETERMINISTIC", "0") == "1"
 
-# W-split CGConv pair (mdl_cgconv_fwd_p / mdl_cgconv_bwd_p: per-node projections P = x [W_tgt | W_src]^T from two dense launches,
-# per edge only the K = 64 edge-feature product): MDL_CG_WSPLIT=1.  DESIGN.md section 4 has the A/B.
-_WSPLIT = os.environ.get("MDL_CG_WSPLIT", "0") == "1"
 
-# By-source sums of the CGConv backward in bf16, accumulated with packed bf16 atomics (mdl_cgconv_bwd_h / mdl_cgconv_bwd_node_h;
-# bf16 mode, C in {32, 64}, G = 50): half the atomic operations and bytes of the fp32 buffer.  MDL_CG_RSRC16=0 restores fp32.
+def set_deterministic(on=True):
+    global _DET
+    prev, _DET = _DET, bool(on)
+    return prev
+
+
+class deterministic:
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = set_deterministic(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        set_deterministic(self.prev)
+        return False
+
+
+def _dflag():
+    return _lib.MDL_DETERMINISTIC if _DET else 0
+
+
+# Which backward edge pass ops.cgconv asks for where both exist (bf16, C = 64, bf16 by-source sums): None = the library's
+# edge-count heuristic (kernel 2 from 4e5 edges), "per_wave" / "edge_lane" force one (tests, A/B).
+K3_VARIANT = None
+
+
+def _k3flag():
+    return {None: 0, "per_wave": _lib.MDL_K3_PER_WAVE, "edge_lane": _lib.MDL_K3_EDGE_LANE}[K3_VARIANT]
+
+
+def last_k3():
+    """1 per-wave kernel, 2 edge-per-lane kernel 2, 3 per-wave kernel in its deterministic shape (mdl_debug_last_k3)"""
+    return int(lib().mdl_debug_last_k3())
+
+
 _GMR_DW = os.environ.get("MDL_GMR_DW", "1") != "0"          # CFConv backward: dh and dw from one walk over the by-source CSR
 _BALANCE = os.environ.get("MDL_CG_BALANCE", "1") != "0"     # cost-balanced node ranges for the edge-per-lane backward
 _PAD128 = os.environ.get("MDL_CG_PAD128", "1") != "0"      # C in (96, 128): static 128-channel kernels on zero-padded rows
+# By-source sums of the CGConv backward in bf16, accumulated with packed bf16 atomics (mdl_cgconv_bwd_h / mdl_cgconv_bwd_node_h;
+# bf16 mode, C in {32, 64, 128}, G = 50): half the atomic operations and bytes of the fp32 buffer; a source row is rounded to bf16
+# once per window flush (1-3 partial sums per node).  MDL_CG_RSRC16=0 restores the fp32 buffer.
 _RSRC16 = os.environ.get("MDL_CG_RSRC16", "1") == "1"
 
 
@@ -545,32 +581,6 @@ class _CGConvFn(torch.autograd.Function):
         wf32, ws32 = w_f.detach().float().contiguous(), w_s.detach().float().contiguous()
         bf32 = None if b_f is None else b_f.detach().float().contiguous()
         bs32 = None if b_s is None else b_s.detach().float().contiguous()
-        ctx.wsplit = None
-        if (_WSPLIT and L.mdl_cgconv_wsplit_bytes(C, G, dt, 0) and E > 0 and x.data_ptr() % 16 == 0
-                and edge_attr.data_ptr() % 4 == 0 and csr.eperm is None):
-            Cp = _rup(C, 32)
-            wpe = torch.empty(L.mdl_cgconv_wsplit_bytes(C, G, dt, 0), dtype=torch.uint8, device=x.device)
-            wproj = torch.empty((2, 2 * Cp, Cp), dtype=torch.bfloat16, device=x.device)
-            bpack = torch.empty(2 * Cp, dtype=torch.float32, device=x.device)
-            check(L.mdl_cgconv_pack_weights_split(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpe), ptr(wproj), ptr(bpack),
-                                                  dt, stream()), "mdl_cgconv_pack_weights_split")
-            pt = torch.empty((N, 2 * Cp), dtype=torch.bfloat16, device=x.device)
-            ps = torch.empty_like(pt)
-            out = torch.empty_like(x)
-
-            def launch():      # (timed as ONE forward: the two projection launches are part of the W-split's price)
-                rc = L.mdl_linear_act(ptr(x), ptr(wproj[0]), None, ptr(pt), N, C, 2 * Cp, 0, dt, stream())
-                rc = rc or L.mdl_linear_act(ptr(x), ptr(wproj[1]), None, ptr(ps), N, C, 2 * Cp, 0, dt, stream())
-                return rc or L.mdl_cgconv_fwd_p(
-                    ptr(x), ptr(pt), ptr(ps), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpe), ptr(bpack),
-                    ptr(out), N, E, C, G, aggr, dt, stream())
-            check(_launch_timed("fwd", launch), "mdl_cgconv_fwd_p")
-            ctx.gate = None
-            ctx.wsplit = (pt, ps)
-            ctx.save_for_backward(x, edge_attr, wf32, ws32, wpe, bpack)
-            ctx.csr, ctx.aggr, ctx.has_bias = csr, aggr, (b_f is not None, b_s is not None)
-            ctx.wdtypes = (w_f.dtype, w_s.dtype)
-            return out
         nbytes = L.mdl_cgconv_wpack_bytes(C, G, dt)
         if nbytes == 0:
             raise MdlError("cgconv: unsupported C=%d G=%d" % (C, G))
@@ -595,20 +605,9 @@ class _CGConvFn(torch.autograd.Function):
         ctx.wn_t = wn_t
         out = torch.empty_like(x)
         edge_attr = csr.sorted_attr(edge_attr)          # CSR order: the kernels never go through eperm
-        # opt-in (MDL_CG_SAVE_GATE=1): training forward on the static bf16 shapes also stores the gate factors (4C bytes
-        # per edge) and the backward edge pass skips the recompute
-        row_bytes = L.mdl_cgconv_gate_row_bytes(C, G, dt) if (_SAVE_GATE and any(ctx.needs_input_grad)) else 0
-        gate = None
-        if row_bytes and E > 0 and x.data_ptr() % 16 == 0 and edge_attr.data_ptr() % 4 == 0:
-            gate = torch.empty((E, row_bytes // 2), dtype=torch.bfloat16, device=x.device)
-            check(_launch_timed("fwd", lambda: L.mdl_cgconv_fwd_save(
-                ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(bpack), ptr(out),
-                ptr(gate), N, E, C, G, aggr, dt, stream())), "mdl_cgconv_fwd_save")
-        else:
-            check(_launch_timed("fwd", lambda: L.mdl_cgconv_fwd(
-                ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
-                ptr(bpack), ptr(out), N, E, Ck, G, aggr, dt, stream())), "mdl_cgconv_fwd")
-        ctx.gate = gate
+        check(_launch_timed("fwd", lambda: L.mdl_cgconv_fwd(
+            ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
+            ptr(bpack), ptr(out), N, E, Ck, G, aggr, dt, stream())), "mdl_cgconv_fwd")
         ctx.save_for_backward(x, edge_attr, wf32, ws32, wpack, bpack)
         ctx.csr, ctx.aggr, ctx.has_bias = csr, aggr, (b_f is not None, b_s is not None)
         ctx.wdtypes = (w_f.dtype, w_s.dtype)
@@ -631,7 +630,7 @@ class _CGConvFn(torch.autograd.Function):
             x = x[:, :C]                                  # (the node-level part below works on the true width)
         r_tgt = torch.empty((N, 2 * Cp), dtype=x.dtype, device=x.device)          # by-target sums, compute dtype
         node_hip = dt == _lib.MDL_BF16 and C == Cp and C in (32, 64)          # K3c consumes r_tgt / r_src
-        rs16 = (_RSRC16 and (node_hip or (Ck == 128 and dt == _lib.MDL_BF16)) and G == 50 and ctx.gate is None and ctx.wsplit is None and E > 0
+        rs16 = (_RSRC16 and (node_hip or (Ck == 128 and dt == _lib.MDL_BF16)) and G == 50 and E > 0
                 and x.data_ptr() % 16 == 0 and edge_attr.data_ptr() % 4 == 0)
         nrs = N * 2 * Cp // 2 if rs16 else N * 2 * Cp                         # fp32 words of the by-source buffer
         keep = _take_rsrc(nrs, x.device) if node_hip else None
@@ -645,30 +644,18 @@ class _CGConvFn(torch.autograd.Function):
         db = small[2 * Cp * GP:2 * Cp * GP + 2 * Cp]
         dwn = small[2 * Cp * GP + 2 * Cp:].view(4 * Cp, C)
         ws = _workspace(x.device, lib().mdl_cgconv_workspace_bytes(N, E, C, G, dt))
-        gate, ctx.gate = ctx.gate, None
-        wsp, ctx.wsplit = ctx.wsplit, None
-        if wsp is not None:
-            check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_p(
-                ptr(wsp[0]), ptr(wsp[1]), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(bpack),
-                ptr(g), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, ptr(ws), ws.numel(), stream())),
-                "mdl_cgconv_bwd_p")
-            del wsp
-        elif gate is not None:
-            check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_saved(
-                ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(gate), ptr(g), ptr(r_tgt), ptr(r_src),
-                ptr(dwe), ptr(db), N, E, C, G, ctx.aggr, dt, ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd_saved")
-            del gate
-        elif rs16:
+        fl = _dflag()
+        if rs16:
             # node ranges of equal COST (far sources make a tile dearer): one prefix per batch, shared by all layers
-            bal = csr.balance() if (_BALANCE and E >= 400000) else None
+            bal = csr.balance() if (_BALANCE and E >= 400000 and not fl) else None
             check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_hb(
                 ptr(xk), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(bpack), ptr(gk),
-                ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, Ck, G, ctx.aggr, dt, ptr(ws), ws.numel(), ptr(bal), stream())),
-                "mdl_cgconv_bwd_h")
+                ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, Ck, G, ctx.aggr, dt | fl | _k3flag(), ptr(ws), ws.numel(), ptr(bal),
+                stream())), "mdl_cgconv_bwd_h")
         else:
             check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd(
                 ptr(xk), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
-                ptr(bpack), ptr(gk), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, Ck, G, ctx.aggr, dt,
+                ptr(bpack), ptr(gk), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, Ck, G, ctx.aggr, dt | fl,
                 ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd")
         # node-level dense part: rows of Wn / dWn = (f_tgt, s_tgt, f_src, s_src)
         if node_hip:
@@ -680,7 +667,7 @@ class _CGConvFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             node_fn = lib().mdl_cgconv_bwd_node_h if rs16 else lib().mdl_cgconv_bwd_node_z
             check(_launch_timed("bwd_node", lambda: node_fn(
-                ptr(x), ptr(g), ptr(r_tgt), ptr(r_src), ptr(wn_t), ptr(dx), ptr(dwn), N, C, dt, 1 if keep is not None else 0,
+                ptr(x), ptr(g), ptr(r_tgt), ptr(r_src), ptr(wn_t), ptr(dx), ptr(dwn), N, C, dt | fl, 1 if keep is not None else 0,
                 stream())), "mdl_cgconv_bwd_node")
             if keep is not None:
                 keep[1] = False                                                                     # handed back zeroed
@@ -707,7 +694,7 @@ class _CGConvFn(torch.autograd.Function):
             xc = x.contiguous()
             for blk, r in enumerate((r_tgt[:, :Cp], r_tgt[:, Cp:], rs_b[:, :Cp], rs_b[:, Cp:])):
                 check(lib().mdl_gemm_tn(ptr(r), r.stride(0), Cp, ptr(xc), xc.stride(0), C, ptr(dwn[blk * Cp:(blk + 1) * Cp]), N,
-                                        dt, stream()), "mdl_gemm_tn")
+                                        dt | fl, stream()), "mdl_gemm_tn")
             dW_f = torch.empty((C, 2 * C + G), dtype=torch.float32, device=x.device)
             dW_s = torch.empty_like(dW_f)
             db_f = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[0] else None
@@ -953,7 +940,7 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
         buf = _zeros_grad(M * K + M, g.device)
         dw, dbv = buf[:M * K].view(M, K), buf[M * K:]
         check(lib().mdl_gemm_tn_act(ptr(g), g.stride(0), M, ptr(act_y[1]), act_y[1].stride(0), act_y[0], ptr(x), x.stride(0), K,
-                                    ptr(dw), ptr(dbv) if ctx.has_bias else None, g.shape[0], dtype_code(g), stream()),
+                                    ptr(dw), ptr(dbv) if ctx.has_bias else None, g.shape[0], dtype_code(g) | _dflag(), stream()),
               "mdl_gemm_tn_act")
         dx = _dx_hip(g, w, act_y) if ctx.needs_input_grad[0] else None
         return dx, dw.to(ctx.wdtype), (dbv.to(ctx.wdtype) if ctx.has_bias else None)
@@ -967,10 +954,10 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
         d1, d2, dbv = buf[:M * kh].view(M, kh), buf[M * kh:M * K].view(M, K - kh), buf[M * K:]
         fused_db = ctx.has_bias and kh <= 158
         check(lib().mdl_gemm_tn_colsum(ptr(g), g.stride(0), M, ptr(x), x.stride(0), kh, ptr(d1), ptr(dbv) if fused_db else None,
-                                       g.shape[0], dtype_code(g), stream()), "mdl_gemm_tn_colsum")
+                                       g.shape[0], dtype_code(g) | _dflag(), stream()), "mdl_gemm_tn_colsum")
         x2 = x[:, kh:]
         check(lib().mdl_gemm_tn_colsum(ptr(g), g.stride(0), M, ptr(x2), x.stride(0), K - kh, ptr(d2), None, g.shape[0],
-                                       dtype_code(g), stream()), "mdl_gemm_tn_colsum")
+                                       dtype_code(g) | _dflag(), stream()), "mdl_gemm_tn_colsum")
         dw = torch.cat([d1, d2], dim=1)
         db = None
         if ctx.has_bias:
@@ -986,7 +973,7 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
     buf = _zeros_grad(Ma * K + Ma, g.device)                                       # dW | db: zero-filled (one fill per step)
     dw, dbv = buf[:Ma * K].view(Ma, K), buf[Ma * K:]
     check(lib().mdl_gemm_tn_colsum(ptr(ga), ga.stride(0), Ma, ptr(x), x.stride(0), K, ptr(dw), ptr(dbv) if fused_db else None,
-                                   g.shape[0], dtype_code(g), stream()), "mdl_gemm_tn_colsum")
+                                   g.shape[0], dtype_code(g) | _dflag(), stream()), "mdl_gemm_tn_colsum")
     dw = dw[:M]
     db = None
     if ctx.has_bias:                          # bias gradient = column sums of g: out of the same pass when the shape allows
@@ -996,8 +983,6 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
 
 _MLP_HEAD = os.environ.get("MDL_MLP_HEAD", "1") != "0"        # post-FC head (post_lin_list + lin_out) as one launch per direction
 _LINEAR_WIDE = os.environ.get("MDL_LINEAR_WIDE", "1") != "0"   # NNConv's Y = x W2r on the streaming kernel
-_MLP2_NEXT = {}        # (input ptr, weight ptr, act) -> output of a dense layer already computed by the previous layer's launch
-_MLP2 = os.environ.get("MDL_MLP2", "0") == "1"       # opt-in: measured slower than the two streaming layers
 
 
 class _LinearActTN(torch.autograd.Function):
@@ -1005,28 +990,14 @@ class _LinearActTN(torch.autograd.Function):
     _LinearTN (library dX, TN GEMM for dW and db); the ReLU mask comes from the saved output."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w_lp, b_lp, act, nxt=None):
+    def forward(ctx, x, weight, bias, w_lp, b_lp, act):
         w = weight.to(x.dtype) if w_lp is None else w_lp
         b = None if bias is None else (bias.to(x.dtype) if b_lp is None else b_lp)
         N, K = x.shape
         M = weight.shape[0]
         out = torch.empty((N, M), dtype=x.dtype, device=x.device)
-        pre = _MLP2_NEXT.pop((x.data_ptr(), w.data_ptr(), act), None) if _MLP2_NEXT else None
-        if pre is not None and tuple(pre[0].shape) == (N, M) and pre[1].shape == x.shape:
-            out = pre[0]                                   # computed by the previous layer's launch (mdl_mlp2)
-        elif nxt is not None:
-            # the NEXT dense layer of the chain in the same launch (mdl_mlp2): its output waits in _MLP2_NEXT for that layer's
-            # own autograd Function, which then launches nothing — both keep their backward passes
-            w2, b2, act2 = nxt
-            y2 = torch.empty((N, w2.shape[0]), dtype=x.dtype, device=x.device)
-            codes = {"relu": 1, "ssp": 2}
-            check(lib().mdl_mlp2(ptr(x), ptr(w), ptr(b), codes.get(act, 0), ptr(w2), ptr(b2), codes.get(act2, 0), ptr(out), ptr(y2),
-                                 N, K, M, w2.shape[0], dtype_code(x), stream()), "mdl_mlp2")
-            _MLP2_NEXT.clear()
-            _MLP2_NEXT[(out.data_ptr(), w2.data_ptr(), act2)] = (y2, out)     # (holds `out`: its memory cannot be reused meanwhile)
-        else:
-            check(lib().mdl_linear_act(ptr(x), ptr(w), ptr(b), ptr(out), N, K, M, {"relu": 1, "ssp": 2}.get(act, 0), dtype_code(x),
-                                       stream()), "mdl_linear_act")
+        check(lib().mdl_linear_act(ptr(x), ptr(w), ptr(b), ptr(out), N, K, M, {"relu": 1, "ssp": 2}.get(act, 0), dtype_code(x),
+                                   stream()), "mdl_linear_act")
         ctx.save_for_backward(x, w, out if act in ("relu", "ssp") else None)
         ctx.wdtype, ctx.has_bias, ctx.shape, ctx.act = weight.dtype, bias is not None, tuple(weight.shape), act
         return out
@@ -1035,7 +1006,7 @@ class _LinearActTN(torch.autograd.Function):
     def backward(ctx, g):
         x, w, out = ctx.saved_tensors
         if ctx.act in ("relu", "ssp") and _tn_act_ok(ctx, g, x, out, w):
-            return _linear_tn_grads(ctx, g, x, w, act_y=(1 if ctx.act == "relu" else 2, out)) + (None, None, None, None)
+            return _linear_tn_grads(ctx, g, x, w, act_y=(1 if ctx.act == "relu" else 2, out)) + (None, None, None)
         if ctx.act == "relu":
             g = torch.ops.aten.threshold_backward(g, out, 0)
         elif ctx.act == "ssp":                     # d/dv (softplus(v) - ln2) = sigmoid(v) = 1 - exp(-(out + ln2))
@@ -1044,7 +1015,7 @@ class _LinearActTN(torch.autograd.Function):
             check(lib().mdl_ssp_bwd(ptr(g), ptr(out), ptr(dpre), g.numel(), dtype_code(g), stream()), "mdl_ssp_bwd")
             g = dpre
         dx, dw, db = _linear_tn_grads(ctx, g.contiguous(), x, w)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None
 
 
 class _LinearGatherAct(torch.autograd.Function):
@@ -1142,7 +1113,7 @@ class _MlpHead(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         Ma = (ctypes.c_int * NL)(*M)
         check(lib().mdl_mlp_head_bwd(ptr(x), _ptr_array(ws), _ptr_array(hs + [None]), ptr(gy), ptr(dx), _ptr_array(dws), _ptr_array(dbs),
-                                     N, K0, NL, Ma, dtype_code(x), stream()), "mdl_mlp_head_bwd")
+                                     N, K0, NL, Ma, dtype_code(x) | _dflag(), stream()), "mdl_mlp_head_bwd")
         grads = []
         for l in range(NL):
             grads.append(dws[l].to(ctx.wdtypes[l]))
@@ -1202,23 +1173,15 @@ def matmul_wide(x, w):
     return x @ w
 
 
-def linear_act(x, weight, bias, act, lowp=None, nxt=None):
+def linear_act(x, weight, bias, act, lowp=None):
     """getattr(F, act)(F.linear(x, weight, bias)) — fused forward for bf16 inputs with dense rows, even in <= 256,
-    out <= 128 and act in (relu, none); anything else composes `linear` with the library activation."""
+    out <= 128 and act in (relu, ssp, none); anything else composes `linear` with the library activation."""
     # (ssp: the one-pass softplus backward works on element PAIRS — an odd width would reach it with an odd element count)
     if (act in ("relu", "ssp", None) and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
             and x.shape[0] >= 1024 and _hip_shape_ok(weight.shape[0], weight.shape[1])
             and (act != "ssp" or weight.shape[0] % 2 == 0)
             and x.data_ptr() % 16 == 0 and weight.requires_grad):
         w_lp, b_lp = (lowp if lowp is not None and lowp[0].dtype == x.dtype else (None, None))
-        # nxt = (weight2, bias2, act2, lowp2): the following dense layer of a chain; both layers in one launch (mdl_mlp2) when
-        # the shapes fit — the caller still applies the second layer, whose Function then finds its output ready
-        if (nxt is not None and _MLP2 and weight.shape[1] <= 64 and weight.shape[0] % 2 == 0 and weight.shape[0] <= 160
-                and nxt[0].shape[0] <= 160 and nxt[0].shape[1] == weight.shape[0] and nxt[2] in ("relu", "ssp", None)
-                and (nxt[2] != "ssp" or nxt[0].shape[0] % 2 == 0) and nxt[0].requires_grad
-                and _hip_shape_ok(nxt[0].shape[0], nxt[0].shape[1]) and nxt[3] is not None and nxt[3][0].dtype == x.dtype
-                and (nxt[1] is None) == (nxt[3][1] is None)):
-            return _LinearActTN.apply(x, weight, bias, w_lp, b_lp, act, (nxt[3][0], nxt[3][1], nxt[2]))
         return _LinearActTN.apply(x, weight, bias, w_lp, b_lp, act)
     y = linear(x, weight, bias, lowp)
     if act is None:
@@ -1333,7 +1296,7 @@ class _BatchNormTrain(torch.autograd.Function):
         gb = None if bias is None else bias.detach().float().contiguous()
         y = torch.empty_like(x)
         nd = _true_rows_for(N)
-        check(lib().mdl_bn_stats_n(ptr(x), ptr(sums), N, C, ptr(nd), dt, stream()), "mdl_bn_stats")
+        check(lib().mdl_bn_stats_n(ptr(x), ptr(sums), N, C, ptr(nd), dt | _dflag(), stream()), "mdl_bn_stats")
         check(lib().mdl_bn_apply_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
                                    ptr(y), N, C, float(eps), float(momentum), ptr(nd), dt, stream()), "mdl_bn_apply")
         ctx.n_dev = nd
@@ -1352,7 +1315,7 @@ class _BatchNormTrain(torch.autograd.Function):
         sums = _zeros_grad(R * C, x.device).view(R, C)                       # (the step's GRADIENT arena, never reused: the totals
         dx = torch.empty_like(x)                                              # rows are returned as parameter gradients)
         nd = ctx.n_dev
-        check(lib().mdl_bn_bwd_stats_n(ptr(dy), ptr(x), ptr(save), ptr(sums), N, C, ptr(nd), dt, stream()), "mdl_bn_bwd_stats")
+        check(lib().mdl_bn_bwd_stats_n(ptr(dy), ptr(x), ptr(save), ptr(sums), N, C, ptr(nd), dt | _dflag(), stream()), "mdl_bn_bwd_stats")
         check(lib().mdl_bn_bwd_apply_n(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, ptr(nd), dt, stream()),
               "mdl_bn_bwd_apply")
         dgamma = sums[R - 1].to(ctx.wdt) if ctx.has[0] else None          # totals row pair published by bwd_apply

@@ -49,9 +49,17 @@ def ddp_cleanup():
 class FlatDataParallel:
     """Wraps a model in place: flat gradient storage + single all-reduce.  Not an nn.Module wrapper —
     the model keeps its own class/attributes, so `model(data)`, `state_dict()` keys and hooks are
-    unchanged (the reference unwraps `model.module`; here there is nothing to unwrap)."""
+    unchanged (the reference unwraps `model.module`; here there is nothing to unwrap).
 
-    def __init__(self, model, process_group=None, broadcast=True, force=None, chunk_bytes=4 << 20):
+    chunk_bytes (default 0 = off): payloads above it are exchanged in TWO chunks.  The chunk membership is not guessed from
+    `parameters()` (registration order is not backward order: GraphModel registers every bn_list.* after every conv_list.*)
+    but OBSERVED: the first step runs the single collective while gradient hooks record the order in which the gradients
+    become ready; rank 0's order is broadcast (one agreed layout), the flat buffer is re-laid out in that order, and from the
+    second step on the first-ready half is packed and all-reduced from the hook of its last member, under the rest of the
+    backward.  Every step then issues exactly two collectives in the same order on every rank — a parameter that got no
+    gradient on this rank only delays its chunk to reduce_grads(), where it is packed as zeros."""
+
+    def __init__(self, model, process_group=None, broadcast=True, force=None, chunk_bytes=0):
         self.model = model
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -64,33 +72,32 @@ class FlatDataParallel:
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("FlatDataParallel: model has no trainable parameters")
-        dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.views = []
-        off = 0
         for p in self.params:
             if p.dtype != torch.float32:
                 raise ValueError("FlatDataParallel expects fp32 master parameters")
-            self.views.append(self.flat_grad[off:off + p.numel()].view_as(p))
-            off += p.numel()
-        # Two-chunk exchange for large payloads (MPNN: 17.5 MB): the parameters are split where the flat buffer reaches half its
-        # size; the SECOND half (the layers the forward runs last) has its gradients first in the backward, so its all-reduce
-        # starts from a hook as soon as the last of them is written and runs under the rest of the backward.  Small payloads
-        # (CGCNN: 0.45 MB, latency bound) keep the single collective.
-        self.split, self._late_left, self._late_work = None, 0, None
+        total = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
+        self._layout(self.params)
+        self._work = self._early_work = None
+        self._side = None
+        # two-chunk exchange: None = off; "observe" = the next backward records the ready order; (k, numel) = params[:k]
+        # (the first `numel` floats of the flat buffer) are the chunk whose exchange starts from a hook
+        self.split = None
+        self._ready, self._early_left = [], 0
         if self.active and chunk_bytes and total * 4 > chunk_bytes and len(self.params) > 1:
-            acc, k = 0, 0
-            while k < len(self.params) - 1 and acc + self.params[k].numel() <= total // 2:
-                acc += self.params[k].numel()
-                k += 1
-            k = max(k, 1)
-            self.split = (k, sum(p.numel() for p in self.params[:k]))
-            for p in self.params[k:]:
-                p.register_post_accumulate_grad_hook(self._late_hook)
+            self.split = "observe"
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._hook)
         self.zero_grad()
         if broadcast and self.world_size > 1:
             self.broadcast_state()
+
+    def _layout(self, params):
+        """views of the flat buffer in the order of `params`"""
+        self.params, self.views, off = list(params), [], 0
+        for p in self.params:
+            self.views.append(self.flat_grad[off:off + p.numel()].view_as(p))
+            off += p.numel()
 
     def broadcast_state(self, src=0):
         """Parameters and buffers from rank `src`, one flat message per dtype."""
@@ -110,8 +117,12 @@ class FlatDataParallel:
     def zero_grad(self):
         for p in self.params:
             p.grad = None
-        if self.split is not None:
-            self._late_left = len(self.params) - self.split[0]
+        self._ready = []
+        if self._early_work is not None:                  # a backward whose gradients were never reduced: drop its exchange
+            self._early_work.wait()
+            self._early_work = None
+        if isinstance(self.split, tuple):
+            self._early_left = self.split[0]
 
     def single_collective(self):
         """One all-reduce per step, always (training.GraphedStep: a rank that replays a captured step and a rank that runs the
@@ -119,15 +130,42 @@ class FlatDataParallel:
         self.split = None
         return self
 
-    def _late_hook(self, _param):
+    def _hook(self, param):
         if self.split is None:
             return
-        self._late_left -= 1
-        if self._late_left == 0 and self._late_work is None and self.active:
+        if self.split == "observe":
+            self._ready.append(param)
+            return
+        if id(param) not in self._early_ids:
+            return
+        self._early_left -= 1
+        if self._early_left == 0 and self._early_work is None:
             # (not inside a stream capture: a captured step issues its collectives outside the graph)
             if self.flat_grad.is_cuda and torch.cuda.is_current_stream_capturing():
                 return
-            self._late_work = self._launch(self.split[0], len(self.params))
+            self._early_work = self._launch(0, self.split[0])
+
+    def _adopt_ready_order(self):
+        """End of the observed step: agree on rank 0's ready order, lay the flat buffer out in it, split it in two."""
+        seen = {id(p) for p in self._ready}
+        order = self._ready + [p for p in self.params if id(p) not in seen]        # never-ready parameters go last
+        index = {id(p): i for i, p in enumerate(self.params)}
+        perm = torch.tensor([index[id(p)] for p in order], dtype=torch.int64, device=self.flat_grad.device)
+        if self.world_size > 1:
+            dist.broadcast(perm, src=0, group=self.group)
+        old = self.params
+        new = [old[i] for i in perm.tolist()]
+        # the gradients of this step already sit in the flat buffer in the OLD layout: move them (one gather, off the hot path)
+        moved = torch.cat([v.reshape(-1) for v in (self.views[i] for i in perm.tolist())])
+        self.flat_grad.copy_(moved)
+        self._layout(new)
+        total, acc, k = self.flat_grad.numel(), 0, 0
+        while k < len(new) - 1 and acc + new[k].numel() <= total // 2:
+            acc += new[k].numel()
+            k += 1
+        k = max(k, 1)
+        self.split = (k, sum(p.numel() for p in new[:k]))
+        self._early_ids = {id(p) for p in new[:k]}
 
     def _launch(self, lo, hi):
         """pack the gradients of params[lo:hi] into their slice of the flat buffer and start its all_reduce(SUM)"""
@@ -136,7 +174,7 @@ class FlatDataParallel:
         buf = self.flat_grad[off0:off1]
         if self.flat_grad.is_cuda:
             dev = self.flat_grad.device
-            if getattr(self, "_side", None) is None:
+            if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
@@ -160,37 +198,42 @@ class FlatDataParallel:
             torch._foreach_copy_(dsts, srcs)
 
     def reduce_grads_async(self, force=False):
-        """Start the gradient exchange: pack + ONE all_reduce(SUM).  On HIP devices both run on a side stream that
-        waits for the backward through an event, so whatever the caller enqueues next on the compute stream (the next
-        batch's assembly and RBF expansion in bench.py / the training loop) overlaps with the collective; finish() makes
-        the compute stream wait for it.  Returns False when there is nothing to exchange (one rank)."""
+        """Start the gradient exchange: pack + all_reduce(SUM) (one, or the second of two when the first-ready chunk left
+        from its hook).  On HIP devices both run on a side stream that waits for the backward through an event, so whatever
+        the caller enqueues next on the compute stream (the next batch's assembly and RBF expansion in bench.py / the
+        training loop) overlaps with the collective; finish() makes the compute stream wait for it.  Returns False when
+        there is nothing to exchange (one rank)."""
         if not (self.active or (force and dist.is_initialized())):
             return False
         lo = 0
-        if self._late_work is not None:
-            lo = self.split[0]            # the late half is already on its way (hook)
-        self._work = self._launch(0, lo if lo else len(self.params))
+        if isinstance(self.split, tuple):
+            if self._early_work is None:                  # a member got no gradient on this rank: same two collectives, now
+                self._early_work = self._launch(0, self.split[0])
+            lo = self.split[0]
+        self._work = self._launch(lo, len(self.params))
         return True
 
     def finish(self):
         """Wait for the exchange started by reduce_grads_async (the compute stream waits; the host does not), average
         (DDP semantics) and leave every .grad a view into the flat buffer."""
-        work = getattr(self, "_work", None)
+        work = self._work
         if work is None:
             return
+        if self._early_work is not None:
+            self._early_work.wait()
+            self._early_work = None
         work.wait()
         self._work = None
-        if self._late_work is not None:
-            self._late_work.wait()
-            self._late_work = None
         if self.flat_grad.is_cuda:
             torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
+        if self.split == "observe":
+            self._adopt_ready_order()
         self.flat_grad.mul_(1.0 / self.world_size)
         for p, v in zip(self.params, self.views):
             p.grad = v
 
     def reduce_grads(self, force=False):
-        """Sum over ranks, then average (DDP semantics).  One pack + one collective per step."""
+        """Sum over ranks, then average (DDP semantics).  One pack + one collective per step (two with chunk_bytes)."""
         if self.reduce_grads_async(force):
             self.finish()
 

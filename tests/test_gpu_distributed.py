@@ -1,0 +1,155 @@
+"""GPU: the data-parallel engine over RCCL on real hardware at world size 1, and bench.py's distributed / strong-scaling code
+paths.  Collected LAST (conftest: marker `last`): everything here spawns processes and talks to RCCL; a failure here must not
+stand in front of a parity test."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.last]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_RCCL_SNIPPET = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from matdeeplearn_amd.training import FlatDataParallel
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+torch.manual_seed(0)
+m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 1)).to(dev)
+dp = FlatDataParallel(m)
+dp.broadcast_state()                      # one flat broadcast per dtype over RCCL
+x = torch.randn(32, 8, device=dev)
+dp.zero_grad()
+m(x).sum().backward()
+ref = [p.grad.clone() for p in m.parameters()]
+dp.reduce_grads(force=True)               # pack + all_reduce(SUM) on the side stream + average: identity at world size 1
+torch.cuda.synchronize()
+for p, r in zip(m.parameters(), ref):
+    assert p.grad.data_ptr() != r.data_ptr() and torch.equal(p.grad, r), "all-reduce at world size 1 must be the identity"
+assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(dp.params, dp.views))
+t = torch.ones(4, device=dev); dist.all_reduce(t); assert float(t.sum()) == 4.0
+print("STAGE identity ok", flush=True)
+
+# the small-batch combination: the captured step (assembly + forward + backward) replayed, then the flat all-reduce and the
+# optimizer step outside the graph (training.GraphedStep(dp=...)); at world size 1 it must equal the fully captured step
+import copy, numpy as np
+from matdeeplearn_amd import models, ops
+from matdeeplearn_amd.process import synthetic_bulk
+from matdeeplearn_amd.training import GraphedStep, make_optimizer
+ds = synthetic_bulk(320, seed=11).to(dev)
+torch.manual_seed(3)
+m_a = models.CGCNN(ds, dim1=64, dim2=64, gc_count=2, post_fc_count=2).to(dev)
+m_b = copy.deepcopy(m_a)
+dp_a = FlatDataParallel(m_a, force=True, chunk_bytes=1024)
+assert dp_a.active and dp_a.split == "observe"
+o_a = make_optimizer(m_a.parameters(), "AdamW", lr=0.002)
+o_b = make_optimizer(m_b.parameters(), "AdamW", lr=0.002, capturable=True)
+with ops.deterministic():                  # (kernel noise off: what is compared is the plumbing)
+    g_a = GraphedStep(ds, m_a, o_a, 64, dp=dp_a)
+    g_b = GraphedStep(ds, m_b, o_b, 64)
+    assert not g_a.opt_in_graph and g_b.opt_in_graph and dp_a.split is None      # one collective per replayed step
+    rng = np.random.default_rng(0)
+    for _ in range(4):
+        ids = rng.choice(len(ds), size=64, replace=False)
+        g_a.step(ids); g_b.step(ids)
+    torch.cuda.synchronize()
+assert g_a.replays == 4 and g_b.replays == 4
+assert abs(float(g_a.loss_value) - float(g_b.loss_value)) <= 1e-6 * max(1.0, abs(float(g_b.loss_value)))
+for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+    # (the fused AdamW inside the graph and the foreach AdamW outside it round differently: 1e-6, not bits)
+    assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), (k, float((a.float() - b.float()).abs().max()))
+print("STAGE graphed-dp ok", flush=True)
+
+# the two-chunk exchange (opt-in): step 0 observes the order in which the gradients become ready, from step 1 on the
+# first-ready chunk is packed and all-reduced from a gradient hook under the rest of the backward.  EXACTNESS, not a tolerance:
+# the gradients the backward left in p.grad (cloned after a device synchronisation, before reduce_grads) must come back from
+# the exchange with the same bits — a pack that ran ahead of a gradient kernel, a wrong slice of the flat buffer or a missing
+# stream dependency all show up here, whatever the kernels' own summation noise is
+batch = ds.collate(np.arange(48))
+def backward(model, dp=None):
+    model.train()
+    for p in model.parameters(): p.grad = None
+    if dp is not None: dp.zero_grad()
+    with ops.zero_arena(dev):
+        torch.nn.functional.l1_loss(model(batch), batch.y).backward()
+m_c = copy.deepcopy(m_b)
+dp_c = FlatDataParallel(m_c, force=True, chunk_bytes=1024)
+assert dp_c.split == "observe"
+for step in range(4):
+    backward(m_c, dp_c)
+    assert (dp_c._early_work is not None) == (step > 0), step
+    torch.cuda.synchronize()
+    ref = {id(p): p.grad.clone() for p in dp_c.params}
+    dp_c.reduce_grads()
+    torch.cuda.synchronize()
+    if step == 0:
+        names = {id(p): k for k, p in m_c.named_parameters()}
+        order = [names[id(p)] for p in dp_c.params]
+        assert order[0].startswith("lin_out") and order[-1].startswith("pre_lin_list.0"), order
+        k = dp_c.split[0]
+        print("READY_ORDER early chunk:", order[:k], "| late:", order[k:], flush=True)
+    for p, v in zip(dp_c.params, dp_c.views):
+        assert p.grad.data_ptr() == v.data_ptr() and torch.equal(p.grad, ref[id(p)]), (step, names[id(p)])
+print("STAGE two-chunk exact ok", flush=True)
+
+# noise floor of the DEFAULT (atomic) kernels: the same backward twice on the same model, no exchange involved — what any
+# HIP-vs-HIP tolerance in default mode has to be a multiple of; and the same comparison in deterministic mode: bits
+m_d = copy.deepcopy(m_b)
+def grads(model, dp=None):
+    backward(model, dp)
+    if dp is not None: dp.reduce_grads()
+    torch.cuda.synchronize()
+    return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+runs = [grads(m_d) for _ in range(6)]
+floor = {k: max(float((r[k] - runs[0][k]).abs().max()) for r in runs[1:]) / (float(runs[0][k].abs().max()) + 1e-30) for k in runs[0]}
+worst = max(floor, key=floor.get)
+print("NOISE_FLOOR default mode, max over 5 repeats of |g - g0|_max / |g0|_max: worst %s %.3e; all: %s"
+      % (worst, floor[worst], {k: float("%.2e" % v) for k, v in floor.items()}), flush=True)
+gc = grads(m_c, dp_c)
+for k in gc:
+    err = float((gc[k] - runs[0][k]).abs().max()) / (float(runs[0][k].abs().max()) + 1e-30)
+    assert err <= 8 * floor[k] + 1e-6, "exchange vs plain backward: %s differs by %.3e of its scale, kernel noise floor %.3e" % (k, err, floor[k])
+with ops.deterministic():
+    d0, d1, dc = grads(m_d), grads(m_d), grads(m_c, dp_c)
+for k in d0:
+    assert torch.equal(d0[k], d1[k]), "deterministic mode is not reproducible: " + k
+    assert torch.equal(d0[k], dc[k]), "two-chunk exchange changed " + k
+print("STAGE noise floor + deterministic ok", flush=True)
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_rccl_backend_executes_on_one_gpu():
+    """The `nccl` (= RCCL) branch of the data-parallel engine on real hardware at world size 1: process-group init bound to the
+    device, flat broadcast, the side-stream pack + all-reduce (identity: bit-exact), the replayed step with the exchange and
+    the optimizer outside the graph (GraphedStep(dp=...)), the hook-started two-chunk exchange (bit-exact against the gradients
+    the backward produced; ready order printed), the kernels' own run-to-run noise floor in default mode (printed, and the
+    bound of the one default-mode comparison) and bit equality of everything in deterministic mode."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_SNIPPET], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):                     # keep the printed ready order / noise floor of this box
+        with open(os.path.join(out_dir, "rccl_world1.log"), "w") as f:
+            f.write(r.stdout[-20000:])
+    assert "RCCL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_bench_distributed_path_executes_on_one_gpu():
+    """bench.py with MDL_FORCE_DIST=1 (process group of one rank: RCCL init, flat exchange on the side stream, the reductions of
+    the timing) and --force-strong (the strong-scaling leg, which otherwise only runs for N > 1)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MDL_FORCE_DIST="1", MASTER_PORT="29534")
+    r = subprocess.run([sys.executable, "bench.py", "--graphs", "640", "--batch", "256", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extras", "--force-strong", "--strong-steps", "3"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1])
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["roofline"]["launches"] == 3 * 4
+    ss = res["strong_scaling"]
+    assert ss["value"] > 0 and ss["batch_graphs_per_gpu"] == 128 and ss["steps"] == 3

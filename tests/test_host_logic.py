@@ -29,6 +29,24 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert handle.mdl_cgconv_wpack_bytes(64, 50, 7) == 0
 
 
+def test_library_reads_no_environment_and_ships_no_experiment_kernels():
+    """include/mdl_hip.h promises a stateless library: libmdl_hip.so must not import getenv (variants are explicit flag bits in
+    `dtype`), and the measured-negative kernels live in the experiments build only (experiments/), not in the product."""
+    import shutil
+    import subprocess
+    from matdeeplearn_amd import _lib
+    nm = shutil.which("nm")
+    if nm is None:
+        pytest.skip("nm not available")
+    undefined = subprocess.run([nm, "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined, "libmdl_hip.so reads the environment"
+    exported = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for gone in ("mdl_cgconv_fwd_save", "mdl_cgconv_bwd_saved", "mdl_cgconv_fwd_p", "mdl_cgconv_bwd_p", "mdl_mlp2", "cb10fwd_kernel",
+                 "cgconv_bwd_ab_kernel"):
+        assert gone not in exported, gone
+    assert _lib.MDL_DETERMINISTIC == 0x100 and "#define MDL_DETERMINISTIC 0x100" in open(os.path.join(ROOT, "include", "mdl_hip.h")).read()
+
+
 def test_ops_fail_loudly_without_a_hip_device():
     from matdeeplearn_amd import nn as mnn, ops
     x = torch.randn(4, 64)
@@ -253,12 +271,13 @@ def _dp_worker(rank, world, port, tmp):
     p1 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     dist.all_gather(gathered, p1)
     assert torch.equal(gathered[0], gathered[1]), "ranks diverged after the optimizer step"
-    # two-chunk exchange (payloads above chunk_bytes): the half of the parameters the forward uses last is reduced from a
-    # hook while the backward still runs, the rest afterwards — same gradients, two collectives, the late one issued first
+    # two-chunk exchange (payloads above chunk_bytes; opt-in): the first step runs ONE collective while hooks observe the order
+    # in which the gradients become ready; from the second step on the first-ready half leaves from a hook while the backward
+    # still runs, the rest afterwards — same gradients, two collectives, the early chunk (offset 0 of the re-laid-out buffer) first
     m2 = omodels.CGCNN(ds, dim1=16, dim2=16, gc_count=2, post_fc_count=1, batch_norm="False")
     m2.load_state_dict(ref.state_dict())
     dp2 = FlatDataParallel(m2, chunk_bytes=1024)
-    assert dp2.split is not None and 0 < dp2.split[0] < len(dp2.params)
+    assert dp2.split == "observe"
     calls = []
     real_all_reduce = dist.all_reduce
 
@@ -267,15 +286,23 @@ def _dp_worker(rank, world, port, tmp):
         return real_all_reduce(t, *a, **k)
     dist.all_reduce = counting_all_reduce
     try:
-        for _ in range(2):                                # twice: the hook countdown re-arms in zero_grad()
+        for step in range(3):                             # the hook countdown re-arms in zero_grad()
             calls.clear()
             dp2.zero_grad()
             (torch.nn.functional.l1_loss(m2(batch), batch.y, reduction="sum") / 8.0).backward()
-            assert calls == [dp2.split[1]], "the late half must be on its way when the backward returns"
-            dp2.reduce_grads()
-            assert calls == [dp2.split[1], 0]
+            if step == 0:
+                assert calls == [], "the observed step exchanges nothing before reduce_grads()"
+                dp2.reduce_grads()
+                assert calls == [0] and isinstance(dp2.split, tuple) and 0 < dp2.split[0] < len(dp2.params)
+                # backward order, not registration order: the output layer's gradients are ready first
+                names = {id(p): k for k, p in m2.named_parameters()}
+                assert names[id(dp2.params[0])].startswith("lin_out") and names[id(dp2.params[-1])].startswith("pre_lin_list.0")
+            else:
+                assert calls == [0], "the first-ready chunk must be on its way when the backward returns"
+                dp2.reduce_grads()
+                assert calls == [0, dp2.split[1]]
             for (k, p), (_, q) in zip(m2.named_parameters(), ref.named_parameters()):
-                assert torch.allclose(p.grad, q.grad / world, rtol=1e-4, atol=1e-6), k
+                assert torch.allclose(p.grad, q.grad / world, rtol=1e-4, atol=1e-6), (step, k)
         dp2.single_collective()                           # what training.GraphedStep asks for: one collective per step
         calls.clear()
         dp2.zero_grad()
@@ -496,16 +523,7 @@ def test_conv_kernels_register_budget():
     assert scratch == 0 and occ == 2                                              # slice per wave
     scratch, occ = find("cgconv_bwd_kernelItLi128ELi50ELi9ELi2ELi1ELi0E")         # 128-channel backward: a few loop-invariant
     assert scratch <= 64 and occ == 1                                             # dwords spill
-    scratch, occ = find("cgconv_bwd_kernelItLi64ELi50ELi9ELi2ELi1ELi1E")          # opt-in W-split backward
-    assert scratch == 0 and occ == 1
-    scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb0ELi1E")      # opt-in W-split forward: a few dwords of
-    assert scratch <= 64 and occ == 2                                             # loop-invariant addresses spill
-    scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb1")          # opt-in saved-gate forward: the 16 pending
-    assert scratch <= 256 and occ == 2                                           # factor dwords spill at GROUP level only
-    scratch, occ = find("cgconv_bwd_ab_kernelILi64")                              # opt-in saved-gate backward
-    assert scratch == 0 and occ == 1
-    for frag in ("2cb10fwd_kernelILi64", "2cb10bwd_kernelILi64",    # cooperative kernels
-                 "cgconv_node_stream_kernelILi64", "cgconv_node_stream_kernelILi32"):    # node-level dense half
+    for frag in ("cgconv_node_stream_kernelILi64", "cgconv_node_stream_kernelILi32"):    # node-level dense half
         scratch, occ = find(frag)
         assert scratch == 0 and occ >= 2
 
@@ -671,27 +689,27 @@ def test_replica_drivers_give_every_trial_its_own_checkpoint_path():
     assert driver._suffixed("out/m", "_model0") == "out/m_model0"
 
 
-def test_sequential_chains_hand_the_next_dense_layer_over(monkeypatch):
-    """nn._seq: in a Linear -> activation -> Linear [-> activation] chain the first layer is told about the second (so that
-    ops.linear_act may compute both in one launch, mdl_mlp2); a lone layer or a Linear -> Linear pair is not."""
+def test_sequential_chains_fuse_each_dense_layer_with_its_activation(monkeypatch):
+    """nn._seq: every Linear of a Sequential goes to ops.linear_act together with the activation module that follows it (one
+    fused dense layer per pair); other modules are applied as they are."""
     from matdeeplearn_amd import nn as mnn
     calls = []
 
-    def fake_linear_act(h, weight, bias, act, lowp=None, nxt=None):
-        calls.append((tuple(weight.shape), act, None if nxt is None else (tuple(nxt[0].shape), nxt[2])))
+    def fake_linear_act(h, weight, bias, act, lowp=None):
+        calls.append((tuple(weight.shape), act))
         return torch.zeros(h.shape[0], weight.shape[0], dtype=h.dtype)
     monkeypatch.setattr(mnn.ops, "linear_act", fake_linear_act)
     h = torch.zeros(4, 6, dtype=torch.bfloat16)                       # bf16 rows, fp32 master weights: the ops path
     seq = torch.nn.Sequential(torch.nn.Linear(6, 10), mnn.ShiftedSoftplus(), torch.nn.Linear(10, 8))
     mnn._seq(seq, h)
-    assert calls == [((10, 6), "ssp", ((8, 10), None)), ((8, 10), None, None)]
+    assert calls == [((10, 6), "ssp"), ((8, 10), None)]
     calls.clear()
     seq = torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.ReLU(), torch.nn.Linear(10, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
     mnn._seq(seq, h)
-    assert calls == [((10, 6), "relu", ((8, 10), "relu")), ((8, 10), "relu", ((3, 8), None)), ((3, 8), None, None)]
+    assert calls == [((10, 6), "relu"), ((8, 10), "relu"), ((3, 8), None)]
     calls.clear()
     mnn._seq(torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.Linear(10, 8)), h)
-    assert calls == [((10, 6), None, None), ((8, 10), None, None)]
+    assert calls == [((10, 6), None), ((8, 10), None)]
 
 
 def test_wide_matmul_falls_back_to_the_library_off_device():
@@ -702,9 +720,11 @@ def test_wide_matmul_falls_back_to_the_library_off_device():
 
 
 def test_two_chunk_exchange_split_and_hook_rearm_in_process(tmp_path):
-    """FlatDataParallel at world size 1 (gloo, forced): the split sits where the flat buffer reaches half its size, the late
-    half's all-reduce is started by the gradient hook of its LAST-written parameter, zero_grad() re-arms it, parameters that
-    get no gradient fall back to the single exchange, and every .grad ends as a view of the flat buffer."""
+    """FlatDataParallel at world size 1 (gloo, forced; chunk_bytes is opt-in): the first step observes the order in which the
+    gradients become ready, the flat buffer is re-laid out in that order and split where it reaches half its size; from then on
+    the first-ready chunk's all-reduce is started by the gradient hook of its LAST member, zero_grad() re-arms it, a member
+    without a gradient delays its chunk to reduce_grads() (still two collectives, zeros packed), the exchange at world size 1
+    is the identity BIT FOR BIT, and every .grad ends as a view of the flat buffer."""
     import torch.distributed as dist
     from matdeeplearn_amd.training import FlatDataParallel
     if dist.is_initialized():
@@ -713,27 +733,52 @@ def test_two_chunk_exchange_split_and_hook_rearm_in_process(tmp_path):
     try:
         torch.manual_seed(0)
         m = torch.nn.Sequential(torch.nn.Linear(8, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+        assert FlatDataParallel(m, force=True).split is None                  # off by default
         dp = FlatDataParallel(m, force=True, chunk_bytes=256)
+        assert dp.split == "observe"
+        x = torch.randn(16, 8)
+        dp.zero_grad()
+        m(x).sum().backward()
+        assert dp._early_work is None
+        ref = {id(p): p.grad.clone() for p in m.parameters()}
+        dp.reduce_grads()
         sizes = [p.numel() for p in dp.params]
         k, off = dp.split
         assert off == sum(sizes[:k]) and off <= sum(sizes) // 2 < off + sizes[k]
-        x = torch.randn(16, 8)
-        for _ in range(2):
+        # ready order = backward order: the last layer first, its bias before / after its weight as autograd delivers them
+        assert {id(p) for p in dp.params[:2]} == {id(m[4].weight), id(m[4].bias)}
+        assert {id(p) for p in dp.params[-2:]} == {id(m[0].weight), id(m[0].bias)}
+        for p, v in zip(dp.params, dp.views):
+            assert torch.equal(p.grad, ref[id(p)]) and p.grad.data_ptr() == v.data_ptr()
+        calls = []
+        real = dist.all_reduce
+
+        def counting(t, *a, **kw):
+            calls.append((t.data_ptr() - dp.flat_grad.data_ptr()) // 4)
+            return real(t, *a, **kw)
+        dist.all_reduce = counting
+        try:
+            for _ in range(2):
+                calls.clear()
+                dp.zero_grad()
+                assert dp._early_left == k and dp._early_work is None
+                m(x).sum().backward()
+                assert dp._early_work is not None and calls == [0]     # started from the hook, before reduce_grads()
+                ref = {id(p): p.grad.clone() for p in m.parameters()}
+                dp.reduce_grads()
+                assert dp._early_work is None and calls == [0, off]
+                for p, v in zip(dp.params, dp.views):
+                    assert torch.equal(p.grad, ref[id(p)]) and p.grad.data_ptr() == v.data_ptr()
+            # a member of the first-ready chunk without a gradient: its chunk leaves from reduce_grads() — still two collectives
+            calls.clear()
             dp.zero_grad()
-            assert dp._late_left == len(sizes) - k and dp._late_work is None
-            m(x).sum().backward()
-            assert dp._late_work is not None                       # started from the hook, before reduce_grads()
-            ref = [p.grad.clone() for p in m.parameters()]
+            h = m[2](torch.relu(m[0](x)))
+            h.sum().backward()                                          # m[4] unused
+            assert dp._early_work is None and calls == []
             dp.reduce_grads()
-            assert dp._late_work is None
-            for p, r, v in zip(dp.params, ref, dp.views):
-                assert torch.equal(p.grad, r) and p.grad.data_ptr() == v.data_ptr()
-        # a parameter of the late half without a gradient: the hook count never reaches zero -> one exchange of everything
-        dp.zero_grad()
-        h = m[2](torch.relu(m[0](x)))
-        h.sum().backward()                                          # m[4] unused
-        assert dp._late_work is None
-        dp.reduce_grads()
-        assert all(float(v.abs().sum()) == 0.0 for p, v in zip(dp.params, dp.views) if p is m[4].weight or p is m[4].bias)
+            assert calls == [0, off]
+            assert all(float(v.abs().sum()) == 0.0 for p, v in zip(dp.params, dp.views) if p is m[4].weight or p is m[4].bias)
+        finally:
+            dist.all_reduce = real
     finally:
         dist.destroy_process_group()

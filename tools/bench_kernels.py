@@ -6,6 +6,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from matdeeplearn_amd import ops, _lib
 from matdeeplearn_amd.process import synthetic_bulk
 
+# the library reads no environment any more: MDL_CG_EP = 0 / 2 here selects the backward edge pass through ops.K3_VARIANT
+_ep = os.environ.get("MDL_CG_EP")
+if _ep == "0":
+    ops.K3_VARIANT = "per_wave"
+elif _ep == "2":
+    ops.K3_VARIANT = "edge_lane"
+else:
+    os.environ["MDL_CG_EP"] = "2"      # what the product runs at this size (labels of the counters below)
+
 ap = argparse.ArgumentParser()
 ap.add_argument("--graphs", type=int, default=8192)
 ap.add_argument("--iters", type=int, default=5)
