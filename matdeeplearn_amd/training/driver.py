@@ -15,7 +15,7 @@ import yaml
 
 from ..process import DeviceLoader, split_data, split_data_CV
 from .dp import FlatDataParallel, ddp_cleanup, ddp_setup
-from .loops import evaluate, make_optimizer, make_scheduler, trainer
+from .loops import evaluate, make_optimizer, make_scheduler, optimizer_state_for_checkpoint, trainer
 
 
 def load_config(path, run_mode="Training", model=None):
@@ -123,7 +123,7 @@ def train_regular(rank, world_size, dataset, job, training, model_params, splits
             if job.get("write_output") == "True":
                 write_results(rows, "%s_%s_outputs.csv" % (name, tag))
         if job.get("save_model") == "True":                                       # training.py:489-510
-            torch.save({"model_state_dict": model.state_dict(), "optimizer_state_dict": opt.state_dict(),
+            torch.save({"model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer_state_for_checkpoint(opt),
                         "scheduler_state_dict": sch.state_dict()}, job.get("model_path", "my_model.pth"))
         log("Train Error: {:.5f}, Val Error: {:.5f}, Test Error: {:.5f}".format(
             out["train_error"], out["val_error"], out["test_error"]))
@@ -152,7 +152,9 @@ def train_repeat(rank, world_size, dataset, job, training, model_params, **kw):
     _, owned = _enter_dist(rank, world_size)
     errs = []
     for i in range(trials):
-        j = dict(job, seed=resolve_seed(0), job_name="%s%d" % (job.get("job_name", "repeat"), i))   # fresh, rank-agreed seed
+        # fresh, rank-agreed seed per trial; names and flags as training.py:728-744 sets them (no checkpoint per trial)
+        j = dict(job, seed=resolve_seed(0), job_name="%s%d" % (job.get("job_name", "repeat"), i), save_model="False",
+                 load_model="False", model_path=_trial_path(job.get("model_path", "my_model.pth"), i))
         r = train_regular(rank, world_size, dataset, j, training, model_params, **kw)
         errs.append([r.get("train_error", np.nan), r.get("val_error", np.nan), r.get("test_error", np.nan)])
     if owned:
@@ -168,11 +170,18 @@ def _gather_objects(obj, world_size):
     return bucket
 
 
-def _suffixed(path, tag):
-    """my_model.pth -> my_model<tag>.pth"""
-    import os
-    root, ext = os.path.splitext(path)
-    return root + tag + ext
+def _trial_path(path, *parts):
+    """The reference's per-trial checkpoint names: repeat trial i -> "<i>_<model_path>" (training.py:744), ensemble member k ->
+    "<k>_<model name>_<model_path>" (training.py:1086-1088); the prefix goes in front of the FILE name, so a model_path with a
+    directory keeps it (the reference's plain string concatenation only works for bare file names)."""
+    head, tail = os.path.split(path)
+    return os.path.join(head, "_".join([str(x) for x in parts] + [tail]))
+
+
+def _member_name(job, models_params, k):
+    """name of ensemble member k as the reference's ensemble_list holds it (training.py:1086)"""
+    names = job.get("ensemble_list")
+    return names[k] if names and k < len(names) else models_params[k].get("model", "model")
 
 
 def train_repeat_replicas(rank, world_size, dataset, job, training, model_params, **kw):
@@ -187,10 +196,9 @@ def train_repeat_replicas(rank, world_size, dataset, job, training, model_params
     seeds = [resolve_seed(0) for _ in range(trials)]                     # agreed on all ranks
     mine = {}
     for t in range(r_id, trials, ws):
-        # every rank is the root of its own single-GPU training here: a checkpoint path shared by all trials (the default
-        # my_model.pth) would be written by several ranks at once — one file per trial instead
-        j = dict(job, seed=seeds[t], job_name="%s%d" % (job.get("job_name", "repeat"), t),
-                 model_path=_suffixed(job.get("model_path", "my_model.pth"), "_trial%d" % t))
+        # names and flags as training.py:728-744 sets them: "<t>_<model_path>", no checkpoint per trial
+        j = dict(job, seed=seeds[t], job_name="%s%d" % (job.get("job_name", "repeat"), t), save_model="False", load_model="False",
+                 model_path=_trial_path(job.get("model_path", "my_model.pth"), t))
         r = train_regular("cuda" if dataset.device is not None and dataset.device.type == "cuda" else "cpu", 1, dataset,
                           j, training, model_params, **kw)             # world_size 1: a local, independent training
         mine[t] = [r.get("train_error", np.nan), r.get("val_error", np.nan), r.get("test_error", np.nan)]
@@ -214,9 +222,9 @@ def train_ensemble_replicas(rank, world_size, dataset, job, training, models_par
     mine = {}
     for k in range(r_id, len(models_params), ws):
         r = train_regular("cuda" if dataset.device is not None and dataset.device.type == "cuda" else "cpu", 1, dataset,
-                          dict(job, seed=seed, job_name="%s_%d" % (job.get("job_name", "ens"), k),
-                               model_path=_suffixed(job.get("model_path", "my_model.pth"), "_model%d" % k)), training,
-                          models_params[k], splits=splits, **kw)
+                          dict(job, seed=seed, job_name="%s%d" % (job.get("job_name", "ens"), k), load_model="False",
+                               model_path=_trial_path(job.get("model_path", "my_model.pth"), k, _member_name(job, models_params, k))),
+                          training, models_params[k], splits=splits, **kw)
         mine[k] = (r.get("test_error", np.nan), r.get("test_rows"))
     allr = {}
     for part in (_gather_objects(mine, ws) if distributed else [mine]):
@@ -259,7 +267,9 @@ def train_ensemble(rank, world_size, dataset, job, training, models_params, **kw
     splits = split_data(len(dataset), training["train_ratio"], training["val_ratio"], training["test_ratio"], seed)
     per_model, preds, target = [], [], None
     for k, mp in enumerate(models_params):
-        r = train_regular(rank, world_size, dataset, dict(job, seed=seed, job_name="%s_%d" % (job.get("job_name", "ens"), k)),
+        r = train_regular(rank, world_size, dataset,
+                          dict(job, seed=seed, job_name="%s%d" % (job.get("job_name", "ens"), k), load_model="False",
+                               model_path=_trial_path(job.get("model_path", "my_model.pth"), k, _member_name(job, models_params, k))),
                           training, mp, splits=splits, **kw)
         per_model.append(r.get("test_error", np.nan))
         if "test_rows" in r:

@@ -34,6 +34,27 @@ def make_optimizer(params, name="AdamW", lr=0.002, **optimizer_args):
     return getattr(torch.optim, name)(plist, lr=lr, **kw)
 
 
+def optimizer_state_for_checkpoint(optimizer):
+    """optimizer.state_dict() in the reference's checkpoint format (training.py:489-510): a capturable optimizer keeps its
+    learning rate in a device tensor (make_optimizer), which a non-capturable / foreach optimizer refuses to load ("lr as a
+    Tensor is not supported") — the checkpoint holds python floats."""
+    sd = optimizer.state_dict()
+    sd = dict(sd, param_groups=[dict(g, lr=float(g["lr"]) if torch.is_tensor(g.get("lr")) else g.get("lr")) for g in sd["param_groups"]])
+    return sd
+
+
+def load_optimizer_state(optimizer, state_dict):
+    """optimizer.load_state_dict for checkpoints written by optimizer_state_for_checkpoint: an optimizer built with a
+    device-tensor learning rate (capturable) keeps ITS tensor (captured graphs hold its address) and receives the value."""
+    lr_tensors = [g["lr"] if torch.is_tensor(g.get("lr")) else None for g in optimizer.param_groups]
+    optimizer.load_state_dict(state_dict)
+    for g, t in zip(optimizer.param_groups, lr_tensors):
+        if t is not None:
+            t.fill_(float(g["lr"]))
+            g["lr"] = t
+    return optimizer
+
+
 def make_scheduler(optimizer, name="ReduceLROnPlateau", **scheduler_args):
     return getattr(torch.optim.lr_scheduler, name)(optimizer, **scheduler_args)
 

@@ -683,10 +683,14 @@ def test_gcnconv_consumes_two_glorot_draws_like_pyg():
         assert torch.equal(conv.lin.weight.detach(), w) and torch.equal(after, torch.rand(3)), cls
 
 
-def test_replica_drivers_give_every_trial_its_own_checkpoint_path():
+def test_trial_checkpoints_carry_the_reference_names():
+    """training.py:744 (repeat: "<i>_<model_path>") and :1086-1088 (ensemble: "<i>_<model name>_<model_path>")"""
     from matdeeplearn_amd.training import driver
-    assert driver._suffixed("my_model.pth", "_trial3") == "my_model_trial3.pth"
-    assert driver._suffixed("out/m", "_model0") == "out/m_model0"
+    assert driver._trial_path("my_model.pth", 3) == "3_my_model.pth"
+    assert driver._trial_path("my_model.pth", 0, "CGCNN_demo") == "0_CGCNN_demo_my_model.pth"
+    assert driver._trial_path("out/m.pth", 2, "SchNet") == "out/2_SchNet_m.pth"
+    assert driver._member_name({"ensemble_list": ["CGCNN_demo", "MPNN_demo"]}, [{}, {}], 1) == "MPNN_demo"
+    assert driver._member_name({}, [{"model": "GCN"}], 0) == "GCN"
 
 
 def test_sequential_chains_fuse_each_dense_layer_with_its_activation(monkeypatch):
@@ -782,3 +786,24 @@ def test_two_chunk_exchange_split_and_hook_rearm_in_process(tmp_path):
             dist.all_reduce = real
     finally:
         dist.destroy_process_group()
+
+
+def test_checkpointed_optimizer_state_holds_float_learning_rates():
+    """A tensor learning rate (what make_optimizer(capturable=True) builds on a device) must not reach the checkpoint: the
+    reference format holds floats, and loading a tensor lr into a non-capturable optimizer raises.  Loading back into an
+    optimizer that keeps a tensor lr leaves ITS tensor in place (a captured graph holds its address) with the loaded value."""
+    from matdeeplearn_amd.training import load_optimizer_state, optimizer_state_for_checkpoint
+    m = torch.nn.Linear(3, 2)
+    lr_t = torch.tensor(0.004)
+    opt = torch.optim.AdamW(m.parameters(), lr=lr_t, capturable=False, foreach=False)
+    m(torch.randn(5, 3)).sum().backward()
+    opt.step()
+    sd = optimizer_state_for_checkpoint(opt)
+    assert isinstance(sd["param_groups"][0]["lr"], float) and abs(sd["param_groups"][0]["lr"] - 0.004) < 1e-9
+    assert opt.param_groups[0]["lr"] is lr_t                       # the live optimizer is untouched
+    plain = torch.optim.AdamW(m.parameters(), lr=0.1)
+    plain.load_state_dict(sd)                                      # what failed with a tensor lr in the checkpoint
+    assert abs(plain.param_groups[0]["lr"] - 0.004) < 1e-9
+    sd["param_groups"][0]["lr"] = 0.001
+    load_optimizer_state(opt, sd)
+    assert opt.param_groups[0]["lr"] is lr_t and abs(float(lr_t) - 0.001) < 1e-9
