@@ -64,7 +64,8 @@ typedef void* mdlStream_t; /* hipStream_t */
 
 int mdl_version(void);
 const char* mdl_last_error_string(void);
-/* Which backward edge pass the last mdl_cgconv_bwd* call of this thread launched (thread-local, like the error string):
+/* Which backward edge pass the last mdl_cgconv_bwd* call of this process launched (a debug value outside the data path; the
+ * callers' autograd engines run backward passes on threads of their own, so it is per process, not per thread):
  * 0 none yet, 1 per-wave kernel, 2 edge-per-lane kernel 2, 3 per-wave kernel in its deterministic shape.  For tests that must
  * know that the kernel they mean to check is the one that ran. */
 int mdl_debug_last_k3(void);

@@ -1906,9 +1906,10 @@ static const CgEnv& cg_env() {
     return e;
 }
 
-// which backward edge pass the last mdl_cgconv_bwd* call of this thread launched (mdl_debug_last_k3: tests assert that the
-// kernel they mean to check is the one that ran): 1 per-wave, 2 edge-per-lane kernel 2, 3 per-wave in deterministic shape
-static thread_local int g_last_k3 = 0;
+// which backward edge pass the last mdl_cgconv_bwd* call of this PROCESS launched (mdl_debug_last_k3: tests assert that the
+// kernel they mean to check is the one that ran; not thread-local — autograd runs the backward on its own thread):
+// 1 per-wave, 2 edge-per-lane kernel 2, 3 per-wave in deterministic shape.  A debug value, no part of the data path.
+static volatile int g_last_k3 = 0;
 
 template <typename T>
 static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const char* name) {

@@ -61,8 +61,10 @@ with ops.deterministic():                  # (kernel noise off: what is compared
 assert g_a.replays == 4 and g_b.replays == 4
 assert abs(float(g_a.loss_value) - float(g_b.loss_value)) <= 1e-6 * max(1.0, abs(float(g_b.loss_value)))
 for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
-    # (the fused AdamW inside the graph and the foreach AdamW outside it round differently: 1e-6, not bits)
-    assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), (k, float((a.float() - b.float()).abs().max()))
+    # (the capturable fused AdamW inside the graph and the plain fused AdamW outside it evaluate the bias corrections
+    # differently, and Adam turns a last-bit difference of a near-zero gradient into a fraction of lr = 2e-3 per step:
+    # measured 3.7e-6 after four steps)
+    assert torch.allclose(a.float(), b.float(), rtol=2e-4, atol=2e-5), (k, float((a.float() - b.float()).abs().max()))
 print("STAGE graphed-dp ok", flush=True)
 
 # the two-chunk exchange (opt-in): step 0 observes the order in which the gradients become ready, from step 1 on the
