@@ -82,6 +82,8 @@ def parse():
     ap.add_argument("--force-strong", action="store_true",
                     help="run the strong-scaling leg at world size 1 too, as if the global batch were shared by two ranks (B / 2 "
                          "graphs per step): executes the N > 1 code path on a one-GPU box (tests)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="assemble every batch on the compute stream at the start of its step instead of one step ahead on a side stream")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--dataset-cache", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "mdl_bench_data"),
                     help="directory for the flat on-disk copy of the synthetic dataset ('' = always regenerate)")
@@ -184,13 +186,22 @@ def main():
     ktimes = {"cgcnn": {"fwd": [], "bwd": []}, "schnet": {"gmr_fwd": []}, "megnet": {"edge_linear": []},
               "gcn": {"gmr_fwd": []}, "mpnn": {"nnconv_fwd": []}}[args.model]
 
+    prefetch = not args.no_prefetch
+
     def make_step(model, dp, opt, dtype):
-        pending = {}                                 # ids (bytes) -> batch assembled during the previous step's all-reduce
+        pending = {}                                 # ids (bytes) -> handle of the batch being assembled one step ahead
 
         def step(ids, timed, next_ids=None):
-            batch = pending.pop(ids.tobytes(), None)
-            if batch is None:
+            ahead = pending.pop(ids.tobytes(), None)
+            if ahead is not None:
+                batch = ds.take_ahead(ahead)
+            else:
                 batch = ds.collate(ids, edge_dtype=dtype, x_dtype=dtype)
+            if next_ids is not None and prefetch:
+                # batch k + 1 is assembled (K8 + K1) on a side stream while this step computes: every step still pays one
+                # assembly inside the timed region, it just no longer sits alone on the device
+                pending.clear()
+                pending[next_ids.tobytes()] = ds.collate_ahead(next_ids, edge_dtype=dtype, x_dtype=dtype)
             dp.zero_grad()
             ops.KERNEL_EVENTS = ktimes if timed else None
             with ops.zero_arena(dev):               # one zero fill per step for the kernels' small accumulators
@@ -199,10 +210,6 @@ def main():
                 loss.backward()
             ops.KERNEL_EVENTS = None
             if dp.reduce_grads_async(force=use_dist):
-                # the collective runs on a side stream: assemble the NEXT batch (K8 + K1) on the compute stream meanwhile
-                if next_ids is not None:
-                    pending.clear()
-                    pending[next_ids.tobytes()] = ds.collate(next_ids, edge_dtype=dtype, x_dtype=dtype)
                 dp.finish()
             opt.step()
             return batch.num_edges, batch.num_nodes
@@ -234,13 +241,15 @@ def main():
                 dist.all_reduce(el, op=dist.ReduceOp.MIN)
             if float(el) >= args.settle_s:
                 break
+    # (prefetch: every step also starts the assembly of the batch that follows on a side stream — the first timed batch during
+    # the last warm-up step, and the last timed step one more (unused) batch, so that the K timed steps contain K assemblies)
     for i in range(args.warmup):
-        step(step_ids[i], False)
+        step(step_ids[i], False, step_ids[i + 1])
     barrier()
     t0 = time.perf_counter()
     edges = nodes = 0
     for i in range(args.warmup, total_steps):
-        e, n = step(step_ids[i], True, step_ids[i + 1] if i + 1 < total_steps else None)
+        e, n = step(step_ids[i], True, step_ids[i + 1] if i + 1 < total_steps else step_ids[0])
         edges += e
         nodes += n
     barrier()
@@ -373,7 +382,7 @@ def main():
     if world == 1 and not args.no_extras:
         from matdeeplearn_amd.training import GraphedStep
 
-        def run_for(step_fn, it, min_s=None, n=None):
+        def run_for(step_fn, it, min_s=None, n=None, ahead=False):
             """step_fn over batches from `it` for >= min_s seconds (or exactly n steps); (edges, steps, seconds, marks).
             No device synchronisation inside the loop: an idle gap lets the GPU drop its clocks, and the ramp back up
             costs tens of milliseconds (seen as 2 ms/step on every 16-step chunk that followed a sync).  The host is
@@ -383,8 +392,10 @@ def main():
             t1 = time.perf_counter()
             e_tot = k = 0
             marks = []
+            nxt = next(it)
             while True:
-                e_tot += step_fn(next(it))[0]
+                cur, nxt = nxt, next(it)
+                e_tot += (step_fn(cur, nxt) if ahead else step_fn(cur))[0]
                 k += 1
                 if n is not None:
                     if k >= n:
@@ -399,7 +410,7 @@ def main():
         # ---- sustained: >= sustain_s seconds of steps.  (a) the eager step of the timed region, (b) the same step as ONE
         # HIP-graph replay per batch (training.GraphedStep: static padded buffers, optimizer inside the graph) ----------
         ms0 = torch.cuda.memory_stats(dev)
-        e_sus, n_sus, dt, marks = run_for(lambda ids: step(ids, False), stream, min_s=args.sustain_s)
+        e_sus, n_sus, dt, marks = run_for(lambda ids, nxt: step(ids, False, nxt), stream, min_s=args.sustain_s, ahead=True)
         ms1 = torch.cuda.memory_stats(dev)
         eager = {"value": round(e_sus / dt, 1), "ms_per_step": round(dt / n_sus * 1e3, 4), "steps": n_sus,
                  "device_mallocs": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),

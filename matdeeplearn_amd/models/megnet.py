@@ -73,8 +73,9 @@ class Megnet_NodeModel(_Mlp):
     def __init__(self, dim, act, batch_norm, batch_track_stats, dropout_rate, fc_layers=2):
         super().__init__("node_mlp", dim * 3, dim, act, batch_norm, batch_track_stats, dropout_rate, fc_layers)
 
-    def forward(self, x, edge_index, edge_attr, u, batch):
-        v_e = ops.scatter_mean(edge_attr, edge_index[0], 0, x.shape[0])      # aggregate at the SOURCE row
+    def forward(self, x, edge_index, edge_attr, u, batch, v_e=None):
+        if v_e is None:
+            v_e = ops.scatter_mean(edge_attr, edge_index[0], 0, x.shape[0])      # aggregate at the SOURCE row
         return self.run(torch.cat([x, v_e, ops.gather(u, batch)], dim=1))
 
 
@@ -82,9 +83,11 @@ class Megnet_GlobalModel(_Mlp):
     def __init__(self, dim, act, batch_norm, batch_track_stats, dropout_rate, fc_layers=2):
         super().__init__("global_mlp", dim * 3, dim, act, batch_norm, batch_track_stats, dropout_rate, fc_layers)
 
-    def forward(self, x, edge_index, edge_attr, u, batch):
+    def forward(self, x, edge_index, edge_attr, u, batch, v_e=None):
         b = u.shape[0]
-        u_e = ops.scatter_mean(ops.scatter_mean(edge_attr, edge_index[0], 0, x.shape[0]), batch, 0, b, assume_sorted=True)
+        if v_e is None:
+            v_e = ops.scatter_mean(edge_attr, edge_index[0], 0, x.shape[0])
+        u_e = ops.scatter_mean(v_e, batch, 0, b, assume_sorted=True)
         u_v = ops.scatter_mean(x, batch, 0, b, assume_sorted=True)
         return self.run(torch.cat([u_e, u_v, u], dim=1))
 
@@ -122,10 +125,16 @@ class _FusedMetaLayer(MetaLayer):
                 # padded static batch no segment made of the unused edge slots)
                 edge_attr = em.run(torch.cat([ops.gather(x, row32), ops.gather(x, col32), edge_attr,
                                               ops.gather(ops.gather(u, batch_n), row32)], dim=1))
+            # the node block and the global block both start from scatter_mean(e', edge_index[0]) (megnet.py:86 and :130): the
+            # same [E, d] -> [N, d] reduction of the same tensor, formed ONCE here (one segmented reduction forward, one backward
+            # and one gradient accumulation over the edge rows less per block)
+            v_e = None
+            if self.node_model is not None and self.global_model is not None:
+                v_e = ops.scatter_mean(edge_attr, edge_index[0], 0, x.shape[0])
             if self.node_model is not None:
-                x = self.node_model(x, edge_index, edge_attr, u, batch)
+                x = self.node_model(x, edge_index, edge_attr, u, batch, v_e=v_e)
             if self.global_model is not None:
-                u = self.global_model(x, edge_index, edge_attr, u, batch)
+                u = self.global_model(x, edge_index, edge_attr, u, batch, v_e=v_e)
             return x, edge_attr, u
         return super().forward(x, edge_index, edge_attr, u, batch)
 

@@ -57,6 +57,14 @@ class Batch:
     def to(self, device):
         return self  # already resident; kept for `data.to(rank)` call-site compatibility (training.py:39)
 
+    def tensors(self):
+        """every device tensor the batch owns (features, targets, index arrays of the CSR)"""
+        out = [v for v in self.__dict__.values() if torch.is_tensor(v)]
+        csr = self.__dict__.get("csr")
+        if csr is not None:
+            out += [t for t in (csr.rowptr, csr.src, csr.tgt, csr.eperm) if torch.is_tensor(t)]
+        return out
+
 
 class GraphDataset:
     """Flat arrays (numpy on the host until .to(device)):
@@ -73,6 +81,7 @@ class GraphDataset:
         self.ids = list(ids)
         self.num_edge_features = int(num_edge_features)
         self.target_index = 0
+        self._side = None               # side stream of collate_ahead()
         lo, hi = dist_range if dist_range is not None else (float(dist.min()), float(dist.max()))
         self.dist_range = (lo, hi)
         # same fp32 arithmetic as NormalizeEdge (process.py:650-653)
@@ -288,6 +297,30 @@ class GraphDataset:
                                          offsets=self._dev["offsets"])
         else:
             b.edge_attr = rbf(dist_norm).to(edge_dtype)
+        return b
+
+    def collate_ahead(self, ids, edge_dtype=torch.float32, x_dtype=None):
+        """collate() of a LATER batch on a side stream: the assembly (K8) and the RBF expansion (K1) are short, latency-bound
+        launches that fit beside the conv kernels of the step that is running (its tails leave CUs idle), which is what the
+        worker processes of the reference's DataLoader (training.py:300-325) buy on the host.  Returns a handle for
+        take_ahead(); the caller's stream is not touched."""
+        dev = self.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(self._side):
+            b = self.collate(ids, edge_dtype=edge_dtype, x_dtype=x_dtype)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        return b, ev
+
+    def take_ahead(self, handle):
+        """the batch of a collate_ahead() handle, ready for the CURRENT stream: that stream waits for the side stream's
+        launches, and the caching allocator is told that the batch's memory (allocated on the side stream) is in use here"""
+        b, ev = handle
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        for t in b.tensors():
+            t.record_stream(cur)
         return b
 
     def assemble(self, ids):
@@ -555,11 +588,14 @@ class DeviceLoader:
     reference relies on at training.py:291-294 — and every rank draws `batch_size` graphs per step."""
 
     def __init__(self, dataset, indices, batch_size, shuffle=False, seed=0, rank=0, world_size=1,
-                 edge_dtype=torch.float32, rbf=None):
+                 edge_dtype=torch.float32, rbf=None, prefetch=None):
         self.ds, self.indices = dataset, np.asarray(indices, dtype=np.int64)
         self.batch_size, self.shuffle, self.seed = int(batch_size), shuffle, int(seed)
         self.rank, self.world_size, self.edge_dtype, self.rbf = rank, world_size, edge_dtype, rbf
         self.epoch = 0
+        # assemble batch k + 1 on a side stream while the caller works on batch k (HIP datasets with the kernel RBF expansion)
+        on_hip = dataset.device is not None and dataset.device.type == "cuda"
+        self.prefetch = (on_hip and rbf is None) if prefetch is None else (bool(prefetch) and on_hip and rbf is None)
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
@@ -582,5 +618,18 @@ class DeviceLoader:
 
     def __iter__(self):
         idx = self._order()
-        for i in range(0, len(idx), self.batch_size):
-            yield self.ds.collate(idx[i:i + self.batch_size], self.edge_dtype, self.rbf, x_dtype=self.edge_dtype)
+        starts = list(range(0, len(idx), self.batch_size))
+        if not self.prefetch or torch.cuda.is_current_stream_capturing():
+            for i in starts:
+                yield self.ds.collate(idx[i:i + self.batch_size], self.edge_dtype, self.rbf, x_dtype=self.edge_dtype)
+            return
+        ahead = None
+        for k, i in enumerate(starts):
+            if ahead is None:
+                ahead = self.ds.collate_ahead(idx[i:i + self.batch_size], self.edge_dtype, x_dtype=self.edge_dtype)
+            batch = self.ds.take_ahead(ahead)
+            ahead = None
+            if k + 1 < len(starts):
+                j = starts[k + 1]
+                ahead = self.ds.collate_ahead(idx[j:j + self.batch_size], self.edge_dtype, x_dtype=self.edge_dtype)
+            yield batch

@@ -129,6 +129,34 @@ def test_loader_by_source_index_matches_the_sort():
             assert float((out - ref).abs().max()) < 1e-4
 
 
+def test_prefetching_loader_yields_the_same_batches():
+    """DeviceLoader(prefetch=True) assembles batch k + 1 on a side stream while the caller works on batch k (collate_ahead /
+    take_ahead: event wait + record_stream).  Same batches, bit for bit, as the in-line loader — also when the caller keeps the
+    device busy between the batches and drops each batch before the next one arrives (allocator reuse across the streams)."""
+    from matdeeplearn_amd.process import DeviceLoader, synthetic_bulk
+    dev = torch.device("cuda:0")
+    ds = synthetic_bulk(500, seed=21).to(dev)
+    idx = np.arange(500)
+    keys = ("x", "edge_attr", "edge_weight", "batch", "y")
+    ref = []
+    for b in DeviceLoader(ds, idx, 64, shuffle=True, seed=3, edge_dtype=torch.bfloat16, prefetch=False):
+        ref.append({k: getattr(b, k).clone() for k in keys} | {"rowptr": b.csr.rowptr.clone(), "src": b.csr.src.clone(), "tgt": b.csr.tgt.clone()})
+    ld = DeviceLoader(ds, idx, 64, shuffle=True, seed=3, edge_dtype=torch.bfloat16)
+    assert ld.prefetch
+    busy = torch.randn(2048, 2048, device=dev)
+    n = 0
+    for b, r in zip(ld, ref):
+        for _ in range(3):
+            busy = torch.tanh(busy @ busy * 1e-3)                       # keep the compute stream ahead of the host
+        for k in keys:
+            assert torch.equal(getattr(b, k), r[k]), (n, k)
+        assert torch.equal(b.csr.rowptr, r["rowptr"]) and torch.equal(b.csr.src, r["src"]) and torch.equal(b.csr.tgt, r["tgt"]), n
+        n += 1
+        del b
+    assert n == len(ref) == len(ld)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("name", ["SchNet", "MEGNet", "GCN", "MPNN"])
 def test_graph_replay_of_the_other_models_matches_eager(name):
     """GraphedStep for the models that also walk the batch by SOURCE and run dense layers over all edge rows: the padded
