@@ -280,9 +280,11 @@ class GraphDataset:
         csr.set_transposed_builder(transposed)
         ops.register_seg_index(src, _weak_call(csr, "seg_src"))   # scatter(..., csr.row / csr.col): no per-batch sort
         ops.register_seg_index(tgt, _weak_call(csr, "seg_tgt"))
+        # (_pack: the uploaded ids / offsets the lazily built by-source index reads later, possibly on another stream than the one
+        # this batch was assembled on — Batch.tensors() must see every allocation of the assembly, see take_ahead)
         return Batch(x=x, edge_attr=None, edge_weight=ew, batch=batch, y=y, u=self._zero_u(B, dev),
                      num_graphs=B, csr=csr, num_nodes=N, num_edges=E,
-                     structure_id=[self.ids[i] for i in ids]), dn
+                     structure_id=[self.ids[i] for i in ids], _pack=pack), dn
 
     def collate(self, ids, edge_dtype=torch.float32, rbf=None, x_dtype=None):
         """Assemble the batch for graph ids (host int array) on the device and expand the edge

@@ -140,7 +140,8 @@ def test_prefetching_loader_yields_the_same_batches():
     keys = ("x", "edge_attr", "edge_weight", "batch", "y")
     ref = []
     for b in DeviceLoader(ds, idx, 64, shuffle=True, seed=3, edge_dtype=torch.bfloat16, prefetch=False):
-        ref.append({k: getattr(b, k).clone() for k in keys} | {"rowptr": b.csr.rowptr.clone(), "src": b.csr.src.clone(), "tgt": b.csr.tgt.clone()})
+        ref.append({k: getattr(b, k).clone() for k in keys} | {"rowptr": b.csr.rowptr.clone(), "src": b.csr.src.clone(), "tgt": b.csr.tgt.clone(),
+                                                               "t": [t.clone() for t in b.csr.transposed()]})
     ld = DeviceLoader(ds, idx, 64, shuffle=True, seed=3, edge_dtype=torch.bfloat16)
     assert ld.prefetch
     busy = torch.randn(2048, 2048, device=dev)
@@ -151,6 +152,10 @@ def test_prefetching_loader_yields_the_same_batches():
         for k in keys:
             assert torch.equal(getattr(b, k), r[k]), (n, k)
         assert torch.equal(b.csr.rowptr, r["rowptr"]) and torch.equal(b.csr.src, r["src"]) and torch.equal(b.csr.tgt, r["tgt"]), n
+        # the by-source index is built lazily, on THIS stream, from ids / offsets uploaded on the side stream: they must still
+        # be alive and unrecycled (a first version of take_ahead missed them: memory fault in the SchNet bench leg)
+        for got, want in zip(b.csr.transposed(), r["t"]):
+            assert torch.equal(got, want), n
         n += 1
         del b
     assert n == len(ref) == len(ld)
