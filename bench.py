@@ -373,6 +373,34 @@ def main():
     if grown:
         res["config"]["dataset_note"] = ("the recipe was drawn to %d graphs (reference-sized: %d) so that every rank's partition "
                                          "of the train split holds a full batch of distinct graphs" % (n_graphs, WORKLOADS[args.model][2]))
+    # the WHOLE conv stack of a step against the HBM roofline (SURVEY 8d yardsticks): algorithmic bytes of every conv block,
+    # forward + backward, divided by the step time — the per-kernel roofline above covers only the block's dominant kernel,
+    # which for SchNet / MEGNet / MPNN is a sliver of the step (config.conv_kernel_share_of_step)
+    L = mkw.get("gc_count", args.gc)
+    if args.model == "cgcnn":
+        stack = L * (ab_fwd + ab_bwd)
+        conv = "K2 + K3 per layer, SURVEY 8d (252 + 390 B/edge/layer at C = 64, bf16, in-degree 13)"
+    elif args.model == "schnet":                     # K4 CFConv forward: E(G s + 4 + F s + 4) + N(2 F s + 4); backward taken as 2x forward
+        F_ = mkw["dim3"]
+        stack = L * 3 * (e_step * (G * s + 4 + F_ * s + 4) + n_step * (2 * F_ * s + 4))
+        conv = "SURVEY 8d K4 forward bytes x 3 per layer (forward + the two backward passes over the same operands)"
+    elif args.model == "megnet":                     # K6 edge block E(4 d s + 8) + node block E d s + 3 N d s; backward taken as 2x forward
+        d = mkw["dim3"]
+        stack = L * 3 * (e_step * (4 * d * s + 8) + e_step * d * s + n_step * 3 * d * s)
+        conv = "SURVEY 8d K6 edge + node block forward bytes x 3 per block"
+    elif args.model == "mpnn":
+        C_, d3 = mkw["dim1"], mkw["dim3"]
+        stack = L * 3 * (n_step * C_ * d3 * s + e_step * (d3 + C_) * s)
+        conv = "K7 forward bytes (N C d3 s + E (d3 + C) s) x 3 per layer"
+    else:
+        F_ = mkw["dim1"]
+        stack = L * 3 * (e_step * (F_ * s + 8) + n_step * (F_ * s + 4))
+        conv = "K4a forward bytes with a scalar edge weight x 3 per layer"
+    step_s = elapsed_max / args.steps
+    res["step_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_step": int(stack), "achieved": round(stack / step_s / 1e9, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(stack / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                            "convention": conv, "note": "conv-stack bytes over the WHOLE step time (assembly, dense layers, "
+                            "BatchNorm, pooling, optimizer included in the time, not in the bytes)"}
     if dom is not None:
         res["roofline"] = roof(dom)
         other = [k for k in have if k != dom]
@@ -512,6 +540,7 @@ def other_models(args):
                          "batch_graphs": j["config"]["batch_graphs_per_gpu"], "dtype": j["dtype"],
                          "roofline_kernel": (j.get("roofline") or {}).get("kernel"), "roofline_frac": (j.get("roofline") or {}).get("frac"),
                          "conv_kernel_share_of_step": j["config"].get("conv_kernel_share_of_step"),
+                         "step_roofline_frac": (j.get("step_roofline") or {}).get("frac"),
                          "val_mae_delta": cb.get("val_mae_delta"), "val_mae_delta_bf16": cb.get("val_mae_delta_bf16"),
                          "pred_max_rel_delta_bf16": cb.get("pred_max_rel_delta_bf16"), "val_graphs": cb.get("val_graphs"),
                          "wall_s": round(time.time() - t0, 1)}
