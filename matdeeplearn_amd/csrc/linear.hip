@@ -41,10 +41,14 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
                                                             int64_t N, int K, int M, int act, GatherAdd ga,
                                                             const bf16_t* __restrict__ xy, int ldo = 0) {
-    // mdl_linear_wide: blockIdx.y = block of 32*NT output columns of a wider layer (ldo = its full width, the leading dimension
-    // of `out`); every other caller has gridDim.y = 1 and ldo = M
-    if (gridDim.y > 1) {
-        const int c0 = (int)blockIdx.y * 32 * NT;
+    // mdl_linear_wide: blockIdx.x = block of 32*NT output columns of a wider layer (ldo = its full width, the leading dimension
+    // of `out`), blockIdx.y = row chunk; every other caller has gridDim.y = 1, ldo = 0 (= M) and blockIdx.x = row chunk
+    // (wide layers are launched with the COLUMN block as the fast grid dimension: the workgroups that run together then cover
+    // whole rows of `out` — 20 KB contiguous per row for NNConv's Y — instead of a 320-byte segment of many rows)
+    const bool wide = ldo > 0;                       // (only mdl_linear_wide passes ldo)
+    const unsigned bx = wide ? blockIdx.y : blockIdx.x, gdx = wide ? gridDim.y : gridDim.x;
+    if (wide) {
+        const int c0 = (int)blockIdx.x * 32 * NT;
         w += (int64_t)c0 * K;
         if (bias) bias += c0;
         out += c0;
@@ -123,9 +127,9 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
             return v;
         }
     };
-    int64_t tile = blockIdx.x;
+    int64_t tile = bx;
     if (tile < n_tiles) load_tile(tile);
-    for (; tile < n_tiles; tile += gridDim.x) {
+    for (; tile < n_tiles; tile += gdx) {
         const int64_t nb = tile * TN;
         __syncthreads();                                    // previous tile's fragments read; W in place
 #pragma unroll
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
                     xfix(xr[16 * Q + k], yr[XACT ? 16 * Q + k : 0]);
         }
         __syncthreads();
-        if (tile + gridDim.x < n_tiles) load_tile(tile + gridDim.x);      // next tile's loads fly during the MFMAs
+        if (tile + gdx < n_tiles) load_tile(tile + gdx);      // next tile's loads fly during the MFMAs
         if (ntb < NT) {                                                    // (NT == 1: waves 2, 3 have no block)
             // blocks (mt, ntb + 2j): one A fragment (x rows) per k-step feeds all of the wave's block columns
             f32x16 acc[NB];
@@ -334,7 +338,7 @@ extern "C" int mdl_linear_wide(const void* x, const void* w, void* out, int64_t 
     do {                                                                                                              \
         auto kf = linear_act_kernel<KP_, 5, false, 0>;                                                                \
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                            \
-        hipLaunchKernelGGL(kf, dim3((unsigned)gx, gy), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x,         \
+        hipLaunchKernelGGL(kf, dim3(gy, (unsigned)gx), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x,         \
                            (const bf16_t*)w, (const bf16_t*)nullptr, (bf16_t*)out, N, K, (int)M, 0, ga,               \
                            (const bf16_t*)nullptr, (int)M);                                                           \
     } while (0)

@@ -128,6 +128,9 @@ __global__ __launch_bounds__(256) void nnconv_msg_bwd_kernel(const T* __restrict
 //             dY [Co x D3]   += DM^T . H     both operands k-major over the EDGES (transpose reads), kept in registers
 // The scalar kernels above move 2 bytes per load while staging Y and keep 100 of 256 threads busy in the dot products:
 // 3.2 ms (forward) / 7.5 ms (backward) per layer on 6e4 nodes / 8e5 edges, 0.06 of the HBM roofline.
+#ifndef MDL_K7_BWD_WGS
+#define MDL_K7_BWD_WGS 2     // workgroups per CU the backward is register-allocated for (LDS allows 3)
+#endif
 constexpr int NM_KP = 128, NM_LD = NM_KP + 8;
 typedef __attribute__((ext_vector_type(4))) short nm_s16x4;
 typedef __attribute__((address_space(3))) nm_s16x4* nm_lds4_t;
@@ -165,6 +168,57 @@ __device__ __forceinline__ void nm_stage_dense(const bf16_t* __restrict__ src, i
         }
     }
 }
+// The same tile from a DENSE [rows][width] block whose bytes form one 16-byte-aligned run (Y_j: Co*D3*2 bytes at a multiple of
+// it): the block is read as flat 16-byte chunks, ALL of a thread's chunks requested before the first one is used (one memory
+// round trip per workgroup instead of one per 8-row trip: the kernel is a chain of such round trips, one workgroup per node),
+// and scattered dword by dword into the padded rows; (row, column) of a dword from a multiplication by ceil(2^32 / (width / 2)).
+// Rows [rows, nrows) and the columns [width, kpad) of every row are zero-filled here (MFMA operands past the matrix).
+template <int MAXC>      // chunks per thread (256 threads x MAXC x 16 B >= rows * width * 2)
+struct NmFlat {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    u4 v[MAXC];
+    // request every chunk of the block (no use of the data: the caller issues other loads behind these)
+    __device__ __forceinline__ void issue(const bf16_t* __restrict__ src, int rows, int width, int tid) {
+        const int nd = rows * (width >> 1), nch = (nd + 3) >> 2;          // dwords, 16-byte chunks (the last one may be partial)
+#pragma unroll
+        for (int u = 0; u < MAXC; ++u) {
+            const int c = tid + 256 * u;
+            // (a chunk that would run past the block is re-read from its start and masked in commit: no load past the matrix)
+            v[u] = *reinterpret_cast<const u4*>(src + 8 * (int64_t)(c < nch && 4 * c + 3 < nd ? c : 0));
+        }
+    }
+    __device__ __forceinline__ void commit(const bf16_t* __restrict__ src, int rows, int width, unsigned w2_inv, bf16_t* tile,
+                                           int nrows, int kpad, int tid) {
+        const int w2 = width >> 1, nd = rows * w2, nch = (nd + 3) >> 2;
+        // zero fill of the padding first (the loads are still flying)
+        for (int q = tid; q < (nrows - rows) * (NM_LD / 2); q += 256)
+            reinterpret_cast<unsigned*>(tile + rows * NM_LD)[q] = 0u;
+        const int pw = (kpad - width) >> 1;
+        for (int q = tid; q < rows * pw; q += 256) {
+            const int r = q / max(pw, 1), c2 = q - r * pw;
+            reinterpret_cast<unsigned*>(tile + r * NM_LD + width)[c2] = 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < MAXC; ++u) {
+            const int c = tid + 256 * u;
+            if (c < nch && 4 * c + 3 < nd) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned d = 4u * c + q;
+                    const unsigned r = __umulhi(d, w2_inv), col = d - r * (unsigned)w2;
+                    *reinterpret_cast<unsigned*>(tile + r * NM_LD + 2 * col) = v[u][q];
+                }
+            }
+        }
+        // a partial last chunk (rows * width not a multiple of 8): dword loads
+        if ((nd & 3) && tid < (nd & 3)) {
+            const unsigned d = (unsigned)(nd & ~3) + tid;
+            const unsigned r = __umulhi(d, w2_inv), col = d - r * (unsigned)w2;
+            *reinterpret_cast<unsigned*>(tile + r * NM_LD + 2 * col) = *reinterpret_cast<const unsigned*>(src + 2 * (int64_t)d);
+        }
+    }
+};
+
 // gathered rows: row r of the tile = src[ids[r], 0:width] (ids[r] < 0: zeros); 32 rows, 8 per wave
 __device__ __forceinline__ void nm_stage_rows(const bf16_t* __restrict__ src, const int* ids, int width, bf16_t* tile, int wv,
                                               int lane) {
@@ -181,10 +235,28 @@ __device__ __forceinline__ void nm_stage_rows(const bf16_t* __restrict__ src, co
     for (int u = 0; u < 8; ++u) *reinterpret_cast<unsigned*>(tile + (wv + 4 * u) * NM_LD + 2 * lane) = v[u];
 }
 
+struct NmRows {
+    unsigned v[8];
+    __device__ __forceinline__ void issue(const bf16_t* __restrict__ src, const int* ids, int width, int wv, int lane) {
+        const int w2 = width >> 1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int id = ids[wv + 4 * u];
+            const bool ok = id >= 0 && lane < w2;
+            v[u] = *reinterpret_cast<const unsigned*>(src + (int64_t)(ok ? id : 0) * width + 2 * (ok ? lane : 0));
+            if (!ok) v[u] = 0u;
+        }
+    }
+    __device__ __forceinline__ void commit(bf16_t* tile, int wv, int lane) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<unsigned*>(tile + (wv + 4 * u) * NM_LD + 2 * lane) = v[u];
+    }
+};
+
 __global__ __launch_bounds__(256, 2) void nnconv_msg_fwd_mfma_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ h,
                                                                      const int32_t* __restrict__ rowptr_s,
                                                                      const int32_t* __restrict__ eid_s, bf16_t* __restrict__ m,
-                                                                     int Co, int D3) {
+                                                                     int Co, int D3, unsigned w2_inv, int flat) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     bf16_t* Ys = reinterpret_cast<bf16_t*>(smem_c);          // [128][LD]
     bf16_t* Hs = Ys + 128 * NM_LD;                            // [32][LD]
@@ -193,13 +265,25 @@ __global__ __launch_bounds__(256, 2) void nnconv_msg_fwd_mfma_kernel(const bf16_
     const int b = rowptr_s[j], e = rowptr_s[j + 1];
     if (b == e) return;
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, hh = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    nm_stage_dense(Y + (int64_t)j * Co * D3, Co, D3, Ys, 128, wv, lane);
     const int KS = (D3 + 15) >> 4;
+    const bf16_t* const Yj = Y + (int64_t)j * Co * D3;
+    // Round trips of a workgroup: the edge ids first, Y_j's chunks behind them, the gathered rows as soon as the ids are in
+    // LDS — the rows travel while Y_j is still arriving, and Y_j is committed to LDS last (waits complete in issue order)
+    int my_id = -1;
+    if (tid < 32) my_id = tid < min(32, e - b) ? (eid_s ? eid_s[b + tid] : b + tid) : -1;
+    NmFlat<7> yf;
+    if (flat) yf.issue(Yj, Co, D3, tid);
     for (int c0 = b; c0 < e; c0 += 32) {
         const int cnt = min(32, e - c0);
-        if (tid < 32) ids[tid] = tid < cnt ? (eid_s ? eid_s[c0 + tid] : c0 + tid) : -1;
-        __syncthreads();                                      // ids visible (and, first trip, Ys complete)
-        nm_stage_rows(h, ids, D3, Hs, wv, lane);
+        if (tid < 32) ids[tid] = c0 == b ? my_id : (tid < cnt ? (eid_s ? eid_s[c0 + tid] : c0 + tid) : -1);
+        __syncthreads();                                      // ids visible
+        NmRows hr;
+        hr.issue(h, ids, D3, wv, lane);
+        if (c0 == b) {
+            if (flat) yf.commit(Yj, Co, D3, w2_inv, Ys, 128, 16 * KS, tid);
+            else nm_stage_dense(Yj, Co, D3, Ys, 128, wv, lane);
+        }
+        hr.commit(Hs, wv, lane);
         __syncthreads();
         if (wv * 32 < Co) {
             f32x16 acc;
@@ -220,11 +304,11 @@ __global__ __launch_bounds__(256, 2) void nnconv_msg_fwd_mfma_kernel(const bf16_
     }
 }
 
-__global__ __launch_bounds__(256, 2) void nnconv_msg_bwd_mfma_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ h,
+__global__ __launch_bounds__(256, MDL_K7_BWD_WGS) void nnconv_msg_bwd_mfma_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ h,
                                                                      const bf16_t* __restrict__ dm,
                                                                      const int32_t* __restrict__ rowptr_s,
                                                                      const int32_t* __restrict__ eid_s, bf16_t* __restrict__ dh,
-                                                                     bf16_t* __restrict__ dY, int Co, int D3) {
+                                                                     bf16_t* __restrict__ dY, int Co, int D3, unsigned w2_inv, int flat) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     bf16_t* Ys = reinterpret_cast<bf16_t*>(smem_c);          // [128][LD]
     bf16_t* Hs = Ys + 128 * NM_LD;                            // [32][LD]
@@ -234,23 +318,42 @@ __global__ __launch_bounds__(256, 2) void nnconv_msg_bwd_mfma_kernel(const bf16_
     const int b = rowptr_s[j], e = rowptr_s[j + 1];
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, hh = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     bf16_t* dYj = dY + (int64_t)j * Co * D3;
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
     if (b == e) {                                             // node without out-edges: dY_j = 0
-        for (int q = tid; q < (Co * D3) / 2; q += 256) reinterpret_cast<unsigned*>(dYj)[q] = 0u;
+        if (flat) {
+            for (int q = tid; q < (Co * D3) / 8; q += 256) reinterpret_cast<u4*>(dYj)[q] = u4{0u, 0u, 0u, 0u};
+            for (int q = ((Co * D3) / 8) * 4 + tid; q < (Co * D3) / 2; q += 256) reinterpret_cast<unsigned*>(dYj)[q] = 0u;
+        } else {
+            for (int q = tid; q < (Co * D3) / 2; q += 256) reinterpret_cast<unsigned*>(dYj)[q] = 0u;
+        }
         return;
     }
-    nm_stage_dense(Y + (int64_t)j * Co * D3, Co, D3, Ys, 128, wv, lane);
+    const int OS = (Co + 15) >> 4;
+    // (the transposed reads of Ys take the o index up to 16 OS: rows [Co, 16 OS) must read as zeros — the flat staging zeroes
+    // rows [Co, 128) —, its column index up to 127: columns >= D3 only reach dh columns that are never stored)
+    const bf16_t* const Yj = Y + (int64_t)j * Co * D3;
+    int my_id = -1;
+    if (tid < 32) my_id = tid < min(32, e - b) ? (eid_s ? eid_s[b + tid] : b + tid) : -1;
+    NmFlat<7> yf;
+    if (flat) yf.issue(Yj, Co, D3, tid);
     f32x16 accY[4];                                           // wave wv: rows o = 32 wv + ..., column tiles kt = 0..3
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accY[kt][r] = 0.0f;
-    const int OS = (Co + 15) >> 4;
     for (int c0 = b; c0 < e; c0 += 32) {
         const int cnt = min(32, e - c0);
-        if (tid < 32) ids[tid] = tid < cnt ? (eid_s ? eid_s[c0 + tid] : c0 + tid) : -1;
+        if (tid < 32) ids[tid] = c0 == b ? my_id : (tid < cnt ? (eid_s ? eid_s[c0 + tid] : c0 + tid) : -1);
         __syncthreads();
-        nm_stage_rows(h, ids, D3, Hs, wv, lane);
-        nm_stage_rows(dm, ids, Co, Ds, wv, lane);
+        NmRows hr, dr;
+        hr.issue(h, ids, D3, wv, lane);
+        dr.issue(dm, ids, Co, wv, lane);
+        if (c0 == b) {
+            if (flat) yf.commit(Yj, Co, D3, w2_inv, Ys, 128, (D3 + 15) & ~15, tid);
+            else nm_stage_dense(Yj, Co, D3, Ys, 128, wv, lane);
+        }
+        hr.commit(Hs, wv, lane);
+        dr.commit(Ds, wv, lane);
         __syncthreads();
         if (wv * 32 < D3) {                                   // dh tile: columns k = 32 wv + i
             f32x16 acc;
@@ -278,6 +381,26 @@ __global__ __launch_bounds__(256, 2) void nnconv_msg_bwd_mfma_kernel(const bf16_
         }
         __syncthreads();
     }
+    if (!flat) {
+        if (wv * 32 < Co) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int k = kt * 32 + i;
+                if (k < D3) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        if (o < Co) dYj[o * D3 + k] = f2bf(accY[kt][r]);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // dY_j leaves as ONE contiguous run of 16-byte stores: the accumulators (rows o in registers, column k = lane) are laid
+    // down densely ([Co][D3] bf16) in the LDS space of the Y tile (every wave is past its last read of it: the loop ends with
+    // a barrier) and copied out chunk by chunk — 64 two-byte store instructions per lane before
+    bf16_t* const od = Ys;
     if (wv * 32 < Co) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -286,11 +409,15 @@ __global__ __launch_bounds__(256, 2) void nnconv_msg_bwd_mfma_kernel(const bf16_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int o = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (o < Co) dYj[o * D3 + k] = f2bf(accY[kt][r]);
+                    if (o < Co) od[o * D3 + k] = f2bf(accY[kt][r]);
                 }
             }
         }
     }
+    __syncthreads();
+    const int nch = (Co * D3) >> 3;
+    for (int c = tid; c < nch; c += 256) reinterpret_cast<u4*>(dYj)[c] = reinterpret_cast<const u4*>(od)[c];
+    for (int q = nch * 4 + tid; q < (Co * D3) >> 1; q += 256) reinterpret_cast<unsigned*>(dYj)[q] = reinterpret_cast<const unsigned*>(od)[q];
 }
 
 static bool nm_ok(int Co, int D3, int dtype, const void* a, const void* b) {
@@ -320,7 +447,11 @@ extern "C" int mdl_nnconv_msg_fwd(const void* Y, const void* h, const int32_t* r
         const int lds_m = (128 + 32) * NM_LD * 2 + 32 * 4;
         auto kf = nnconv_msg_fwd_mfma_kernel;
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds_m);
-        hipLaunchKernelGGL(kf, dim3((unsigned)N), dim3(256), lds_m, st, (const bf16_t*)Y, (const bf16_t*)h, rowptr_s, eid_s, (bf16_t*)m, Co, D3);
+        // flat staging of Y_j: every node's block must start on a 16-byte boundary and fit the per-thread chunk budget
+        const int flat = (((int64_t)Co * D3 * 2) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 && Co * D3 <= 256 * 7 * 8) ? 1 : 0;
+        const unsigned w2_inv = (unsigned)((0x100000000ull + (D3 / 2) - 1) / (D3 / 2));
+        hipLaunchKernelGGL(kf, dim3((unsigned)N), dim3(256), lds_m, st, (const bf16_t*)Y, (const bf16_t*)h, rowptr_s, eid_s, (bf16_t*)m, Co, D3,
+                           w2_inv, flat);
         return check_launch("mdl_nnconv_msg_fwd");
     }
     const int lds = (Co * (D3 + 1) + D3) * 4;
@@ -349,8 +480,11 @@ extern "C" int mdl_nnconv_msg_bwd(const void* Y, const void* h, const void* dm, 
         const int lds_m = (128 + 64) * NM_LD * 2 + 32 * 4;
         auto kf = nnconv_msg_bwd_mfma_kernel;
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds_m);
+        const int flat = (((int64_t)Co * D3 * 2) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 &&
+                          reinterpret_cast<uintptr_t>(dY) % 16 == 0 && Co * D3 <= 256 * 7 * 8) ? 1 : 0;
+        const unsigned w2_inv = (unsigned)((0x100000000ull + (D3 / 2) - 1) / (D3 / 2));
         hipLaunchKernelGGL(kf, dim3((unsigned)N), dim3(256), lds_m, st, (const bf16_t*)Y, (const bf16_t*)h, (const bf16_t*)dm, rowptr_s, eid_s,
-                           (bf16_t*)dh, (bf16_t*)dY, Co, D3);
+                           (bf16_t*)dh, (bf16_t*)dY, Co, D3, w2_inv, flat);
         return check_launch("mdl_nnconv_msg_bwd");
     }
     const int lds = (Co * (D3 + 1) + D3 + Co) * 4;
