@@ -12,6 +12,7 @@ GRPS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
       "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum")
 [ "${PMC_ONLY:-}" = "traffic" ] && GRPS=("FETCH_SIZE" "WRITE_SIZE")
 [ "${PMC_ONLY:-}" = "sq" ] && GRPS=("${GRPS[0]}" "${GRPS[1]}")
+[ -n "${GRPS_SEL:-}" ] && GRPS=("${GRPS[@]:0:${GRPS_SEL}}")      # the first n groups (4 = SQ instruction mix + FETCH_SIZE + WRITE_SIZE)
 for grp in "${GRPS[@]}"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o p -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --iters 2 "$@" > $OUT/p$i.log 2>&1
