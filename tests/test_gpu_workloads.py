@@ -250,7 +250,7 @@ def test_cfg2_bf16_by_source_sums_train_like_fp32_sums():
             # (the bf16 sums through the kernel the headline batch runs — edge-per-lane kernel 2 — whatever this batch's size)
             ops.K3_VARIANT = "edge_lane" if flag else None
             try:
-                x = x0.to(dtype).requires_grad_(True)
+                x = x0.detach().to(dtype).clone().requires_grad_(True)          # (a fresh leaf: .to() of the same dtype returns x0 itself)
                 out = ops.cgconv(x, None, ea32.to(dtype), wf, bf, ws, bs, "mean", csr=csr)
                 (out.float() * gout).sum().backward()
             finally:
