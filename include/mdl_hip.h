@@ -337,6 +337,18 @@ int mdl_gemm_tn_colsum(const void* a, int64_t lda, int M, const void* b, int64_t
  * Same shape limits as mdl_gemm_tn_colsum. */
 int mdl_gemm_tn_act(const void* a, int64_t lda, int M, const void* y, int64_t ldy, int act, const void* b, int64_t ldb,
                     int K, float* c, float* colsum, int64_t N, int dtype, mdlStream_t stream);
+/* The whole backward of a tall dense layer y = act(x w^T + b) in one streaming pass: with g' = g .* act'(y) (as above),
+ *     dw[M, K] (fp32, caller zero-fills) += g'^T . x      db[M] (fp32, zero-filled; may be NULL) += column sums of g'
+ *     dx[N, K] (bf16, leading dim lddx)   = g' . w        w: [M, K] bf16 row-major (the layer's weight)
+ * xout: 0, or 1 / 2 when x is itself the relu / shifted-softplus OUTPUT of the layer in front and dx is wanted w.r.t. that
+ * layer's pre-activation: dx .*= act_in'(x), taken from the staged x tile (the layer in front then needs act = 0 and no y).
+ * gm (may be NULL): [N, M] bf16, dense — receives g' itself (for callers that reduce it further: the gathered tables of K6).
+ * Replaces autograd's threshold_backward / softplus_backward + mm (dX) + mm (dW) + sum (db) of the edge-level Linears at
+ * matdeeplearn/models/megnet.py:41-56,84-101 and matdeeplearn/models/schnet.py:81 (InteractionBlock.mlp): g, y, x are read
+ * once.  Even 34 <= M <= 160, 34 <= K <= 160 (158 with db), even ldg / ldx / ldy, bf16 only; MDL_DETERMINISTIC: one workgroup. */
+int mdl_dense_bwd(const void* g, int64_t ldg, int M, const void* y, int64_t ldy, int act, const void* x, int64_t ldx, int K,
+                  const void* w, void* dx, int64_t lddx, int xout, void* gm, float* dw, float* db, int64_t N, int dtype,
+                  mdlStream_t stream);
 
 /* ---- generic gather / edge-weighted gather-reduce (SchNet CFConv, GCNConv, MEGNet, NNConv) ------
  * Replace the index_select + elementwise + torch_scatter sequence of PyG MessagePassing.propagate at

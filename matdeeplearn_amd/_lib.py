@@ -56,6 +56,7 @@ PROTOTYPES = {
     "mdl_bn_bwd_stats": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "mdl_bn_bwd_apply": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _vp]),
     "mdl_linear_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mdl_dense_bwd": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mdl_linear_act_in": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_ssp_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "mdl_linear_gather_act": (_i32, [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp]),

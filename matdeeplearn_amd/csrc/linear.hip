@@ -17,6 +17,10 @@
 #endif
 #include <type_traits>
 
+#ifndef MDL_LIN_GRID
+#define MDL_LIN_GRID 512        // workgroups of a launch (2 per CU)
+#endif
+
 namespace mdl {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_l;
@@ -267,7 +271,7 @@ static int linear_launch(const void* x, const void* xy, int xact, const void* w,
     const int kp = K <= 64 ? 64 : (K <= 128 ? 128 : (K <= 160 ? 160 : 256));
     const int nt = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 128 ? 4 : 5));
     int64_t grid = cdiv(N, 64);
-    if (grid > 512) grid = 512;
+    if (grid > MDL_LIN_GRID) grid = MDL_LIN_GRID;
     const int lds = (32 * nt + 64) * (kp + 8) * 2;
 #define MDL_LIN_K(KP_, NT_, G_, X_)                                                                                  \
     do {                                                                                                             \

@@ -876,6 +876,8 @@ class _LinearTN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
+        if _dense_bwd_ok(ctx, g, x, w):
+            return _dense_bwd(ctx, g, x, w) + (None, None)
         dx, dw, db = _linear_tn_grads(ctx, g.contiguous(), x, w)
         return dx, dw, db, None, None
 
@@ -917,6 +919,41 @@ def _dx_hip(g, w, act_y=None):
         return dx
     assert act_y is None
     return g @ w
+
+
+_DENSE_BWD = os.environ.get("MDL_DENSE_BWD", "1") != "0"     # dX + dW + db of a tall dense layer in one pass (csrc/dense_bwd.hip)
+
+
+def _dense_bwd_ok(ctx, g, x, w, y=None):
+    """mdl_dense_bwd takes this layer's backward: the input gradient is wanted, even widths in [34, 160] that are not both
+    above 128 (those shapes hold W^T and both tiles in LDS for one workgroup per CU only and run no faster than the pair),
+    dword-addressable rows."""
+    M, K = ctx.shape
+    kb = K + (1 if ctx.has_bias else 0)
+    return (_DENSE_BWD and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16 and g.is_cuda and g.shape[0] >= 1024
+            and 34 <= M <= 160 and 34 <= K and kb <= 160 and M % 2 == 0 and K % 2 == 0 and not (M > 128 and kb > 128)
+            and g.stride(1) == 1 and x.stride(1) == 1 and g.stride(0) % 2 == 0 and x.stride(0) % 2 == 0
+            and g.data_ptr() % 4 == 0 and x.data_ptr() % 4 == 0 and w.is_contiguous() and w.dtype == torch.bfloat16
+            and x.dtype == torch.bfloat16
+            and (y is None or (y.dtype == torch.bfloat16 and y.stride(1) == 1 and y.stride(0) % 2 == 0 and y.data_ptr() % 4 == 0)))
+
+
+def _dense_bwd(ctx, g, x, w, act_y=None, xout=0, want_gm=False):
+    """(dx, dW, db[, g']) of y = act(x W^T + b) from ONE pass over g, y, x (callers check _dense_bwd_ok); act_y = (code, y):
+    g is the gradient w.r.t. the activated output; xout: x is the relu (1) / shifted-softplus (2) output of a private layer in
+    front and dx is returned w.r.t. that layer's pre-activation; want_gm: also return g' = g .* act'(y) (bf16, dense)."""
+    M, K = ctx.shape
+    N = g.shape[0]
+    buf = _zeros_grad(M * K + M, g.device)
+    dw, dbv = buf[:M * K].view(M, K), buf[M * K:]
+    dx = torch.empty((N, K), dtype=g.dtype, device=g.device)
+    gm = torch.empty((N, M), dtype=g.dtype, device=g.device) if want_gm else None
+    code, y = act_y if act_y is not None else (0, None)
+    check(lib().mdl_dense_bwd(ptr(g), g.stride(0), M, ptr(y), 0 if y is None else y.stride(0), code, ptr(x), x.stride(0), K,
+                              ptr(w), ptr(dx), K, xout, ptr(gm), ptr(dw), ptr(dbv) if ctx.has_bias else None, N,
+                              dtype_code(g) | _dflag(), stream()), "mdl_dense_bwd")
+    out = (dx, dw.to(ctx.wdtype), dbv.to(ctx.wdtype) if ctx.has_bias else None)
+    return out + (gm,) if want_gm else out
 
 
 def _tn_act_ok(ctx, g, x, y, w=None):
@@ -1005,6 +1042,9 @@ class _LinearActTN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w, out = ctx.saved_tensors
+        code = {"relu": 1, "ssp": 2}.get(ctx.act, 0)
+        if _dense_bwd_ok(ctx, g, x, w, out if code else None):
+            return _dense_bwd(ctx, g, x, w, (code, out) if code else None) + (None, None, None)
         if ctx.act in ("relu", "ssp") and _tn_act_ok(ctx, g, x, out, w):
             return _linear_tn_grads(ctx, g, x, w, act_y=(1 if ctx.act == "relu" else 2, out)) + (None, None, None)
         if ctx.act == "relu":
@@ -1043,10 +1083,17 @@ class _LinearGatherAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w, out = ctx.saved_tensors
-        if ctx.act == "relu":
-            g = torch.ops.aten.threshold_backward(g, out, 0)
-        g = g.contiguous()
-        dx, dw, db = _linear_tn_grads(ctx, g, x, w)
+        if _dense_bwd_ok(ctx, g, x, w, out if ctx.act == "relu" else None):
+            # one pass: dX, dW, db and the masked gradient rows the table gradients are segment sums of
+            need_gm = any(ctx.needs_input_grad[5 + t] and ctx.rows[t] is not None for t in range(ctx.ntab))
+            res = _dense_bwd(ctx, g, x, w, (1, out) if ctx.act == "relu" else None, want_gm=need_gm and ctx.act == "relu")
+            dx, dw, db = res[:3]
+            g = res[3] if len(res) > 3 else g.contiguous()
+        else:
+            if ctx.act == "relu":
+                g = torch.ops.aten.threshold_backward(g, out, 0)
+            g = g.contiguous()
+            dx, dw, db = _linear_tn_grads(ctx, g, x, w)
         dts = []
         for t in range(ctx.ntab):
             need = ctx.needs_input_grad[5 + t] and ctx.rows[t] is not None

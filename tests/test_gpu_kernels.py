@@ -658,6 +658,46 @@ def test_gemm_tn_act_matches_torch(N, M, K, act):
     close(cs, am.sum(0), 1e-4, 2e-5 * N ** 0.5)
 
 
+@pytest.mark.parametrize("N,M,K,act,xout,bias", [(3001, 100, 100, 1, 0, True), (2100, 150, 150, 0, 2, True), (1000, 64, 114, 1, 1, True),
+                                                 (777, 150, 50, 2, 0, True), (5000, 128, 64, 0, 0, False), (64, 100, 100, 1, 1, True),
+                                                 (4099, 160, 160, 2, 2, False), (1500, 34, 158, 1, 0, True)])
+def test_dense_bwd_matches_torch(N, M, K, act, xout, bias):
+    """The one-pass backward of a tall dense layer (mdl_dense_bwd: dW, db and dX from one read of g, y, x) vs the three
+    separate fp32 products on the same bf16-rounded operands; act = derivative of the layer's own activation from its saved
+    output, xout = derivative of the activation in FRONT of the layer from the layer's input (pre-activation hand-over)."""
+    from matdeeplearn_amd import _lib
+    gen = torch.Generator().manual_seed(N + M + K + act)
+    d = dev()
+    g = torch.randn(N, M, generator=gen).to(torch.bfloat16).to(d)
+    pre = torch.randn(N, M, generator=gen) * 2
+    y = (torch.relu(pre) if act == 1 else torch.nn.functional.softplus(pre) - 0.6931471805599453).to(torch.bfloat16).to(d)
+    xin = torch.randn(N, K, generator=gen) * 2
+    x = (torch.relu(xin) if xout == 1 else (torch.nn.functional.softplus(xin) - 0.6931471805599453 if xout == 2 else xin)).to(torch.bfloat16).to(d)
+    w = (torch.randn(M, K, generator=gen) / M ** 0.5).to(torch.bfloat16).to(d)
+    dx = torch.full((N, K), float("nan"), dtype=torch.bfloat16, device=d)
+    dw, db = torch.zeros(M, K, device=d), torch.zeros(M, device=d)
+    gmo = torch.full((N, M), float("nan"), dtype=torch.bfloat16, device=d) if N % 2 else None     # (every other case also asks for g')
+    _lib.check(_lib.lib().mdl_dense_bwd(_lib.ptr(g), g.stride(0), M, _lib.ptr(y) if act else None, y.stride(0), act, _lib.ptr(x),
+                                        x.stride(0), K, _lib.ptr(w), _lib.ptr(dx), dx.stride(0), xout, _lib.ptr(gmo), _lib.ptr(dw),
+                                        _lib.ptr(db) if bias else None, N, _lib.MDL_BF16, _lib.stream()), "mdl_dense_bwd")
+
+    def dact(code, out):
+        if code == 1:
+            return (out.float() > 0).float()
+        if code == 2:
+            return 1.0 - torch.exp(-(out.float() + 0.6931471805599453))
+        return torch.ones_like(out, dtype=torch.float32)
+
+    gm = (g.float() * dact(act, y)).to(torch.bfloat16).float()          # what threshold_backward / mdl_ssp_bwd would have written
+    close(dw, gm.t() @ x.float(), 1e-4, 2e-5 * N ** 0.5)
+    if bias:
+        close(db, gm.sum(0), 1e-4, 2e-5 * N ** 0.5)
+    close(dx, (gm @ w.float()) * dact(xout, x), 1e-2, 1e-2)
+    if gmo is not None:
+        assert torch.equal(gmo.float(), gm) or act == 2
+        close(gmo, gm, 1e-2, 1e-3)
+
+
 @pytest.mark.parametrize("K", [300, 420])
 def test_wide_input_linear_takes_its_weight_gradient_from_two_tn_gemms(K):
     """ops.linear with 256 < in <= 512 (MEGNet's node block: 3 x 100 concatenated columns): library forward, dW as two

@@ -31,3 +31,15 @@ for rows in rows_list:
         bb = torch.randn(M, device=d).to(torch.bfloat16); o = torch.empty(rows, M, device=d, dtype=torch.bfloat16)
         t("linear %d->%d act %d rows %d" % (K, M, act, rows), lambda: L.mdl_linear_act(P(x), P(w), P(bb), P(o), rows, K, M, act, _lib.MDL_BF16, st()),
           rows * (M + K) * 2)
+    for (K, M, xact) in ((100, 100, 1), (150, 150, 2)):
+        g = torch.randn(rows, K, device=d).to(torch.bfloat16); y = torch.randn(rows, K, device=d).to(torch.bfloat16)
+        w = torch.randn(M, K, device=d).to(torch.bfloat16); o = torch.empty(rows, M, device=d, dtype=torch.bfloat16)
+        t("linear_in %d->%d xact %d rows %d" % (K, M, xact, rows),
+          lambda: L.mdl_linear_act_in(P(g), P(y), xact, P(w), None, P(o), rows, K, M, 0, _lib.MDL_BF16, st()), rows * (M + 2 * K) * 2)
+    for (K, M, act, xout) in ((100, 100, 1, 0), (100, 100, 0, 1), (150, 150, 0, 2), (150, 150, 2, 0)):
+        g = torch.randn(rows, M, device=d).to(torch.bfloat16); y = torch.randn(rows, M, device=d).to(torch.bfloat16)
+        x = torch.randn(rows, K, device=d).to(torch.bfloat16); w = torch.randn(M, K, device=d).to(torch.bfloat16)
+        dx = torch.empty(rows, K, device=d, dtype=torch.bfloat16); dw = torch.zeros(M, K, device=d); db = torch.zeros(M, device=d)
+        t("dense_bwd %d<-%d act %d xout %d rows %d" % (K, M, act, xout, rows),
+          lambda: L.mdl_dense_bwd(P(g), M, M, P(y) if act else None, M, act, P(x), K, K, P(w), P(dx), K, xout, None, P(dw), P(db), rows,
+                                  _lib.MDL_BF16, st()), rows * ((2 if act else 1) * M + 2 * K) * 2)
