@@ -40,17 +40,23 @@ extern "C" int mdl_dense_bwd(const void* g, int64_t ldg, int M, const void* y, i
     int64_t grid = cdiv(N, 64);
     if (grid > grid_cap) grid = grid_cap;
     const int lds = (64 * (32 * mt + 8) + 64 * (32 * nt + 8) + 32 * nt * (32 * mt + 8)) * 2;
-#define MDL_DB_K(MT_, NT_, A_)                                                                                               \
+#define MDL_DB_K(MT_, NT_, A_, NW_)                                                                                          \
     do {                                                                                                                     \
-        auto kf = gemm_tn_stream_kernel<MT_, NT_, A_, true>;                                                                 \
+        auto kf = gemm_tn_stream_kernel<MT_, NT_, A_, true, NW_>;                                                            \
         hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                          \
         if (e != hipSuccess) { set_error("mdl_dense_bwd: LDS attribute (%d B): %s", lds, hipGetErrorString(e)); return MDL_E_LAUNCH; } \
-        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)g, (int)ldg, M, (const bf16_t*)x,    \
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * NW_), lds, st, (const bf16_t*)g, (int)ldg, M, (const bf16_t*)x, \
                            (int)ldx, K, dw, db, N, (const bf16_t*)y, (int)ldy, (const bf16_t*)w, (bf16_t*)dx, (int)lddx, xout, (bf16_t*)gm); \
     } while (0)
+// waves per workgroup (measured on 1.5e6 rows, tools/bench_dense.py): a 5-tile side needs 8 (one 4-wave workgroup per CU ran
+// 150 x 150 in 611 us, 8 waves in 434); 4-tile shapes take 8 without an activation staging (288 -> 225 us) and 4 with one
+// (the y tile's extra registers and staging work cost the 8-wave form its second workgroup's overlap: 285 vs 334 us)
 #define MDL_DB(MT_, NT_)                                                                                                     \
     do {                                                                                                                     \
-        if (act == 0) MDL_DB_K(MT_, NT_, 0); else if (act == 1) MDL_DB_K(MT_, NT_, 1); else MDL_DB_K(MT_, NT_, 2);           \
+        constexpr bool wide = (MT_ > 4 || NT_ > 4);                                                                          \
+        if (act == 0) MDL_DB_K(MT_, NT_, 0, 8);                                                                              \
+        else if (act == 1) MDL_DB_K(MT_, NT_, 1, (wide ? 8 : 4));                                                            \
+        else MDL_DB_K(MT_, NT_, 2, (wide ? 8 : 4));                                                                          \
     } while (0)
     if (mt == 2) { if (nt == 2) MDL_DB(2, 2); else if (nt == 4) MDL_DB(2, 4); else MDL_DB(2, 5); }
     else if (mt == 4) { if (nt == 2) MDL_DB(4, 2); else if (nt == 4) MDL_DB(4, 4); else MDL_DB(4, 5); }

@@ -921,17 +921,17 @@ def _dx_hip(g, w, act_y=None):
     return g @ w
 
 
+_DENSE_BWD_WIDE = os.environ.get("MDL_DENSE_BWD_WIDE", "1") != "0"   # ... also when both widths exceed 128 (SchNet's 150 x 150 filter layer)
 _DENSE_BWD = os.environ.get("MDL_DENSE_BWD", "1") != "0"     # dX + dW + db of a tall dense layer in one pass (csrc/dense_bwd.hip)
 
 
 def _dense_bwd_ok(ctx, g, x, w, y=None):
-    """mdl_dense_bwd takes this layer's backward: the input gradient is wanted, even widths in [34, 160] that are not both
-    above 128 (those shapes hold W^T and both tiles in LDS for one workgroup per CU only and run no faster than the pair),
-    dword-addressable rows."""
+    """mdl_dense_bwd takes this layer's backward: the input gradient is wanted, even widths in [34, 160], dword-addressable
+    rows."""
     M, K = ctx.shape
     kb = K + (1 if ctx.has_bias else 0)
     return (_DENSE_BWD and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16 and g.is_cuda and g.shape[0] >= 1024
-            and 34 <= M <= 160 and 34 <= K and kb <= 160 and M % 2 == 0 and K % 2 == 0 and not (M > 128 and kb > 128)
+            and 34 <= M <= 160 and 34 <= K and kb <= 160 and M % 2 == 0 and K % 2 == 0 and (_DENSE_BWD_WIDE or not (M > 128 and kb > 128))
             and g.stride(1) == 1 and x.stride(1) == 1 and g.stride(0) % 2 == 0 and x.stride(0) % 2 == 0
             and g.data_ptr() % 4 == 0 and x.data_ptr() % 4 == 0 and w.is_contiguous() and w.dtype == torch.bfloat16
             and x.dtype == torch.bfloat16
