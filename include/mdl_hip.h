@@ -209,7 +209,7 @@ int mdl_ssp_bwd(const void* g, const void* y, void* dx, int64_t n, int dtype, md
  *     out[e, :] = act( x[e, :] W^T + bias + p1[idx1[e], :] + p2[idx2[e], :] + p3[idx3[e], :] )        bf16, act 0 none / 1 relu
  * x: [N, K] (the edge state), W: [M, K], p_i: [rows_i, M] per-node / per-graph projections of the OTHER column blocks of
  * the reference's concatenated input [x[row] | x[col] | e | u[batch]] (any p_i may be NULL).  The [E, 4d] concatenation and
- * its K = 4d product never exist.  Same shape limits as mdl_linear_act. */
+ * its K = 4d product never exist.  Same shape limits as mdl_linear_act; with tables M <= 128 and rows_i * M * 2 < 2^31 bytes. */
 int mdl_linear_gather_act(const void* x, const void* w, const void* bias, const void* p1, const int32_t* idx1,
                           const void* p2, const int32_t* idx2, const void* p3, const int32_t* idx3, void* out,
                           int64_t N, int K, int M, int act, int dtype, mdlStream_t stream);

@@ -40,7 +40,7 @@ struct GatherAdd {
 // is the one with x .* act'(y) (relu: y > 0, shifted softplus: 1 - exp(-(y + ln 2))) — the dX product of a fused
 // Linear + activation, with the activation derivative applied while the tile is staged, like gemm_tn.hip does for dW:
 // `threshold_backward` / the softplus backward never run as a pass over [N, K] of their own.
-template <int KP, int NT, bool GATHER = false, int XACT = 0>     // KP: K padded to {64, 128, 160, 256}; NT: 32-column tiles of the output (M <= 32*NT)
+template <int KP, int NT, int GATHER = 0, int XACT = 0>     // KP: K padded to {64, 128, 160, 256}; NT: 32-column tiles of the output (M <= 32*NT); GATHER: tables
 __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
                                                             int64_t N, int K, int M, int act, GatherAdd ga,
@@ -135,6 +135,14 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
     if (tile < n_tiles) load_tile(tile);
     for (; tile < n_tiles; tile += gdx) {
         const int64_t nb = tile * TN;
+        // K6: the row indices of this tile's gathered table rows are requested here, a whole staging + MFMA phase ahead of the
+        // epilogue that uses them (they depend on the row only: one coalesced load per table for all of the wave's block
+        // columns), so a block column pays ONE dependent round trip (its table rows) instead of two
+        int gidl[GATHER ? GATHER : 1];                      // lane l: the index of row (l & 31) of this wave's block row
+        if constexpr (GATHER != 0) {
+#pragma unroll
+            for (int t = 0; t < GATHER; ++t) gidl[t] = ga.idx[t][min(nb + (wv & 1) * 32 + i, N - 1)];
+        }
         __syncthreads();                                    // previous tile's fragments read; W in place
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -167,29 +175,36 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
                 }
             }
             const int64_t remr = N - nb - mt * 32;                        // rows of this block row that exist
+            if constexpr (GATHER != 0) {
+                // + the gathered projection rows (clamped row index: rows past N are computed on a valid row and then dropped by
+                // the store's range check): all table loads of a block column go out before the first add
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int colc = min(min(ntb + 2 * j, NT - 1) * 32 + i, M - 1);
+                    float gv[GATHER][16];
+#pragma unroll
+                    for (int t = 0; t < GATHER; ++t) {
+                        // (32-bit byte offsets into the table through a buffer resource: one address register per load — as 64-bit
+                        // pointers the 16 x GATHER x NB addresses in flight spilled; tables are < 2 GB by the launcher's check)
+                        const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(ga.p[t]), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            // (the row's index sits in lane `row` of gidl: a cross-lane read instead of 16 registers per table)
+                            const int id = __builtin_amdgcn_ds_bpermute(4 * ((r & 3) + 8 * (r >> 2) + 4 * h), gidl[t]);
+                            gv[t][r] = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(tr, (id * M + colc) * 2, 0, 0));
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < GATHER; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[j][r] += gv[t][r];
+                    __builtin_amdgcn_sched_barrier(0);      // (the next column's loads stay behind these adds: both columns' rows in flight spill)
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int nt = ntb + 2 * j, col = nt * 32 + i;
                 if (nt < NT) {
-                    if constexpr (GATHER) {
-                        // + the gathered projection rows (clamped row index: rows past N are computed on a valid row and then
-                        // dropped by the store's range check).  All index loads first, then all table loads: two round trips.
-                        const int colc = min(col, M - 1);
-#pragma unroll
-                        for (int t = 0; t < 3; ++t) {
-                            if (ga.p[t]) {
-                                int id[16];
-#pragma unroll
-                                for (int r = 0; r < 16; ++r)
-                                    id[r] = ga.idx[t][min(nb + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, N - 1)];
-                                float v[16];
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) v[r] = bf2f(ga.p[t][(int64_t)id[r] * M + colc]);
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) acc[j][r] += v[r];
-                            }
-                        }
-                    }
                     if (col < M && remr > 0) {
                         // (range = up to the end of this block row's last existing row; with column blocks the rows are ldo wide)
                         const int64_t rbytes = ((remr - 1) * (int64_t)ldo + M) * 2;
@@ -229,7 +244,7 @@ extern "C" int mdl_linear_act(const void* x, const void* w, const void* bias, vo
 }
 
 static int linear_launch(const void* x, const void* xy, int xact, const void* w, const void* bias, const mdl::GatherAdd& ga,
-                         bool gather, void* out, int64_t N, int K, int M, int act, mdlStream_t stream);
+                         int gather, void* out, int64_t N, int K, int M, int act, mdlStream_t stream);
 
 extern "C" int mdl_linear_act_in(const void* x, const void* y, int xact, const void* w, const void* bias, void* out, int64_t N,
                                  int K, int M, int act, int dtype, mdlStream_t stream) {
@@ -243,7 +258,7 @@ extern "C" int mdl_linear_act_in(const void* x, const void* y, int xact, const v
     MDL_REQUIRE(N >= 0 && (N == 0 || (x && w && out)), MDL_E_ARG, "mdl_linear_act: bad arguments");
     MDL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 4 == 0 && reinterpret_cast<uintptr_t>(w) % 4 == 0, MDL_E_ARG, "mdl_linear_act_in: misaligned pointer");
     if (N == 0) return MDL_OK;
-    return linear_launch(x, y, xact, w, bias, GatherAdd{}, false, out, N, K, M, act, stream);
+    return linear_launch(x, y, xact, w, bias, GatherAdd{}, 0, out, N, K, M, act, stream);
 }
 
 extern "C" int mdl_linear_gather_act(const void* x, const void* w, const void* bias, const void* p1, const int32_t* idx1,
@@ -252,8 +267,13 @@ extern "C" int mdl_linear_gather_act(const void* x, const void* w, const void* b
     using namespace mdl;
     MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_linear_act: bf16 only");
     MDL_REQUIRE((!p1 || idx1) && (!p2 || idx2) && (!p3 || idx3), MDL_E_ARG, "mdl_linear_gather_act: table without index");
-    const bool gather = p1 || p2 || p3;
-    GatherAdd ga = {{(const bf16_t*)p1, (const bf16_t*)p2, (const bf16_t*)p3}, {idx1, idx2, idx3}};
+    MDL_REQUIRE(!(p1 || p2 || p3) || M <= 128, MDL_E_UNSUPP, "mdl_linear_gather_act: gathered tables need M <= 128 (got %d)", M);
+    // (the tables present are packed to the front: the kernel is instantiated per table COUNT)
+    GatherAdd ga = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    int gather = 0;
+    if (p1) { ga.p[gather] = (const bf16_t*)p1; ga.idx[gather++] = idx1; }
+    if (p2) { ga.p[gather] = (const bf16_t*)p2; ga.idx[gather++] = idx2; }
+    if (p3) { ga.p[gather] = (const bf16_t*)p3; ga.idx[gather++] = idx3; }
     MDL_REQUIRE(K >= 4 && K <= 256 && K % 2 == 0 && M >= 1 && M <= 160 && (M <= 128 || K <= 160), MDL_E_UNSUPP,
                 "mdl_linear_act: need even 4<=K<=256 and 1<=M<=160 (K<=160 when M>128) (got K=%d M=%d)", K, M);
     MDL_REQUIRE(act >= 0 && act <= 2, MDL_E_ARG, "mdl_linear_act: act must be 0 (none), 1 (relu) or 2 (shifted softplus)");
@@ -265,7 +285,7 @@ extern "C" int mdl_linear_gather_act(const void* x, const void* w, const void* b
 }
 
 static int linear_launch(const void* x, const void* xy, int xact, const void* w, const void* bias, const mdl::GatherAdd& ga,
-                         bool gather, void* out, int64_t N, int K, int M, int act, mdlStream_t stream) {
+                         int gather, void* out, int64_t N, int K, int M, int act, mdlStream_t stream) {
     using namespace mdl;
     hipStream_t st = (hipStream_t)stream;
     const int kp = K <= 64 ? 64 : (K <= 128 ? 128 : (K <= 160 ? 160 : 256));
@@ -282,10 +302,13 @@ static int linear_launch(const void* x, const void* xy, int xact, const void* w,
     } while (0)
 #define MDL_LIN(KP_, NT_)                                                                                            \
     do {                                                                                                             \
-        if (gather) MDL_LIN_K(KP_, NT_, true, 0);                                                                    \
-        else if (xact == 1) MDL_LIN_K(KP_, NT_, false, 1);                                                           \
-        else if (xact == 2) MDL_LIN_K(KP_, NT_, false, 2);                                                           \
-        else MDL_LIN_K(KP_, NT_, false, 0);                                                                          \
+        constexpr int NG_ = (NT_ <= 4) ? 1 : 0;       /* (the gathering forms exist for M <= 128 only) */           \
+        if (gather == 1) MDL_LIN_K(KP_, NT_, 1 * NG_, 0);                                                            \
+        else if (gather == 2) MDL_LIN_K(KP_, NT_, 2 * NG_, 0);                                                       \
+        else if (gather == 3) MDL_LIN_K(KP_, NT_, 3 * NG_, 0);                                                       \
+        else if (xact == 1) MDL_LIN_K(KP_, NT_, 0, 1);                                                           \
+        else if (xact == 2) MDL_LIN_K(KP_, NT_, 0, 2);                                                           \
+        else MDL_LIN_K(KP_, NT_, 0, 0);                                                                          \
     } while (0)
     if (kp == 64) { if (nt == 1) MDL_LIN(64, 1); else if (nt == 2) MDL_LIN(64, 2); else if (nt == 4) MDL_LIN(64, 4); else MDL_LIN(64, 5); }
     else if (kp == 128) { if (nt == 1) MDL_LIN(128, 1); else if (nt == 2) MDL_LIN(128, 2); else if (nt == 4) MDL_LIN(128, 4); else MDL_LIN(128, 5); }
@@ -340,7 +363,7 @@ extern "C" int mdl_linear_wide(const void* x, const void* w, void* out, int64_t 
     const GatherAdd ga{};
 #define MDL_WIDE(KP_)                                                                                                 \
     do {                                                                                                              \
-        auto kf = linear_act_kernel<KP_, 5, false, 0>;                                                                \
+        auto kf = linear_act_kernel<KP_, 5, 0, 0>;                                                                \
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                            \
         hipLaunchKernelGGL(kf, dim3(gy, (unsigned)gx), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x,         \
                            (const bf16_t*)w, (const bf16_t*)nullptr, (bf16_t*)out, N, K, (int)M, 0, ga,               \
