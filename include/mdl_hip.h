@@ -279,6 +279,11 @@ int mdl_bn_bwd_stats_n(const void* dy, const void* x, const float* save, float* 
                        const int64_t* n_rows_dev, int dtype, mdlStream_t stream);
 int mdl_bn_bwd_apply_n(const void* dy, const void* x, const float* save, float* sums, const float* gamma, void* dx,
                        int64_t N, int C, const int64_t* n_rows_dev, int dtype, mdlStream_t stream);
+/* same, for Linear -> ReLU -> BatchNorm1d (the layer order of the reference's MEGNet blocks, matdeeplearn/models/megnet.py:47-48):
+ * x is the ReLU's output and dx the gradient w.r.t. the ReLU's INPUT (zero where x <= 0), so that the dense layer's backward
+ * behind it (mdl_dense_bwd with act = 0) needs neither the activation staging nor x's rows for the mask.  bf16 only. */
+int mdl_bn_bwd_apply_relu_n(const void* dy, const void* x, const float* save, float* sums, const float* gamma, void* dx,
+                            int64_t N, int C, const int64_t* n_rows_dev, int dtype, mdlStream_t stream);
 int mdl_bn_stats(const void* x, float* sums, int64_t N, int C, int dtype, mdlStream_t stream);
 int mdl_bn_apply(const void* x, float* sums, const float* gamma, const float* beta, float* save,
                  float* running_mean, float* running_var, void* y, int64_t N, int C, float eps, float momentum,

@@ -166,7 +166,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
-template <typename T, int W>
+// MASK (mdl_bn_bwd_apply_relu_n): x is the OUTPUT of a ReLU (Linear -> ReLU -> BatchNorm, the layer order of the MEGNet blocks,
+// megnet.py:47-48) and what is written is the gradient w.r.t. that ReLU's input: dx is zeroed where x <= 0, so the dense
+// layer's backward behind it needs neither the activation staging nor a read of x's rows for the mask.
+template <typename T, int W, bool MASK = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ save, float* __restrict__ sums,
                                                            const float* __restrict__ gamma, T* __restrict__ dx, int64_t Ncap,
@@ -204,7 +207,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         for (int u = 0; u < U; ++u) {
             const int64_t q = q0 + u * stride;
 #pragma unroll
-            for (int j = 0; j < W; ++j) vd[u][j] = gs[j] * (vd[u][j] - k0[j] - (vx[u][j] - mean[j]) * istd[j] * k1[j]);
+            for (int j = 0; j < W; ++j) {
+                const float d = gs[j] * (vd[u][j] - k0[j] - (vx[u][j] - mean[j]) * istd[j] * k1[j]);
+                vd[u][j] = (!MASK || vx[u][j] > 0.0f) ? d : 0.0f;
+            }
             if (q < total) V::st(dx + (q / CG) * C + cg * W, vd[u]);
         }
         q0 += U * stride;
@@ -314,19 +320,34 @@ extern "C" int mdl_bn_bwd_apply(const void* dy, const void* x, const float* save
                                 void* dx, int64_t N, int C, int dtype, mdlStream_t stream) {
     return mdl_bn_bwd_apply_n(dy, x, save, sums, gamma, dx, N, C, nullptr, dtype, stream);
 }
-extern "C" int mdl_bn_bwd_apply_n(const void* dy, const void* x, const float* save, float* sums, const float* gamma,
-                                  void* dx, int64_t N, int C, const int64_t* n_dev, int dtype, mdlStream_t stream) {
+static int bn_bwd_apply_launch(const char* name, bool mask, const void* dy, const void* x, const float* save, float* sums, const float* gamma,
+                               void* dx, int64_t N, int C, const int64_t* n_dev, int dtype, mdlStream_t stream) {
     using namespace mdl;
     dtype &= MDL_DTYPE_MASK;
-    int rc = bn_check("mdl_bn_bwd_apply", N, C, dtype, x);
+    int rc = bn_check(name, N, C, dtype, x);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     int64_t g = cdiv(N * (C / bn_width(C, dtype)), 256 * 4);
     if (g > 768) g = 768;          // 3 fat blocks per CU: the per-block statistics prologue amortises (measured 512..2048)
     if (g < 1) g = 1;
     const int W = bn_width(C, dtype);
+    if (mask) {
+        MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "%s: bf16 only", name);
+        if (W == 8) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 8, true>), dim3((unsigned)g), dim3(bn_threads(C, 8)), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, gamma, (bf16_t*)dx, N, C, n_dev);
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 4, true>), dim3((unsigned)g), dim3(bn_threads(C, 4)), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, gamma, (bf16_t*)dx, N, C, n_dev);
+        return check_launch(name);
+    }
     if (dtype == MDL_BF16 && W == 8) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 8>), dim3((unsigned)g), dim3(bn_threads(C, 8)), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, gamma, (bf16_t*)dx, N, C, n_dev);
     else if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 4>), dim3((unsigned)g), dim3(bn_threads(C, 4)), 0, st, (const bf16_t*)dy, (const bf16_t*)x, save, sums, gamma, (bf16_t*)dx, N, C, n_dev);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), dim3((unsigned)g), dim3(bn_threads(C, 4)), 0, st, (const float*)dy, (const float*)x, save, sums, gamma, (float*)dx, N, C, n_dev);
-    return check_launch("mdl_bn_bwd_apply");
+    return check_launch(name);
+}
+
+extern "C" int mdl_bn_bwd_apply_n(const void* dy, const void* x, const float* save, float* sums, const float* gamma,
+                                  void* dx, int64_t N, int C, const int64_t* n_dev, int dtype, mdlStream_t stream) {
+    return bn_bwd_apply_launch("mdl_bn_bwd_apply", false, dy, x, save, sums, gamma, dx, N, C, n_dev, dtype, stream);
+}
+extern "C" int mdl_bn_bwd_apply_relu_n(const void* dy, const void* x, const float* save, float* sums, const float* gamma,
+                                       void* dx, int64_t N, int C, const int64_t* n_dev, int dtype, mdlStream_t stream) {
+    return bn_bwd_apply_launch("mdl_bn_bwd_apply_relu", true, dy, x, save, sums, gamma, dx, N, C, n_dev, dtype, stream);
 }

@@ -13,7 +13,7 @@ from torch import nn
 
 from .. import ops
 from ..nn import BatchNorm1d, MetaLayer, Set2Set
-from ._base import GraphModel, dense, dense_act
+from ._base import GraphModel, _lowp, dense, dense_act
 
 
 class _Mlp(nn.Module):
@@ -26,13 +26,22 @@ class _Mlp(nn.Module):
         self.bn_list = nn.ModuleList(
             [BatchNorm1d(dim, track_running_stats=track) for _ in range(fc_layers + 1)] if batch_norm == "True" else [])
 
-    def _tail(self, out, first):
-        """BatchNorm / dropout of layer `first`, then the remaining Linear -> act -> BatchNorm -> dropout layers."""
+    def _tail(self, out, first, normed=False):
+        """BatchNorm / dropout of layer `first` (normed: its BatchNorm has been applied already), then the remaining
+        Linear -> act -> BatchNorm -> dropout layers; in bf16 a Linear -> ReLU -> BatchNorm triple with batch statistics is one
+        fused autograd node (BatchNorm1d.after_linear_relu)."""
         lins = getattr(self, self.list_name)
         for i in range(first, len(lins)):
+            done = normed and i == first
             if i > first:
-                out = dense_act(lins[i], out, self.act)
-            if self.batch_norm == "True":
+                z = None
+                if self.batch_norm == "True" and self.act == "relu" and out.dtype != lins[i].weight.dtype:
+                    z = self.bn_list[i].after_linear_relu(out, lins[i].weight, lins[i].bias, _lowp(lins[i]))
+                if z is not None:
+                    out, done = z, True
+                else:
+                    out = dense_act(lins[i], out, self.act)
+            if self.batch_norm == "True" and not done:
                 out = self.bn_list[i](out)
             out = F.dropout(out, p=self.dropout_rate, training=self.training)
         return out
@@ -65,6 +74,10 @@ class Megnet_EdgeModel(_Mlp):
         # the kernel gathers two tables, and the per-graph gradient is a 25-row reduction over nodes instead of a
         # 325-row one over edges
         p_dst = ops.linear(x, wb, None) + ops.gather(p_glb, batch_n)
+        if self.batch_norm == "True":
+            z = self.bn_list[0].after_linear_relu(edge_attr, wc, None, None, [(p_src, row), (p_dst, col)])
+            if z is not None:
+                return self._tail(z, 0, normed=True)
         out = ops.linear_gather_act(edge_attr, wc, None, self.act, [(p_src, row), (p_dst, col)])
         return self._tail(out, 0)
 

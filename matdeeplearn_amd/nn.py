@@ -340,6 +340,18 @@ class BatchNorm1d(nn.BatchNorm1d):
         self._sync_counter()
         return super().forward(x)
 
+    def after_linear_relu(self, h, weight, bias, lowp=None, gathered=None):
+        """self(relu(F.linear(h, weight, bias) + gathered rows)) as one fused autograd node (ops.linear_relu_bn) when this
+        module normalises with batch statistics and the layer has a fusable shape; None otherwise (the caller composes)."""
+        use_batch_stats = self.training or not self.track_running_stats
+        if not (use_batch_stats and self.momentum is not None and ops.linear_relu_bn_ok(h, weight, bias is not None, gathered)):
+            return None
+        rm = rv = None
+        if self.training and self.track_running_stats:
+            rm, rv = self.running_mean, self.running_var
+            self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1
+        return ops.linear_relu_bn(h, weight, bias, lowp, self.weight, self.bias, rm, rv, self.eps, self.momentum, gathered)
+
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         self._sync_counter()
         super()._save_to_state_dict(destination, prefix, keep_vars)

@@ -1370,5 +1370,98 @@ class _BatchNormTrain(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None
 
 
+class _LinearReluBN(torch.autograd.Function):
+    """BatchNorm1d(relu(x W^T + b [+ sum_i table_i[idx_i]])) in training mode as ONE autograd node (the layer order of the
+    reference's MEGNet blocks, megnet.py:41-56).  Forward: the streaming dense layer (K6 when tables are gathered), then the
+    BatchNorm statistics and apply kernels.  Backward: the BatchNorm backward's apply pass also takes the ReLU mask (it reads the
+    ReLU output anyway: mdl_bn_bwd_apply_relu_n), so what it writes is the gradient w.r.t. the pre-activation — the dense
+    backward behind it runs without an activation staging (no second read of the output rows, the faster 8-wave form) and the
+    gathered tables' gradients are segment sums of the same rows (no separate masked copy).  (Folding the BatchNorm apply
+    into the dense backward's staging instead was measured no faster: experiments/patches/linear_relu_bn_fold.patch.)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_lp, b_lp, bn_w, bn_b, rm, rv, eps, momentum, idx, *tables):
+        w = weight.to(x.dtype) if w_lp is None else w_lp
+        b = None if bias is None else (bias.to(x.dtype) if b_lp is None else b_lp)
+        N, K = x.shape
+        M = weight.shape[0]
+        dt = dtype_code(x)
+        y = torch.empty((N, M), dtype=x.dtype, device=x.device)
+        tabs = [None if t is None else t.contiguous() for t in tables]
+        if tabs:
+            tb = tabs + [None] * (3 - len(tabs))
+            ids = list(idx) + [None] * (3 - len(idx))
+            check(_launch_timed("edge_linear", lambda: lib().mdl_linear_gather_act(
+                ptr(x), ptr(w), ptr(b), ptr(tb[0]), ptr(ids[0]), ptr(tb[1]), ptr(ids[1]), ptr(tb[2]), ptr(ids[2]), ptr(y),
+                N, K, M, 1, dt, stream())), "mdl_linear_gather_act")
+        else:
+            check(lib().mdl_linear_act(ptr(x), ptr(w), ptr(b), ptr(y), N, K, M, 1, dt, stream()), "mdl_linear_act")
+        R = lib().mdl_bn_sums_rows()
+        buf = _zeros_step((R + 2, M), x.device)
+        sums, save = buf[:R], buf[R:]
+        gw = None if bn_w is None else bn_w.detach().float().contiguous()
+        gb = None if bn_b is None else bn_b.detach().float().contiguous()
+        z = torch.empty_like(y)
+        nd = _true_rows_for(N)
+        check(lib().mdl_bn_stats_n(ptr(y), ptr(sums), N, M, ptr(nd), dt | _dflag(), stream()), "mdl_bn_stats")
+        check(lib().mdl_bn_apply_n(ptr(y), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(rm), ptr(rv), ptr(z), N, M, float(eps),
+                                   float(momentum), ptr(nd), dt, stream()), "mdl_bn_apply")
+        ctx.save_for_backward(x, w, y, save, gw)
+        ctx.n_dev, ctx.idx, ctx.rows, ctx.ntab = nd, list(idx), [None if t is None else t.shape[0] for t in tabs], len(tabs)
+        ctx.wdtype, ctx.has_bias, ctx.shape = weight.dtype, bias is not None, tuple(weight.shape)
+        ctx.bn_has = (bn_w is not None, bn_b is not None)
+        ctx.bn_wdt = None if bn_w is None else bn_w.dtype
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, w, y, save, gw = ctx.saved_tensors
+        M, K = ctx.shape
+        N = x.shape[0]
+        gz = gz.contiguous()
+        dt = dtype_code(x)
+        R = lib().mdl_bn_sums_rows()
+        sums = _zeros_grad(R * M, x.device).view(R, M)
+        gp = torch.empty_like(y)                                                 # gradient w.r.t. the Linear's output (pre-activation)
+        check(lib().mdl_bn_bwd_stats_n(ptr(gz), ptr(y), ptr(save), ptr(sums), N, M, ptr(ctx.n_dev), dt | _dflag(), stream()),
+              "mdl_bn_bwd_stats")
+        check(lib().mdl_bn_bwd_apply_relu_n(ptr(gz), ptr(y), ptr(save), ptr(sums), ptr(gw), ptr(gp), N, M, ptr(ctx.n_dev), dt,
+                                            stream()), "mdl_bn_bwd_apply_relu")
+        dgamma = sums[R - 1].to(ctx.bn_wdt) if ctx.bn_has[0] else None
+        dbeta = sums[R - 2].to(ctx.bn_wdt) if ctx.bn_has[1] else None
+        buf = _zeros_grad(M * K + M, x.device)
+        dw, dbv = buf[:M * K].view(M, K), buf[M * K:]
+        dx = torch.empty((N, K), dtype=x.dtype, device=x.device)
+        check(lib().mdl_dense_bwd(ptr(gp), M, M, None, 0, 0, ptr(x), x.stride(0), K, ptr(w), ptr(dx), K, 0, None, ptr(dw),
+                                  ptr(dbv) if ctx.has_bias else None, N, dt | _dflag(), stream()), "mdl_dense_bwd")
+        dts = []
+        for t in range(ctx.ntab):
+            need = ctx.needs_input_grad[12 + t] and ctx.rows[t] is not None
+            dts.append(scatter(gp, ctx.idx[t], 0, ctx.rows[t], "sum") if need else None)
+        return (dx if ctx.needs_input_grad[0] else None, dw.to(ctx.wdtype), dbv.to(ctx.wdtype) if ctx.has_bias else None,
+                None, None, dgamma, dbeta, None, None, None, None, None) + tuple(dts)
+
+
+def linear_relu_bn_ok(x, weight, has_bias, gathered=None):
+    """The fused Linear -> ReLU -> BatchNorm1d(train) node takes this layer: bf16 rows with a gradient, the dense-backward
+    shapes (even widths in [34, 160], not both above 128), at most three gathered tables."""
+    M, K = weight.shape
+    kb = K + (1 if has_bias else 0)
+    return (_DENSE_BWD and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.shape[0] >= 1024
+            and x.requires_grad and torch.is_grad_enabled() and weight.requires_grad
+            and 34 <= M <= (128 if gathered else 160) and 34 <= K and kb <= 160 and M % 2 == 0 and K % 2 == 0
+            and not (M > 128 and kb > 128) and M % 4 == 0 and x.data_ptr() % 16 == 0 and (gathered is None or len(gathered) <= 3))
+
+
+def linear_relu_bn(x, weight, bias, lowp, bn_weight, bn_bias, running_mean, running_var, eps, momentum, gathered=None):
+    """BatchNorm1d(relu(F.linear(x, weight, bias) + sum_i table_i[index_i])) with batch statistics (callers check
+    linear_relu_bn_ok); `gathered` = [(table [rows, M], index [N] int), ...]."""
+    w_lp, b_lp = (lowp if lowp is not None and lowp[0].dtype == x.dtype else (None, None))
+    gathered = gathered or []
+    idx = [ix if ix.dtype == torch.int32 else ix.to(torch.int32) for _, ix in gathered]
+    return _LinearReluBN.apply(x, weight, bias, w_lp, b_lp, bn_weight, bn_bias, running_mean, running_var, eps, momentum, idx,
+                               *[t.to(x.dtype) for t, _ in gathered])
+
+
 def batch_norm_train(x, weight, bias, running_mean, running_var, eps=1e-5, momentum=0.1):
     return _BatchNormTrain.apply(x, weight, bias, running_mean, running_var, eps, momentum)

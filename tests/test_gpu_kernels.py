@@ -698,6 +698,67 @@ def test_dense_bwd_matches_torch(N, M, K, act, xout, bias):
         close(gmo, gm, 1e-2, 1e-3)
 
 
+@pytest.mark.parametrize("tables", [0, 2])
+def test_linear_relu_batchnorm_node_matches_torch_and_the_separate_layers(tables):
+    """BatchNorm1d(relu(Linear(x) [+ gathered rows])) as one autograd node (ops.linear_relu_bn: the BatchNorm backward writes
+    the pre-activation gradient, the one-pass dense backward takes it without an activation staging) (a) against fp32 torch on
+    the same bf16-rounded operands, (b) against the same chain built from the separate product layers — the masked
+    BatchNorm backward must reproduce `threshold_backward` of the unmasked one exactly, so dX agrees bit for bit and the
+    reductions to accumulation order."""
+    from matdeeplearn_amd import nn as mnn, ops
+    d = dev()
+    N, K, M, R = 6001, 100, 100, 257
+    g = torch.Generator().manual_seed(40 + tables)
+    r16 = lambda t: t.to(torch.bfloat16).float()
+    x = r16(torch.randn(N, K, generator=g))
+    W, b = r16(torch.randn(M, K, generator=g) / K ** 0.5), r16(torch.randn(M, generator=g) * 0.1)
+    tabs = [r16(torch.randn(R, M, generator=g) * 0.5) for _ in range(tables)]
+    ids = [torch.randint(0, R, (N,), generator=g) for _ in range(tables)]
+    gamma, beta = torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g) * 0.2
+    gout = torch.randn(N, M, generator=g)
+
+    # (a) fp32 torch
+    leaves = [t.clone().requires_grad_(True) for t in [x, W, b, gamma, beta] + tabs]
+    xo, Wo, bo, go_, beo = leaves[:5]
+    pre = torch.nn.functional.linear(xo, Wo, bo)
+    for t, ix in zip(leaves[5:], ids):
+        pre = pre + t[ix]
+    ref = torch.nn.functional.batch_norm(torch.relu(pre), None, None, go_, beo, True, 0.1, 1e-5)
+    (ref * gout).sum().backward()
+
+    def run(fused):
+        bn = mnn.BatchNorm1d(M).to(d)
+        with torch.no_grad():
+            bn.weight.copy_(gamma); bn.bias.copy_(beta)
+        xd = x.to(d).to(torch.bfloat16).requires_grad_(True)
+        Wd, bd = W.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+        td = [t.to(d).to(torch.bfloat16).requires_grad_(True) for t in tabs]
+        gath = [(t, ix.to(d).int()) for t, ix in zip(td, ids)] or None
+        if fused:
+            z = bn.after_linear_relu(xd, Wd, bd, None, gath)
+            assert z is not None
+        elif gath:
+            z = bn(ops.linear_gather_act(xd, Wd, bd, "relu", gath))
+        else:
+            z = bn(ops.linear_act(xd, Wd, bd, "relu"))
+        (z.float() * gout.to(d)).sum().backward()
+        return [z.detach(), xd.grad, Wd.grad, bd.grad, bn.weight.grad, bn.bias.grad] + [t.grad for t in td] + [bn.running_mean.clone(), bn.running_var.clone()]
+
+    with ops.deterministic():
+        fu, se = run(True), run(False)
+    names = ["out", "dx", "dW", "db", "dgamma", "dbeta"] + ["dtab%d" % k for k in range(tables)] + ["running_mean", "running_var"]
+    refs = [ref.detach(), xo.grad, Wo.grad, bo.grad, go_.grad, beo.grad] + [t.grad for t in leaves[5:]]
+    for nm, a, r_ in zip(names, fu, refs):                                          # (a)
+        scale = float(r_.abs().max())
+        err = float((a.float().cpu() - r_).abs().max())
+        assert err <= 5e-2 * max(scale, 0.1 * float(xo.grad.abs().max())), (nm, err, scale)
+    for nm, a, c in zip(names, fu, se):                                             # (b)
+        if nm in ("out", "dx", "running_mean", "running_var"):
+            assert torch.equal(a, c), nm
+        else:
+            close(a, c, 2e-3, 2e-3 * float(c.float().abs().max()))
+
+
 @pytest.mark.parametrize("K", [300, 420])
 def test_wide_input_linear_takes_its_weight_gradient_from_two_tn_gemms(K):
     """ops.linear with 256 < in <= 512 (MEGNet's node block: 3 x 100 concatenated columns): library forward, dW as two
