@@ -97,6 +97,13 @@ int mdl_segment_reduce_fwd(const void* src, const int32_t* rowptr, const int32_t
 int mdl_segment_reduce_bwd(const void* grad_out, const int32_t* rowptr, const int32_t* seg,
                            const int32_t* perm, const int32_t* argmax, void* grad_src, int64_t N,
                            int64_t E, int64_t C, int reduce, int dtype, mdlStream_t stream);
+/* same for MDL_SUM / MDL_MEAN with a second gradient of the same source rows added on the way out:
+ * grad_src[r, :] = (scattered grad_out)[r, :] + addend[r, :] — the accumulation autograd forms with one more pass over
+ * [E, C] when the reduced tensor also feeds a residual (matdeeplearn/models/megnet.py:86 with :321-336).  Rows must be a
+ * multiple of 4 elements (bf16) and 8-byte aligned. */
+int mdl_segment_reduce_bwd_add(const void* grad_out, const int32_t* rowptr, const int32_t* seg, const int32_t* perm,
+                               const void* addend, void* grad_src, int64_t N, int64_t E, int64_t C, int reduce, int dtype,
+                               mdlStream_t stream);
 
 /* ---- K2/K3: fused CGConv ------------------------------------------------------------------
  * Replaces torch_geometric.nn.CGConv(channels=C, dim=G, aggr, batch_norm=False) as constructed at

@@ -25,6 +25,7 @@ PROTOTYPES = {
     "mdl_csr_rowptr": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "mdl_segment_reduce_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "mdl_segment_reduce_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
+    "mdl_segment_reduce_bwd_add": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
     "mdl_cgconv_wpack_bytes": (_sz, [_i32, _i32, _i32]),
     "mdl_cgconv_pack_weights": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mdl_cgconv_pack_weights_node": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),

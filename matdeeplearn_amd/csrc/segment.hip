@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256) void seg_fwd_vec_kernel(const T* __restrict__ 
 template <typename T, int REDUCE, int W>
 __global__ __launch_bounds__(256) void seg_bwd_vec_kernel(const T* __restrict__ go, const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ seg, const int32_t* __restrict__ perm,
-                                                          T* __restrict__ gs, int64_t E, int CG) {
+                                                          T* __restrict__ gs, int64_t E, int CG, const T* __restrict__ addend) {
+    // addend (optional, [E, C] like gs): a second gradient of the same source rows, added on the way out — the sum autograd
+    // would form with one more read-read-write pass over [E, C] (mdl_segment_reduce_bwd_add)
     typedef VecW<T, W> V;
     const int64_t total = E * CG;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -154,7 +156,14 @@ __global__ __launch_bounds__(256) void seg_bwd_vec_kernel(const T* __restrict__ 
 #pragma unroll
             for (int j = 0; j < W; ++j) g[j] = g[j] / cnt;
         }
-        V::st(gs + ((int64_t)(perm ? perm[k] : k) * CG + cg) * W, g);
+        const int64_t o = ((int64_t)(perm ? perm[k] : k) * CG + cg) * W;
+        if (addend) {
+            float a[W];
+            V::ld(addend + o, a);
+#pragma unroll
+            for (int j = 0; j < W; ++j) g[j] += a[j];
+        }
+        V::st(gs + o, g);
     }
 }
 
@@ -206,21 +215,27 @@ static int seg_fwd(const T* src, const int32_t* rowptr, const int32_t* perm, T* 
 
 template <typename T>
 static int seg_bwd(const T* go, const int32_t* rowptr, const int32_t* seg, const int32_t* perm,
-                   const int32_t* argmax, T* gs, int64_t N, int64_t E, int64_t C, int reduce, hipStream_t st) {
+                   const int32_t* argmax, T* gs, int64_t N, int64_t E, int64_t C, int reduce, hipStream_t st,
+                   const T* addend = nullptr) {
     dim3 b(256);
-    const int vw = ((reduce == MDL_SUM || reduce == MDL_MEAN) && E * C != 0) ? vec_width<T>(go, gs, C) : 0;
+    int vw = ((reduce == MDL_SUM || reduce == MDL_MEAN) && E * C != 0) ? vec_width<T>(go, gs, C) : 0;
+    if (addend) {
+        const int va = vw ? vec_width<T>(addend, gs, C) : 0;
+        if (va < vw) vw = va;
+        if (!vw) { set_error("mdl_segment_reduce_bwd_add: needs sum / mean and rows of a vector multiple (8-byte aligned)"); return MDL_E_UNSUPP; }
+    }
     if (vw) {
         const int CG = (int)(C / vw);
         dim3 gv(grid_for(E * CG));
         if constexpr (sizeof(T) == 2) {
             if (vw == 4) {
-                if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_SUM, 4>), gv, b, 0, st, go, rowptr, seg, perm, gs, E, CG);
-                else hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_MEAN, 4>), gv, b, 0, st, go, rowptr, seg, perm, gs, E, CG);
+                if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_SUM, 4>), gv, b, 0, st, go, rowptr, seg, perm, gs, E, CG, addend);
+                else hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_MEAN, 4>), gv, b, 0, st, go, rowptr, seg, perm, gs, E, CG, addend);
                 return check_launch("mdl_segment_reduce_bwd");
             }
         }
-        if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_SUM, Vec<T>::W>), gv, b, 0, st, go, rowptr, seg, perm, gs, E, CG);
-        else hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_MEAN, Vec<T>::W>), gv, b, 0, st, go, rowptr, seg, perm, gs, E, CG);
+        if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_SUM, Vec<T>::W>), gv, b, 0, st, go, rowptr, seg, perm, gs, E, CG, addend);
+        else hipLaunchKernelGGL((seg_bwd_vec_kernel<T, MDL_MEAN, Vec<T>::W>), gv, b, 0, st, go, rowptr, seg, perm, gs, E, CG, addend);
         return check_launch("mdl_segment_reduce_bwd");
     }
     switch (reduce) {
@@ -278,5 +293,20 @@ extern "C" int mdl_segment_reduce_bwd(const void* grad_out, const int32_t* rowpt
     if (dtype == MDL_F32) return seg_bwd<float>((const float*)grad_out, rowptr, seg, perm, argmax, (float*)grad_src, N, E, C, reduce, st);
     if (dtype == MDL_BF16) return seg_bwd<bf16_t>((const bf16_t*)grad_out, rowptr, seg, perm, argmax, (bf16_t*)grad_src, N, E, C, reduce, st);
     set_error("mdl_segment_reduce_bwd: unsupported dtype %d", dtype);
+    return MDL_E_UNSUPP;
+}
+
+extern "C" int mdl_segment_reduce_bwd_add(const void* grad_out, const int32_t* rowptr, const int32_t* seg, const int32_t* perm,
+                                          const void* addend, void* grad_src, int64_t N, int64_t E, int64_t C, int reduce,
+                                          int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(N >= 0 && E >= 0 && C > 0, MDL_E_ARG, "mdl_segment_reduce_bwd_add: bad sizes");
+    MDL_REQUIRE((reduce == MDL_SUM || reduce == MDL_MEAN) && (E == 0 || (seg && addend && grad_src)), MDL_E_ARG,
+                "mdl_segment_reduce_bwd_add: sum / mean only, seg and addend required");
+    if (E == 0) return MDL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MDL_F32) return seg_bwd<float>((const float*)grad_out, rowptr, seg, perm, nullptr, (float*)grad_src, N, E, C, reduce, st, (const float*)addend);
+    if (dtype == MDL_BF16) return seg_bwd<bf16_t>((const bf16_t*)grad_out, rowptr, seg, perm, nullptr, (bf16_t*)grad_src, N, E, C, reduce, st, (const bf16_t*)addend);
+    set_error("mdl_segment_reduce_bwd_add: unsupported dtype %d", dtype);
     return MDL_E_UNSUPP;
 }

@@ -126,7 +126,9 @@ def _run_embed(seq, h):
 class _FusedMetaLayer(MetaLayer):
     """MetaLayer (megnet.py:235-253) that hands the edge model the UNGATHERED node state when it can fuse the gathers."""
 
-    def forward(self, x, edge_index, edge_attr=None, u=None, batch=None, idx=None):
+    def forward(self, x, edge_index, edge_attr=None, u=None, batch=None, idx=None, e_res=None):
+        """e_res: the edge state the caller adds to this layer's edge output (megnet.py:321-336); when given, the returned
+        edge tensor is that SUM (formed with the by-source mean of the output in one autograd node)."""
         em = self.edge_model
         if idx is not None and em is not None and hasattr(em, "forward_fused"):
             row32, col32, batch_n = idx
@@ -141,15 +143,21 @@ class _FusedMetaLayer(MetaLayer):
             # the node block and the global block both start from scatter_mean(e', edge_index[0]) (megnet.py:86 and :130): the
             # same [E, d] -> [N, d] reduction of the same tensor, formed ONCE here (one segmented reduction forward, one backward
             # and one gradient accumulation over the edge rows less per block)
-            v_e = None
+            v_e, e_out = None, None
             if self.node_model is not None and self.global_model is not None:
-                v_e = ops.scatter_mean(edge_attr, edge_index[0], 0, x.shape[0])
+                if e_res is not None:
+                    e_out, v_e = ops.residual_scatter(edge_attr, e_res, edge_index[0], x.shape[0], "mean")
+                else:
+                    v_e = ops.scatter_mean(edge_attr, edge_index[0], 0, x.shape[0])
             if self.node_model is not None:
                 x = self.node_model(x, edge_index, edge_attr, u, batch, v_e=v_e)
             if self.global_model is not None:
                 u = self.global_model(x, edge_index, edge_attr, u, batch, v_e=v_e)
-            return x, edge_attr, u
-        return super().forward(x, edge_index, edge_attr, u, batch)
+            if e_res is not None and e_out is None:
+                e_out = edge_attr + e_res
+            return x, (edge_attr if e_res is None else e_out), u
+        x, e, u = super().forward(x, edge_index, edge_attr, u, batch)
+        return x, (e if e_res is None else e + e_res), u
 
 
 class MEGNet(GraphModel):
@@ -185,11 +193,12 @@ class MEGNet(GraphModel):
             e_t = _run_embed(self.e_embed_list[i], data.edge_attr.to(cd) if i == 0 else e)
             x_t = _run_embed(self.x_embed_list[i], out if i == 0 else x)
             u_t = _run_embed(self.u_embed_list[i], data.u.to(cd) if i == 0 else u)
-            x_o, e_o, u_o = conv(x_t, ei, e_t, u_t, data.batch, idx=idx)
+            # (the edge residual is formed inside the layer, together with the by-source mean of its edge output)
+            x_o, e, u_o = conv(x_t, ei, e_t, u_t, data.batch, idx=idx, e_res=e_t if i == 0 else e)
             if i == 0:
-                x, e, u = x_o + x_t, e_o + e_t, u_o + u_t
+                x, u = x_o + x_t, u_o + u_t
             else:
-                x, e, u = x_o + x, e_o + e, u_o + u
+                x, u = x_o + x, u_o + u
         n = x.shape[0]
         if self.pool_order == "early":
             if self.pool == "set2set":

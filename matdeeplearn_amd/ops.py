@@ -320,6 +320,45 @@ class _SegmentReduce(torch.autograd.Function):
         return gs, None, None
 
 
+class _ResidualSegmentReduce(torch.autograd.Function):
+    """(src + res, reduce(src by segment)) as one autograd node: `src` feeds a residual sum AND a segmented reduction (the edge
+    state of a MEGNet block: e' + e and scatter_mean(e', row), megnet.py:86 with :321-336), so its gradient is the sum of two
+    [E, C] tensors — formed here inside the reduction's backward (mdl_segment_reduce_bwd_add) instead of by autograd's
+    separate accumulation pass."""
+
+    @staticmethod
+    def forward(ctx, src, res, si, reduce):
+        C = src.shape[1]
+        out = torch.empty((si.N, C), dtype=src.dtype, device=src.device)
+        check(lib().mdl_segment_reduce_fwd(ptr(src), ptr(si.rowptr), ptr(si.perm), ptr(out), None, si.N, C, reduce,
+                                           dtype_code(src), stream()), "mdl_segment_reduce_fwd")
+        ctx.si, ctx.reduce = si, reduce
+        return src + res, out
+
+    @staticmethod
+    def backward(ctx, g_sum, g_red):
+        si = ctx.si
+        g_sum, g_red = g_sum.contiguous(), g_red.contiguous()
+        gs = torch.empty_like(g_sum)
+        check(lib().mdl_segment_reduce_bwd_add(ptr(g_red), ptr(si.rowptr), ptr(si.seg), ptr(si.perm), ptr(g_sum), ptr(gs),
+                                               si.N, si.E, g_sum.shape[1], ctx.reduce, dtype_code(g_sum), stream()),
+              "mdl_segment_reduce_bwd_add")
+        return gs, g_sum, None, None
+
+
+def residual_scatter(src, res, index, dim_size, reduce="mean", assume_sorted=False):
+    """(src + res, scatter(src, index, 0, dim_size, reduce)) — one node when the shapes allow (2-D contiguous rows of a
+    multiple of 4 elements, sum / mean, an index whose segments cover every row), the two separate ops otherwise."""
+    if (reduce in ("sum", "mean") and src.dim() == 2 and src.is_cuda and src.is_contiguous() and res.is_contiguous()
+            and res.shape == src.shape and res.dtype == src.dtype and src.shape[1] % 4 == 0 and src.data_ptr() % 16 == 0
+            and src.shape[0] > 0 and torch.is_grad_enabled() and src.requires_grad):
+        require_hip(src, index)
+        si = _seg_index(index, dim_size, assume_sorted)
+        if not si.partial and si.E == src.shape[0]:
+            return _ResidualSegmentReduce.apply(src, res, si, _lib.REDUCE[reduce])
+    return src + res, scatter(src, index, 0, dim_size, reduce, assume_sorted)
+
+
 def scatter(src, index, dim=0, dim_size=None, reduce="sum", assume_sorted=False, seg_index=None):
     """torch_scatter.scatter(src, index, dim=0, dim_size, reduce) semantics.  When
     dim_size is None it is index.max()+1, which costs a host sync — pass dim_size on hot paths.

@@ -759,6 +759,48 @@ def test_linear_relu_batchnorm_node_matches_torch_and_the_separate_layers(tables
             close(a, c, 2e-3, 2e-3 * float(c.float().abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+def test_residual_scatter_node_matches_the_two_ops(dtype, reduce):
+    """ops.residual_scatter = (src + res, scatter(src, index)) with the two gradients of `src` summed inside the reduction's
+    backward (mdl_segment_reduce_bwd_add): values and gradients against index_add_ in fp32, and against the separate ops
+    (fp32: bit-equal — same arithmetic, one pass less)."""
+    from matdeeplearn_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(77)
+    E, C, N = 5003, 100, 311
+    index = torch.randint(0, N, (E,), generator=g)                       # unsorted: the by-source index of a target-sorted edge list
+    src0, res0 = torch.randn(E, C, generator=g).to(dtype), torch.randn(E, C, generator=g).to(dtype)
+    g1, g2 = torch.randn(E, C, generator=g).to(dtype), torch.randn(N, C, generator=g).to(dtype)
+
+    def run(fused):
+        src, res = src0.to(d).requires_grad_(True), res0.to(d).requires_grad_(True)
+        idx = index.to(d)
+        if fused:
+            s, v = ops.residual_scatter(src, res, idx, N, reduce)
+        else:
+            s, v = src + res, ops.scatter(src, idx, 0, N, reduce)
+        ((s * g1.to(d)).sum() + (v * g2.to(d)).sum()).backward()
+        return s.detach(), v.detach(), src.grad, res.grad
+
+    fu, se = run(True), run(False)
+    for a, b in zip(fu, se):
+        if dtype == torch.float32:
+            assert torch.equal(a, b)
+        else:                     # (bf16: the separate ops round the scattered gradient before the sum, the node rounds once)
+            close(a, b, 1e-2, 1e-2)
+    sf, rf = src0.float().requires_grad_(True), res0.float().requires_grad_(True)
+    v = torch.zeros(N, C).index_add_(0, index, sf)
+    if reduce == "mean":
+        v = v / torch.bincount(index, minlength=N).clamp(min=1).unsqueeze(1)
+    (((sf + rf) * g1.float()).sum() + (v * g2.float()).sum()).backward()
+    tol = (1e-5, 1e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+    close(fu[0], sf.detach() + rf.detach(), *tol)
+    close(fu[1], v.detach(), *tol)
+    close(fu[2], sf.grad, *tol)
+    close(fu[3], rf.grad, *tol)
+
+
 @pytest.mark.parametrize("K", [300, 420])
 def test_wide_input_linear_takes_its_weight_gradient_from_two_tn_gemms(K):
     """ops.linear with 256 < in <= 512 (MEGNet's node block: 3 x 100 concatenated columns): library forward, dW as two
