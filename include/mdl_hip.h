@@ -54,11 +54,14 @@ enum {
  *                      one wave per channel slice for the CGConv edge pass).  A few hundred times slower: meant for
  *                      HIP-vs-HIP regression checks (graph replay vs eager, padded rows, data-parallel exchange).
  *   MDL_K3_PER_WAVE /  mdl_cgconv_bwd_h / _hb only: force the per-wave kernel / the edge-per-lane kernel 2 instead of
- *   MDL_K3_EDGE_LANE   the edge-count heuristic (kernel 2 from 4e5 edges). */
+ *   MDL_K3_EDGE_LANE   the edge-count heuristic (kernel 2 from 4e5 edges).
+ *   MDL_BN_UNSHIFTED   mdl_bn_apply_n only: the sums are plain sum x / sum x^2 (written by mdl_linear_act_stats) instead of
+ *                      the sums about the first row that mdl_bn_stats forms. */
 #define MDL_DTYPE_MASK 0xff
 #define MDL_DETERMINISTIC 0x100
 #define MDL_K3_PER_WAVE 0x200
 #define MDL_K3_EDGE_LANE 0x400
+#define MDL_BN_UNSHIFTED 0x800
 
 typedef void* mdlStream_t; /* hipStream_t */
 
@@ -217,6 +220,14 @@ int mdl_ssp_bwd(const void* g, const void* y, void* dx, int64_t n, int dtype, md
  * x: [N, K] (the edge state), W: [M, K], p_i: [rows_i, M] per-node / per-graph projections of the OTHER column blocks of
  * the reference's concatenated input [x[row] | x[col] | e | u[batch]] (any p_i may be NULL).  The [E, 4d] concatenation and
  * its K = 4d product never exist.  Same shape limits as mdl_linear_act; with tables M <= 128 and rows_i * M * 2 < 2^31 bytes. */
+/* mdl_linear_gather_act (tables optional) that also takes the BatchNorm statistics of its output on the way out: the
+ * epilogue adds, per column, sum out and sum out^2 of the rounded bf16 values of the rows below *n_rows_dev (NULL = all N)
+ * into one of the MDL_BN_REPLICAS copies of bn_sums (layout of mdl_bn_stats; caller zero-fills), so that
+ * Linear -> ReLU -> BatchNorm1d (matdeeplearn/models/megnet.py:47-48) needs no statistics pass over [N, M]:
+ * follow with mdl_bn_apply_n(..., dtype | MDL_BN_UNSHIFTED).  Even 34 <= M <= 160, K <= 160. */
+int mdl_linear_act_stats(const void* x, const void* w, const void* bias, const void* p1, const int32_t* idx1, const void* p2,
+                         const int32_t* idx2, const void* p3, const int32_t* idx3, void* out, int64_t N, int K, int M, int act,
+                         float* bn_sums, const int64_t* n_rows_dev, int dtype, mdlStream_t stream);
 int mdl_linear_gather_act(const void* x, const void* w, const void* bias, const void* p1, const int32_t* idx1,
                           const void* p2, const int32_t* idx2, const void* p3, const int32_t* idx3, void* out,
                           int64_t N, int K, int M, int act, int dtype, mdlStream_t stream);

@@ -12,6 +12,7 @@ MDL_F32, MDL_BF16 = 0, 1
 MDL_SUM, MDL_MEAN, MDL_MAX = 0, 1, 2
 # execution flags OR-ed into the `dtype` argument (include/mdl_hip.h)
 MDL_DTYPE_MASK, MDL_DETERMINISTIC, MDL_K3_PER_WAVE, MDL_K3_EDGE_LANE = 0xFF, 0x100, 0x200, 0x400
+MDL_BN_UNSHIFTED = 0x800       # mdl_bn_apply_n: plain sums (written by mdl_linear_act_stats)
 REDUCE = {"sum": MDL_SUM, "add": MDL_SUM, "mean": MDL_MEAN, "max": MDL_MAX}
 
 _vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -59,6 +60,7 @@ PROTOTYPES = {
     "mdl_bn_bwd_apply": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _vp]),
     "mdl_linear_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_dense_bwd": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "mdl_linear_act_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mdl_linear_act_in": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_ssp_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "mdl_linear_gather_act": (_i32, [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp]),

@@ -40,11 +40,16 @@ struct GatherAdd {
 // is the one with x .* act'(y) (relu: y > 0, shifted softplus: 1 - exp(-(y + ln 2))) — the dX product of a fused
 // Linear + activation, with the activation derivative applied while the tile is staged, like gemm_tn.hip does for dW:
 // `threshold_backward` / the softplus backward never run as a pass over [N, K] of their own.
-template <int KP, int NT, int GATHER = 0, int XACT = 0>     // KP: K padded to {64, 128, 160, 256}; NT: 32-column tiles of the output (M <= 32*NT); GATHER: tables
+// STATS (mdl_linear_act_stats): the layer feeds a training-mode BatchNorm1d; the per-column sum and sum of squares of the
+// ROUNDED outputs are kept per thread over the grid-stride loop and added to one of the MDL_BN_REPLICAS copies of the
+// BatchNorm sums at the end, so the statistics pass over [N, M] (mdl_bn_stats) does not run.
+template <int KP, int NT, int GATHER = 0, int XACT = 0, bool STATS = false>     // KP: K padded to {64, 128, 160, 256}; NT: 32-column tiles of the output (M <= 32*NT); GATHER: tables
 __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
                                                             int64_t N, int K, int M, int act, GatherAdd ga,
-                                                            const bf16_t* __restrict__ xy, int ldo = 0) {
+                                                            const bf16_t* __restrict__ xy, int ldo = 0,
+                                                            float* __restrict__ stats = nullptr,
+                                                            const int64_t* __restrict__ n_dev = nullptr) {
     // mdl_linear_wide: blockIdx.x = block of 32*NT output columns of a wider layer (ldo = its full width, the leading dimension
     // of `out`), blockIdx.y = row chunk; every other caller has gridDim.y = 1, ldo = 0 (= M) and blockIdx.x = row chunk
     // (wide layers are launched with the COLUMN block as the fast grid dimension: the workgroups that run together then cover
@@ -131,6 +136,13 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
             return v;
         }
     };
+    float st0[STATS ? NB : 1], st1[STATS ? NB : 1];
+    int64_t n_true = N;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { st0[j] = 0.0f; st1[j] = 0.0f; }
+        if (n_dev) n_true = max((int64_t)1, min(*n_dev, N));
+    }
     int64_t tile = bx;
     if (tile < n_tiles) load_tile(tile);
     for (; tile < n_tiles; tile += gdx) {
@@ -222,9 +234,29 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
                                 const float l = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-LOG2E_F * fabsf(v)));
                                 v = fmaf(0.5f, v + fabsf(v), fmaf(LN2_F, l, -LN2_F));
                             }
-                            __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(v), os, vo + ((r & 3) + 8 * (r >> 2)) * ldo * 2, 0, 0);
+                            const bf16_t vb = f2bf(v);
+                            if constexpr (STATS) {
+                                const float vr = (nb + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < n_true) ? bf2f(vb) : 0.0f;
+                                st0[j] += vr;
+                                st1[j] = fmaf(vr, vr, st1[j]);
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b16((short)vb, os, vo + ((r & 3) + 8 * (r >> 2)) * ldo * 2, 0, 0);
                         }
                     }
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        if (ntb < NT) {
+            float* dst = stats + (size_t)(bx % MDL_BN_REPLICAS) * 2 * M;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int nt = ntb + 2 * j, col = nt * 32 + i;
+                const float t0 = st0[j] + __shfl_xor(st0[j], 32), t1 = st1[j] + __shfl_xor(st1[j], 32);
+                if (nt < NT && col < M && h == 0) {
+                    unsafeAtomicAdd(dst + col, t0);
+                    unsafeAtomicAdd(dst + M + col, t1);
                 }
             }
         }
@@ -244,7 +276,8 @@ extern "C" int mdl_linear_act(const void* x, const void* w, const void* bias, vo
 }
 
 static int linear_launch(const void* x, const void* xy, int xact, const void* w, const void* bias, const mdl::GatherAdd& ga,
-                         int gather, void* out, int64_t N, int K, int M, int act, mdlStream_t stream);
+                         int gather, void* out, int64_t N, int K, int M, int act, mdlStream_t stream, float* stats = nullptr,
+                         const int64_t* n_dev = nullptr);
 
 extern "C" int mdl_linear_act_in(const void* x, const void* y, int xact, const void* w, const void* bias, void* out, int64_t N,
                                  int K, int M, int act, int dtype, mdlStream_t stream) {
@@ -284,8 +317,31 @@ extern "C" int mdl_linear_gather_act(const void* x, const void* w, const void* b
     return linear_launch(x, nullptr, 0, w, bias, ga, gather, out, N, K, M, act, stream);
 }
 
+extern "C" int mdl_linear_act_stats(const void* x, const void* w, const void* bias, const void* p1, const int32_t* idx1,
+                                    const void* p2, const int32_t* idx2, const void* p3, const int32_t* idx3, void* out, int64_t N,
+                                    int K, int M, int act, float* bn_sums, const int64_t* n_dev, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_linear_act_stats: bf16 only");
+    MDL_REQUIRE(bn_sums, MDL_E_ARG, "mdl_linear_act_stats: needs the BatchNorm sums buffer");
+    MDL_REQUIRE((!p1 || idx1) && (!p2 || idx2) && (!p3 || idx3), MDL_E_ARG, "mdl_linear_act_stats: table without index");
+    GatherAdd ga = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    int gather = 0;
+    if (p1) { ga.p[gather] = (const bf16_t*)p1; ga.idx[gather++] = idx1; }
+    if (p2) { ga.p[gather] = (const bf16_t*)p2; ga.idx[gather++] = idx2; }
+    if (p3) { ga.p[gather] = (const bf16_t*)p3; ga.idx[gather++] = idx3; }
+    MDL_REQUIRE(K >= 4 && K <= 160 && K % 2 == 0 && M >= 34 && M <= 160 && M % 2 == 0 && (!gather || M <= 128), MDL_E_UNSUPP,
+                "mdl_linear_act_stats: need even 4<=K<=160 and even 34<=M<=160 (<=128 with tables) (got K=%d M=%d)", K, M);
+    MDL_REQUIRE(act >= 0 && act <= 2, MDL_E_ARG, "mdl_linear_act_stats: act must be 0 (none), 1 (relu) or 2 (shifted softplus)");
+    MDL_REQUIRE(N >= 0 && (N == 0 || (x && w && out)), MDL_E_ARG, "mdl_linear_act_stats: bad arguments");
+    MDL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(w) % 4 == 0 &&
+                reinterpret_cast<uintptr_t>(out) % 2 == 0, MDL_E_ARG, "mdl_linear_act_stats: misaligned pointer");
+    if (N == 0) return MDL_OK;
+    return linear_launch(x, nullptr, 0, w, bias, ga, gather, out, N, K, M, act, stream, bn_sums, n_dev);
+}
+
 static int linear_launch(const void* x, const void* xy, int xact, const void* w, const void* bias, const mdl::GatherAdd& ga,
-                         int gather, void* out, int64_t N, int K, int M, int act, mdlStream_t stream) {
+                         int gather, void* out, int64_t N, int K, int M, int act, mdlStream_t stream, float* stats,
+                         const int64_t* n_dev) {
     using namespace mdl;
     hipStream_t st = (hipStream_t)stream;
     const int kp = K <= 64 ? 64 : (K <= 128 ? 128 : (K <= 160 ? 160 : 256));
@@ -298,8 +354,31 @@ static int linear_launch(const void* x, const void* xy, int xact, const void* w,
         auto kf = linear_act_kernel<KP_, NT_, G_, X_>;                                                               \
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                           \
         hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
-                           (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, ga, (const bf16_t*)xy, 0);               \
+                           (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, ga, (const bf16_t*)xy, 0, (float*)nullptr, \
+                           (const int64_t*)nullptr);                                                                 \
     } while (0)
+#define MDL_LIN_S(KP_, NT_, G_)                                                                                      \
+    do {                                                                                                             \
+        auto kf = linear_act_kernel<KP_, NT_, G_, 0, true>;                                                          \
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                           \
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
+                           (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, ga, (const bf16_t*)xy, 0, stats, n_dev); \
+    } while (0)
+    if (stats) {
+        // (the statistics forms exist for the shapes of the one-pass dense backward: 34 <= M <= 160, K <= 160; 0 or 2 tables)
+        if (kp > 160 || nt < 2 || (gather != 0 && gather != 2) || (gather && nt > 4) || xact != 0) {
+            set_error("mdl_linear_act_stats: unsupported shape (K=%d M=%d tables=%d)", K, M, gather);
+            return MDL_E_UNSUPP;
+        }
+#define MDL_LIN_SK(KP_)                                                                                              \
+        do {                                                                                                         \
+            if (gather) { if (nt == 2) MDL_LIN_S(KP_, 2, 2); else MDL_LIN_S(KP_, 4, 2); }                             \
+            else { if (nt == 2) MDL_LIN_S(KP_, 2, 0); else if (nt == 4) MDL_LIN_S(KP_, 4, 0); else MDL_LIN_S(KP_, 5, 0); } \
+        } while (0)
+        if (kp == 64) MDL_LIN_SK(64); else if (kp == 128) MDL_LIN_SK(128); else MDL_LIN_SK(160);
+#undef MDL_LIN_SK
+        return check_launch("mdl_linear_act_stats");
+    }
 #define MDL_LIN(KP_, NT_)                                                                                            \
     do {                                                                                                             \
         constexpr int NG_ = (NT_ <= 4) ? 1 : 0;       /* (the gathering forms exist for M <= 128 only) */           \
@@ -316,6 +395,7 @@ static int linear_launch(const void* x, const void* xy, int xact, const void* w,
     else { if (nt == 1) MDL_LIN(256, 1); else if (nt == 2) MDL_LIN(256, 2); else MDL_LIN(256, 4); }
 #undef MDL_LIN
 #undef MDL_LIN_K
+#undef MDL_LIN_S
     return check_launch("mdl_linear_act");
 }
 
@@ -367,7 +447,7 @@ extern "C" int mdl_linear_wide(const void* x, const void* w, void* out, int64_t 
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                            \
         hipLaunchKernelGGL(kf, dim3(gy, (unsigned)gx), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x,         \
                            (const bf16_t*)w, (const bf16_t*)nullptr, (bf16_t*)out, N, K, (int)M, 0, ga,               \
-                           (const bf16_t*)nullptr, (int)M);                                                           \
+                           (const bf16_t*)nullptr, (int)M, (float*)nullptr, (const int64_t*)nullptr);                 \
     } while (0)
     if (kp == 64) MDL_WIDE(64); else if (kp == 128) MDL_WIDE(128); else MDL_WIDE(160);
 #undef MDL_WIDE

@@ -1427,24 +1427,33 @@ class _LinearReluBN(torch.autograd.Function):
         dt = dtype_code(x)
         y = torch.empty((N, M), dtype=x.dtype, device=x.device)
         tabs = [None if t is None else t.contiguous() for t in tables]
-        if tabs:
-            tb = tabs + [None] * (3 - len(tabs))
-            ids = list(idx) + [None] * (3 - len(idx))
+        tb = tabs + [None] * (3 - len(tabs))
+        ids = list(idx) + [None] * (3 - len(idx))
+        R = lib().mdl_bn_sums_rows()
+        buf = _zeros_step((R + 2, M), x.device)
+        sums, save = buf[:R], buf[R:]
+        nd = _true_rows_for(N)
+        # the statistics of the BatchNorm ride in the dense layer's epilogue (plain per-column sums of the rounded outputs) —
+        # except in deterministic mode, where the one-workgroup statistics kernel gives the run-to-run reproducible sums
+        in_epilogue = not _DET and len(tabs) in (0, 2) and K <= 160
+        if in_epilogue:
+            check(_launch_timed("edge_linear", lambda: lib().mdl_linear_act_stats(
+                ptr(x), ptr(w), ptr(b), ptr(tb[0]), ptr(ids[0]), ptr(tb[1]), ptr(ids[1]), ptr(tb[2]), ptr(ids[2]), ptr(y),
+                N, K, M, 1, ptr(sums), ptr(nd), dt, stream())), "mdl_linear_act_stats")
+        elif tabs:
             check(_launch_timed("edge_linear", lambda: lib().mdl_linear_gather_act(
                 ptr(x), ptr(w), ptr(b), ptr(tb[0]), ptr(ids[0]), ptr(tb[1]), ptr(ids[1]), ptr(tb[2]), ptr(ids[2]), ptr(y),
                 N, K, M, 1, dt, stream())), "mdl_linear_gather_act")
         else:
             check(lib().mdl_linear_act(ptr(x), ptr(w), ptr(b), ptr(y), N, K, M, 1, dt, stream()), "mdl_linear_act")
-        R = lib().mdl_bn_sums_rows()
-        buf = _zeros_step((R + 2, M), x.device)
-        sums, save = buf[:R], buf[R:]
         gw = None if bn_w is None else bn_w.detach().float().contiguous()
         gb = None if bn_b is None else bn_b.detach().float().contiguous()
         z = torch.empty_like(y)
-        nd = _true_rows_for(N)
-        check(lib().mdl_bn_stats_n(ptr(y), ptr(sums), N, M, ptr(nd), dt | _dflag(), stream()), "mdl_bn_stats")
+        if not in_epilogue:
+            check(lib().mdl_bn_stats_n(ptr(y), ptr(sums), N, M, ptr(nd), dt | _dflag(), stream()), "mdl_bn_stats")
         check(lib().mdl_bn_apply_n(ptr(y), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(rm), ptr(rv), ptr(z), N, M, float(eps),
-                                   float(momentum), ptr(nd), dt, stream()), "mdl_bn_apply")
+                                   float(momentum), ptr(nd), dt | (_lib.MDL_BN_UNSHIFTED if in_epilogue else 0), stream()),
+              "mdl_bn_apply")
         ctx.save_for_backward(x, w, y, save, gw)
         ctx.n_dev, ctx.idx, ctx.rows, ctx.ntab = nd, list(idx), [None if t is None else t.shape[0] for t in tabs], len(tabs)
         ctx.wdtype, ctx.has_bias, ctx.shape = weight.dtype, bias is not None, tuple(weight.shape)

@@ -746,12 +746,16 @@ def test_linear_relu_batchnorm_node_matches_torch_and_the_separate_layers(tables
 
     with ops.deterministic():
         fu, se = run(True), run(False)
+    fd = run(True)            # default mode: the BatchNorm statistics come out of the dense layer's epilogue (mdl_linear_act_stats)
     names = ["out", "dx", "dW", "db", "dgamma", "dbeta"] + ["dtab%d" % k for k in range(tables)] + ["running_mean", "running_var"]
     refs = [ref.detach(), xo.grad, Wo.grad, bo.grad, go_.grad, beo.grad] + [t.grad for t in leaves[5:]]
-    for nm, a, r_ in zip(names, fu, refs):                                          # (a)
-        scale = float(r_.abs().max())
-        err = float((a.float().cpu() - r_).abs().max())
-        assert err <= 5e-2 * max(scale, 0.1 * float(xo.grad.abs().max())), (nm, err, scale)
+    for res in (fu, fd):
+        for nm, a, r_ in zip(names, res, refs):                                     # (a)
+            scale = float(r_.abs().max())
+            err = float((a.float().cpu() - r_).abs().max())
+            assert err <= 5e-2 * max(scale, 0.1 * float(xo.grad.abs().max())), (nm, err, scale)
+    close(fd[-2], fu[-2], 1e-4, 1e-5)                                               # running statistics: epilogue sums vs statistics kernel
+    close(fd[-1], fu[-1], 1e-4, 1e-5)
     for nm, a, c in zip(names, fu, se):                                             # (b)
         if nm in ("out", "dx", "running_mean", "running_var"):
             assert torch.equal(a, c), nm
