@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
-from ..nn import BatchNorm1d, MetaLayer, Set2Set
+from ..nn import BatchNorm1d, MetaLayer, Set2Set, _seq
 from ._base import GraphModel, _lowp, dense, dense_act
 
 
@@ -110,17 +110,9 @@ def _embed(i, d):
 
 
 def _run_embed(seq, h):
-    """Sequential(Linear, ReLU, Linear, ReLU) (megnet.py:222-247) with each Linear + ReLU pair as one fused dense layer."""
-    mods = list(seq)
-    k = 0
-    while k < len(mods):
-        if isinstance(mods[k], nn.Linear) and k + 1 < len(mods) and isinstance(mods[k + 1], nn.ReLU):
-            h = dense_act(mods[k], h, "relu")
-            k += 2
-        else:
-            h = dense(mods[k], h) if isinstance(mods[k], nn.Linear) else mods[k](h)
-            k += 1
-    return h
+    """Sequential(Linear, ReLU, Linear, ReLU) (megnet.py:222-247) with each Linear + ReLU pair as one fused dense layer and
+    the first ReLU's derivative handed to the second layer's backward (nn._seq)."""
+    return _seq(seq, h)
 
 
 class _FusedMetaLayer(MetaLayer):

@@ -62,7 +62,7 @@ def lowp_copies(lin):
     return sh[0], sh[1]
 
 
-def _lin(lin, h, act=None):
+def _lin(lin, h, act=None, in_act=None, out_pre=False):
     """nn.Linear (+ activation) applied in the dtype of h (fp32 master weights, bf16 activations): the streaming HIP dense
     layer for bf16 rows, the library otherwise."""
     if h.dtype == lin.weight.dtype:
@@ -70,25 +70,45 @@ def _lin(lin, h, act=None):
         if act is None:
             return y
         return F.softplus(y) - math.log(2.0) if act == "ssp" else getattr(F, act)(y)
-    return ops.linear_act(h, lin.weight, lin.bias, act, lowp_copies(lin))
+    return ops.linear_act(h, lin.weight, lin.bias, act, lowp_copies(lin), in_act, out_pre)
 
 
 def _seq(seq, h):
-    """Sequential of Linear / activation modules; a Linear followed by ShiftedSoftplus / ReLU runs as ONE fused dense layer."""
+    """Sequential of Linear / activation modules; a Linear followed by ShiftedSoftplus / ReLU runs as ONE fused dense layer.
+    Between two fused layers of the chain the intermediate tensor is private to this function, so the activation derivative
+    is handed down the chain (ops._LinearActTN: the later layer's backward returns the gradient w.r.t. the earlier layer's
+    pre-activation, the earlier layer's backward reads neither its output nor applies a derivative)."""
     mods = list(seq)
-    k = 0
+    layers, k = [], 0                                   # (module, act) per step; act is None for non-Linear modules
     while k < len(mods):
         m = mods[k]
         if isinstance(m, nn.Linear):
-            def act_of(j):
-                a = mods[j] if j < len(mods) else None
-                return "ssp" if isinstance(a, ShiftedSoftplus) else ("relu" if isinstance(a, nn.ReLU) else None)
-            act = act_of(k + 1)
-            h = _lin(m, h, act)
+            a = mods[k + 1] if k + 1 < len(mods) else None
+            act = "ssp" if isinstance(a, ShiftedSoftplus) else ("relu" if isinstance(a, nn.ReLU) else None)
+            layers.append((m, act))
             k += 2 if act else 1
         else:
-            h = m(h)
+            layers.append((m, False))
             k += 1
+    handed = False                                      # the previous step was a fused layer told to expect a pre-activation gradient
+    for j, (m, act) in enumerate(layers):
+        if act is False:
+            h, handed = m(h), False
+            continue
+        nxt = layers[j + 1] if j + 1 < len(layers) else None
+        fused = h.dtype != m.weight.dtype and ops.linear_act_fused_ok(h, m.weight, act)
+        # hand this layer's derivative to the next one: both fused, this one activated, the next one a Linear on our output
+        give = (fused and act in ("relu", "ssp") and nxt is not None and nxt[1] is not False and torch.is_grad_enabled()
+                and nxt[0].weight.requires_grad and nxt[0].in_features == m.out_features
+                and ops._hip_shape_ok(nxt[0].out_features, nxt[0].in_features)
+                and (nxt[1] != "ssp" or nxt[0].out_features % 2 == 0) and h.shape[0] >= 1024)
+        prev_act = layers[j - 1][1] if handed else None
+        if fused:
+            h = _lin(m, h, act, in_act=prev_act, out_pre=give)
+        else:
+            assert not handed
+            h = _lin(m, h, act)
+        handed = give
     return h
 
 

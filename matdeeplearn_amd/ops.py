@@ -1063,10 +1063,15 @@ _LINEAR_WIDE = os.environ.get("MDL_LINEAR_WIDE", "1") != "0"   # NNConv's Y = x 
 
 class _LinearActTN(torch.autograd.Function):
     """act(x W^T + b) with the forward as ONE streaming HIP kernel (GEMM + bias + activation) and the backward of
-    _LinearTN (library dX, TN GEMM for dW and db); the ReLU mask comes from the saved output."""
+    _LinearTN (one-pass dense backward, or library dX + TN GEMM for dW and db); the ReLU mask comes from the saved output.
+
+    Chains of such layers whose intermediate outputs nobody else sees (nn._seq) hand the activation derivative DOWN the chain:
+    in_act = code of the activation that produced x (x is that layer's output): the input gradient is returned w.r.t. that
+    layer's PRE-activation (dx .* act'(x), from the x tile the backward stages anyway); out_pre: the gradient arriving here
+    already is w.r.t. this layer's pre-activation (the layer behind applied in_act), so no derivative, no read of the output."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w_lp, b_lp, act):
+    def forward(ctx, x, weight, bias, w_lp, b_lp, act, in_act=0, out_pre=False):
         w = weight.to(x.dtype) if w_lp is None else w_lp
         b = None if bias is None else (bias.to(x.dtype) if b_lp is None else b_lp)
         N, K = x.shape
@@ -1074,27 +1079,35 @@ class _LinearActTN(torch.autograd.Function):
         out = torch.empty((N, M), dtype=x.dtype, device=x.device)
         check(lib().mdl_linear_act(ptr(x), ptr(w), ptr(b), ptr(out), N, K, M, {"relu": 1, "ssp": 2}.get(act, 0), dtype_code(x),
                                    stream()), "mdl_linear_act")
-        ctx.save_for_backward(x, w, out if act in ("relu", "ssp") else None)
+        ctx.save_for_backward(x, w, out if act in ("relu", "ssp") and not out_pre else None)
         ctx.wdtype, ctx.has_bias, ctx.shape, ctx.act = weight.dtype, bias is not None, tuple(weight.shape), act
+        ctx.in_act, ctx.out_pre = int(in_act), bool(out_pre)
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, w, out = ctx.saved_tensors
-        code = {"relu": 1, "ssp": 2}.get(ctx.act, 0)
+        code = 0 if ctx.out_pre else {"relu": 1, "ssp": 2}.get(ctx.act, 0)
+        tail = (None, None, None, None, None)
         if _dense_bwd_ok(ctx, g, x, w, out if code else None):
-            return _dense_bwd(ctx, g, x, w, (code, out) if code else None) + (None, None, None)
-        if ctx.act in ("relu", "ssp") and _tn_act_ok(ctx, g, x, out, w):
-            return _linear_tn_grads(ctx, g, x, w, act_y=(1 if ctx.act == "relu" else 2, out)) + (None, None, None)
-        if ctx.act == "relu":
-            g = torch.ops.aten.threshold_backward(g, out, 0)
-        elif ctx.act == "ssp":                     # d/dv (softplus(v) - ln2) = sigmoid(v) = 1 - exp(-(out + ln2))
-            g = g.contiguous()
-            dpre = torch.empty_like(g)
-            check(lib().mdl_ssp_bwd(ptr(g), ptr(out), ptr(dpre), g.numel(), dtype_code(g), stream()), "mdl_ssp_bwd")
-            g = dpre
-        dx, dw, db = _linear_tn_grads(ctx, g.contiguous(), x, w)
-        return dx, dw, db, None, None, None
+            return _dense_bwd(ctx, g, x, w, (code, out) if code else None, xout=ctx.in_act) + tail
+        if code and _tn_act_ok(ctx, g, x, out, w):
+            dx, dw, db = _linear_tn_grads(ctx, g, x, w, act_y=(code, out))
+        else:
+            if code == 1:
+                g = torch.ops.aten.threshold_backward(g, out, 0)
+            elif code == 2:                            # d/dv (softplus(v) - ln2) = sigmoid(v) = 1 - exp(-(out + ln2))
+                g = g.contiguous()
+                dpre = torch.empty_like(g)
+                check(lib().mdl_ssp_bwd(ptr(g), ptr(out), ptr(dpre), g.numel(), dtype_code(g), stream()), "mdl_ssp_bwd")
+                g = dpre
+            dx, dw, db = _linear_tn_grads(ctx, g.contiguous(), x, w)
+        if dx is not None and ctx.in_act:              # the hand-over on the paths without the fused epilogue
+            if ctx.in_act == 1:
+                dx = torch.ops.aten.threshold_backward(dx, x, 0)
+            else:
+                dx = (dx.float() * (1.0 - torch.exp(-(x.float() + 0.6931471805599453)))).to(dx.dtype)
+        return (dx, dw, db) + tail
 
 
 class _LinearGatherAct(torch.autograd.Function):
@@ -1259,16 +1272,24 @@ def matmul_wide(x, w):
     return x @ w
 
 
-def linear_act(x, weight, bias, act, lowp=None):
-    """getattr(F, act)(F.linear(x, weight, bias)) — fused forward for bf16 inputs with dense rows, even in <= 256,
-    out <= 128 and act in (relu, ssp, none); anything else composes `linear` with the library activation."""
+def linear_act_fused_ok(x, weight, act):
+    """the fused dense layer (_LinearActTN) takes (x, weight, act)"""
     # (ssp: the one-pass softplus backward works on element PAIRS — an odd width would reach it with an odd element count)
-    if (act in ("relu", "ssp", None) and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
+    return (act in ("relu", "ssp", None) and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
             and x.shape[0] >= 1024 and _hip_shape_ok(weight.shape[0], weight.shape[1])
             and (act != "ssp" or weight.shape[0] % 2 == 0)
-            and x.data_ptr() % 16 == 0 and weight.requires_grad):
+            and x.data_ptr() % 16 == 0 and weight.requires_grad)
+
+
+def linear_act(x, weight, bias, act, lowp=None, in_act=None, out_pre=False):
+    """getattr(F, act)(F.linear(x, weight, bias)) — fused forward for bf16 inputs with dense rows, even in <= 256,
+    out <= 128 and act in (relu, ssp, none); anything else composes `linear` with the library activation.
+    in_act / out_pre: the activation hand-over of a private chain (see _LinearActTN; callers check linear_act_fused_ok for
+    both layers first)."""
+    if linear_act_fused_ok(x, weight, act):
         w_lp, b_lp = (lowp if lowp is not None and lowp[0].dtype == x.dtype else (None, None))
-        return _LinearActTN.apply(x, weight, bias, w_lp, b_lp, act)
+        return _LinearActTN.apply(x, weight, bias, w_lp, b_lp, act, {"relu": 1, "ssp": 2}.get(in_act, 0), out_pre)
+    assert not in_act and not out_pre, "linear_act: activation hand-over on a layer that is not fused"
     y = linear(x, weight, bias, lowp)
     if act is None:
         return y

@@ -805,6 +805,58 @@ def test_residual_scatter_node_matches_the_two_ops(dtype, reduce):
     close(fu[3], rf.grad, *tol)
 
 
+@pytest.mark.parametrize("x_grad", [False, True])
+def test_dense_chain_hands_the_activation_derivative_down(x_grad):
+    """nn._seq on Linear -> ShiftedSoftplus -> Linear -> ReLU -> Linear in bf16: between fused layers the later layer's backward
+    returns the gradient w.r.t. the earlier layer's pre-activation (mdl_dense_bwd's xout) and the earlier one applies no
+    derivative; output and all gradients against fp32 torch on bf16-rounded weights, with and without an input gradient
+    (SchNet's filter network has none)."""
+    from matdeeplearn_amd import nn as mnn, ops
+    d = dev()
+    torch.manual_seed(12)
+    N = 3001
+    seq = torch.nn.Sequential(torch.nn.Linear(50, 150), mnn.ShiftedSoftplus(), torch.nn.Linear(150, 150), torch.nn.ReLU(),
+                              torch.nn.Linear(150, 64))
+    with torch.no_grad():
+        for p_ in seq.parameters():
+            p_.copy_(p_.to(torch.bfloat16).float())
+    ref = [p_.detach().clone().requires_grad_(True) for p_ in seq.parameters()]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, 50, generator=g).to(torch.bfloat16).float()
+    gout = torch.randn(N, 64, generator=g)
+    xr = x.clone().requires_grad_(x_grad)
+    h = torch.nn.functional.softplus(torch.nn.functional.linear(xr, ref[0], ref[1])) - 0.6931471805599453
+    pre2 = torch.nn.functional.linear(h, ref[2], ref[3])
+    yr = torch.nn.functional.linear(torch.relu(pre2), ref[4], ref[5])
+    (yr * gout).sum().backward()
+    seq.to(d)
+
+    def run(handed):
+        for p_ in seq.parameters():
+            p_.grad = None
+        xd = x.to(d).to(torch.bfloat16).requires_grad_(x_grad)
+        if handed:
+            y = mnn._seq(seq, xd)
+        else:                                             # the same fused layers, every one applying its own derivative
+            h1 = ops.linear_act(xd, seq[0].weight, seq[0].bias, "ssp")
+            h2 = ops.linear_act(h1, seq[2].weight, seq[2].bias, "relu")
+            y = ops.linear_act(h2, seq[4].weight, seq[4].bias, None)
+        (y.float() * gout.to(d)).sum().backward()
+        return [y.detach()] + [p_.grad.clone() for p_ in seq.parameters()] + ([xd.grad] if x_grad else [])
+
+    ha, se = run(True), run(False)
+    refs = [yr.detach()] + [r.grad for r in ref] + ([xr.grad] if x_grad else [])
+    fro = lambda a, r: float((a.float().cpu() - r.float().cpu()).norm() / r.float().norm().clamp(min=1e-6))
+    assert ha[0].dtype == torch.bfloat16 and torch.equal(ha[0], se[0])
+    # against fp32 torch: relative Frobenius error — a pre-activation within bf16 rounding of the ReLU kink flips its mask (a
+    # fraction f of the elements, error ~ sqrt(f): a few per cent here), not a kernel property; against the chain without the
+    # hand-over (same forward, same masks) only the rounding of the intermediate gradients differs
+    for k, (a, r) in enumerate(zip(ha, refs)):
+        assert fro(a, r) <= 8e-2, (k, fro(a, r))
+    for k, (a, c) in enumerate(zip(ha, se)):
+        assert fro(a, c) <= 1e-2, (k, fro(a, c))
+
+
 @pytest.mark.parametrize("K", [300, 420])
 def test_wide_input_linear_takes_its_weight_gradient_from_two_tn_gemms(K):
     """ops.linear with 256 < in <= 512 (MEGNet's node block: 3 x 100 concatenated columns): library forward, dW as two
