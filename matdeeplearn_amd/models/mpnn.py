@@ -5,6 +5,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import ops
 from ..nn import NNConv
 from ._base import GraphModel
 
@@ -16,8 +17,13 @@ def gru_step(gru, x, h):
     fp32 GEMMs and tensor-op kernels — a third of the MPNN step; the parameters stay those of the nn.GRU module
     (state_dict keys gru_list.{i}.weight_ih_l0, ...)."""
     cd = x.dtype
-    gi = F.linear(x, gru.weight_ih_l0.to(cd), gru.bias_ih_l0.to(cd)).float()
-    gh = F.linear(h.to(cd), gru.weight_hh_l0.to(cd), gru.bias_hh_l0.to(cd)).float()
+    if cd == torch.bfloat16 and x.is_cuda:
+        # (ops.linear: the gate matrices' weight gradients — [3C, C] with the contraction over 6e4 rows — on the TN GEMM)
+        gi = ops.linear(x, gru.weight_ih_l0, gru.bias_ih_l0).float()
+        gh = ops.linear(h.to(cd), gru.weight_hh_l0, gru.bias_hh_l0).float()
+    else:
+        gi = F.linear(x, gru.weight_ih_l0.to(cd), gru.bias_ih_l0.to(cd)).float()
+        gh = F.linear(h.to(cd), gru.weight_hh_l0.to(cd), gru.bias_hh_l0.to(cd)).float()
     i_r, i_z, i_n = gi.chunk(3, dim=1)
     h_r, h_z, h_n = gh.chunk(3, dim=1)
     r = torch.sigmoid(i_r + h_r)

@@ -929,6 +929,13 @@ def _tn_split_ok(x, weight):
             and kh <= 256 and K - kh <= 256)
 
 
+def _tn_wide_out_ok(x, weight):
+    """dW of a Linear with MANY outputs and few inputs (the GRU's 3C x C gate matrices, mpnn.py:160-161) as TN GEMMs of the
+    TRANSPOSED product: dW^T[K, M] = x^T g in column chunks of <= 150 outputs (_linear_tn_grads)"""
+    M, K = weight.shape
+    return (160 < M <= 600 and M % 2 == 0 and 4 <= K <= 160 and K % 2 == 0 and x.stride(0) % 2 == 0 and x.data_ptr() % 4 == 0)
+
+
 def _hip_shape_ok(M, K):
     """(out, in) features the streaming dense kernels take: linear.hip forward and gemm_tn.hip weight gradient."""
     return 1 <= M <= 160 and 4 <= K <= 256 and K % 2 == 0 and (M <= 128 or (K <= 160 and M % 2 == 0))
@@ -1021,6 +1028,24 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
         dx = _dx_hip(g, w, act_y) if ctx.needs_input_grad[0] else None
         return dx, dw.to(ctx.wdtype), (dbv.to(ctx.wdtype) if ctx.has_bias else None)
     dx = _dx_hip(g, w) if ctx.needs_input_grad[0] else None
+    if M > 160:
+        # many outputs, few inputs: the transposed product dW^T = x^T g, one TN GEMM per chunk of <= 150 gradient columns
+        # (the library runs the (M x N)(N x K) form of this N ~ 6e4 contraction at 234 us for 300 x 100; this is 2 x ~15 us)
+        nch = -(-M // 150)
+        mc = ((M + nch - 1) // nch + 1) & ~1
+        buf = _zeros_grad(K * M, g.device)
+        parts, off = [], 0
+        for m0 in range(0, M, mc):
+            m1 = min(m0 + mc, M)
+            c = buf[off:off + K * (m1 - m0)].view(K, m1 - m0)
+            off += K * (m1 - m0)
+            gs = g[:, m0:m1]
+            check(lib().mdl_gemm_tn_colsum(ptr(x), x.stride(0), K, ptr(gs), g.stride(0), m1 - m0, ptr(c), None, g.shape[0],
+                                           dtype_code(g) | _dflag(), stream()), "mdl_gemm_tn_colsum")
+            parts.append(c)
+        dw = torch.cat(parts, dim=1).t()
+        db = g.sum(dim=0, dtype=torch.float32).to(ctx.wdtype) if ctx.has_bias else None
+        return dx, dw.to(ctx.wdtype), db
     if K > 256:
         # wide inputs (MEGNet's node block: [x | v_e | u[batch]] = 3d columns): the TN GEMM takes <= 256 input columns, so dW
         # is two products over column halves of x (the library's (M x N)(N x K) form runs this K = N ~ 1e5 contraction on 9
@@ -1302,7 +1327,7 @@ def linear(x, weight, bias, lowp=None):
     """F.linear in the dtype of x (fp32 master weights); bf16 inputs with many rows, out <= 128, in <= 256 take the
     HIP TN GEMM for dW, anything else the library autograd path.  `lowp` = (weight, bias) already cast to x.dtype."""
     if (x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] >= 1024
-            and (weight.shape[0] <= 128 or _hip_shape_ok(weight.shape[0], weight.shape[1]))
+            and (weight.shape[0] <= 128 or _hip_shape_ok(weight.shape[0], weight.shape[1]) or _tn_wide_out_ok(x, weight))
             and (weight.shape[1] <= 256 or _tn_split_ok(x, weight)) and weight.requires_grad):
         if lowp is not None and lowp[0].dtype == x.dtype:
             return _LinearTN.apply(x, weight, bias, lowp[0], lowp[1])

@@ -881,6 +881,30 @@ def test_wide_input_linear_takes_its_weight_gradient_from_two_tn_gemms(K):
     close(x.grad, xr.grad, 3e-2, 2e-2)
 
 
+@pytest.mark.parametrize("M,K", [(300, 100), (192, 64), (450, 150)])
+def test_wide_output_linear_takes_its_weight_gradient_from_transposed_tn_gemms(M, K):
+    """ops.linear with many outputs and few inputs (the GRU gate matrices of MPNN, [3C, C]): library forward and dX, dW as
+    TN GEMMs of the transposed product x^T g in column chunks; vs fp32 torch on the same bf16-rounded operands."""
+    from matdeeplearn_amd import ops
+    N = 5003
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev()).requires_grad_(True)
+    w = (torch.randn(M, K, generator=g) / K ** 0.5).to(dev()).requires_grad_(True)
+    b = (torch.randn(M, generator=g) * 0.1).to(dev()).requires_grad_(True)
+    go = torch.randn(N, M, generator=g).to(dev())
+    y = ops.linear(x, w, b)
+    (y.float() * go).sum().backward()
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = b.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr, wr, br)
+    (yr * go.to(torch.bfloat16).float()).sum().backward()
+    close(y, yr, 1e-2, 1e-2)
+    close(w.grad, wr.grad, 1e-3, 1e-3 * float(wr.grad.abs().max()))
+    close(b.grad, br.grad, 3e-2, 3e-2)
+    close(x.grad, xr.grad, 3e-2, 2e-2)
+
+
 @pytest.mark.parametrize("act", ["relu", "ssp"])
 def test_linear_act_without_input_grad(act):
     """A fused dense layer whose input needs no gradient (SchNet's filter network on the edge features): the backward
