@@ -695,25 +695,45 @@ def test_trial_checkpoints_carry_the_reference_names():
 
 def test_sequential_chains_fuse_each_dense_layer_with_its_activation(monkeypatch):
     """nn._seq: every Linear of a Sequential goes to ops.linear_act together with the activation module that follows it (one
-    fused dense layer per pair); other modules are applied as they are."""
+    fused dense layer per pair); other modules are applied as they are.  Between two layers that both run as fused dense
+    layers the activation derivative is handed down the chain: the earlier layer is told `out_pre` (its gradient arrives as a
+    pre-activation gradient), the later one `in_act` = the earlier layer's activation — and only then."""
     from matdeeplearn_amd import nn as mnn
     calls = []
 
-    def fake_linear_act(h, weight, bias, act, lowp=None):
-        calls.append((tuple(weight.shape), act))
+    def fake_linear_act(h, weight, bias, act, lowp=None, in_act=None, out_pre=False):
+        calls.append((tuple(weight.shape), act, in_act, out_pre))
         return torch.zeros(h.shape[0], weight.shape[0], dtype=h.dtype)
     monkeypatch.setattr(mnn.ops, "linear_act", fake_linear_act)
     h = torch.zeros(4, 6, dtype=torch.bfloat16)                       # bf16 rows, fp32 master weights: the ops path
     seq = torch.nn.Sequential(torch.nn.Linear(6, 10), mnn.ShiftedSoftplus(), torch.nn.Linear(10, 8))
-    mnn._seq(seq, h)
-    assert calls == [((10, 6), "ssp"), ((8, 10), None)]
+    mnn._seq(seq, h)                                                  # (CPU rows: no layer is fused, nothing is handed over)
+    assert calls == [((10, 6), "ssp", None, False), ((8, 10), None, None, False)]
     calls.clear()
-    seq = torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.ReLU(), torch.nn.Linear(10, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
-    mnn._seq(seq, h)
-    assert calls == [((10, 6), "relu"), ((8, 10), "relu"), ((3, 8), None)]
+    seq5 = torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.ReLU(), torch.nn.Linear(10, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    mnn._seq(seq5, h)
+    assert [c[:2] for c in calls] == [((10, 6), "relu"), ((8, 10), "relu"), ((3, 8), None)]
     calls.clear()
     mnn._seq(torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.Linear(10, 8)), h)
-    assert calls == [((10, 6), None), ((8, 10), None)]
+    assert [c[:2] for c in calls] == [((10, 6), None), ((8, 10), None)]
+    # every layer fused (as on bf16 device rows): ssp -> relu -> none chain of even widths, 2048 rows
+    calls.clear()
+    monkeypatch.setattr(mnn.ops, "linear_act_fused_ok", lambda x, w, act: True)
+    big = torch.zeros(2048, 50, dtype=torch.bfloat16)
+    chain = torch.nn.Sequential(torch.nn.Linear(50, 150), mnn.ShiftedSoftplus(), torch.nn.Linear(150, 150), torch.nn.ReLU(),
+                                torch.nn.Linear(150, 64))
+    mnn._seq(chain, big)
+    assert calls == [((150, 50), "ssp", None, True), ((150, 150), "relu", "ssp", True), ((64, 150), None, "relu", False)]
+    # a module between two Linears ends the hand-over; a last activated layer keeps its own derivative
+    calls.clear()
+    broken = torch.nn.Sequential(torch.nn.Linear(50, 150), torch.nn.ReLU(), torch.nn.Dropout(0.0), torch.nn.Linear(150, 64), torch.nn.ReLU())
+    mnn._seq(broken, big)
+    assert calls == [((150, 50), "relu", None, False), ((64, 150), "relu", None, False)]
+    # without autograd nothing is handed over
+    calls.clear()
+    with torch.no_grad():
+        mnn._seq(chain, big)
+    assert [c[2:] for c in calls] == [(None, False)] * 3
 
 
 def test_wide_matmul_falls_back_to_the_library_off_device():
