@@ -155,3 +155,20 @@ def test_bench_distributed_path_executes_on_one_gpu():
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["roofline"]["launches"] == 3 * 4
     ss = res["strong_scaling"]
     assert ss["value"] > 0 and ss["batch_graphs_per_gpu"] == 128 and ss["steps"] == 3
+
+
+def test_bench_under_the_driver_launcher_on_one_gpu():
+    """The command line the driver uses for N > 1 — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` — with N = 1 and MDL_FORCE_DIST=1: the launcher's environment (RANK,
+    LOCAL_RANK, WORLD_SIZE, MASTER_*) is what initialises the RCCL process group, and rank 0 prints the one JSON line."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MDL_FORCE_DIST="1")
+    env.pop("MASTER_PORT", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "1", "--graphs", "640", "--batch", "256",
+                        "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-extras"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 1 and res["steps"] == 3 and res["warmup"] == 2 and res["value"] > 0
+    assert res["config"]["parallelism"] == "dp1" and res["scaling"] == "weak"
