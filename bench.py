@@ -84,6 +84,8 @@ def parse():
                          "graphs per step): executes the N > 1 code path on a one-GPU box (tests)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="assemble every batch on the compute stream at the start of its step instead of one step ahead on a side stream")
+    ap.add_argument("--event-stride", type=int, default=0,
+                    help="HIP events around the roofline kernels on every n-th timed step (0 = 4 for >= 8 steps, else every step)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--dataset-cache", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "mdl_bench_data"),
                     help="directory for the flat on-disk copy of the synthetic dataset ('' = always regenerate)")
@@ -248,10 +250,19 @@ def main():
     barrier()
     t0 = time.perf_counter()
     edges = nodes = 0
+    # HIP events around the roofline kernels on every `ev_stride`-th timed step (every step for short runs): the event pairs are
+    # measurement overhead inside the timed region (a record in front of and behind each of the 8 conv launches costs the
+    # default run 35-55 us per step, measured with and without them on one box), so the default run pays it on a quarter of
+    # its steps; the roofline still comes from launches of the timed region (`roofline.launches`, `roofline.events`)
+    ev_stride = args.event_stride or (4 if args.steps >= 8 else 1)
+    ev_edges = ev_nodes = ev_steps = 0
     for i in range(args.warmup, total_steps):
-        e, n = step(step_ids[i], True, step_ids[i + 1] if i + 1 < total_steps else step_ids[0])
+        ev_on = (i - args.warmup) % ev_stride == 0
+        e, n = step(step_ids[i], ev_on, step_ids[i + 1] if i + 1 < total_steps else step_ids[0])
         edges += e
         nodes += n
+        if ev_on:
+            ev_edges, ev_nodes, ev_steps = ev_edges + e, ev_nodes + n, ev_steps + 1
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -295,28 +306,29 @@ def main():
     s = 2 if args.dtype == "bf16" else 4
     G = ds.num_edge_features
     e_step, n_step = edges / args.steps, nodes / args.steps
+    e_ev, n_ev = ev_edges / max(ev_steps, 1), ev_nodes / max(ev_steps, 1)       # per step, over the steps that carried events
     dur = {k: [a.elapsed_time(b) * 1e-3 for a, b in v] for k, v in ktimes.items()}   # seconds
     avg = {k: (sum(v) / len(v) if v else float("nan")) for k, v in dur.items()}
     tot = {k: sum(v) for k, v in dur.items()}
     if args.model == "cgcnn":
-        ab_fwd, ab_bwd = algorithmic_bytes(e_step, n_step, mkw["dim1"], G, s)
+        ab_fwd, ab_bwd = algorithmic_bytes(e_ev, n_ev, mkw["dim1"], G, s)
         ab = {"fwd": ab_fwd, "bwd": ab_bwd}
         kname = {"fwd": "mdl_cgconv_fwd", "bwd": "mdl_cgconv_bwd"}
     elif args.model == "schnet":                     # K4a (aggregation only): E(2 F s + 8) + N(F s + 4)   (csrc/gather.hip)
         F_ = mkw["dim3"]
-        ab = {"gmr_fwd": e_step * (2 * F_ * s + 8) + n_step * (F_ * s + 4)}
+        ab = {"gmr_fwd": e_ev * (2 * F_ * s + 8) + n_ev * (F_ * s + 4)}
         kname = {"gmr_fwd": "mdl_gather_mul_reduce"}
     elif args.model == "gcn":                        # K4a with a scalar edge weight: E(F s + 8) + N(F s + 4)
         F_ = mkw["dim1"]
-        ab = {"gmr_fwd": e_step * (F_ * s + 8) + n_step * (F_ * s + 4)}
+        ab = {"gmr_fwd": e_ev * (F_ * s + 8) + n_ev * (F_ * s + 4)}
         kname = {"gmr_fwd": "mdl_gather_mul_reduce"}
     elif args.model == "mpnn":                       # K7: N C d3 s (Y, read once per source node) + E (d3 + C) s   (csrc/nnconv.hip)
         C_, d3 = mkw["dim1"], mkw["dim3"]
-        ab = {"nnconv_fwd": n_step * C_ * d3 * s + e_step * (d3 + C_) * s}
+        ab = {"nnconv_fwd": n_ev * C_ * d3 * s + e_ev * (d3 + C_) * s}
         kname = {"nnconv_fwd": "mdl_nnconv_msg_fwd"}
     else:                                            # K6: E(d s [e in] + d s [out] + 3 d s [gathered rows] + 12)
         d = mkw["dim3"]
-        ab = {"edge_linear": e_step * (5 * d * s + 12)}
+        ab = {"edge_linear": e_ev * (5 * d * s + 12)}
         kname = {"edge_linear": "mdl_linear_gather_act"}
     have = [k for k in ab if dur.get(k)]
     dom = max(have, key=lambda k: tot[k]) if have else None
@@ -339,7 +351,7 @@ def main():
         if args.model == "cgcnn" and mkw["dim1"] == 64 and args.dtype == "bf16":
             for k in ("fwd", "bwd"):
                 if "mdl_cgconv_" + k in tj:
-                    traffic[k] = int(tj["mdl_cgconv_" + k]["bytes"] * e_step / tj["E"])
+                    traffic[k] = int(tj["mdl_cgconv_" + k]["bytes"] * e_ev / tj["E"])
     except (OSError, ValueError, KeyError):
         pass
 
@@ -349,6 +361,8 @@ def main():
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(k),
                 "traffic_source": traffic_src if traffic.get(k) is not None else None,
                 "avg_launch_us": round(avg[k] * 1e6, 2), "launches": len(dur[k]),
+                "events": "HIP event pairs on the launch stream, every %s timed step (%d of %d)"
+                          % ("" if ev_stride == 1 else "%d-th" % ev_stride, ev_steps, args.steps),
                 "algorithmic_bytes_per_launch": int(ab[k])}
 
     value = edges_all / elapsed_max
@@ -366,7 +380,7 @@ def main():
                                   args.dtype, gen_name, len(ds), B),
                    "batch_graphs_per_gpu": B, "edges_per_step_per_gpu": int(e_step), "nodes_per_step_per_gpu": int(n_step),
                    "parallelism": "dp%d" % world, "dataset_load_s": round(gen_s, 1), "dataset_source": data_src, "settle_steps": settle_steps,
-                   "conv_kernel_share_of_step": round(sum(tot.values()) / elapsed, 3)},
+                   "conv_kernel_share_of_step": round(sum(tot.values()) / max(ev_steps, 1) * args.steps / elapsed, 3)},
     }
     if strong is not None:
         res["strong_scaling"] = strong
