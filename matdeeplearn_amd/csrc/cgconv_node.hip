@@ -15,6 +15,10 @@
 #include "mdl_common.h"
 
 
+#ifndef MDL_K3C_NW
+#define MDL_K3C_NW 8        // waves per workgroup of the C = 64 node kernel (see the kernel's comment)
+#endif
+
 namespace mdl {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -35,8 +39,11 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 // the grid-stride loop, flushed once with fp32 atomics).
 // RS16: r_src arrives in bf16 as well (the edge pass accumulated it with packed bf16 atomics, mdl_cgconv_bwd_h): half the
 // bytes to read and to zero, no conversion.
-template <int CP, bool RS16 = false>
-__global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gout,
+// NW: waves per workgroup.  The kernel runs one workgroup per CU (its tiles and Wn^T take 77 KB of LDS at C = 64, and every
+// workgroup ends with 4Cp*C atomics on the same addresses), so 4 waves are ONE wave per SIMD; 8 waves split the staging and the
+// dWn blocks in half per wave and put two waves on every SIMD.
+template <int CP, bool RS16 = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void cgconv_node_stream_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gout,
                                                                     const bf16_t* __restrict__ r_tgt,
                                                                     const float* __restrict__ r_src,
                                                                     const bf16_t* __restrict__ wn_t, bf16_t* __restrict__ dx,
@@ -50,17 +57,19 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
     constexpr int NT = CP / 32;          // 32-wide feature tiles
     constexpr int TCH = 2 * CP / 8;      // 16-byte chunks per r_tgt row (8 bf16)
     constexpr int SCH = 2 * CP / 4;      // 16-byte chunks per r_src row (4 floats)
-    constexpr int NTL = TN * TCH / 256;  // r_tgt chunks per thread: 4 (CP 64) / 2 (CP 32)
-    constexpr int NSL = RS16 ? NTL : TN * SCH / 256;  // r_src chunks per thread: 8 / 4 (fp32), like r_tgt when it is bf16
+    constexpr int NTH = 64 * NW;         // threads
+    constexpr int NTL = TN * TCH / NTH;  // r_tgt chunks per thread: 4 (CP 64) / 2 (CP 32) with 4 waves
+    constexpr int NSL = RS16 ? NTL : TN * SCH / NTH;  // r_src chunks per thread: 8 / 4 (fp32), like r_tgt when it is bf16
     constexpr int XCH = CP / 8;          // 16-byte chunks per x row
-    constexpr int NXL = TN * XCH / 256;  // x chunks per thread: 2 / 1
-    constexpr int MJ = (K4 / 32) * NT / 4;   // (32-row, 32-col) dWn blocks per wave: 4 / 1
+    constexpr int NXL = TN * XCH / NTH;  // x chunks per thread: 2 / 1
+    constexpr int MJ = (K4 / 32) * NT / NW;  // (32-row, 32-col) dWn blocks per wave: 4 / 1
+    static_assert(NTL >= 1 && NSL >= 1 && NXL >= 1 && MJ >= 1, "too many waves for this width");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* wl = reinterpret_cast<bf16_t*>(smem);                    // Wn^T  [CP][LD]
     bf16_t* rl = wl + CP * LD;                                       // R tile [TN][LD]  (columns: r_tgt | r_src)
     bf16_t* xl = rl + TN * LD;                                       // x tile [TN][LX]
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int q = tid; q < CP * (K4 / 8); q += 256) {
+    for (int q = tid; q < CP * (K4 / 8); q += NTH) {
         const int row = q / (K4 / 8), c8 = q - row * (K4 / 8);
         *reinterpret_cast<bf16x8*>(wl + row * LD + c8 * 8) = *reinterpret_cast<const bf16x8*>(wn_t + row * K4 + c8 * 8);
     }
@@ -76,8 +85,8 @@ __global__ __launch_bounds__(256, 2) void cgconv_node_stream_kernel(const bf16_t
     u32x4_t xreg[NXL];
     // thread -> chunk mapping: chunk c = l*256 + tid; the chunk counts per row divide 256, so the row advances by a
     // constant per l
-    static_assert(256 % TCH == 0 && 256 % SCH == 0 && 256 % XCH == 0, "chunk mapping");
-    constexpr int TROWS = 256 / TCH, SROWS = 256 / SCH, XROWS = 256 / XCH;     // rows covered by one load of the workgroup
+    static_assert(NTH % TCH == 0 && NTH % SCH == 0 && NTH % XCH == 0, "chunk mapping");
+    constexpr int TROWS = NTH / TCH, SROWS = NTH / SCH, XROWS = NTH / XCH;     // rows covered by one load of the workgroup
     const int trow0 = tid / TCH, tcc = tid % TCH, srow0 = tid / SCH, scc = tid % SCH, xrow0 = tid / XCH, xcc = tid % XCH;
     // Buffer loads: the tile base is uniform (a fresh resource per tile, so any N works), each thread keeps ONE 32-bit
     // byte offset per array plus a constant per-l row stride in the same VOFFSET expression (the range check covers
@@ -293,9 +302,9 @@ static int bwd_node_launch(const void* x, const void* grad_out, const void* r_tg
                                           // (measured 128 / 256 / 512 / 1024 blocks: 70 / 56 / 67 / 97 us)
     if (C == 64) {
         const int lds = (64 * (256 + 8) + 64 * (256 + 8) + 64 * (64 + 8)) * 2;
-        auto kf = rs16 ? cgconv_node_stream_kernel<64, true> : cgconv_node_stream_kernel<64, false>;
+        auto kf = rs16 ? cgconv_node_stream_kernel<64, true, MDL_K3C_NW> : cgconv_node_stream_kernel<64, false, MDL_K3C_NW>;
         set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
-        hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
+        hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(64 * MDL_K3C_NW), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
                            (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N, zero_src);
     } else {
         const int lds = (32 * (128 + 8) + 64 * (128 + 8) + 64 * (32 + 8)) * 2;

@@ -12,6 +12,10 @@
 #include "mdl_common.h"
 #include <cstdlib>
 
+// waves per workgroup of the streaming kernel's weight-gradient forms: 8 for the shapes with a 5-tile side (register-allocated
+// for one workgroup per CU: 150 x 150 on 1.5e6 rows 258 -> 233 us, 150 x 50 128 -> 125), 4 otherwise (100 x 100: 136 vs 144 us)
+#define MDL_TN_NW(MT_, NT_) (((MT_) > 4 || (NT_) > 4) ? 8 : 4)
+
 namespace mdl {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_g;
@@ -124,11 +128,11 @@ extern "C" int mdl_gemm_tn_act(const void* a, int64_t lda, int M, const void* y,
             if (sgrid > grid_cap) sgrid = grid_cap;
 #define MDL_TNS(MT_, NT_)                                                                                                   \
     do {                                                                                                                    \
-        if (act == 0) hipLaunchKernelGGL((gemm_tn_stream_kernel<MT_, NT_, 0>), dim3((unsigned)sgrid), dim3(256), 0, st,      \
+        if (act == 0) hipLaunchKernelGGL((gemm_tn_stream_kernel<MT_, NT_, 0, false, MDL_TN_NW(MT_, NT_)>), dim3((unsigned)sgrid), dim3(64 * MDL_TN_NW(MT_, NT_)), 0, st,      \
             (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, colsum, N, (const bf16_t*)nullptr, 0);          \
-        else if (act == 1) hipLaunchKernelGGL((gemm_tn_stream_kernel<MT_, NT_, 1>), dim3((unsigned)sgrid), dim3(256), 0, st, \
+        else if (act == 1) hipLaunchKernelGGL((gemm_tn_stream_kernel<MT_, NT_, 1, false, MDL_TN_NW(MT_, NT_)>), dim3((unsigned)sgrid), dim3(64 * MDL_TN_NW(MT_, NT_)), 0, st, \
             (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, colsum, N, (const bf16_t*)y, (int)ldy);         \
-        else hipLaunchKernelGGL((gemm_tn_stream_kernel<MT_, NT_, 2>), dim3((unsigned)sgrid), dim3(256), 0, st,               \
+        else hipLaunchKernelGGL((gemm_tn_stream_kernel<MT_, NT_, 2, false, MDL_TN_NW(MT_, NT_)>), dim3((unsigned)sgrid), dim3(64 * MDL_TN_NW(MT_, NT_)), 0, st,               \
             (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, colsum, N, (const bf16_t*)y, (int)ldy);         \
     } while (0)
             if (mt == 1) { if (nt == 1) MDL_TNS(1, 1); else if (nt == 2) MDL_TNS(1, 2); else if (nt == 4) MDL_TNS(1, 4); else MDL_TNS(1, 5); }
