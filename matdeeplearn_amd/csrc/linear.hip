@@ -20,6 +20,11 @@
 #ifndef MDL_LIN_GRID
 #define MDL_LIN_GRID 512        // workgroups of a launch (2 per CU)
 #endif
+// waves per workgroup: 8 (each wave stages 8 rows of the 64-row tile and owns half as many output blocks; two workgroups
+// still share a CU) except for KP = 160, whose 75 KB of LDS and wider rows leave the 8-wave form one workgroup per CU
+// (1.5e6 rows, tools/bench_dense.py: 100 -> 100 137 -> 124 us, 114 -> 64 109 -> 98, 50 -> 150 209 -> 190, the wide layer of
+// MPNN -8 %; 150 -> 150 217 -> 263 us)
+#define MDL_LIN_NW(KP_) ((KP_) == 160 ? 4 : 8)
 
 namespace mdl {
 
@@ -44,7 +49,7 @@ struct GatherAdd {
 // ROUNDED outputs are kept per thread over the grid-stride loop and added to one of the MDL_BN_REPLICAS copies of the
 // BatchNorm sums at the end, so the statistics pass over [N, M] (mdl_bn_stats) does not run.
 template <int KP, int NT, int GATHER = 0, int XACT = 0, bool STATS = false>     // KP: K padded to {64, 128, 160, 256}; NT: 32-column tiles of the output (M <= 32*NT); GATHER: tables
-__global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(64 * MDL_LIN_NW(KP), 2) void linear_act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
                                                             int64_t N, int K, int M, int act, GatherAdd ga,
                                                             const bf16_t* __restrict__ xy, int ldo = 0,
@@ -66,7 +71,8 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
     if (ldo == 0) ldo = M;
     constexpr int TN = 64;
     constexpr int LD = KP + 8;                       // LDS row stride (bf16): odd number of 16-byte slots
-    constexpr int NB = (NT + 1) / 2;                 // output blocks per wave: block row wv & 1, block columns (wv >> 1) + 2j
+    constexpr int NW = MDL_LIN_NW(KP), XS = NW / 2, RPW = 64 / NW, NTH = 64 * NW;
+    constexpr int NB = (NT + XS - 1) / XS;           // output blocks per wave: block row wv & 1, block columns (wv >> 1) + XS j
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* wl = reinterpret_cast<bf16_t*>(smem);    // [32*NT][LD]
     bf16_t* xl = wl + 32 * NT * LD;                  // [TN][LD]
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
     const int k2 = K >> 1;                           // dwords per row
 
     // W -> LDS, zero padded to [32*NT][KP]
-    for (int q = tid; q < 32 * NT * (KP / 2); q += 256) {
+    for (int q = tid; q < 32 * NT * (KP / 2); q += NTH) {
         const int row = q / (KP / 2), d = q - row * (KP / 2);
         unsigned v = 0u;
         if (row < M && d < k2) v = *reinterpret_cast<const unsigned*>(w + (int64_t)row * K + 2 * d);
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
     float bv[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int col = (ntb + 2 * j) * 32 + i;
+        const int col = (ntb + XS * j) * 32 + i;
         bv[j] = (bias && col < M) ? bf2f(bias[col]) : 0.0f;
     }
 
@@ -93,9 +99,9 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
     // the VGPR offset (range checked): rows past N and columns K..KP-1 read as zeros, so the padding columns of the LDS
     // tile are rewritten with zeros by every tile and nothing needs a clamp.  (The previous version fetched the tile as
     // flat 16-byte chunks and split every dword into (row, column) with a multiply-high: ~8 VALU per dword.)
-    constexpr int DW = KP / 2, Q = DW / 64, R = DW % 64, NR = R ? 16 * R / 64 : 0, NLX = 16 * Q + NR;
+    constexpr int DW = KP / 2, Q = DW / 64, R = DW % 64, NR = R ? RPW * R / 64 : 0, NLX = RPW * Q + NR;
     constexpr unsigned FAR = 0x40000000u;
-    const int w16 = 16 * wv;
+    const int w16 = RPW * wv;
     const unsigned xrow = (unsigned)K * 2u;          // dense rows
     const int64_t n_tiles = (N + TN - 1) / TN;
     unsigned xr[NLX], yr[XACT ? NLX : 1];
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>((XACT ? xy : x) + nb * (int64_t)K), 0,
                                                                             (int)(bytes < cap ? bytes : cap), 0x00020000);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+        for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int j = 0; j < Q; ++j) {
                 const int d = lane + 64 * j;
@@ -120,8 +126,8 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
                 const unsigned off = (d < k2) ? (unsigned)(w16 + k * (64 / R) + rr) * xrow + 4u * d : FAR;
-                xr[16 * Q + k] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
-                if constexpr (XACT != 0) yr[16 * Q + k] = __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0);
+                xr[RPW * Q + k] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+                if constexpr (XACT != 0) yr[RPW * Q + k] = __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0);
             }
         }
     };
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
         }
         __syncthreads();                                    // previous tile's fragments read; W in place
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+        for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int j = 0; j < Q; ++j)
                 *reinterpret_cast<unsigned*>(xl + (w16 + r) * LD + 2 * (lane + 64 * j)) = xfix(xr[r * Q + j], yr[XACT ? r * Q + j : 0]);
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
 #pragma unroll
             for (int k = 0; k < NR; ++k)
                 *reinterpret_cast<unsigned*>(xl + (w16 + k * (64 / R) + lane / R) * LD + 2 * (64 * Q + lane % R)) =
-                    xfix(xr[16 * Q + k], yr[XACT ? 16 * Q + k : 0]);
+                    xfix(xr[RPW * Q + k], yr[XACT ? RPW * Q + k : 0]);
         }
         __syncthreads();
         if (tile + gdx < n_tiles) load_tile(tile + gdx);      // next tile's loads fly during the MFMAs
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(xl + (mt * 32 + i) * LD + 16 * kk + 8 * h);
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    const int nt = min(ntb + 2 * j, NT - 1);              // (a block column past NT repeats the last one — no
+                    const int nt = min(ntb + XS * j, NT - 1);              // (a block column past NT repeats the last one — no
                     const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + (nt * 32 + i) * LD + 16 * kk + 8 * h);   // branch in the
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);                       // MFMA chain — and is not stored)
                 }
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
                 // the store's range check): all table loads of a block column go out before the first add
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    const int colc = min(min(ntb + 2 * j, NT - 1) * 32 + i, M - 1);
+                    const int colc = min(min(ntb + XS * j, NT - 1) * 32 + i, M - 1);
                     float gv[GATHER][16];
 #pragma unroll
                     for (int t = 0; t < GATHER; ++t) {
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const int nt = ntb + 2 * j, col = nt * 32 + i;
+                const int nt = ntb + XS * j, col = nt * 32 + i;
                 if (nt < NT) {
                     if (col < M && remr > 0) {
                         // (range = up to the end of this block row's last existing row; with column blocks the rows are ldo wide)
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(const bf16_t* __rest
             float* dst = stats + (size_t)(bx % MDL_BN_REPLICAS) * 2 * M;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const int nt = ntb + 2 * j, col = nt * 32 + i;
+                const int nt = ntb + XS * j, col = nt * 32 + i;
                 const float t0 = st0[j] + __shfl_xor(st0[j], 32), t1 = st1[j] + __shfl_xor(st1[j], 32);
                 if (nt < NT && col < M && h == 0) {
                     unsafeAtomicAdd(dst + col, t0);
@@ -353,7 +359,7 @@ static int linear_launch(const void* x, const void* xy, int xact, const void* w,
     do {                                                                                                             \
         auto kf = linear_act_kernel<KP_, NT_, G_, X_>;                                                               \
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                           \
-        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * MDL_LIN_NW(KP_)), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
                            (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, ga, (const bf16_t*)xy, 0, (float*)nullptr, \
                            (const int64_t*)nullptr);                                                                 \
     } while (0)
@@ -361,7 +367,7 @@ static int linear_launch(const void* x, const void* xy, int xact, const void* w,
     do {                                                                                                             \
         auto kf = linear_act_kernel<KP_, NT_, G_, 0, true>;                                                          \
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                           \
-        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * MDL_LIN_NW(KP_)), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
                            (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, ga, (const bf16_t*)xy, 0, stats, n_dev); \
     } while (0)
     if (stats) {
@@ -445,7 +451,7 @@ extern "C" int mdl_linear_wide(const void* x, const void* w, void* out, int64_t 
     do {                                                                                                              \
         auto kf = linear_act_kernel<KP_, 5, 0, 0>;                                                                \
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                            \
-        hipLaunchKernelGGL(kf, dim3(gy, (unsigned)gx), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x,         \
+        hipLaunchKernelGGL(kf, dim3(gy, (unsigned)gx), dim3(64 * MDL_LIN_NW(KP_)), lds, (hipStream_t)stream, (const bf16_t*)x,         \
                            (const bf16_t*)w, (const bf16_t*)nullptr, (bf16_t*)out, N, K, (int)M, 0, ga,               \
                            (const bf16_t*)nullptr, (int)M, (float*)nullptr, (const int64_t*)nullptr);                 \
     } while (0)
