@@ -256,10 +256,13 @@ struct NmRows {
 __global__ __launch_bounds__(256, 2) void nnconv_msg_fwd_mfma_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ h,
                                                                      const int32_t* __restrict__ rowptr_s,
                                                                      const int32_t* __restrict__ eid_s, bf16_t* __restrict__ m,
-                                                                     int Co, int D3, unsigned w2_inv, int flat) {
+                                                                     int Co, int D3, unsigned w2_inv, int flat, int yrows) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
-    bf16_t* Ys = reinterpret_cast<bf16_t*>(smem_c);          // [128][LD]
-    bf16_t* Hs = Ys + 128 * NM_LD;                            // [32][LD]
+    // yrows: rows of the Y_j tile that are allocated — 128, or (flat staging) only the Co rows that exist: the fragments of the
+    // last 32-column block then run over into the tiles behind (finite garbage in output columns >= Co, which are not stored),
+    // and 36 KB instead of 44 KB of LDS let four workgroups share a CU instead of three
+    bf16_t* Ys = reinterpret_cast<bf16_t*>(smem_c);          // [yrows][LD]
+    bf16_t* Hs = Ys + yrows * NM_LD;                          // [32][LD]
     int* ids = reinterpret_cast<int*>(Hs + 32 * NM_LD);       // [32]
     const int j = blockIdx.x;
     const int b = rowptr_s[j], e = rowptr_s[j + 1];
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void nnconv_msg_fwd_mfma_kernel(const bf16_
         NmRows hr;
         hr.issue(h, ids, D3, wv, lane);
         if (c0 == b) {
-            if (flat) yf.commit(Yj, Co, D3, w2_inv, Ys, 128, 16 * KS, tid);
+            if (flat) yf.commit(Yj, Co, D3, w2_inv, Ys, yrows, 16 * KS, tid);
             else nm_stage_dense(Yj, Co, D3, Ys, 128, wv, lane);
         }
         hr.commit(Hs, wv, lane);
@@ -444,14 +447,19 @@ extern "C" int mdl_nnconv_msg_fwd(const void* Y, const void* h, const int32_t* r
     MDL_REQUIRE(Y && h && rowptr_s && m, MDL_E_ARG, "mdl_nnconv_msg_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (nm_ok(Co, D3, dtype, Y, h) && reinterpret_cast<uintptr_t>(m) % 2 == 0) {
-        const int lds_m = (128 + 32) * NM_LD * 2 + 32 * 4;
         auto kf = nnconv_msg_fwd_mfma_kernel;
-        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds_m);
         // flat staging of Y_j: every node's block must start on a 16-byte boundary and fit the per-thread chunk budget
         const int flat = (((int64_t)Co * D3 * 2) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 && Co * D3 <= 256 * 7 * 8) ? 1 : 0;
+#ifndef MDL_K7_YROWS_FULL
+        const int yrows = flat ? Co : 128;
+#else
+        const int yrows = 128;
+#endif
+        const int lds_m = (yrows + 32) * NM_LD * 2 + 32 * 4;
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), (128 + 32) * NM_LD * 2 + 32 * 4);
         const unsigned w2_inv = (unsigned)((0x100000000ull + (D3 / 2) - 1) / (D3 / 2));
         hipLaunchKernelGGL(kf, dim3((unsigned)N), dim3(256), lds_m, st, (const bf16_t*)Y, (const bf16_t*)h, rowptr_s, eid_s, (bf16_t*)m, Co, D3,
-                           w2_inv, flat);
+                           w2_inv, flat, yrows);
         return check_launch("mdl_nnconv_msg_fwd");
     }
     const int lds = (Co * (D3 + 1) + D3) * 4;
