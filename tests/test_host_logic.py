@@ -736,6 +736,29 @@ def test_sequential_chains_fuse_each_dense_layer_with_its_activation(monkeypatch
     assert [c[2:] for c in calls] == [(None, False)] * 3
 
 
+def test_dense_layer_dispatch_predicates():
+    """The shape / dtype predicates that route a dense layer to the fused HIP forms (pure host logic): the one-pass backward
+    takes even widths in [34, 160]; the Linear -> ReLU -> BatchNorm node additionally wants bf16 device rows with a gradient;
+    the transposed TN path takes many-output / few-input Linears (the GRU gate matrices); nothing of this applies to CPU rows."""
+    from matdeeplearn_amd import ops
+
+    class Ctx:
+        def __init__(self, M, K, bias=True, need=True):
+            self.shape, self.has_bias, self.needs_input_grad = (M, K), bias, (need,)
+    g = torch.zeros(2048, 100, dtype=torch.bfloat16)
+    x = torch.zeros(2048, 100, dtype=torch.bfloat16)
+    w = torch.zeros(100, 100, dtype=torch.bfloat16)
+    assert not ops._dense_bwd_ok(Ctx(100, 100), g, x, w)                          # CPU tensors: never
+    w300 = torch.zeros(300, 100)
+    assert ops._tn_wide_out_ok(x, w300) and not ops._tn_wide_out_ok(x, torch.zeros(100, 100))
+    assert not ops._tn_wide_out_ok(x, torch.zeros(300, 200)) and not ops._tn_wide_out_ok(x, torch.zeros(301, 100))
+    xr = torch.zeros(2048, 100, dtype=torch.bfloat16, requires_grad=True)
+    wp = torch.zeros(100, 100, requires_grad=True)
+    assert not ops.linear_relu_bn_ok(xr, wp, True)                                # CPU rows
+    assert not ops.linear_act_fused_ok(xr, wp, "relu")
+    assert ops._hip_shape_ok(150, 150) and ops._hip_shape_ok(128, 256) and not ops._hip_shape_ok(150, 200) and not ops._hip_shape_ok(64, 51)
+
+
 def test_wide_matmul_falls_back_to_the_library_off_device():
     """ops.matmul_wide only takes the streaming kernel for bf16 rows on a HIP device; anything else is `x @ w`."""
     from matdeeplearn_amd import ops
