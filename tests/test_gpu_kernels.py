@@ -805,18 +805,20 @@ def test_residual_scatter_node_matches_the_two_ops(dtype, reduce):
     close(fu[3], rf.grad, *tol)
 
 
+@pytest.mark.parametrize("mid", [150, 160])
 @pytest.mark.parametrize("x_grad", [False, True])
-def test_dense_chain_hands_the_activation_derivative_down(x_grad):
+def test_dense_chain_hands_the_activation_derivative_down(x_grad, mid):
     """nn._seq on Linear -> ShiftedSoftplus -> Linear -> ReLU -> Linear in bf16: between fused layers the later layer's backward
     returns the gradient w.r.t. the earlier layer's pre-activation (mdl_dense_bwd's xout) and the earlier one applies no
     derivative; output and all gradients against fp32 torch on bf16-rounded weights, with and without an input gradient
-    (SchNet's filter network has none)."""
+    (SchNet's filter network has none).  mid = 160: with its bias column the second layer's input is one column wider than the one-pass backward takes, so
+    the hand-over runs on the fallback path (streaming dX kernel + TN GEMM, the derivative applied to dX afterwards)."""
     from matdeeplearn_amd import nn as mnn, ops
     d = dev()
     torch.manual_seed(12)
     N = 3001
-    seq = torch.nn.Sequential(torch.nn.Linear(50, 150), mnn.ShiftedSoftplus(), torch.nn.Linear(150, 150), torch.nn.ReLU(),
-                              torch.nn.Linear(150, 64))
+    seq = torch.nn.Sequential(torch.nn.Linear(50, mid), mnn.ShiftedSoftplus(), torch.nn.Linear(mid, 150 if mid == 150 else 128), torch.nn.ReLU(),
+                              torch.nn.Linear(150 if mid == 150 else 128, 64))
     with torch.no_grad():
         for p_ in seq.parameters():
             p_.copy_(p_.to(torch.bfloat16).float())
