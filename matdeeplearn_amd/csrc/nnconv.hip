@@ -131,6 +131,9 @@ __global__ __launch_bounds__(256) void nnconv_msg_bwd_kernel(const T* __restrict
 #ifndef MDL_K7_BWD_WGS
 #define MDL_K7_BWD_WGS 2     // workgroups per CU the backward is register-allocated for (LDS allows 3)
 #endif
+#ifndef MDL_K7_BWD_SMALLC
+#define MDL_K7_BWD_SMALLC 5  // chunks per thread of the small-block form (see mdl_nnconv_msg_bwd)
+#endif
 constexpr int NM_KP = 128, NM_LD = NM_KP + 8;
 typedef __attribute__((ext_vector_type(4))) short nm_s16x4;
 typedef __attribute__((address_space(3))) nm_s16x4* nm_lds4_t;
@@ -307,7 +310,8 @@ __global__ __launch_bounds__(256, 2) void nnconv_msg_fwd_mfma_kernel(const bf16_
     }
 }
 
-__global__ __launch_bounds__(256, MDL_K7_BWD_WGS) void nnconv_msg_bwd_mfma_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ h,
+template <int MAXC>      // 16-byte chunks of Y_j per thread (5 covers 100 x 100, 7 the largest block: 128 x 112)
+__global__ __launch_bounds__(256, MAXC <= 5 ? 3 : MDL_K7_BWD_WGS) void nnconv_msg_bwd_mfma_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ h,
                                                                      const bf16_t* __restrict__ dm,
                                                                      const int32_t* __restrict__ rowptr_s,
                                                                      const int32_t* __restrict__ eid_s, bf16_t* __restrict__ dh,
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256, MDL_K7_BWD_WGS) void nnconv_msg_bwd_mfma_kerne
     const bf16_t* const Yj = Y + (int64_t)j * Co * D3;
     int my_id = -1;
     if (tid < 32) my_id = tid < min(32, e - b) ? (eid_s ? eid_s[b + tid] : b + tid) : -1;
-    NmFlat<7> yf;
+    NmFlat<MAXC> yf;
     if (flat) yf.issue(Yj, Co, D3, tid);
     f32x16 accY[4];                                           // wave wv: rows o = 32 wv + ..., column tiles kt = 0..3
 #pragma unroll
@@ -486,13 +490,22 @@ extern "C" int mdl_nnconv_msg_bwd(const void* Y, const void* h, const void* dm, 
     hipStream_t st = (hipStream_t)stream;
     if (nm_ok(Co, D3, dtype, Y, h) && reinterpret_cast<uintptr_t>(dm) % 4 == 0 && reinterpret_cast<uintptr_t>(dY) % 4 == 0) {
         const int lds_m = (128 + 64) * NM_LD * 2 + 32 * 4;
-        auto kf = nnconv_msg_bwd_mfma_kernel;
-        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds_m);
         const int flat = (((int64_t)Co * D3 * 2) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 &&
                           reinterpret_cast<uintptr_t>(dY) % 16 == 0 && Co * D3 <= 256 * 7 * 8) ? 1 : 0;
         const unsigned w2_inv = (unsigned)((0x100000000ull + (D3 / 2) - 1) / (D3 / 2));
-        hipLaunchKernelGGL(kf, dim3((unsigned)N), dim3(256), lds_m, st, (const bf16_t*)Y, (const bf16_t*)h, (const bf16_t*)dm, rowptr_s, eid_s,
-                           (bf16_t*)dh, (bf16_t*)dY, Co, D3, w2_inv, flat);
+        // blocks of up to 100 x 100 (MPNN_demo) fit five chunks per thread: 8 staging registers less, which is what lets the
+        // kernel be register-allocated for the three workgroups per CU its LDS allows
+        if (flat && Co * D3 <= 256 * MDL_K7_BWD_SMALLC * 8) {
+            auto kf = nnconv_msg_bwd_mfma_kernel<MDL_K7_BWD_SMALLC>;
+            (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds_m);
+            hipLaunchKernelGGL(kf, dim3((unsigned)N), dim3(256), lds_m, st, (const bf16_t*)Y, (const bf16_t*)h, (const bf16_t*)dm, rowptr_s,
+                               eid_s, (bf16_t*)dh, (bf16_t*)dY, Co, D3, w2_inv, flat);
+        } else {
+            auto kf = nnconv_msg_bwd_mfma_kernel<7>;
+            (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds_m);
+            hipLaunchKernelGGL(kf, dim3((unsigned)N), dim3(256), lds_m, st, (const bf16_t*)Y, (const bf16_t*)h, (const bf16_t*)dm, rowptr_s,
+                               eid_s, (bf16_t*)dh, (bf16_t*)dY, Co, D3, w2_inv, flat);
+        }
         return check_launch("mdl_nnconv_msg_bwd");
     }
     const int lds = (Co * (D3 + 1) + D3 + Co) * 4;
