@@ -24,7 +24,9 @@
 // still share a CU) except for KP = 160, whose 75 KB of LDS and wider rows leave the 8-wave form one workgroup per CU
 // (1.5e6 rows, tools/bench_dense.py: 100 -> 100 137 -> 124 us, 114 -> 64 109 -> 98, 50 -> 150 209 -> 190, the wide layer of
 // MPNN -8 %; 150 -> 150 217 -> 263 us)
-#define MDL_LIN_NW(KP_) ((KP_) == 160 ? 4 : 8)
+// The gathering forms (K6) keep 4 as well: with the table rows in flight they need 137-148 registers, so an 8-wave workgroup
+// would be alone on its CU (228 -> ~275 us on the MEGNet bench batch).
+#define MDL_LIN_NW(KP_, G_) (((KP_) == 160 || (G_) != 0) ? 4 : 8)
 
 namespace mdl {
 
@@ -49,7 +51,7 @@ struct GatherAdd {
 // ROUNDED outputs are kept per thread over the grid-stride loop and added to one of the MDL_BN_REPLICAS copies of the
 // BatchNorm sums at the end, so the statistics pass over [N, M] (mdl_bn_stats) does not run.
 template <int KP, int NT, int GATHER = 0, int XACT = 0, bool STATS = false>     // KP: K padded to {64, 128, 160, 256}; NT: 32-column tiles of the output (M <= 32*NT); GATHER: tables
-__global__ __launch_bounds__(64 * MDL_LIN_NW(KP), 2) void linear_act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(64 * MDL_LIN_NW(KP, GATHER), 2) void linear_act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
                                                             int64_t N, int K, int M, int act, GatherAdd ga,
                                                             const bf16_t* __restrict__ xy, int ldo = 0,
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(64 * MDL_LIN_NW(KP), 2) void linear_act_kernel(cons
     if (ldo == 0) ldo = M;
     constexpr int TN = 64;
     constexpr int LD = KP + 8;                       // LDS row stride (bf16): odd number of 16-byte slots
-    constexpr int NW = MDL_LIN_NW(KP), XS = NW / 2, RPW = 64 / NW, NTH = 64 * NW;
+    constexpr int NW = MDL_LIN_NW(KP, GATHER), XS = NW / 2, RPW = 64 / NW, NTH = 64 * NW;
     constexpr int NB = (NT + XS - 1) / XS;           // output blocks per wave: block row wv & 1, block columns (wv >> 1) + XS j
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* wl = reinterpret_cast<bf16_t*>(smem);    // [32*NT][LD]
@@ -359,7 +361,7 @@ static int linear_launch(const void* x, const void* xy, int xact, const void* w,
     do {                                                                                                             \
         auto kf = linear_act_kernel<KP_, NT_, G_, X_>;                                                               \
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                           \
-        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * MDL_LIN_NW(KP_)), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * MDL_LIN_NW(KP_, G_)), lds, st, (const bf16_t*)x, (const bf16_t*)w,     \
                            (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, ga, (const bf16_t*)xy, 0, (float*)nullptr, \
                            (const int64_t*)nullptr);                                                                 \
     } while (0)
@@ -367,7 +369,7 @@ static int linear_launch(const void* x, const void* xy, int xact, const void* w,
     do {                                                                                                             \
         auto kf = linear_act_kernel<KP_, NT_, G_, 0, true>;                                                          \
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                           \
-        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * MDL_LIN_NW(KP_)), lds, st, (const bf16_t*)x, (const bf16_t*)w,         \
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * MDL_LIN_NW(KP_, G_)), lds, st, (const bf16_t*)x, (const bf16_t*)w,     \
                            (const bf16_t*)bias, (bf16_t*)out, N, K, M, act, ga, (const bf16_t*)xy, 0, stats, n_dev); \
     } while (0)
     if (stats) {
@@ -451,7 +453,7 @@ extern "C" int mdl_linear_wide(const void* x, const void* w, void* out, int64_t 
     do {                                                                                                              \
         auto kf = linear_act_kernel<KP_, 5, 0, 0>;                                                                \
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                            \
-        hipLaunchKernelGGL(kf, dim3(gy, (unsigned)gx), dim3(64 * MDL_LIN_NW(KP_)), lds, (hipStream_t)stream, (const bf16_t*)x,         \
+        hipLaunchKernelGGL(kf, dim3(gy, (unsigned)gx), dim3(64 * MDL_LIN_NW(KP_, 0)), lds, (hipStream_t)stream, (const bf16_t*)x,         \
                            (const bf16_t*)w, (const bf16_t*)nullptr, (bf16_t*)out, N, K, (int)M, 0, ga,               \
                            (const bf16_t*)nullptr, (int)M, (float*)nullptr, (const int64_t*)nullptr);                 \
     } while (0)
