@@ -417,8 +417,8 @@ def _rup(a, b):
     return (a + b - 1) // b * b
 
 
-# bench.py sets this to {"fwd": [], "bwd": []} to collect (start, end) HIP events recorded on the
-# launch stream around the two conv kernels; None (default) = no events.
+# bench.py sets this to {"fwd": [], "bwd": [], "bwd_node": [], "bwd_grads": []} to collect (start, end) HIP events recorded
+# on the launch stream around the conv kernels (K2; K3 = edge pass + node kernel + gradient assembly); None = no events.
 KERNEL_EVENTS = None
 
 
@@ -714,8 +714,8 @@ class _CGConvFn(torch.autograd.Function):
             dW_s = torch.empty_like(dW_f)
             db_f = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[0] else None
             db_s = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[1] else None
-            check(lib().mdl_cgconv_assemble_grads(ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s),
-                                                  stream()), "mdl_cgconv_assemble_grads")
+            check(_launch_timed("bwd_grads", lambda: lib().mdl_cgconv_assemble_grads(
+                ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s), stream())), "mdl_cgconv_assemble_grads")
             return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None
         if dt == _lib.MDL_BF16 and Cp == 128 and C % 2 == 0 and N > 0:
             # wide layers (C = 100 / 128): the same products on the streaming kernels.  r_tgt / r_src keep their padded

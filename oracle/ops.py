@@ -343,3 +343,74 @@ def cgconv_dense(x, edge_index, edge_attr, w_f, b_f, w_s, b_s):
         if msgs:
             out[i] = out[i] + torch.stack(msgs).mean(0)
     return out
+
+
+def cfconv_loop(x, edge_index, edge_weight, edge_attr, mlp0_w, mlp0_b, mlp2_w, mlp2_b, lin1_w, lin2_w, lin2_b, lin_w, lin_b, cutoff):
+    """InteractionBlock (A.3) edge by edge, no scatter, no nn.Module: filter W_e = mlp2(ssp(mlp0 e_e)) * C(d_e) with the cosine
+    cutoff C(d) = (cos(d pi / cutoff) + 1) / 2, message h_j * W_e with h = lin1 x (no bias), sum at the TARGET, then
+    lin(ssp(lin2 agg)).  An independent restatement for tests/test_oracle_selfcheck.py."""
+    ssp = lambda t: torch.log1p(torch.exp(t)) - math.log(2.0)
+    n = x.shape[0]
+    h = x @ lin1_w.T
+    agg = torch.zeros(n, lin1_w.shape[0], dtype=x.dtype)
+    for e in range(edge_index.shape[1]):
+        j, i = int(edge_index[0, e]), int(edge_index[1, e])
+        w = mlp2_w @ ssp(mlp0_w @ edge_attr[e] + mlp0_b) + mlp2_b
+        agg[i] = agg[i] + h[j] * w * (0.5 * (math.cos(float(edge_weight[e]) * math.pi / cutoff) + 1.0))
+    return ssp(agg @ lin2_w.T + lin2_b) @ lin_w.T + lin_b
+
+
+def nnconv_loop(x, edge_index, edge_attr, nn0_w, nn0_b, nn2_w, nn2_b, root_w, bias, aggr="mean"):
+    """NNConv (A.4) edge by edge: Theta_e = reshape(nn2 relu(nn0 e_e), [C_in, C_out]) (row-major .view), message x_j^T Theta_e,
+    mean over the incoming edges of the TARGET (0 for none), + root_w x_i + bias."""
+    n, c_in = x.shape
+    c_out = root_w.shape[0]
+    out = x @ root_w.T + bias
+    for i in range(n):
+        msgs = []
+        for e in range(edge_index.shape[1]):
+            if int(edge_index[1, e]) != i:
+                continue
+            theta = (nn2_w @ torch.clamp(nn0_w @ edge_attr[e] + nn0_b, min=0) + nn2_b).reshape(c_in, c_out)
+            msgs.append(x[int(edge_index[0, e])] @ theta)
+        if msgs:
+            s = torch.stack(msgs).sum(0)
+            out[i] = out[i] + (s / len(msgs) if aggr == "mean" else s)
+    return out
+
+
+def gcnconv_dense(x, edge_index, edge_weight, lin_w, bias):
+    """GCNConv(add_self_loops=False) (A.5) as dense matrices: A[i, j] = sum of the weights of the edges j -> i, weighted
+    in-degree deg_i = sum_j A[i, j], out = D^-1/2 A D^-1/2 (x W^T) + bias with 0 for deg = 0 (inf -> 0)."""
+    n = x.shape[0]
+    A = torch.zeros(n, n, dtype=x.dtype)
+    for e in range(edge_index.shape[1]):
+        A[int(edge_index[1, e]), int(edge_index[0, e])] += edge_weight[e]
+    deg = A.sum(1)
+    dis = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
+    return (dis[:, None] * A * dis[None, :]) @ (x @ lin_w.T) + bias
+
+
+def set2set_loop(x, batch, w_ih, w_hh, b_ih, b_hh, steps):
+    """Set2Set (A.6) graph by graph with the one-layer LSTM cell written out (gate order i, f, g, o of torch.nn.LSTM):
+    q* = 0; repeat: (q, c) = LSTMCell(q*, (q, c)); a_n = softmax over the graph's nodes of <x_n, q>; r = sum a_n x_n;
+    q* = [q | r].  No scatter, no nn.LSTM."""
+    b = int(batch.max()) + 1
+    C = x.shape[1]
+    out = []
+    for g in range(b):
+        xs = x[batch == g]
+        hq = torch.zeros(C, dtype=x.dtype)
+        c = torch.zeros(C, dtype=x.dtype)
+        q_star = torch.zeros(2 * C, dtype=x.dtype)
+        for _ in range(steps):
+            gates = w_ih @ q_star + b_ih + w_hh @ hq + b_hh
+            i_, f_, g_, o_ = gates[:C], gates[C:2 * C], gates[2 * C:3 * C], gates[3 * C:]
+            c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(g_)
+            hq = torch.sigmoid(o_) * torch.tanh(c)
+            e = xs @ hq
+            a = torch.exp(e - e.max())
+            a = a / a.sum()
+            q_star = torch.cat([hq, (a[:, None] * xs).sum(0)])
+        out.append(q_star)
+    return torch.stack(out)

@@ -172,3 +172,29 @@ def test_bench_under_the_driver_launcher_on_one_gpu():
     res = json.loads(line[0])
     assert res["n_gpus"] == 1 and res["steps"] == 3 and res["warmup"] == 2 and res["value"] > 0
     assert res["config"]["parallelism"] == "dp1" and res["scaling"] == "weak"
+
+
+def test_bench_megnet_leg_reproduces_in_fresh_processes(tmp_path):
+    """The cfg4 leg of the driver line, exactly as bench.other_models launches it, twice in fresh processes (the first
+    generates the dataset, the second maps it from the flat-file cache): round 4's driver read 54.4 ms/step for a leg the
+    builder measured at 19 — six steps behind a fixed 0.3-s settle phase had timed a fresh box's first-use costs.  With the
+    settle phase running until the step time has converged the two processes must agree within 10 %, the timed region must
+    not call hipMalloc, and its four-step groups must agree with each other."""
+    vals = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "bench.py", "--model", "megnet", "--steps", "20", "--warmup", "3", "--settle-s", "0.5",
+                            "--settle-cap-s", "3.0", "--no-extras", "--graphs", str(int(4096 * 1.25 / 0.8) + 64), "--cpu-steps", "0",
+                            "--no-cpu-baseline", "--dataset-cache", str(tmp_path), "--no-other-models"], cwd=ROOT,
+                           capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert line, r.stdout[-2000:] + r.stderr[-2000:]
+        vals.append(json.loads(line[-1]))
+    ms = [v["ms_per_step"] for v in vals]
+    print("megnet leg, two fresh processes: %s ms/step; by 4: %s; settle %s; mallocs %s"
+          % (ms, [v["config"]["ms_per_step_by_4"] for v in vals], [v["config"]["settle_steps"] for v in vals],
+             [v["config"]["device_mallocs"] for v in vals]))
+    assert vals[0]["config"]["dataset_source"] == "generated" and vals[1]["config"]["dataset_source"] == "flat file"
+    assert max(ms) <= 1.10 * min(ms), ms
+    for v in vals:
+        by4 = v["config"]["ms_per_step_by_4"]
+        assert len(by4) == 5 and max(by4) <= 1.25 * min(by4), by4

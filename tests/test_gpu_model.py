@@ -221,3 +221,63 @@ def test_product_matches_reference_wrapper_goldens(case):
         ev = model(b).cpu()
     ref = torch.from_numpy(z[case + "/pred_eval"])
     assert torch.allclose(ev, ref, rtol=1e-4, atol=1e-4 * (float(ref.abs().max()) + 1e-6))
+
+
+# ------------------------------------------------------------------------------------------------
+# HIP MEGNet against the vectors of the reference's OWN megnet.py (tests/golden/megnet.npz, make_golden.py: the one conv
+# block whose arithmetic lives under /root/reference, megnet.py:16-371): no oracle object on this path.  Four tags:
+# training-mode prediction, every parameter gradient, BatchNorm buffers after the forward, eval-mode prediction.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,kw", [("bn", dict(batch_norm="True")), ("nobn", dict(batch_norm="False")),
+                                    ("max", dict(batch_norm="False", pool="global_max_pool")),
+                                    ("late", dict(batch_norm="True", pool_order="late"))])
+def test_product_megnet_matches_reference_goldens(tag, kw):
+    from matdeeplearn_amd import models
+    z = np.load(os.path.join(G_DIR, "megnet.npz"))
+    d = torch.device("cuda:0")
+    ns = types.SimpleNamespace
+    B = int(z["batch"].max()) + 1
+    b = ns(x=torch.from_numpy(z["x"]).to(d), edge_index=torch.from_numpy(z["edge_index"]).to(d),
+           edge_attr=torch.from_numpy(z["edge_attr"]).to(d), u=torch.from_numpy(z["u"]).to(d),
+           batch=torch.from_numpy(z["batch"]).to(d), num_graphs=B)
+    y = torch.from_numpy(z["y"]).to(d)
+    model = models.MEGNet(DS(), dim1=32, dim2=24, dim3=16, pre_fc_count=1, gc_count=2, gc_fc_count=1, post_fc_count=2, **kw)
+    sd = {k[len(tag) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/sd/")}
+    assert list(model.state_dict()) == list(sd), "state_dict key skeleton / order differs from the reference"
+    pre = {k: v.clone() for k, v in sd.items()}          # the saved buffers are POST-forward: reset them for the training pass
+    for k in pre:
+        if k.endswith("running_mean"):
+            pre[k].zero_()
+        elif k.endswith("running_var"):
+            pre[k].fill_(1.0)
+        elif k.endswith("num_batches_tracked"):
+            pre[k].zero_()
+    model.load_state_dict(pre)
+    model.to(d).train()
+    pred = model(b)
+    ref = torch.from_numpy(z[tag + "/pred_train"])
+    scale = float(ref.abs().max()) + 1e-6
+    assert torch.allclose(pred.cpu(), ref, rtol=1e-4, atol=1e-4 * scale), (pred.cpu() - ref).abs().max()
+    torch.nn.functional.l1_loss(pred, y).backward()
+    grads = {k: z["%s/grad/%s" % (tag, k)] for k, _ in model.named_parameters()}
+    gmax = max(float(np.abs(g).max()) for g in grads.values() if g.size)
+    for k, p in model.named_parameters():
+        g = grads[k]
+        if g.size == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        g = torch.from_numpy(g)
+        s = float(g.abs().max()) + 1e-9
+        # same bound as the wrapper goldens: 1e-2 of the tensor's own scale + 1e-4 of the model's largest gradient (ReLU mask
+        # flips between two fp32 summation orders; biases in front of a BatchNorm hold rounding noise on both sides)
+        err = float((p.grad.cpu() - g).abs().max())
+        assert err <= 1e-2 * s + 1e-4 * gmax, (k, err, s, gmax)
+    for k, v in model.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            r = sd[k].float()
+            assert torch.allclose(v.float().cpu(), r, rtol=1e-4, atol=1e-5 * (float(r.abs().max()) + 1.0)), k
+    model.eval()
+    with torch.no_grad():
+        ev = model(b).cpu()
+    ref = torch.from_numpy(z[tag + "/pred_eval"])
+    assert torch.allclose(ev, ref, rtol=1e-4, atol=1e-4 * (float(ref.abs().max()) + 1e-6))

@@ -151,3 +151,113 @@ def test_oracle_models_run_and_have_reference_state_dict_keys(name):
               "MEGNet": "conv_list.0.edge_model.edge_mlp.0.weight", "MPNN": "gru_list.0.weight_ih_l0",
               "GCN": "conv_list.0.lin.weight"}[name]
     assert expect in keys
+
+
+# ------------------------------------------------------------------------------------------------
+# Second, independent derivations (oracle/ops.py: *_loop / *_dense, fp64 python loops written from SURVEY Appendix A, sharing
+# no code with the operator classes): value AND gradient of every PyG operator the oracle restates.  Together with the
+# reading of Appendix A against the published 2.0.1 sources this is the whole pin of the PyG arithmetic.
+# ------------------------------------------------------------------------------------------------
+def _grads(fn, params):
+    for p in params:
+        p.grad = None
+    fn().square().sum().backward()
+    return [p.grad.clone() for p in params]
+
+
+def test_cfconv_second_derivation_value_and_gradients():
+    torch.manual_seed(13)
+    n, H, G, Fn, cutoff = 8, 5, 4, 7, 8.0
+    ei = _graph(n, 13)
+    blk = oops.InteractionBlock(H, G, Fn, cutoff).double()
+    for p in blk.parameters():                       # (biases are initialised to zero: make every term visible)
+        p.data = p.data + 0.1 * torch.randn_like(p)
+    x = torch.randn(n, H, dtype=torch.float64, requires_grad=True)
+    ew = torch.rand(ei.shape[1], dtype=torch.float64) * 8
+    ew[ei[0] == ei[1]] = 0.0                        # self loops carry distance 0 (cutoff factor 1), process.py:301-305
+    ea = torch.rand(ei.shape[1], G, dtype=torch.float64)
+    P = [x] + list(blk.parameters())
+    a = lambda: blk(x, ei, ew, ea)
+    b = lambda: oops.cfconv_loop(x, ei, ew, ea, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias,
+                                 blk.conv.lin1.weight, blk.conv.lin2.weight, blk.conv.lin2.bias, blk.lin.weight, blk.lin.bias, cutoff)
+    assert torch.allclose(a(), b(), rtol=1e-11, atol=1e-12)
+    for ga, gb in zip(_grads(a, P), _grads(b, P)):
+        assert torch.allclose(ga, gb, rtol=1e-9, atol=1e-11)
+    perm = torch.randperm(ei.shape[1])
+    assert torch.allclose(blk(x, ei[:, perm], ew[perm], ea[perm]), a(), rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("aggr", ["mean", "add"])
+def test_nnconv_second_derivation_value_and_gradients(aggr):
+    torch.manual_seed(14)
+    n, C, G, d3 = 7, 4, 3, 5
+    ei = _graph(n, 14)
+    ei = ei[:, ei[1] != 2]                            # a node without incoming edges: its mean is 0, root + bias remain
+    net = torch.nn.Sequential(torch.nn.Linear(G, d3), torch.nn.ReLU(), torch.nn.Linear(d3, C * C))
+    conv = oops.NNConv(C, C, net, aggr=aggr).double()
+    conv.bias.data = torch.randn(C, dtype=torch.float64)
+    x = torch.randn(n, C, dtype=torch.float64, requires_grad=True)
+    ea = torch.rand(ei.shape[1], G, dtype=torch.float64)
+    P = [x] + list(conv.parameters())
+    a = lambda: conv(x, ei, ea)
+    b = lambda: oops.nnconv_loop(x, ei, ea, net[0].weight, net[0].bias, net[2].weight, net[2].bias, conv.lin.weight, conv.bias,
+                                 "mean" if aggr == "mean" else "sum")
+    assert torch.allclose(a(), b(), rtol=1e-11, atol=1e-12)
+    for ga, gb in zip(_grads(a, P), _grads(b, P)):
+        assert torch.allclose(ga, gb, rtol=1e-9, atol=1e-11)
+
+
+def test_gcnconv_second_derivation_value_and_gradients():
+    torch.manual_seed(15)
+    n, C, Co = 8, 5, 6
+    ei = _graph(n, 15)
+    ei = ei[:, ~((ei[1] == 3) & (ei[0] != 3))]        # node 3 keeps only its zero-weight self loop: weighted in-degree 0 -> 0
+    gcn = oops.GCNConv(C, Co, improved=True, add_self_loops=False).double()
+    gcn.bias.data = torch.randn(Co, dtype=torch.float64)
+    x = torch.randn(n, C, dtype=torch.float64, requires_grad=True)
+    w = torch.rand(ei.shape[1], dtype=torch.float64) * 5 + 0.1
+    w[ei[0] == ei[1]] = 0.0
+    P = [x] + list(gcn.parameters())
+    a = lambda: gcn(x, ei, w)
+    b = lambda: oops.gcnconv_dense(x, ei, w, gcn.lin.weight, gcn.bias)
+    assert torch.allclose(a(), b(), rtol=1e-11, atol=1e-12)
+    assert torch.allclose(a()[3], gcn.bias)           # nothing arrives at a node of weighted in-degree 0
+    for ga, gb in zip(_grads(a, P), _grads(b, P)):
+        assert torch.allclose(ga, gb, rtol=1e-9, atol=1e-11)
+
+
+def test_set2set_second_derivation_value_and_gradients():
+    torch.manual_seed(16)
+    C, steps = 4, 3
+    s2s = oops.Set2Set(C, processing_steps=steps).double()
+    x = torch.randn(9, C, dtype=torch.float64, requires_grad=True)
+    batch = torch.tensor([0, 0, 0, 0, 1, 2, 2, 2, 2])          # a one-node graph in the middle
+    L = s2s.lstm
+    P = [x] + list(s2s.parameters())
+    a = lambda: s2s(x, batch)
+    b = lambda: oops.set2set_loop(x, batch, L.weight_ih_l0, L.weight_hh_l0, L.bias_ih_l0, L.bias_hh_l0, steps)
+    assert a().shape == (3, 2 * C)
+    assert torch.allclose(a(), b(), rtol=1e-10, atol=1e-12)    # (the operator adds 1e-16 to the softmax denominator)
+    for ga, gb in zip(_grads(a, P), _grads(b, P)):
+        assert torch.allclose(ga, gb, rtol=1e-8, atol=1e-11)
+
+
+def test_pyg_operator_gradchecks():
+    """torch.autograd.gradcheck of the restated operators (the loops above share autograd with them: this checks the
+    analytic gradients against finite differences)."""
+    torch.manual_seed(17)
+    n, C, G = 5, 3, 2
+    ei = _graph(n, 17)
+    E = ei.shape[1]
+    x = torch.randn(n, C, dtype=torch.float64, requires_grad=True)
+    ea = torch.rand(E, G, dtype=torch.float64)
+    ew = torch.rand(E, dtype=torch.float64) * 6 + 0.2
+    blk = oops.InteractionBlock(C, G, 4, 8.0).double()
+    assert torch.autograd.gradcheck(lambda x_: blk(x_, ei, ew, ea), (x,))
+    net = torch.nn.Sequential(torch.nn.Linear(G, 3), torch.nn.Softplus(), torch.nn.Linear(3, C * C))   # (smooth: no ReLU kink)
+    conv = oops.NNConv(C, C, net).double()
+    assert torch.autograd.gradcheck(lambda x_: conv(x_, ei, ea), (x,))
+    gcn = oops.GCNConv(C, C, improved=True, add_self_loops=False).double()
+    assert torch.autograd.gradcheck(lambda x_: gcn(x_, ei, ew), (x,))
+    s2s = oops.Set2Set(C, processing_steps=2).double()
+    assert torch.autograd.gradcheck(lambda x_: s2s(x_, torch.tensor([0, 0, 1, 1, 1])), (x,))
