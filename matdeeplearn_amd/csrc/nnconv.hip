@@ -453,7 +453,8 @@ extern "C" int mdl_nnconv_msg_fwd(const void* Y, const void* h, const int32_t* r
     if (nm_ok(Co, D3, dtype, Y, h) && reinterpret_cast<uintptr_t>(m) % 2 == 0) {
         auto kf = nnconv_msg_fwd_mfma_kernel;
         // flat staging of Y_j: every node's block must start on a 16-byte boundary and fit the per-thread chunk budget
-        const int flat = (((int64_t)Co * D3 * 2) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 && Co * D3 <= 256 * 7 * 8) ? 1 : 0;
+        // (D3 >= 4: the staging splits a dword index by w2 = D3 / 2 with a 32-bit reciprocal, and 2^32 / 1 does not fit one)
+        const int flat = (D3 >= 4 && ((int64_t)Co * D3 * 2) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 && Co * D3 <= 256 * 7 * 8) ? 1 : 0;
 #ifndef MDL_K7_YROWS_FULL
         const int yrows = flat ? Co : 128;
 #else
@@ -490,7 +491,7 @@ extern "C" int mdl_nnconv_msg_bwd(const void* Y, const void* h, const void* dm, 
     hipStream_t st = (hipStream_t)stream;
     if (nm_ok(Co, D3, dtype, Y, h) && reinterpret_cast<uintptr_t>(dm) % 4 == 0 && reinterpret_cast<uintptr_t>(dY) % 4 == 0) {
         const int lds_m = (128 + 64) * NM_LD * 2 + 32 * 4;
-        const int flat = (((int64_t)Co * D3 * 2) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 &&
+        const int flat = (D3 >= 4 && ((int64_t)Co * D3 * 2) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 &&
                           reinterpret_cast<uintptr_t>(dY) % 16 == 0 && Co * D3 <= 256 * 7 * 8) ? 1 : 0;
         const unsigned w2_inv = (unsigned)((0x100000000ull + (D3 / 2) - 1) / (D3 / 2));
         // blocks of up to 100 x 100 (MPNN_demo) fit five chunks per thread: 8 staging registers less, which is what lets the

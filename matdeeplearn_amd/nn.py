@@ -121,18 +121,12 @@ class ShiftedSoftplus(nn.Module):
         return F.softplus(x) - self.shift
 
 
-_CUTOFF = [None, None]
-
-
-def _cosine_cutoff(edge_weight, cutoff):
-    """0.5 (cos(d pi / cutoff) + 1) of a batch's distances: a function of the batch alone, so the interaction blocks of a model
-    (same edge_weight tensor, same cutoff) share one evaluation instead of four elementwise launches per block."""
-    key = (edge_weight.data_ptr(), edge_weight._version, edge_weight.numel(), float(cutoff), edge_weight.device)
-    # (static buffers of the HIP-graph path are rewritten in place by kernels the version counter does not see: no cache there;
-    # the cached entry keeps its edge_weight tensor alive, so its address cannot be recycled under the key)
-    if _CUTOFF[0] != key or ops.NO_INDEX_CACHE or (edge_weight.is_cuda and torch.cuda.is_current_stream_capturing()):
-        _CUTOFF[0], _CUTOFF[1] = key, (0.5 * (torch.cos(edge_weight.float() * (math.pi / cutoff)) + 1.0), edge_weight)
-    return _CUTOFF[1][0]
+def cosine_cutoff(edge_weight, cutoff):
+    """0.5 (cos(d pi / cutoff) + 1) of a batch's distances, [E] fp32: a function of the batch alone.  A model evaluates it
+    ONCE per forward and hands it to its interaction blocks (`cut=`) instead of four elementwise launches per block; nothing
+    is cached across calls (a cache keyed on the tensor would go stale on the static buffers of the HIP-graph path, which
+    kernels rewrite in place, and would pin the previous batch)."""
+    return 0.5 * (torch.cos(edge_weight.float() * (math.pi / cutoff)) + 1.0)
 
 
 class CFConv(nn.Module):
@@ -149,10 +143,10 @@ class CFConv(nn.Module):
         nn.init.xavier_uniform_(self.lin2.weight)
         self.lin2.bias.data.fill_(0)
 
-    def forward(self, x, edge_index, edge_weight, edge_attr, csr=None):
+    def forward(self, x, edge_index, edge_weight, edge_attr, csr=None, cut=None):
         if csr is None:
             csr = ops.csr_for(edge_index, x.shape[0])
-        c = _cosine_cutoff(edge_weight, self.cutoff)                                  # [E] fp32
+        c = cosine_cutoff(edge_weight, self.cutoff) if cut is None else cut           # [E] fp32
         w = _seq(self.nn, edge_attr)                                                  # filter  [E, F]
         h = _lin(self.lin1, x)
         agg = ops.gather_mul_reduce(h, csr, w=w.to(h.dtype), scale=c, reduce="sum")
@@ -177,8 +171,8 @@ class InteractionBlock(nn.Module):
         nn.init.xavier_uniform_(self.lin.weight)
         self.lin.bias.data.fill_(0)
 
-    def forward(self, x, edge_index, edge_weight, edge_attr, csr=None):
-        return _lin(self.lin, self.act(self.conv(x, edge_index, edge_weight, edge_attr, csr=csr)))
+    def forward(self, x, edge_index, edge_weight, edge_attr, csr=None, cut=None):
+        return _lin(self.lin, self.act(self.conv(x, edge_index, edge_weight, edge_attr, csr=csr, cut=cut)))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -65,6 +65,18 @@ class Batch:
             out += [t for t in (csr.rowptr, csr.src, csr.tgt, csr.eperm) if torch.is_tensor(t)]
         return out
 
+    def record_stream(self, stream):
+        """Tell the caching allocator that `stream` uses this batch's memory.  A batch is OWNED by the stream that was current
+        when it was collated / taken from the loader (DeviceLoader, take_ahead); a consumer that touches it on ANOTHER stream —
+        a data-parallel side stream, a user stream in predict() — calls this once (and orders the streams with an event), or
+        the memory may be handed out again while that stream still reads it once the batch is dropped."""
+        if stream is None:
+            return self
+        for t in self.tensors():
+            if t.is_cuda:
+                t.record_stream(stream)
+        return self
+
 
 class GraphDataset:
     """Flat arrays (numpy on the host until .to(device)):
@@ -233,6 +245,10 @@ class GraphDataset:
         t = c.get((B, str(dev)))
         if t is None:
             t = c[(B, str(dev))] = torch.zeros(B, 3, device=dev)
+            if t.is_cuda:
+                # a cached constant is shared by every stream that ever collates (the prefetching side stream creates it as
+                # often as not): wait once for its fill, after which no consumer needs an event; it is never freed
+                torch.cuda.current_stream(t.device).synchronize()
         return t
 
     def assemble_hip(self, ids, x_dtype=torch.float32):
@@ -321,9 +337,7 @@ class GraphDataset:
         b, ev = handle
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
-        for t in b.tensors():
-            t.record_stream(cur)
-        return b
+        return b.record_stream(cur)       # (from here on the batch belongs to `cur`: see Batch.record_stream)
 
     def assemble(self, ids):
         """Index arithmetic of the batch assembly (plain tensor ops; device agnostic so the CPU test
@@ -595,7 +609,10 @@ class DeviceLoader:
         self.batch_size, self.shuffle, self.seed = int(batch_size), shuffle, int(seed)
         self.rank, self.world_size, self.edge_dtype, self.rbf = rank, world_size, edge_dtype, rbf
         self.epoch = 0
-        # assemble batch k + 1 on a side stream while the caller works on batch k (HIP datasets with the kernel RBF expansion)
+        # assemble batch k + 1 on a side stream while the caller works on batch k (HIP datasets with the kernel RBF expansion).
+        # Ownership: a yielded batch belongs to the stream that was current when the iterator handed it out (take_ahead orders
+        # that stream behind the assembly and records it with the allocator); a consumer on another stream calls
+        # Batch.record_stream(stream) — see there.
         on_hip = dataset.device is not None and dataset.device.type == "cuda"
         self.prefetch = (on_hip and rbf is None) if prefetch is None else (bool(prefetch) and on_hip and rbf is None)
 

@@ -147,8 +147,15 @@ class FlatDataParallel:
 
     def _adopt_ready_order(self):
         """End of the observed step: agree on rank 0's ready order, lay the flat buffer out in it, split it in two."""
-        seen = {id(p) for p in self._ready}
-        order = self._ready + [p for p in self.params if id(p) not in seen]        # never-ready parameters go last
+        # (two backward passes before one exchange — gradient accumulation, a warm-up backward without dp.zero_grad() — fire
+        # every hook twice: keep each parameter's FIRST appearance)
+        seen, ready = set(), []
+        for p in self._ready:
+            if id(p) not in seen:
+                seen.add(id(p))
+                ready.append(p)
+        order = ready + [p for p in self.params if id(p) not in seen]              # never-ready parameters go last
+        assert len(order) == len(self.params), "ready order must be a permutation of the parameters"
         index = {id(p): i for i, p in enumerate(self.params)}
         perm = torch.tensor([index[id(p)] for p in order], dtype=torch.int64, device=self.flat_grad.device)
         if self.world_size > 1:
@@ -231,6 +238,11 @@ class FlatDataParallel:
         self.flat_grad.mul_(1.0 / self.world_size)
         for p, v in zip(self.params, self.views):
             p.grad = v
+        # the exchange is over: the next backward counts its early chunk from the start, whoever clears the gradients
+        # (dp.zero_grad() or the optimizer's zero_grad())
+        self._ready = []
+        if isinstance(self.split, tuple):
+            self._early_left = self.split[0]
 
     def reduce_grads(self, force=False):
         """Sum over ranks, then average (DDP semantics).  One pack + one collective per step (two with chunk_bytes)."""

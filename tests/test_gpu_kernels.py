@@ -359,7 +359,8 @@ def test_cgconv_c_abi_eperm_and_workspace_paths():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("n,Ci,Co,D3", [(300, 100, 100, 100), (57, 24, 24, 16), (40, 20, 36, 50), (64, 32, 128, 128), (33, 16, 30, 34)])
+@pytest.mark.parametrize("n,Ci,Co,D3", [(300, 100, 100, 100), (57, 24, 24, 16), (40, 20, 36, 50), (64, 32, 128, 128), (33, 16, 30, 34),
+                                        (40, 8, 4, 2)])      # (D3 = 2: the flat Y_j staging must not be chosen, w2 = 1)
 def test_nnconv_contraction_matches_oracle(dtype, n, Ci, Co, D3):
     """K7 through nn.NNConv (Y = x W2r per node, per-edge mat-vec by source) against the oracle's NNConv, which builds the
     per-edge Ci x Co matrices like the reference does: output and every gradient (x, edge network, root weight, bias)."""

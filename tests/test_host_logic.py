@@ -831,6 +831,53 @@ def test_two_chunk_exchange_split_and_hook_rearm_in_process(tmp_path):
         dist.destroy_process_group()
 
 
+def test_two_chunk_exchange_survives_accumulation_and_foreign_zero_grad(tmp_path):
+    """(advisor, round 4) Two backward passes before the first reduce_grads() — gradient accumulation, a warm-up backward without
+    dp.zero_grad() — fire every observe hook twice: the ready order must still be a permutation of the parameters.  And in
+    steady state the early chunk's countdown re-arms when the exchange finishes, so a loop that clears gradients with the
+    optimizer's zero_grad() (not dp.zero_grad()) keeps the hook-started first collective."""
+    import torch.distributed as dist
+    from matdeeplearn_amd.training import FlatDataParallel
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this interpreter")
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "pg"), rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Linear(8, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+        dp = FlatDataParallel(m, force=True, chunk_bytes=256)
+        x = torch.randn(16, 8)
+        dp.zero_grad()
+        m(x).sum().backward()
+        m(x).sum().backward()                                   # accumulation: every hook has fired twice
+        assert len(dp._ready) == 2 * len(dp.params)
+        ref = {id(p): p.grad.clone() for p in m.parameters()}
+        dp.reduce_grads()
+        assert isinstance(dp.split, tuple) and sorted(map(id, dp.params)) == sorted(map(id, m.parameters()))
+        assert sum(v.numel() for v in dp.views) == dp.flat_grad.numel()
+        for p in m.parameters():
+            assert torch.equal(p.grad, ref[id(p)])
+        opt = torch.optim.SGD(m.parameters(), lr=0.0)
+        calls = []
+        real = dist.all_reduce
+
+        def counting(t, *a, **kw):
+            calls.append((t.data_ptr() - dp.flat_grad.data_ptr()) // 4)
+            return real(t, *a, **kw)
+        dist.all_reduce = counting
+        try:
+            for _ in range(3):
+                calls.clear()
+                opt.zero_grad(set_to_none=True)                 # NOT dp.zero_grad()
+                m(x).sum().backward()
+                assert calls == [0], "the first-ready chunk leaves from its hook without dp.zero_grad()"
+                dp.reduce_grads()
+                assert calls == [0, dp.split[1]]
+        finally:
+            dist.all_reduce = real
+    finally:
+        dist.destroy_process_group()
+
+
 def test_checkpointed_optimizer_state_holds_float_learning_rates():
     """A tensor learning rate (what make_optimizer(capturable=True) builds on a device) must not reach the checkpoint: the
     reference format holds floats, and loading a tensor lr into a non-capturable optimizer raises.  Loading back into an
