@@ -82,6 +82,12 @@
 #ifndef MDL_BWD_DERIV2
 #define MDL_BWD_DERIV2 0  // 1: bf16 backward with the select-free gate derivative (Gate<true>::deriv2, 3 VALU fewer per element): measured +-0
 #endif
+#ifndef MDL_FWD_RANGE_EDGES
+#define MDL_FWD_RANGE_EDGES 64   // edges per node range (= per wave) below which the launch shrinks instead: two 32-edge tiles
+#endif
+#ifndef MDL_BWD_RANGE_EDGES
+#define MDL_BWD_RANGE_EDGES 64
+#endif
 #ifndef MDL_BWD_WAVES
 #define MDL_BWD_WAVES 1   // waves per SIMD the backward kernel is register-allocated for
 #endif
@@ -1968,7 +1974,7 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
 
     const bool all_slices = !bwd && fast && MDL_FWD_ALLSLICES && MDL_CG_WM == 1 && (sizeof(T) == 2 || w_lds);
     // one node range per wave (per slice), at least ~2 edge tiles each; see NodeRange
-    const int64_t ranges = std::max<int64_t>(1, std::min<int64_t>(cdiv(p.E, 64), p.N));
+    const int64_t ranges = std::max<int64_t>(1, std::min<int64_t>(cdiv(p.E, bwd ? MDL_BWD_RANGE_EDGES : MDL_FWD_RANGE_EDGES), p.N));
     int64_t items = ranges * (all_slices ? 1 : d.NS);
     int64_t grid = cdiv(items, waves);
     // backward is register-allocated for MDL_BWD_WAVES waves per SIMD: 1 -> one 4-wave workgroup per CU
@@ -2148,7 +2154,7 @@ static int cg_launch_bwd_ab(CgParams& p, hipStream_t st, const char* name) {
     p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16 + 128 * OHS * 2;
     const int waves = 4;
     const int lds = waves * p.wave_lds_bytes;
-    const int64_t ranges = std::max<int64_t>(1, std::min<int64_t>(cdiv(p.E, 64), p.N));
+    const int64_t ranges = std::max<int64_t>(1, std::min<int64_t>(cdiv(p.E, bwd ? MDL_BWD_RANGE_EDGES : MDL_FWD_RANGE_EDGES), p.N));
     int64_t grid = cdiv(ranges * d.NS, waves);
     const CgEnv& env = cg_env();
     const int64_t cap = 256 * (env.ab_wgs > 0 ? env.ab_wgs : 1);

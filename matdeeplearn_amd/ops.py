@@ -591,9 +591,23 @@ _RSRC16 = os.environ.get("MDL_CG_RSRC16", "1") == "1"
 _RSRC = {}
 
 
+_RSRC_CAP = {}
+
+
 def _take_rsrc(nfloats, device):
     if torch.cuda.is_current_stream_capturing():
-        return None
+        # A captured step adopts the buffer its warm-up iterations left behind (training.GraphedStep runs the step eagerly on a
+        # side stream, synchronises, then captures): allocated outside the capture, zero on entry, handed back zeroed by the
+        # node kernel at the end of every layer — so every replay finds it zero, and the four zero fills per step
+        # (53 MB each at the bench batch) that a fresh tensor per layer cost are gone.  The buffer leaves the eager table for
+        # good (the graph owns its address); without a clean candidate the caller falls back to a fresh zero-filled tensor.
+        ent = _RSRC_CAP.get(device.index)
+        if ent is None or ent[0].numel() < nfloats:
+            cand = [k for k, v in _RSRC.items() if k[0] == device.index and not v[1] and v[0].numel() >= nfloats]
+            if not cand:
+                return None
+            ent = _RSRC_CAP[device.index] = _RSRC.pop(max(cand, key=lambda k: _RSRC[k][0].numel()))
+        return ent
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ent = _RSRC.get(key)
     if ent is None or ent[0].numel() < nfloats or ent[1]:
@@ -1246,9 +1260,11 @@ class _MlpHead(torch.autograd.Function):
 
 
 def mlp_head_ok(x, lins, act):
-    """the fused head takes bf16 rows on the device, 1..4 dense layers of width <= 64 (hidden widths even) with ReLU between"""
+    """the fused head takes bf16 rows on the device, 1..4 dense layers of width <= 64 (hidden widths even) with ReLU between.
+    Any row count: at the reference's batch size (100 graphs, config.yml:136) the layer-by-layer fallback is ~35 launches of
+    4-8 us each (library GEMMs, casts, ReLU masks, bias sums) against two."""
     if not (_MLP_HEAD and act == "relu" and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
-            and 1 <= len(lins) <= 4 and x.shape[0] >= 256 and x.shape[1] <= 64 and x.shape[1] % 2 == 0 and x.data_ptr() % 4 == 0):
+            and 1 <= len(lins) <= 4 and x.shape[0] >= 1 and x.shape[1] <= 64 and x.shape[1] % 2 == 0 and x.data_ptr() % 4 == 0):
         return False
     k = x.shape[1]
     for j, lin in enumerate(lins):

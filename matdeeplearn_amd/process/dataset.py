@@ -46,6 +46,10 @@ class Batch:
 
     @property
     def edge_index(self):
+        fill = self.__dict__.get("_edge_index_fill")
+        if fill is not None and self.__dict__.get("_edge_index_stale", False):
+            fill()                                                        # (static batch: refill the int64 view on first use)
+            self._edge_index_stale = False
         if self._edge_index is None:
             self._edge_index = torch.stack([self.csr.src.long(), self.csr.tgt.long()])
             ops.register_csr(self._edge_index, self.csr)
@@ -480,7 +484,10 @@ class StaticBatch:
         dev = ds.device
         B, F, G = int(batch_size), ds.num_features, ds.num_edge_features
         self.ds, self.B, self.n_cap, self.e_cap = ds, B, int(n_cap), int(e_cap)
-        self.pack = torch.zeros(3 * B + 2, dtype=torch.int64, device=dev)      # ids [B] | noff [B+1] | eoff [B+1]
+        # ids [B] | noff [B+1] | eoff [B+1] (int64) | the pooling index's row pointers [B+2] as int32 (two per word): one upload
+        self._npack = 3 * B + 2
+        self.pack_all = torch.zeros(self._npack + (B + 3) // 2, dtype=torch.int64, device=dev)
+        self.pack = self.pack_all[:self._npack]
         self.n_dev = self.pack[2 * B:2 * B + 1]                                # noff[B] = number of nodes that exist
         self.e_dev = self.pack[3 * B + 1:3 * B + 2]
         self.x = torch.zeros((self.n_cap, F), dtype=x_dtype, device=dev)
@@ -506,13 +513,19 @@ class StaticBatch:
         if len({self.n_cap, self.e_cap, B + 1}) != 3:
             raise ops.MdlError("StaticBatch: node capacity %d, edge capacity %d and graph rows %d must be pairwise distinct"
                                % (self.n_cap, self.e_cap, B + 1))
-        self.pool_rowptr = torch.zeros(B + 2, dtype=torch.int32, device=dev)
+        self.pool_rowptr = self.pack_all[self._npack:].view(torch.int32)[:B + 2]    # (uploaded with the ids: no launch)
         self.pool_seg = torch.full((self.n_cap,), B, dtype=torch.int32, device=dev)
         self.batch = Batch(pool_index=ops.make_seg_index(self.pool_rowptr, self.pool_seg, partial=True), x=self.x,
                            true_rows={self.n_cap: self.n_dev, self.e_cap: self.e_dev, B + 1: self.b_dev}, edge_attr=self.edge_attr, edge_weight=self.ew, batch=self.batch_idx, y=self.y,
                            u=torch.zeros(B + 1, 3, device=dev), num_graphs=B + 1, csr=csr, num_nodes=self.n_cap,
                            num_edges=self.e_cap, n_dev=self.n_dev, structure_id=None)
         self.batch._edge_index = self.edge_index
+
+        def _fill_edge_index():
+            self.edge_index[0].copy_(self.src)
+            self.edge_index[1].copy_(self.tgt)
+        self.batch._edge_index_fill = _fill_edge_index
+        self.batch._edge_index_stale = True
         ops.register_csr(self.edge_index, csr)
         # every index tensor a model may hand to scatter() maps to the loader's segment index: no sorts inside the graph,
         # and the unused tail of the buffers stays outside every segment
@@ -521,7 +534,7 @@ class StaticBatch:
         ops.register_seg_index(self.src, csr.seg_src())
         ops.register_seg_index(self.tgt, csr.seg_tgt())
         ops.register_seg_index(self.batch_idx, self.batch.pool_index)
-        self._pinned = [torch.zeros(3 * B + 2, dtype=torch.int64).pin_memory() for _ in range(ring)]
+        self._pinned = [torch.zeros(self.pack_all.numel(), dtype=torch.int64).pin_memory() for _ in range(ring)]
         self._events = [None] * ring
         self._slot = 0
         self.true_nodes = self.true_edges = 0
@@ -545,8 +558,13 @@ class StaticBatch:
         self._slot = (k + 1) % len(self._pinned)
         if self._events[k] is not None:
             self._events[k].synchronize()                       # the copy that last used this pinned slot has finished
-        self._pinned[k].copy_(torch.from_numpy(np.concatenate([ids, noff, eoff])))
-        self.pack.copy_(self._pinned[k], non_blocking=True)
+        # node -> graph pooling index straight from the prefix offsets.  The dummy graph B is EMPTY (the padding rows belong to
+        # no segment): as one segment of thousands of rows it would be walked by a single lane group
+        prp = np.zeros(2 * ((self.B + 3) // 2), dtype=np.int32)
+        prp[:self.B + 1] = noff
+        prp[self.B + 1] = noff[-1]
+        self._pinned[k].copy_(torch.from_numpy(np.concatenate([ids, noff, eoff, prp.view(np.int64)])))
+        self.pack_all.copy_(self._pinned[k], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._events[k] = ev
@@ -573,26 +591,28 @@ class StaticBatch:
             "mdl_assemble_transposed")
         _lib.check(_lib.lib().mdl_pad_edge_tail(p(noff_d), p(eoff_d), B, self.n_cap, self.e_cap, p(self.src), p(self.tgt),
                                                 p(self.col_s), p(self.eid_s), p(self.src_s), _lib.stream()), "mdl_pad_edge_tail")
-        self.edge_index[0].copy_(self.src)
-        self.edge_index[1].copy_(self.tgt)
+        self.batch._edge_index_stale = True       # the int64 [2, e_cap] view: refilled when (and if) a model reads batch.edge_index
         ops.rbf_expand(self.dn, 0.0, 1.0, ds.num_edge_features, 0.2, offsets=d["offsets"], out=self.edge_attr)
-        # node -> graph pooling index straight from the prefix offsets.  The dummy graph B is EMPTY here (the padding rows
-        # belong to no segment): as one segment of thousands of rows it would be walked by a single lane group
-        self.pool_rowptr.copy_(torch.cat([noff_d, noff_d[-1:]]))
-        self.pool_seg.copy_(self.batch_idx)
+        self.pool_seg.copy_(self.batch_idx)       # (its row pointers arrived with the ids: StaticBatch.load)
         # the static CSR outlives the batch: its work-balance prefix (CGConv backward) is rebuilt with the batch, in place
         self.batch.csr.refresh_balance()
         return self.batch
 
 
-def static_capacity(ds, batch_size, indices=None, slack=6.0, quantum=1024):
+def static_capacity(ds, batch_size, indices=None, slack=6.0, quantum=None):
     """(n_cap, e_cap) for StaticBatch: mean + `slack` standard deviations of a random batch's node / edge count, rounded
-    up — a batch that still exceeds it takes the eager path."""
+    up — a batch that still exceeds it takes the eager path.  quantum None: 1024 rows for large capacities, 256 / 64 for
+    small ones (at the reference's batch size a 1024-row quantum alone is 40 % of padding: every padded tile is a tile of
+    work for the conv kernels)."""
     idx = np.arange(len(ds)) if indices is None else np.asarray(indices)
     nn = (ds.node_ptr[idx + 1] - ds.node_ptr[idx]).astype(np.float64)
     ne = (ds.edge_ptr[idx + 1] - ds.edge_ptr[idx]).astype(np.float64)
     B = float(batch_size)
-    cap = lambda v: int(-(-(B * v.mean() + slack * v.std() * np.sqrt(B)) // quantum) * quantum)
+
+    def cap(v):
+        raw = B * v.mean() + slack * v.std() * np.sqrt(B)
+        q = quantum if quantum else (1024 if raw >= 32768 else 256 if raw >= 4096 else 64)
+        return int(-(-raw // q) * q)
     return cap(nn), cap(ne)
 
 

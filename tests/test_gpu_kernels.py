@@ -1043,7 +1043,8 @@ def test_cfconv_backward_in_one_walk_matches_the_pair():
     close(dw1, dw0, 1e-2, 1e-3)          # (a * b) * c against (a * c) * b before the bf16 rounding
 
 
-@pytest.mark.parametrize("shape", [(3000 + 17, 64, (64, 64, 64, 1)), (700, 50, (32, 2)), (1000, 64, (40,)), (257, 16, (64, 64, 8))])
+@pytest.mark.parametrize("shape", [(3000 + 17, 64, (64, 64, 64, 1)), (700, 50, (32, 2)), (1000, 64, (40,)), (257, 16, (64, 64, 8)),
+                                   (101, 64, (64, 64, 64, 1)), (37, 64, (64, 1)), (1, 64, (64, 64, 1))])     # the reference's batch size and below
 def test_fused_post_fc_head_matches_the_layer_by_layer_path(shape):
     """csrc/mlp.hip (post_lin_list + lin_out as one launch per direction) against the same chain on the streaming dense layers
     and against an fp32 torch reference: outputs, input gradient, every weight / bias gradient; ragged row counts, a
