@@ -107,8 +107,9 @@ for C in (64, 32):
             _lib.check(L.mdl_cgconv_bwd_saved(P(ea), P(csr.rowptr), P(csr.src), P(csr.tgt), P(gate), P(gout), P(r_tgt), P(r_src),
                                               P(dwe), P(db), n, E, C, G, 1, dt, None, 0, st()), "bwd_saved")
         else:
-            _lib.check(L.mdl_cgconv_bwd(P(x), P(ea), P(csr.rowptr), P(csr.src), P(csr.tgt), None, P(wpack), P(bpack), P(gout),
-                                        P(r_tgt), P(r_src), P(dwe), P(db), n, E, C, G, 1, dt, None, 0, st()), "bwd")
+            _lib.check(L.mdl_cgconv_bwd_ex(_lib.cg_args(dtype=dt, aggr=1, N=n, E=E, C=C, G=G, x=x, edge_attr=ea, rowptr=csr.rowptr, src=csr.src,
+                                                        tgt=csr.tgt, wpack=wpack, bpack=bpack, grad_out=gout, r_tgt=r_tgt, r_src=r_src,
+                                                        r_src_dtype=_lib.MDL_F32, dwe=dwe, db=db), st()), "bwd")
         res.append((r_tgt, r_src, dwe, db))
     for a, b in zip(res[1], res[0]):
         close(a, b, 2e-2, 1e-2)
@@ -167,8 +168,9 @@ for C in (64, 32):
             _lib.check(L.mdl_cgconv_bwd_p(P(pt), P(ps), P(ea), P(csr.rowptr), P(csr.src), P(csr.tgt), P(wpe), P(bpack2), P(gout), P(r_tgt),
                                           P(r_src), P(dwe), P(db), n, E, C, G, 1, dt, None, 0, st()), "bwd_p")
         else:
-            _lib.check(L.mdl_cgconv_bwd(P(x), P(ea), P(csr.rowptr), P(csr.src), P(csr.tgt), None, P(wpack), P(bpack), P(gout),
-                                        P(r_tgt), P(r_src), P(dwe), P(db), n, E, C, G, 1, dt, None, 0, st()), "bwd")
+            _lib.check(L.mdl_cgconv_bwd_ex(_lib.cg_args(dtype=dt, aggr=1, N=n, E=E, C=C, G=G, x=x, edge_attr=ea, rowptr=csr.rowptr, src=csr.src,
+                                                        tgt=csr.tgt, wpack=wpack, bpack=bpack, grad_out=gout, r_tgt=r_tgt, r_src=r_src,
+                                                        r_src_dtype=_lib.MDL_F32, dwe=dwe, db=db), st()), "bwd")
         res.append((r_tgt, r_src, dwe, db))
     for a, b in zip(res[1], res[0]):
         close(a, b, 3e-2, 3e-2)

@@ -44,7 +44,7 @@ enum {
     MDL_E_LAUNCH = -3   /* hipGetLastError() after a launch             */
 };
 
-/* Execution flags: OR-ed into the `dtype` argument of the entry points that say so.  The library keeps no mode state and
+/* Execution flags (for the positional entry points: OR-ed into the `dtype` argument of those that say so).  The library keeps no mode state and
  * reads no environment variable; what a caller (or a test) wants, it passes with the call.
  *   MDL_DETERMINISTIC  run-to-run bit-reproducible results.  By default the gradient reductions combine per-workgroup
  *                      partial sums with floating-point atomics (r_src / dwe / db of the CGConv backward, dWn, the TN
@@ -53,15 +53,18 @@ enum {
  *                      sum receives its terms from ONE wave in program order (one workgroup for the streaming kernels,
  *                      one wave per channel slice for the CGConv edge pass).  A few hundred times slower: meant for
  *                      HIP-vs-HIP regression checks (graph replay vs eager, padded rows, data-parallel exchange).
- *   MDL_K3_PER_WAVE /  mdl_cgconv_bwd_h / _hb only: force the per-wave kernel / the edge-per-lane kernel 2 instead of
- *   MDL_K3_EDGE_LANE   the edge-count heuristic (kernel 2 from 4e5 edges).
- *   MDL_BN_UNSHIFTED   mdl_bn_apply_n only: the sums are plain sum x / sum x^2 (written by mdl_linear_act_stats) instead of
- *                      the sums about the first row that mdl_bn_stats forms. */
+ *   MDL_K3_PER_WAVE /  MdlCgConv.flags of mdl_cgconv_bwd_ex with bf16 by-source sums: force the per-wave kernel / the
+ *   MDL_K3_EDGE_LANE   edge-per-lane kernel 2 instead of the edge-count heuristic (kernel 2 from 4e5 edges).
+ *   MDL_BN_SHIFT_ROW   mdl_bn_apply_n only: the sums were formed by the PRODUCER of the rows (mdl_linear_act_stats,
+ *                      mdl_cgconv_fwd_ex) about the per-column shift it stored behind the totals rows of the sums buffer
+ *                      (row 2 MDL_BN_REPLICAS + 2), instead of about the first row as mdl_bn_stats forms them.
+ * The struct entry points (MdlCgConv, MdlCgNode) carry their flags in a field of their own; the positional entry points of
+ * the dense / BatchNorm kernels take them OR-ed into `dtype`. */
 #define MDL_DTYPE_MASK 0xff
 #define MDL_DETERMINISTIC 0x100
 #define MDL_K3_PER_WAVE 0x200
 #define MDL_K3_EDGE_LANE 0x400
-#define MDL_BN_UNSHIFTED 0x800
+#define MDL_BN_SHIFT_ROW 0x800
 
 typedef void* mdlStream_t; /* hipStream_t */
 
@@ -133,60 +136,96 @@ int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_t* rowptr, 
                    const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
                    void* out, int64_t N, int64_t E, int C, int G, int aggr, int dtype, mdlStream_t stream);
 
-/* Backward edge pass.  With dpre_k = d loss / d (W z_k + b) in R^{2Cp} (f half | s half):
- *     r_tgt[i, :] = sum_{k: tgt_k = i} dpre_k      [N, 2Cp] in `dtype`, written once per node (no atomics)
- *     r_src[j, :] += sum_{k: src_k = j} dpre_k     fp32 atomics; caller zero-fills
- *     dwe[c, g]   += sum_k dpre_k[c] * edge_attr_k[g]   [2Cp, Gp] fp32, Gp = 64*ceil(G/64); caller zero-fills
- *     db[c]       += sum_i r_tgt[i, c]                  [2Cp] fp32 bias gradient; caller zero-fills; may be NULL
- * from which the caller forms (dense, node level): dx = g + r_tgt W_tgt + r_src W_src, dW_tgt = r_tgt^T x,
- * dW_src = r_src^T x — by library GEMMs or by mdl_cgconv_bwd_node.  The gate pre-activations are
- * recomputed, not stored. */
-/* `dtype` may carry MDL_DETERMINISTIC (one wave per channel slice: r_src / dwe / db bit-reproducible). */
-int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
-                   const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
-                   const void* grad_out, void* r_tgt, float* r_src, float* dwe, float* db, int64_t N,
-                   int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes, mdlStream_t stream);
+/* ---- CGConv, struct entry points (round 5) ------------------------------------------------------------------------------
+ * The forward with its optional epilogue, the backward edge pass and the node kernel each take ONE argument struct: every
+ * variant the positional entry points of rounds 1-4 had grown (`_bwd`, `_bwd_h`, `_bwd_hb`, `_bwd_node`, `_bwd_node_z`,
+ * `_bwd_node_h`) is a field here, and the execution flags have a field of their own instead of riding in `dtype`.
+ * `size` must be sizeof(the struct): a caller built against another layout is rejected (MDL_E_ARG), never misread; fields
+ * a call does not use are zero.  Same reference call site as above (cgcnn.py:80-83,136-145 and its autograd backward). */
+typedef struct MdlCgConv {
+    uint32_t size;            /* sizeof(MdlCgConv) */
+    int32_t dtype;            /* MDL_F32 | MDL_BF16: x, edge_attr, out, grad_out, r_tgt */
+    uint32_t flags;           /* bwd: MDL_DETERMINISTIC | MDL_K3_PER_WAVE | MDL_K3_EDGE_LANE; fwd: 0 */
+    int32_t aggr;             /* MDL_MEAN | MDL_SUM */
+    int64_t N, E;
+    int32_t C, G;
+    const void* x;            /* [N, C] */
+    const void* edge_attr;    /* [E, G], CSR order unless eperm is given */
+    const int32_t* rowptr;    /* [N + 1] */
+    const int32_t* src;       /* [E] */
+    const int32_t* tgt;       /* [E] */
+    const int32_t* eperm;     /* [E] or NULL: row of edge_attr for CSR slot k (generic kernels) */
+    const void* wpack;        /* mdl_cgconv_pack_weights */
+    const float* bpack;
+    /* forward (mdl_cgconv_fwd_ex) */
+    void* out;                /* [N, C] */
+    float* bn_sums;           /* optional: statistics of `out` for the training-mode BatchNorm1d behind the layer
+                               * (cgcnn.py:143), formed in the epilogue — per column sum (v - shift) and sum (v - shift)^2 of the
+                               * ROUNDED outputs over the rows that exist, into one of the MDL_BN_REPLICAS copies (layout of
+                               * mdl_bn_stats, caller zero-fills, (2 MDL_BN_REPLICAS + 3) * C floats: the kernel stores the shift
+                               * it used in the row behind the totals rows); follow with
+                               * mdl_bn_apply_n(..., dtype | MDL_BN_SHIFT_ROW).  bf16, C in {32, 64}, G = 50, no eperm. */
+    const float* bn_shift;    /* [C] fp32 or NULL (zeros): any per-column value near the column mean, e.g. the beta of the
+                               * BatchNorm in front of the layer — keeps E[v^2] - E[v]^2 from cancelling in fp32 */
+    const int64_t* bn_rows;   /* device row count of a padded static batch, or NULL (N) */
+    /* backward edge pass (mdl_cgconv_bwd_ex).  With dpre_k = d loss / d (W z_k + b) in R^{2Cp} (f half | s half):
+     *     r_tgt[i, :] = sum_{k: tgt_k = i} dpre_k      [N, 2Cp] in `dtype`, written once per node (no atomics)
+     *     r_src[j, :] += sum_{k: src_k = j} dpre_k     [N, 2Cp] in r_src_dtype, atomics; caller zero-fills
+     *     dwe[c, g]   += sum_k dpre_k[c] * edge_attr_k[g]   [2Cp, Gp] fp32, Gp = 64*ceil(G/64); caller zero-fills
+     *     db[c]       += sum_i r_tgt[i, c]                  [2Cp] fp32 bias gradient; caller zero-fills; may be NULL
+     * from which the node level forms dx = g + r_tgt W_tgt + r_src W_src, dW_tgt = r_tgt^T x, dW_src = r_src^T x
+     * (mdl_cgconv_bwd_node_ex, or library GEMMs).  The gate pre-activations are recomputed, not stored. */
+    const void* grad_out;     /* [N, C] */
+    void* r_tgt;
+    void* r_src;
+    int32_t r_src_dtype;      /* MDL_F32; or MDL_BF16 (dtype MDL_BF16, C in {32, 64, 128}, G = 50, no eperm): packed bf16 atomics,
+                               * half the atomic operations and bytes; what the balance prefix and the MDL_K3_* flags go with */
+    int32_t reserved;
+    float* dwe;
+    float* db;
+    void* workspace;          /* optional scratch, mdl_cgconv_workspace_bytes (dynamic group scheduling of the per-wave kernel) */
+    size_t workspace_bytes;
+    const int32_t* balance;   /* optional [N + 1] inclusive cost prefix (mdl_cgconv_balance + cumsum): the workgroups of the
+                               * edge-per-lane kernel take node ranges of equal COST; NULL: equal edge + node counts */
+} MdlCgConv;
+int mdl_cgconv_fwd_ex(const MdlCgConv* args, mdlStream_t stream);
+int mdl_cgconv_bwd_ex(const MdlCgConv* args, mdlStream_t stream);
 
-/* mdl_cgconv_bwd with the by-source sums in bf16 (MDL_BF16, C in {32, 64}, G = 50, edge features in CSR order): r_src is a
- * [N, 2Cp] bf16 array (zero-filled by the caller) accumulated with packed bf16 atomics — half the atomic operations and half
- * the bytes of the fp32 form, and half the bytes its one consumer reads.  mdl_cgconv_bwd_node_h is that consumer:
- * mdl_cgconv_bwd_node_z for a bf16 r_src (zero_src = 1 hands it back zeroed).  r_tgt, dwe, db as in mdl_cgconv_bwd. */
-int mdl_cgconv_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src, const int32_t* tgt,
-                     const void* wpack, const float* bpack, const void* grad_out, void* r_tgt, void* r_src, float* dwe,
-                     float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
-                     mdlStream_t stream);
 /* Work balance of the edge-per-lane backward: cost[0] = 0, cost[n + 1] = cost of node n in quarter units (4 per edge and node,
  * + 5 per edge whose source is 48 or more rows away from its target, + 4 for a node without edges: 32 of them make an empty
- * tile that costs a full tile's time).  The caller turns it into an inclusive prefix sum
- * (int32, [N + 1]) and hands it to mdl_cgconv_bwd_hb, whose workgroups then take node ranges of equal COST instead of equal
- * edge + node counts (graphs wider than the by-source window make their tiles dearer; topology only: one prefix per batch
- * serves every layer).  NULL balance = mdl_cgconv_bwd_h.  `dtype` of mdl_cgconv_bwd_h / _hb may carry MDL_DETERMINISTIC,
- * MDL_K3_PER_WAVE or MDL_K3_EDGE_LANE; mdl_cgconv_bwd_node* and the flag-aware dense kernels below take MDL_DETERMINISTIC. */
+ * tile that costs a full tile's time).  The caller turns it into an inclusive prefix sum (int32, [N + 1]) for
+ * MdlCgConv.balance (topology only: one prefix per batch serves every layer). */
 int mdl_cgconv_balance(const int32_t* rowptr, const int32_t* src, int64_t N, int32_t* cost, mdlStream_t stream);
-int mdl_cgconv_bwd_hb(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src, const int32_t* tgt,
-                      const void* wpack, const float* bpack, const void* grad_out, void* r_tgt, void* r_src, float* dwe,
-                      float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
-                      const int32_t* balance, mdlStream_t stream);
-int mdl_cgconv_bwd_node_h(const void* x, const void* grad_out, const void* r_tgt, void* r_src, const void* wn_t, void* dx,
-                          float* dwn, int64_t N, int C, int dtype, int zero_src, mdlStream_t stream);
 
-/* Optional scratch for mdl_cgconv_bwd (caller-owned device memory, contents ignored; the library zeroes what it
- * uses, on the stream).  With it the backward hands 32-node groups to its waves dynamically (large problems);
+/* Optional scratch for mdl_cgconv_bwd_ex (caller-owned device memory, contents ignored; the library zeroes what it
+ * uses, on the stream).  With it the per-wave backward hands 32-node groups to its waves dynamically (large problems);
  * without it (NULL / 0) every wave gets a fixed edge-balanced node range.  Same results up to the order of the
  * fp32 atomic adds into r_src / dwe / db. */
 size_t mdl_cgconv_workspace_bytes(int64_t N, int64_t E, int C, int G, int dtype);
 
-/* Node-level dense half of the CGConv backward (same reference call site), one pass over r_tgt/r_src:
+/* Node-level dense half of the CGConv backward (same reference call site), one pass over r_tgt / r_src:
  *     dx  [N, C]   = grad_out + [r_tgt | r_src] @ Wn          Wn = wn_t^T, wn_t: [C, 4Cp] in `dtype`
  *     dwn [4Cp, C] += [r_tgt | r_src]^T @ x                   fp32, caller zero-fills
- * Row blocks of Wn / dwn: (f_tgt, s_tgt, f_src, s_src), each Cp rows.  Supported: dtype MDL_BF16,
- * C in {32, 64} (C == Cp); otherwise MDL_E_UNSUPP and the caller uses library GEMMs. */
-int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const void* r_tgt, const float* r_src,
-                        const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype, mdlStream_t stream);
-/* same; zero_src != 0: r_src [N, 2*Cp] is handed back ZEROED (this kernel is its only reader), so a caller that keeps ONE
- * r_src buffer for all layers and steps never fills it again — mdl_cgconv_bwd accumulates into it with atomics. */
-int mdl_cgconv_bwd_node_z(const void* x, const void* grad_out, const void* r_tgt, float* r_src, const void* wn_t, void* dx,
-                          float* dwn, int64_t N, int C, int dtype, int zero_src, mdlStream_t stream);
+ * Row blocks of Wn / dwn: (f_tgt, s_tgt, f_src, s_src), each Cp rows.  Supported: dtype MDL_BF16, C in {32, 64} (C == Cp);
+ * otherwise MDL_E_UNSUPP and the caller uses library GEMMs.  zero_src != 0: r_src is handed back ZEROED (this kernel is its
+ * only reader), so a caller that keeps ONE r_src buffer for all layers and steps never fills it again. */
+typedef struct MdlCgNode {
+    uint32_t size;            /* sizeof(MdlCgNode) */
+    int32_t dtype;            /* MDL_BF16 */
+    uint32_t flags;           /* MDL_DETERMINISTIC (one workgroup: every dwn element gets its terms from one wave) */
+    int32_t zero_src;
+    int64_t N;
+    int32_t C;
+    int32_t r_src_dtype;      /* MDL_F32 | MDL_BF16: what the edge pass accumulated */
+    const void* x;            /* [N, C] */
+    const void* grad_out;     /* [N, C] */
+    const void* r_tgt;        /* [N, 2Cp] in dtype */
+    void* r_src;              /* [N, 2Cp] in r_src_dtype */
+    const void* wn_t;         /* [C, 4Cp] in dtype (mdl_cgconv_pack_node_weights / mdl_cgconv_pack_weights_node) */
+    void* dx;                 /* [N, C] */
+    float* dwn;               /* [4Cp, C] */
+} MdlCgNode;
+int mdl_cgconv_bwd_node_ex(const MdlCgNode* args, mdlStream_t stream);
 
 /* Small layout helpers around the backward (replace the cat / transpose / cast / clone chain autograd would run):
  *   wn_t [C, 4Cp] (bf16) = Wn^T for mdl_cgconv_bwd_node from the two nn.Linear weights [C, 2C+G] (fp32);
@@ -224,7 +263,8 @@ int mdl_ssp_bwd(const void* g, const void* y, void* dx, int64_t n, int dtype, md
  * epilogue adds, per column, sum out and sum out^2 of the rounded bf16 values of the rows below *n_rows_dev (NULL = all N)
  * into one of the MDL_BN_REPLICAS copies of bn_sums (layout of mdl_bn_stats; caller zero-fills), so that
  * Linear -> ReLU -> BatchNorm1d (matdeeplearn/models/megnet.py:47-48) needs no statistics pass over [N, M]:
- * follow with mdl_bn_apply_n(..., dtype | MDL_BN_UNSHIFTED).  Even 34 <= M <= 160, K <= 160. */
+ * follow with mdl_bn_apply_n(..., dtype | MDL_BN_SHIFT_ROW): the sums are formed about output row 0, which the
+ * kernel evaluates for itself and stores behind the totals rows (bn_sums holds (2 MDL_BN_REPLICAS + 3) * M floats).  Even 34 <= M <= 160, K <= 160. */
 int mdl_linear_act_stats(const void* x, const void* w, const void* bias, const void* p1, const int32_t* idx1, const void* p2,
                          const int32_t* idx2, const void* p3, const int32_t* idx3, void* out, int64_t N, int K, int M, int act,
                          float* bn_sums, const int64_t* n_rows_dev, int dtype, mdlStream_t stream);

@@ -10,12 +10,50 @@ LIB_PATH = os.environ.get("MDL_HIP_LIB") or os.path.join(HERE, "lib", "libmdl_hi
 
 MDL_F32, MDL_BF16 = 0, 1
 MDL_SUM, MDL_MEAN, MDL_MAX = 0, 1, 2
-# execution flags OR-ed into the `dtype` argument (include/mdl_hip.h)
+# execution flags (include/mdl_hip.h): the `flags` field of the struct entry points, OR-ed into `dtype` for the positional ones
 MDL_DTYPE_MASK, MDL_DETERMINISTIC, MDL_K3_PER_WAVE, MDL_K3_EDGE_LANE = 0xFF, 0x100, 0x200, 0x400
-MDL_BN_UNSHIFTED = 0x800       # mdl_bn_apply_n: plain sums (written by mdl_linear_act_stats)
+MDL_BN_SHIFT_ROW = 0x800       # mdl_bn_apply_n: sums about the shift row their producer stored behind the totals rows
+MDL_BN_REPLICAS = 16
 REDUCE = {"sum": MDL_SUM, "add": MDL_SUM, "mean": MDL_MEAN, "max": MDL_MAX}
 
 _vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_u32 = ctypes.c_uint32
+
+
+class MdlCgConv(ctypes.Structure):
+    """include/mdl_hip.h: arguments of mdl_cgconv_fwd_ex / mdl_cgconv_bwd_ex (unused fields stay zero)"""
+    _fields_ = [("size", _u32), ("dtype", _i32), ("flags", _u32), ("aggr", _i32), ("N", _i64), ("E", _i64), ("C", _i32), ("G", _i32),
+                ("x", _vp), ("edge_attr", _vp), ("rowptr", _vp), ("src", _vp), ("tgt", _vp), ("eperm", _vp), ("wpack", _vp),
+                ("bpack", _vp), ("out", _vp), ("bn_sums", _vp), ("bn_shift", _vp), ("bn_rows", _vp), ("grad_out", _vp),
+                ("r_tgt", _vp), ("r_src", _vp), ("r_src_dtype", _i32), ("reserved", _i32), ("dwe", _vp), ("db", _vp),
+                ("workspace", _vp), ("workspace_bytes", _sz), ("balance", _vp)]
+
+
+class MdlCgNode(ctypes.Structure):
+    """include/mdl_hip.h: arguments of mdl_cgconv_bwd_node_ex"""
+    _fields_ = [("size", _u32), ("dtype", _i32), ("flags", _u32), ("zero_src", _i32), ("N", _i64), ("C", _i32), ("r_src_dtype", _i32),
+                ("x", _vp), ("grad_out", _vp), ("r_tgt", _vp), ("r_src", _vp), ("wn_t", _vp), ("dx", _vp), ("dwn", _vp)]
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+def cg_args(**kw):
+    """MdlCgConv from keyword arguments; tensors become device pointers"""
+    a = MdlCgConv()
+    a.size = ctypes.sizeof(MdlCgConv)
+    for k, v in kw.items():
+        setattr(a, k, _dp(v) if torch.is_tensor(v) else v)
+    return a
+
+
+def cg_node_args(**kw):
+    a = MdlCgNode()
+    a.size = ctypes.sizeof(MdlCgNode)
+    for k, v in kw.items():
+        setattr(a, k, _dp(v) if torch.is_tensor(v) else v)
+    return a
 
 # name -> (restype, argtypes); kept in one table so tests can check it against include/mdl_hip.h
 PROTOTYPES = {
@@ -31,14 +69,11 @@ PROTOTYPES = {
     "mdl_cgconv_pack_weights": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mdl_cgconv_pack_weights_node": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "mdl_cgconv_fwd": (_i32, [_vp] * 9 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
-    "mdl_cgconv_bwd": (_i32, [_vp] * 13 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, ctypes.c_size_t, _vp]),
+    "mdl_cgconv_fwd_ex": (_i32, [ctypes.POINTER(MdlCgConv), _vp]),
+    "mdl_cgconv_bwd_ex": (_i32, [ctypes.POINTER(MdlCgConv), _vp]),
+    "mdl_cgconv_bwd_node_ex": (_i32, [ctypes.POINTER(MdlCgNode), _vp]),
     "mdl_cgconv_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i32, _i32, _i32]),
-    "mdl_cgconv_bwd_h": (_i32, [_vp] * 12 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
-    "mdl_cgconv_bwd_hb": (_i32, [_vp] * 12 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp, _vp]),
     "mdl_cgconv_balance": (_i32, [_vp, _vp, _i64, _vp, _vp]),
-    "mdl_cgconv_bwd_node_h": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
-    "mdl_cgconv_bwd_node": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _vp]),
-    "mdl_cgconv_bwd_node_z": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "mdl_cgconv_pack_node_weights": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "mdl_cgconv_assemble_grads": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mdl_assemble_batch": (_i32, [_vp] * 20 + [_i32, _i32, _i32, _i32, _i32, _vp]),

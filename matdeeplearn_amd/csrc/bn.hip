@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        float* __restrict__ save, float* __restrict__ run_mean,
                                                        float* __restrict__ run_var, T* __restrict__ y, int64_t Ncap, int C,
                                                        float eps, float momentum, const int64_t* __restrict__ n_dev,
-                                                       int unshifted) {
+                                                       int shift_row) {
     typedef VecW<T, W> V;
     constexpr int U = 4;                                     // four independent 16-byte loads in flight per thread
     const int64_t N = n_dev ? max((int64_t)1, min(*n_dev, Ncap)) : Ncap;
@@ -121,9 +121,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     for (int u = 0; u < U; ++u) V::ld(x + (min(q0 + u * stride, total - 1) / CG) * C + cg * W, v[u]);
     float mean[W], scale[W], shiftv[W], sh[W];
     V::ld(x + cg * W, sh);
-    if (unshifted) {                                          // MDL_BN_UNSHIFTED: plain sums (mdl_linear_act_stats)
+    if (shift_row) {                                          // MDL_BN_SHIFT_ROW: the producer of the sums (mdl_linear_act_stats,
+        const float* srow = sums + (size_t)(2 * BN_R + 2) * C;   // mdl_cgconv_fwd_ex) left its shift behind the totals rows
 #pragma unroll
-        for (int j = 0; j < W; ++j) sh[j] = 0.0f;
+        for (int j = 0; j < W; ++j) sh[j] = srow[cg * W + j];
     }
     bn_totals(sums, tot, C, sums + (size_t)BN_R * 2 * C);
     const float invn = 1.0f / (float)N;
@@ -288,7 +289,7 @@ extern "C" int mdl_bn_apply_n(const void* x, float* sums, const float* gamma, co
                               float* running_mean, float* running_var, void* y, int64_t N, int C, float eps, float momentum,
                               const int64_t* n_dev, int dtype, mdlStream_t stream) {
     using namespace mdl;
-    const int unshifted = (dtype & MDL_BN_UNSHIFTED) ? 1 : 0;
+    const int shift_row = (dtype & MDL_BN_SHIFT_ROW) ? 1 : 0;
     dtype &= MDL_DTYPE_MASK;
     int rc = bn_check("mdl_bn_apply", N, C, dtype, x);
     if (rc) return rc;
@@ -297,9 +298,9 @@ extern "C" int mdl_bn_apply_n(const void* x, float* sums, const float* gamma, co
     if (g > 768) g = 768;          // 3 fat blocks per CU: the per-block statistics prologue amortises (measured 512..2048)
     if (g < 1) g = 1;
     const int W = bn_width(C, dtype);
-    if (dtype == MDL_BF16 && W == 8) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 8>), dim3((unsigned)g), dim3(bn_threads(C, 8)), 0, st, (const bf16_t*)x, sums, gamma, beta, save, running_mean, running_var, (bf16_t*)y, N, C, eps, momentum, n_dev, unshifted);
-    else if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 4>), dim3((unsigned)g), dim3(bn_threads(C, 4)), 0, st, (const bf16_t*)x, sums, gamma, beta, save, running_mean, running_var, (bf16_t*)y, N, C, eps, momentum, n_dev, unshifted);
-    else hipLaunchKernelGGL((bn_apply_kernel<float, 4>), dim3((unsigned)g), dim3(bn_threads(C, 4)), 0, st, (const float*)x, sums, gamma, beta, save, running_mean, running_var, (float*)y, N, C, eps, momentum, n_dev, unshifted);
+    if (dtype == MDL_BF16 && W == 8) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 8>), dim3((unsigned)g), dim3(bn_threads(C, 8)), 0, st, (const bf16_t*)x, sums, gamma, beta, save, running_mean, running_var, (bf16_t*)y, N, C, eps, momentum, n_dev, shift_row);
+    else if (dtype == MDL_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 4>), dim3((unsigned)g), dim3(bn_threads(C, 4)), 0, st, (const bf16_t*)x, sums, gamma, beta, save, running_mean, running_var, (bf16_t*)y, N, C, eps, momentum, n_dev, shift_row);
+    else hipLaunchKernelGGL((bn_apply_kernel<float, 4>), dim3((unsigned)g), dim3(bn_threads(C, 4)), 0, st, (const float*)x, sums, gamma, beta, save, running_mean, running_var, (float*)y, N, C, eps, momentum, n_dev, shift_row);
     return check_launch("mdl_bn_apply");
 }
 

@@ -155,6 +155,13 @@ struct CgParams {
                               // (mdl_cgconv_balance); null: edges + nodes in front of a node
     int rs16;           // bwd, bf16: r_src is a bf16 array accumulated with packed bf16 atomics (mdl_cgconv_bwd_h)
     int flags;          // host side: MDL_DETERMINISTIC / MDL_K3_* bits the caller OR-ed into `dtype`
+    // fwd, optional (mdl_cgconv_fwd_ex): statistics of the layer's OUTPUT for the training-mode BatchNorm1d behind it (cgcnn.py:143)
+    // in the epilogue — per column sum (v - shift) and sum (v - shift)^2 of the ROUNDED outputs over the rows that exist, into
+    // one of the MDL_BN_REPLICAS copies of the sums (layout of mdl_bn_stats; caller zero-fills); the shift row the sums are
+    // about is published behind the sums' totals rows for mdl_bn_apply_n(... | MDL_BN_SHIFT_ROW)
+    float* bn_sums;
+    const float* bn_shift;     // [C] fp32 or null (= 0): any per-column value near the column mean (the previous BatchNorm's beta)
+    const int64_t* bn_nrows;   // device row count of a padded static batch, or null (= N)
     const void* pt;     // W-split kernels: per-node projections P_t = x [W_f,tgt ; W_s,tgt]^T and P_s = x [W_f,src ; W_s,src]^T,
     const void* ps;     // [N, 2Cp] each in the compute dtype (columns f | s), scaled like the packed weights
     int64_t N, E;
@@ -839,7 +846,9 @@ struct GroupInfo {
 #define MDL_FWD_THREADS 256     // workgroup size of the forward kernel (waves share one LDS copy of W)
 #define MDL_FWD_WAVES 2         // waves per SIMD it is register-allocated for
 #endif
-template <typename T, int CP_, int G_, int VEC, int EW, int WM, bool AB_ = false, int WSP = 0>   // WM: 0 global, 1 LDS, 2 registers
+// BN_: the instantiation whose epilogue also forms the BatchNorm statistics of the output (p.bn_sums) — a variant of its own, so
+// that the plain forward keeps its register allocation (it sits at 252 of 256 VGPRs)
+template <typename T, int CP_, int G_, int VEC, int EW, int WM, bool AB_ = false, int WSP = 0, bool BN_ = false>   // WM: 0 global, 1 LDS, 2 registers
 __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_kernel(CgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Mma<T> M;
@@ -898,6 +907,46 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
                 R.nb = gwu == nw_total - 1 ? (int)p.N : wave_lower_bound(p.rowptr, (int)p.N, cut(gwu + 1), lane);
             }
         }
+        // BatchNorm statistics of the output (p.bn_sums).  The forward has no register to spare across its tile loop (252 VGPRs
+        // at two waves per SIMD), so the running sums live in the wave's LDS region ([2][CP_] floats behind the staging
+        // buffers, zeroed by setup_wave): a group's epilogue adds its rows' contributions, the wave's exit turns them into two
+        // atomics per channel on one of the MDL_BN_REPLICAS copies of the sums.
+        constexpr bool bnst = BN_;
+        // (address from scalars at every use: a pointer kept across the tile loop is two more VGPRs the kernel does not have)
+        auto bnl_at = [&](int k) -> float* {
+            const int wvs = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const int w_bytes = (p.w_elems * (int)sizeof(T) + 15) & ~15;
+            return reinterpret_cast<float*>(smem + w_bytes + (wvs + 1) * p.wave_lds_bytes - 2 * CP_ * 4) + k;
+        };
+        int bn_rows = (int)p.N;
+        if (bnst) {
+            if (p.bn_nrows) bn_rows = (int)max((int64_t)1, min(*p.bn_nrows, p.N));
+            if (gw == 0 && h == 0) {            // the shift row the sums are about, for the apply kernel (behind the totals rows)
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl)
+                    p.bn_sums[(size_t)(2 * MDL_BN_REPLICAS + 2) * CP_ + sl * 32 + i] = p.bn_shift ? p.bn_shift[sl * 32 + i] : 0.0f;
+            }
+        }
+        auto bn_add = [&](int sl, float t0, float t1) {      // this lane's sums over its rows -> the wave's LDS totals (h == 0 lanes)
+            t0 += __shfl_xor(t0, 32);
+            t1 += __shfl_xor(t1, 32);
+            if (h == 0) {
+                *bnl_at(sl * 32 + i) += t0;
+                *bnl_at(CP_ + sl * 32 + i) += t1;
+            }
+        };
+        auto bn_flush = [&]() {
+            if (!bnst) return;
+            wave_lds_fence();
+            float* dst = p.bn_sums + (size_t)(gw % MDL_BN_REPLICAS) * 2 * CP_;
+            if (h == 0) {
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl) {
+                    unsafeAtomicAdd(dst + sl * 32 + i, *bnl_at(sl * 32 + i));
+                    unsafeAtomicAdd(dst + CP_ + sl * 32 + i, *bnl_at(CP_ + sl * 32 + i));
+                }
+            }
+        };
         if (R.na >= R.nb) return;
         // The wave walks its groups as one continuous stream: the next group's row pointers are requested
         // at the top of the current group, and the indices / edge-feature words of the next group's first
@@ -955,6 +1004,19 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
                             if (q + u * WAVE < v1) os[q + u * WAVE] = v[u];
+                    }
+                }
+                if (bnst && G.n0 < bn_rows) {                      // (rare: isolated nodes below the row count; the padding is excluded)
+#pragma unroll
+                    for (int sl = 0; sl < NSL; ++sl) {
+                        const float sh = p.bn_shift ? p.bn_shift[sl * 32 + i] : 0.0f;
+                        float t0 = 0.0f, t1 = 0.0f;
+                        for (int n = G.n0 + h; n < min(ne, bn_rows); n += 2) {
+                            const float v = (float)Elem<T>::ld(x + (int64_t)n * dm.C + sl * 32 + i) - sh;
+                            t0 += v;
+                            t1 = fmaf(v, v, t1);
+                        }
+                        bn_add(sl, t0, t1);
                     }
                 }
                 if (ne >= R.nb) break;
@@ -1107,20 +1169,32 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_ker
 #pragma unroll
                 for (int r = 0; r < 16; ++r) invr[r] = __shfl(invd, d_row(r, h));
 #pragma unroll
-                for (int sl = 0; sl < NSL; ++sl)
+                for (int sl = 0; sl < NSL; ++sl) {
+                    const float sh = (bnst && p.bn_shift) ? p.bn_shift[sl * 32 + i] : 0.0f;
+                    float t0 = 0.0f, t1 = 0.0f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int n = G.n0 + d_row(r, h);
                         float a = acc_out[sl][r] * GT::M_SCALE;
                         if (p.aggr == MDL_MEAN) a *= invr[r];
-                        if (n < G.n1) Elem<T>::st(out + (int64_t)n * dm.C + sl * 32 + i, xr[sl][r] + a);
+                        const float v = xr[sl][r] + a;
+                        if (n < G.n1) Elem<T>::st(out + (int64_t)n * dm.C + sl * 32 + i, v);
+                        if (bnst) {
+                            // the statistics of what the BatchNorm will READ: the rounded value, rows that exist only
+                            const float vr = (n < G.n1 && n < bn_rows) ? Elem<T>::rnd(v) - sh : 0.0f;
+                            t0 += vr;
+                            t1 = fmaf(vr, vr, t1);
+                        }
                     }
+                    if (bnst) bn_add(sl, t0, t1);
+                }
             }
             TMARK(11);
             if (!hasN) break;
             G = GN;
             primed = nextHasEdges;
         }
+        bn_flush();
         TFLUSH(0);
         return;
     }
@@ -1942,7 +2016,8 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
 
     const int et_bytes = (32 * d.EKS * (int)sizeof(T) + 15) & ~15;
     // e tile, tgt-slot bytes, source ids, src-slot bytes, bitmap, one-hot tables (32 + 32 + 64 rows)
-    p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16 + ((bwd && sizeof(T) == 2) ? 128 * OHS * 2 + 64 + 256 : 0);
+    p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16 + ((bwd && sizeof(T) == 2) ? 128 * OHS * 2 + 64 + 256 : 0) +
+                       ((!bwd && p.bn_sums) ? 2 * d.Cp * 4 : 0);      // forward with BatchNorm statistics: the wave's [2][Cp] running sums
     const int w_bytes = (p.w_elems * (int)sizeof(T) + 15) & ~15;
     // MDL_DETERMINISTIC (backward): ONE wave per channel slice walks the whole batch — every sum this kernel forms with atomics
     // (r_src rows, dwe, db) then receives its terms from a single wave in program order, i.e. the same bits on every run.
@@ -2074,6 +2149,19 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
 
 #endif
 
+    if constexpr (sizeof(T) == 2) {
+        if (!bwd && p.bn_sums) {       // forward with the BatchNorm statistics in its epilogue: the static all-slices kernel only
+            if (!(fast && all_slices && w_lds)) { set_error("%s: BatchNorm statistics need the static bf16 kernels", name); return MDL_E_UNSUPP; }
+            auto kf = d.Cp == 64 ? cgconv_fwd_kernel<T, 64, 50, 9, 2, 1, false, 0, true> : cgconv_fwd_kernel<T, 32, 50, 9, 2, 1, false, 0, true>;
+            hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
+            if (e != hipSuccess) { set_error("%s: LDS attribute (%d B): %s", name, lds, hipGetErrorString(e)); return MDL_E_LAUNCH; }
+            hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
+            return check_launch(name);
+        }
+    } else if (!bwd && p.bn_sums) {
+        set_error("%s: BatchNorm statistics are bf16 only", name);
+        return MDL_E_UNSUPP;
+    }
 #define MDL_CG_LAUNCH(CP_, G_, VEC_, EW_, WM_)                                                               \
     do {                                                                                                     \
         auto kf = bwd ? cgconv_bwd_kernel<T, CP_, G_, VEC_, EW_, WM_> : cgconv_fwd_kernel<T, CP_, G_, VEC_, EW_, WM_>; \
@@ -2253,6 +2341,35 @@ extern "C" int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_
     return cg_launch<float>(false, p, dtype, (hipStream_t)stream, "mdl_cgconv_fwd");
 }
 
+static int cg_fwd_stats_ok(int C, int G, int dtype) {      // the static all-slices forward: the kernel that has the epilogue
+    return (dtype == MDL_BF16 && G == 50 && (C == 32 || C == 64) && MDL_FWD_ALLSLICES && MDL_CG_WM == 1) ? 1 : 0;
+}
+
+extern "C" int mdl_cgconv_fwd_ex(const MdlCgConv* a, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(a && a->size == sizeof(MdlCgConv), MDL_E_ARG, "mdl_cgconv_fwd_ex: argument struct of another layout (size %u, expected %u)",
+                a ? a->size : 0u, (unsigned)sizeof(MdlCgConv));
+    MDL_REQUIRE((a->flags & ~(uint32_t)MDL_DETERMINISTIC) == 0, MDL_E_ARG, "mdl_cgconv_fwd_ex: unknown flag bits %#x", a->flags);
+    int rc = cg_check("mdl_cgconv_fwd_ex", a->x, a->edge_attr, a->rowptr, a->src, a->tgt, a->wpack, a->bpack, a->N, a->E, a->C, a->G,
+                      a->aggr, a->dtype);
+    if (rc) return rc;
+    MDL_REQUIRE(a->N == 0 || a->out, MDL_E_ARG, "mdl_cgconv_fwd_ex: null out");
+    CgParams p = {};
+    p.x = a->x; p.ea = a->edge_attr; p.rowptr = a->rowptr; p.src = a->src; p.tgt = a->tgt; p.eperm = a->eperm;
+    p.wpack = a->wpack; p.bpack = a->bpack; p.out = a->out; p.N = a->N; p.E = a->E; p.C = a->C; p.G = a->G; p.aggr = a->aggr;
+    if (a->bn_sums) {
+        // BatchNorm statistics in the epilogue: the static all-slices kernel only (bf16, C in {32, 64}, G = 50, CSR-ordered edge features)
+        MDL_REQUIRE(cg_fwd_stats_ok(a->C, a->G, a->dtype) && !a->eperm && a->E > 0 &&
+                        reinterpret_cast<uintptr_t>(a->x) % 16 == 0 && reinterpret_cast<uintptr_t>(a->out) % 16 == 0 &&
+                        reinterpret_cast<uintptr_t>(a->edge_attr) % 4 == 0,
+                    MDL_E_UNSUPP, "mdl_cgconv_fwd_ex: BatchNorm statistics need bf16, C in {32, 64}, G = 50, edge features in CSR order, "
+                                  "16-byte aligned x / out (C=%d G=%d dtype=%d)", a->C, a->G, a->dtype);
+        p.bn_sums = a->bn_sums; p.bn_shift = a->bn_shift; p.bn_nrows = a->bn_rows;
+    }
+    if (a->dtype == MDL_BF16) return cg_launch<bf16_t>(false, p, a->dtype, (hipStream_t)stream, "mdl_cgconv_fwd_ex");
+    return cg_launch<float>(false, p, a->dtype, (hipStream_t)stream, "mdl_cgconv_fwd_ex");
+}
+
 extern "C" size_t mdl_cgconv_workspace_bytes(int64_t, int64_t, int, int, int) { return 64; }
 
 #if MDL_EXPERIMENTS   // saved-gate pair, W-split pair (declared in experiments/mdl_hip_experiments.h)
@@ -2395,66 +2512,43 @@ extern "C" int mdl_cgconv_balance(const int32_t* rowptr, const int32_t* src, int
     return check_launch("mdl_cgconv_balance");
 }
 
-static int cg_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
-                    const int32_t* tgt, const void* wpack, const float* bpack, const void* grad_out, void* r_tgt,
-                    void* r_src, float* dwe, float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype,
-                    void* workspace, size_t ws_bytes, const int32_t* balance, mdlStream_t stream);
-extern "C" int mdl_cgconv_bwd_hb(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
-                                 const int32_t* tgt, const void* wpack, const float* bpack, const void* grad_out, void* r_tgt,
-                                 void* r_src, float* dwe, float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype,
-                                 void* workspace, size_t ws_bytes, const int32_t* balance, mdlStream_t stream) {
-    return cg_bwd_h(x, edge_attr, rowptr, src, tgt, wpack, bpack, grad_out, r_tgt, r_src, dwe, db, N, E, C, G, aggr, dtype, workspace,
-                    ws_bytes, balance, stream);
-}
-extern "C" int mdl_cgconv_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
-                                const int32_t* tgt, const void* wpack, const float* bpack, const void* grad_out, void* r_tgt,
-                                void* r_src, float* dwe, float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype,
-                                void* workspace, size_t ws_bytes, mdlStream_t stream) {
-    return cg_bwd_h(x, edge_attr, rowptr, src, tgt, wpack, bpack, grad_out, r_tgt, r_src, dwe, db, N, E, C, G, aggr, dtype, workspace,
-                    ws_bytes, nullptr, stream);
-}
-static int cg_bwd_h(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
-                    const int32_t* tgt, const void* wpack, const float* bpack, const void* grad_out, void* r_tgt,
-                    void* r_src, float* dwe, float* db, int64_t N, int64_t E, int C, int G, int aggr, int dtype,
-                    void* workspace, size_t ws_bytes, const int32_t* balance, mdlStream_t stream) {
+extern "C" int mdl_cgconv_bwd_ex(const MdlCgConv* a, mdlStream_t stream) {
     using namespace mdl;
-    const int flags = dtype & ~MDL_DTYPE_MASK;
-    dtype &= MDL_DTYPE_MASK;
-    int rc = cg_check("mdl_cgconv_bwd_h", x, edge_attr, rowptr, src, tgt, wpack, bpack, N, E, C, G, aggr, dtype);
+    MDL_REQUIRE(a && a->size == sizeof(MdlCgConv), MDL_E_ARG, "mdl_cgconv_bwd_ex: argument struct of another layout (size %u, expected %u)",
+                a ? a->size : 0u, (unsigned)sizeof(MdlCgConv));
+    MDL_REQUIRE((a->flags & ~(uint32_t)(MDL_DETERMINISTIC | MDL_K3_PER_WAVE | MDL_K3_EDGE_LANE)) == 0, MDL_E_ARG,
+                "mdl_cgconv_bwd_ex: unknown flag bits %#x", a->flags);
+    const int dtype = a->dtype;
+    int rc = cg_check("mdl_cgconv_bwd_ex", a->x, a->edge_attr, a->rowptr, a->src, a->tgt, a->wpack, a->bpack, a->N, a->E, a->C, a->G,
+                      a->aggr, dtype);
     if (rc) return rc;
-    MDL_REQUIRE(dtype == MDL_BF16 && G == 50 && (C == 32 || C == 64 || C == 128), MDL_E_UNSUPP,
-                "mdl_cgconv_bwd_h: unsupported C=%d G=%d dtype=%d (bf16, C in {32, 64, 128}, G = 50)", C, G, dtype);
-    MDL_REQUIRE(N == 0 || (grad_out && r_tgt && r_src && dwe), MDL_E_ARG, "mdl_cgconv_bwd_h: null pointer");
-    MDL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(edge_attr) % 4 == 0 &&
-                    reinterpret_cast<uintptr_t>(r_src) % 4 == 0, MDL_E_ARG, "mdl_cgconv_bwd_h: x must be 16-byte, edge_attr / r_src 4-byte aligned");
+    MDL_REQUIRE(a->N == 0 || (a->grad_out && a->r_tgt && a->r_src && a->dwe), MDL_E_ARG, "mdl_cgconv_bwd_ex: null pointer");
+    MDL_REQUIRE(a->r_src_dtype == MDL_F32 || a->r_src_dtype == MDL_BF16, MDL_E_ARG, "mdl_cgconv_bwd_ex: r_src_dtype must be MDL_F32 or MDL_BF16");
     CgParams p = {};
-    p.x = x; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = nullptr;
-    p.wpack = wpack; p.bpack = bpack; p.gout = grad_out; p.r_tgt = r_tgt; p.r_src = static_cast<float*>(r_src); p.dwe = dwe; p.db = db;
-    p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr; p.rs16 = 1; p.balance = balance; p.flags = flags;
-    p.ctr = (workspace && ws_bytes >= mdl_cgconv_workspace_bytes(N, E, C, G, dtype)) ? static_cast<unsigned*>(workspace) : nullptr;
-    return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd_h");
-}
-
-extern "C" int mdl_cgconv_bwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
-                              const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,
-                              const void* grad_out, void* r_tgt, float* r_src, float* dwe, float* db, int64_t N,
-                              int64_t E, int C, int G, int aggr, int dtype, void* workspace, size_t ws_bytes,
-                              mdlStream_t stream) {
-    using namespace mdl;
-    const int flags = dtype & ~MDL_DTYPE_MASK;
-    dtype &= MDL_DTYPE_MASK;
-    int rc = cg_check("mdl_cgconv_bwd", x, edge_attr, rowptr, src, tgt, wpack, bpack, N, E, C, G, aggr, dtype);
-    if (rc) return rc;
-    MDL_REQUIRE(N == 0 || (grad_out && r_tgt && r_src && dwe), MDL_E_ARG, "mdl_cgconv_bwd: null pointer");
-    CgParams p = {};
-    p.flags = flags;
-    p.x = x; p.ea = edge_attr; p.rowptr = rowptr; p.src = src; p.tgt = tgt; p.eperm = eperm;
-    p.wpack = wpack; p.bpack = bpack; p.gout = grad_out; p.r_tgt = r_tgt; p.r_src = r_src; p.dwe = dwe; p.db = db;
-    p.N = N; p.E = E; p.C = C; p.G = G; p.aggr = aggr;
+    p.flags = (int)a->flags;
+    p.x = a->x; p.ea = a->edge_attr; p.rowptr = a->rowptr; p.src = a->src; p.tgt = a->tgt; p.eperm = a->eperm;
+    p.wpack = a->wpack; p.bpack = a->bpack; p.gout = a->grad_out; p.r_tgt = a->r_tgt; p.r_src = static_cast<float*>(a->r_src);
+    p.dwe = a->dwe; p.db = a->db;
+    p.N = a->N; p.E = a->E; p.C = a->C; p.G = a->G; p.aggr = a->aggr;
     // optional caller workspace: work counters for dynamic group scheduling (zeroed here, on the stream)
-    p.ctr = (workspace && ws_bytes >= mdl_cgconv_workspace_bytes(N, E, C, G, dtype)) ? static_cast<unsigned*>(workspace) : nullptr;
-    if (dtype == MDL_BF16) return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd");
-    return cg_launch<float>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd");
+    p.ctr = (a->workspace && a->workspace_bytes >= mdl_cgconv_workspace_bytes(a->N, a->E, a->C, a->G, dtype))
+                ? static_cast<unsigned*>(a->workspace) : nullptr;
+    if (a->r_src_dtype == MDL_BF16) {
+        // by-source sums in bf16 (packed bf16 atomics): the static bf16 kernels, edge features in CSR order
+        MDL_REQUIRE(dtype == MDL_BF16 && a->G == 50 && (a->C == 32 || a->C == 64 || a->C == 128) && !a->eperm, MDL_E_UNSUPP,
+                    "mdl_cgconv_bwd_ex: bf16 by-source sums need bf16, C in {32, 64, 128}, G = 50, no eperm (C=%d G=%d dtype=%d)",
+                    a->C, a->G, dtype);
+        MDL_REQUIRE(reinterpret_cast<uintptr_t>(a->x) % 16 == 0 && reinterpret_cast<uintptr_t>(a->edge_attr) % 4 == 0 &&
+                        reinterpret_cast<uintptr_t>(a->r_src) % 4 == 0, MDL_E_ARG,
+                    "mdl_cgconv_bwd_ex: x must be 16-byte, edge_attr / r_src 4-byte aligned");
+        p.rs16 = 1;
+        p.balance = a->balance;
+    } else {
+        MDL_REQUIRE(!a->balance && (a->flags & (MDL_K3_PER_WAVE | MDL_K3_EDGE_LANE)) == 0, MDL_E_ARG,
+                    "mdl_cgconv_bwd_ex: the balance prefix and the MDL_K3_* flags go with bf16 by-source sums");
+    }
+    if (dtype == MDL_BF16) return cg_launch<bf16_t>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd_ex");
+    return cg_launch<float>(true, p, dtype, (hipStream_t)stream, "mdl_cgconv_bwd_ex");
 }
 
 extern "C" int mdl_debug_last_k3(void) { return mdl::g_last_k3; }

@@ -263,24 +263,16 @@ extern "C" int mdl_cgconv_assemble_grads(const float* dwn, const float* dwe, con
     return check_launch("mdl_cgconv_assemble_grads");
 }
 
-extern "C" int mdl_cgconv_bwd_node(const void* x, const void* grad_out, const void* r_tgt, const float* r_src,
-                                   const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype,
-                                   mdlStream_t stream) {
-    return mdl_cgconv_bwd_node_z(x, grad_out, r_tgt, const_cast<float*>(r_src), wn_t, dx, dwn, N, C, dtype, 0, stream);
-}
-
 static int bwd_node_launch(const void* x, const void* grad_out, const void* r_tgt, float* r_src, const void* wn_t, void* dx,
                            float* dwn, int64_t N, int C, int dtype, int zero_src, bool rs16, mdlStream_t stream);
 
-extern "C" int mdl_cgconv_bwd_node_z(const void* x, const void* grad_out, const void* r_tgt, float* r_src,
-                                     const void* wn_t, void* dx, float* dwn, int64_t N, int C, int dtype, int zero_src,
-                                     mdlStream_t stream) {
-    return bwd_node_launch(x, grad_out, r_tgt, r_src, wn_t, dx, dwn, N, C, dtype, zero_src, false, stream);
-}
-
-extern "C" int mdl_cgconv_bwd_node_h(const void* x, const void* grad_out, const void* r_tgt, void* r_src, const void* wn_t,
-                                     void* dx, float* dwn, int64_t N, int C, int dtype, int zero_src, mdlStream_t stream) {
-    return bwd_node_launch(x, grad_out, r_tgt, static_cast<float*>(r_src), wn_t, dx, dwn, N, C, dtype, zero_src, true, stream);
+extern "C" int mdl_cgconv_bwd_node_ex(const MdlCgNode* a, mdlStream_t stream) {
+    MDL_REQUIRE(a && a->size == sizeof(MdlCgNode), MDL_E_ARG, "mdl_cgconv_bwd_node_ex: argument struct of another layout (size %u, expected %u)",
+                a ? a->size : 0u, (unsigned)sizeof(MdlCgNode));
+    MDL_REQUIRE((a->flags & ~(uint32_t)MDL_DETERMINISTIC) == 0, MDL_E_ARG, "mdl_cgconv_bwd_node_ex: unknown flag bits %#x", a->flags);
+    MDL_REQUIRE(a->r_src_dtype == MDL_F32 || a->r_src_dtype == MDL_BF16, MDL_E_ARG, "mdl_cgconv_bwd_node_ex: r_src_dtype must be MDL_F32 or MDL_BF16");
+    return bwd_node_launch(a->x, a->grad_out, a->r_tgt, static_cast<float*>(a->r_src), a->wn_t, a->dx, a->dwn, a->N, a->C,
+                           a->dtype | (int)a->flags, a->zero_src, a->r_src_dtype == MDL_BF16, stream);
 }
 
 static int bwd_node_launch(const void* x, const void* grad_out, const void* r_tgt, float* r_src, const void* wn_t, void* dx,

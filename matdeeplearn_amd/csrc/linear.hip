@@ -144,12 +144,44 @@ __global__ __launch_bounds__(64 * MDL_LIN_NW(KP, GATHER), 2) void linear_act_ker
             return v;
         }
     };
-    float st0[STATS ? NB : 1], st1[STATS ? NB : 1];
+    float st0[STATS ? NB : 1], st1[STATS ? NB : 1], shv[STATS ? NB : 1];
     int64_t n_true = N;
     if constexpr (STATS) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) { st0[j] = 0.0f; st1[j] = 0.0f; }
         if (n_dev) n_true = max((int64_t)1, min(*n_dev, N));
+        // The sums are formed about a per-column SHIFT near the column mean — E[v^2] - E[v]^2 in fp32 cancels for a post-ReLU
+        // column whose mean is far above its spread (mdl_bn_stats shifts by the first row for the same reason).  Every
+        // workgroup evaluates output row 0 for itself (one K-long dot product per column from the global weights: same
+        // instructions, same bits everywhere), workgroup 0 publishes it behind the totals rows of the sums for
+        // mdl_bn_apply_n(... | MDL_BN_SHIFT_ROW).  The x tile's LDS area is free until the first tile is staged.
+        float* shl = reinterpret_cast<float*>(xl);
+        if (tid < M) {
+            float a = bias ? bf2f(bias[tid]) : 0.0f;
+            const unsigned* wr0 = reinterpret_cast<const unsigned*>(w + (int64_t)tid * K);
+            const unsigned* xr0 = reinterpret_cast<const unsigned*>(x);
+            for (int d = 0; d < k2; ++d) {
+                const unsigned wv2 = wr0[d], xv2 = xr0[d];
+                a = fmaf(__uint_as_float(wv2 << 16), __uint_as_float(xv2 << 16), a);
+                a = fmaf(__uint_as_float(wv2 & 0xffff0000u), __uint_as_float(xv2 & 0xffff0000u), a);
+            }
+            if constexpr (GATHER != 0) {
+#pragma unroll
+                for (int t = 0; t < GATHER; ++t) a += bf2f(ga.p[t][(int64_t)ga.idx[t][0] * M + tid]);
+            }
+            if (act == 1) a = a > 0.0f ? a : 0.0f;
+            else if (act == 2) a = fmaf(0.5f, a + fabsf(a), fmaf(LN2_F, __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-LOG2E_F * fabsf(a))), -LN2_F));
+            a = bf2f(f2bf(a));
+            shl[tid] = a;
+            if (bx == 0) stats[(size_t)(2 * MDL_BN_REPLICAS + 2) * M + tid] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int col = (ntb + XS * j) * 32 + i;
+            shv[j] = col < M ? shl[col] : 0.0f;
+        }
+        // (the first barrier of the tile loop stands between these reads and the staging writes)
     }
     int64_t tile = bx;
     if (tile < n_tiles) load_tile(tile);
@@ -244,7 +276,7 @@ __global__ __launch_bounds__(64 * MDL_LIN_NW(KP, GATHER), 2) void linear_act_ker
                             }
                             const bf16_t vb = f2bf(v);
                             if constexpr (STATS) {
-                                const float vr = (nb + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < n_true) ? bf2f(vb) : 0.0f;
+                                const float vr = (nb + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < n_true) ? bf2f(vb) - shv[j] : 0.0f;
                                 st0[j] += vr;
                                 st1[j] = fmaf(vr, vr, st1[j]);
                             }

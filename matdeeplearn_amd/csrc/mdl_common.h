@@ -37,11 +37,13 @@ template <> struct Elem<float> {
     static constexpr int dtype = MDL_F32;
     __device__ static __forceinline__ float ld(const float* p) { return *p; }
     __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float rnd(float v) { return v; }            // the value st() leaves in memory
 };
 template <> struct Elem<bf16_t> {
     static constexpr int dtype = MDL_BF16;
     __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+    __device__ static __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }
 };
 
 // ---- 16-byte row vectors (W elements) <-> floats ------------------------------------------------

@@ -22,6 +22,10 @@ class CGCNN(GraphModel):
     def forward(self, data):
         x, edge_attr, csr = self._inputs(data)
         out = self._pre(x)
+        bn_on = self.batch_norm == "True"
         for i, conv in enumerate(self.conv_list):
-            out = self._drop(self._bn(i, conv(out, None, edge_attr, csr=csr)))
+            # conv -> bn as one call: the BatchNorm's statistics are formed in the conv kernel's epilogue where the layer has the
+            # shape for it (nn.CGConv.forward); the sums' shift = the beta of the BatchNorm whose output this layer reads
+            prev = self.bn_list[i - 1].bias if (bn_on and i > 0) else None
+            out = self._drop(conv(out, None, edge_attr, csr=csr, bn=self.bn_list[i] if bn_on else None, bn_shift=prev))
         return self._head(out, data)

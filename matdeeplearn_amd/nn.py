@@ -31,11 +31,22 @@ class CGConv(nn.Module):
         self.lin_f.reset_parameters()
         self.lin_s.reset_parameters()
 
-    def forward(self, x, edge_index, edge_attr=None, csr=None):
+    def forward(self, x, edge_index, edge_attr=None, csr=None, bn=None, bn_shift=None):
+        """PyG's forward(x, edge_index, edge_attr).  Extra keywords of this build: `csr` (the batch's ops.EdgeCSR; no lookup by
+        edge_index), and `bn` — the BatchNorm1d the caller applies to the result (cgcnn.py:143): when it normalises with batch
+        statistics and the layer runs on the static bf16 kernels, bn(conv(x)) is returned with the statistics formed in the
+        conv kernel's epilogue (`bn_shift`: [C] values near the column means, e.g. the beta of the BatchNorm in front)."""
         if edge_attr is None:
             edge_attr = x.new_zeros((edge_index.shape[1], 0))
-        return ops.cgconv(x, edge_index, edge_attr, self.lin_f.weight, self.lin_f.bias, self.lin_s.weight,
-                          self.lin_s.bias, self.aggr, csr=csr)
+        if bn is not None:
+            if csr is None:
+                csr = ops.csr_for(edge_index, x.shape[0])
+            y = bn.after_cgconv(self, x, edge_index, edge_attr, csr, bn_shift)
+            if y is not None:
+                return y
+        y = ops.cgconv(x, edge_index, edge_attr, self.lin_f.weight, self.lin_f.bias, self.lin_s.weight,
+                       self.lin_s.bias, self.aggr, csr=csr)
+        return y if bn is None else bn(y)
 
     def extra_repr(self):
         return "%d, dim=%d, aggr=%s" % (self.channels, self.dim, self.aggr)
@@ -353,6 +364,20 @@ class BatchNorm1d(nn.BatchNorm1d):
             return ops.batch_norm_train(x, self.weight, self.bias, rm, rv, self.eps, self.momentum)
         self._sync_counter()
         return super().forward(x)
+
+    def after_cgconv(self, conv, x, edge_index, edge_attr, csr, shift=None):
+        """self(conv(x, ...)) with the statistics in the conv kernel's epilogue (ops.cgconv_bn) when this module normalises with
+        batch statistics and the layer has the shape for it; None otherwise (the caller composes)."""
+        use_batch_stats = self.training or not self.track_running_stats
+        if not (use_batch_stats and self.momentum is not None and self.num_features == x.shape[1] and ops.bn_supported(x)
+                and ops.cgconv_bn_stats_ok(x, edge_attr, csr)):
+            return None
+        rm = rv = None
+        if self.training and self.track_running_stats:
+            rm, rv = self.running_mean, self.running_var
+            self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1
+        return ops.cgconv_bn(x, edge_index, edge_attr, conv.lin_f.weight, conv.lin_f.bias, conv.lin_s.weight, conv.lin_s.bias,
+                             conv.aggr, csr, self.weight, self.bias, rm, rv, self.eps, self.momentum, shift)
 
     def after_linear_relu(self, h, weight, bias, lowp=None, gathered=None):
         """self(relu(F.linear(h, weight, bias) + gathered rows)) as one fused autograd node (ops.linear_relu_bn) when this

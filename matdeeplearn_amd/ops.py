@@ -617,7 +617,7 @@ def _take_rsrc(nfloats, device):
 
 class _CGConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, edge_attr, w_f, b_f, w_s, b_s, csr, aggr):
+    def forward(ctx, x, edge_attr, w_f, b_f, w_s, b_s, csr, aggr, bn=None):
         require_hip(x, edge_attr, w_f, w_s)
         if edge_attr.requires_grad:
             raise MdlError("cgconv: gradients w.r.t. edge_attr are not implemented (the reference's edge features are "
@@ -658,9 +658,13 @@ class _CGConvFn(torch.autograd.Function):
         ctx.wn_t = wn_t
         out = torch.empty_like(x)
         edge_attr = csr.sorted_attr(edge_attr)          # CSR order: the kernels never go through eperm
-        check(_launch_timed("fwd", lambda: L.mdl_cgconv_fwd(
-            ptr(x), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
-            ptr(bpack), ptr(out), N, E, Ck, G, aggr, dt, stream())), "mdl_cgconv_fwd")
+        # statistics of the output for the BatchNorm behind the layer, in the kernel's epilogue (bn = (sums buffer, shift)): the
+        # static bf16 kernels only — the caller (cgconv_bn_stats_ok) has checked
+        bn_sums, bn_shift = bn if bn is not None else (None, None)
+        args = _lib.cg_args(dtype=dt, aggr=aggr, N=N, E=E, C=Ck, G=G, x=x, edge_attr=edge_attr, rowptr=csr.rowptr, src=csr.src,
+                            tgt=csr.tgt, wpack=wpack, bpack=bpack, out=out, bn_sums=bn_sums, bn_shift=bn_shift,
+                            bn_rows=_true_rows_for(N) if bn_sums is not None else None)
+        check(_launch_timed("fwd", lambda: L.mdl_cgconv_fwd_ex(args, stream())), "mdl_cgconv_fwd_ex")
         ctx.save_for_backward(x, edge_attr, wf32, ws32, wpack, bpack)
         ctx.csr, ctx.aggr, ctx.has_bias = csr, aggr, (b_f is not None, b_s is not None)
         ctx.wdtypes = (w_f.dtype, w_s.dtype)
@@ -698,18 +702,13 @@ class _CGConvFn(torch.autograd.Function):
         dwn = small[2 * Cp * GP + 2 * Cp:].view(4 * Cp, C)
         ws = _workspace(x.device, lib().mdl_cgconv_workspace_bytes(N, E, C, G, dt))
         fl = _dflag()
-        if rs16:
-            # node ranges of equal COST (far sources make a tile dearer): one prefix per batch, shared by all layers
-            bal = csr.balance() if (_BALANCE and E >= 400000 and not fl) else None
-            check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_hb(
-                ptr(xk), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(bpack), ptr(gk),
-                ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, Ck, G, ctx.aggr, dt | fl | _k3flag(), ptr(ws), ws.numel(), ptr(bal),
-                stream())), "mdl_cgconv_bwd_h")
-        else:
-            check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd(
-                ptr(xk), ptr(edge_attr), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), None, ptr(wpack),
-                ptr(bpack), ptr(gk), ptr(r_tgt), ptr(r_src), ptr(dwe), ptr(db), N, E, Ck, G, ctx.aggr, dt | fl,
-                ptr(ws), ws.numel(), stream())), "mdl_cgconv_bwd")
+        # node ranges of equal COST (far sources make a tile dearer): one prefix per batch, shared by all layers
+        bal = csr.balance() if (rs16 and _BALANCE and E >= 400000 and not fl) else None
+        eargs = _lib.cg_args(dtype=dt, flags=fl | (_k3flag() if rs16 else 0), aggr=ctx.aggr, N=N, E=E, C=Ck, G=G, x=xk, edge_attr=edge_attr,
+                             rowptr=csr.rowptr, src=csr.src, tgt=csr.tgt, wpack=wpack, bpack=bpack, grad_out=gk, r_tgt=r_tgt, r_src=r_src,
+                             r_src_dtype=_lib.MDL_BF16 if rs16 else _lib.MDL_F32, dwe=dwe, db=db, workspace=ws, workspace_bytes=ws.numel(),
+                             balance=bal)
+        check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_ex(eargs, stream())), "mdl_cgconv_bwd_ex")
         # node-level dense part: rows of Wn / dWn = (f_tgt, s_tgt, f_src, s_src)
         if node_hip:
             wn_t, ctx.wn_t = getattr(ctx, "wn_t", None), None                                      # Wn^T (packed by the forward)
@@ -718,10 +717,10 @@ class _CGConvFn(torch.autograd.Function):
                 check(lib().mdl_cgconv_pack_node_weights(ptr(wf32), ptr(ws32), C, G, ptr(wn_t), dt, stream()),
                       "mdl_cgconv_pack_node_weights")
             dx = torch.empty_like(x)
-            node_fn = lib().mdl_cgconv_bwd_node_h if rs16 else lib().mdl_cgconv_bwd_node_z
-            check(_launch_timed("bwd_node", lambda: node_fn(
-                ptr(x), ptr(g), ptr(r_tgt), ptr(r_src), ptr(wn_t), ptr(dx), ptr(dwn), N, C, dt | fl, 1 if keep is not None else 0,
-                stream())), "mdl_cgconv_bwd_node")
+            nargs = _lib.cg_node_args(dtype=dt, flags=fl, zero_src=1 if keep is not None else 0, N=N, C=C,
+                                      r_src_dtype=_lib.MDL_BF16 if rs16 else _lib.MDL_F32, x=x, grad_out=g, r_tgt=r_tgt, r_src=r_src,
+                                      wn_t=wn_t, dx=dx, dwn=dwn)
+            check(_launch_timed("bwd_node", lambda: lib().mdl_cgconv_bwd_node_ex(nargs, stream())), "mdl_cgconv_bwd_node_ex")
             if keep is not None:
                 keep[1] = False                                                                     # handed back zeroed
             dW_f = torch.empty((C, 2 * C + G), dtype=torch.float32, device=x.device)
@@ -730,7 +729,7 @@ class _CGConvFn(torch.autograd.Function):
             db_s = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[1] else None
             check(_launch_timed("bwd_grads", lambda: lib().mdl_cgconv_assemble_grads(
                 ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s), stream())), "mdl_cgconv_assemble_grads")
-            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None
+            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None, None
         if dt == _lib.MDL_BF16 and Cp == 128 and C % 2 == 0 and N > 0:
             # wide layers (C = 100 / 128): the same products on the streaming kernels.  r_tgt / r_src keep their padded
             # [N, 2 Cp] layout (padded columns are exact zeros), so  dx = g + r_tgt Wn_t + r_src Wn_s  is two library GEMMs on
@@ -754,7 +753,7 @@ class _CGConvFn(torch.autograd.Function):
             db_s = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[1] else None
             check(lib().mdl_cgconv_assemble_grads(ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s),
                                                   stream()), "mdl_cgconv_assemble_grads")
-            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None
+            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None, None
         Wn = torch.cat([wf32[:, :C], ws32[:, :C], wf32[:, C:2 * C], ws32[:, C:2 * C]], dim=0)      # [4C, C]
         rt = r_tgt.view(N, 2, Cp)[:, :, :C]                                                        # library GEMMs
         rs = r_src.view(N, 2, Cp)[:, :, :C]
@@ -767,16 +766,43 @@ class _CGConvFn(torch.autograd.Function):
         dW_s = torch.cat([dWn[C:2 * C], dWn[3 * C:4 * C], dwe_s], dim=1).to(ctx.wdtypes[1])
         db_f = db[:C].clone() if ctx.has_bias[0] else None
         db_s = db[Cp:Cp + C].clone() if ctx.has_bias[1] else None
-        return dx, None, dW_f, db_f, dW_s, db_s, None, None
+        return dx, None, dW_f, db_f, dW_s, db_s, None, None, None
 
 
-def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None):
-    """CGConv forward.  x [N,C], edge_index [2,E], edge_attr [E,G]; returns [N,C]."""
+def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None, bn_stats=None):
+    """CGConv forward.  x [N,C], edge_index [2,E], edge_attr [E,G]; returns [N,C].
+    bn_stats = (sums [2 R + 3, C] fp32 zero-filled, shift [C] fp32 or None): the kernel's epilogue also forms the statistics
+    of its output for the BatchNorm behind the layer (callers check cgconv_bn_stats_ok first)."""
     if aggr not in ("mean", "add", "sum"):
         raise MdlError("cgconv: aggr must be mean or add")
     if csr is None:
         csr = csr_for(edge_index, x.shape[0])
-    return _CGConvFn.apply(x, edge_attr, w_f, b_f, w_s, b_s, csr, _lib.REDUCE[aggr])
+    return _CGConvFn.apply(x, edge_attr, w_f, b_f, w_s, b_s, csr, _lib.REDUCE[aggr], bn_stats)
+
+
+_CG_BN_STATS = os.environ.get("MDL_CG_BN_STATS", "1") != "0"      # BatchNorm statistics in the CGConv forward's epilogue (A/B switch)
+
+
+def cgconv_bn_stats_ok(x, edge_attr, csr):
+    """The CGConv forward can form the statistics of its output for the BatchNorm1d behind it: the static bf16 kernels
+    (C in {32, 64}, G = 50, edge features in CSR order, 16-byte aligned rows), training with batch statistics, not in
+    deterministic mode (there the one-workgroup statistics kernel gives the run-to-run reproducible sums)."""
+    return (_CG_BN_STATS and not _DET and x.is_cuda and x.dtype == torch.bfloat16 and edge_attr.dtype == torch.bfloat16 and x.dim() == 2
+            and x.shape[1] in (32, 64) and edge_attr.shape[1] == 50 and csr.eperm is None and csr.E > 0 and x.shape[0] >= 2
+            and x.is_contiguous() and x.data_ptr() % 16 == 0 and edge_attr.data_ptr() % 4 == 0)
+
+
+def cgconv_bn(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr, csr, bn_weight, bn_bias, running_mean, running_var, eps, momentum,
+              shift=None):
+    """BatchNorm1d(train)(cgconv(...)) — cgcnn.py:136-145 — with the statistics pass over [N, C] folded into the conv kernel's
+    epilogue: the sums are formed about `shift` ([C] fp32 near the column means: the beta of the BatchNorm in FRONT of the layer,
+    None = 0) and normalised by mdl_bn_apply_n(MDL_BN_SHIFT_ROW)."""
+    C = x.shape[1]
+    R = lib().mdl_bn_sums_rows()
+    buf = _zeros_step((R + 3, C), x.device)                  # sums (copies + totals) | shift row | save (mean, invstd)
+    y = cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr, csr=csr,
+               bn_stats=(buf, None if shift is None else shift.detach().float().contiguous()))
+    return _BatchNormTrain.apply(y, bn_weight, bn_bias, running_mean, running_var, eps, momentum, buf)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1434,19 +1460,22 @@ def bn_sums_rows():
 
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, pre=None):
         N, C = x.shape
         dt = dtype_code(x)
         R = lib().mdl_bn_sums_rows()
-        buf = _zeros_step((R + 2, C), x.device)                               # rows 0..R-1: sums (copies + totals), then save
-        sums, save = buf[:R], buf[R:]
+        # pre: [R + 3, C] buffer whose sums the PRODUCER of x has already formed about the shift in row R (cgconv_bn)
+        buf = _zeros_step((R + 2, C), x.device) if pre is None else pre       # rows 0..R-1: sums (copies + totals) [| shift] | save
+        sums, save = buf[:R], buf[-2:]
         gw = None if weight is None else weight.detach().float().contiguous()
         gb = None if bias is None else bias.detach().float().contiguous()
         y = torch.empty_like(x)
         nd = _true_rows_for(N)
-        check(lib().mdl_bn_stats_n(ptr(x), ptr(sums), N, C, ptr(nd), dt | _dflag(), stream()), "mdl_bn_stats")
+        if pre is None:
+            check(lib().mdl_bn_stats_n(ptr(x), ptr(sums), N, C, ptr(nd), dt | _dflag(), stream()), "mdl_bn_stats")
         check(lib().mdl_bn_apply_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
-                                   ptr(y), N, C, float(eps), float(momentum), ptr(nd), dt, stream()), "mdl_bn_apply")
+                                   ptr(y), N, C, float(eps), float(momentum), ptr(nd),
+                                   dt | (_lib.MDL_BN_SHIFT_ROW if pre is not None else 0), stream()), "mdl_bn_apply")
         ctx.n_dev = nd
         ctx.save_for_backward(x, save, gw)
         ctx.has = (weight is not None, bias is not None)
@@ -1468,7 +1497,7 @@ class _BatchNormTrain(torch.autograd.Function):
               "mdl_bn_bwd_apply")
         dgamma = sums[R - 1].to(ctx.wdt) if ctx.has[0] else None          # totals row pair published by bwd_apply
         dbeta = sums[R - 2].to(ctx.wdt) if ctx.has[1] else None
-        return dx, dgamma, dbeta, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None
 
 
 class _LinearReluBN(torch.autograd.Function):
@@ -1492,10 +1521,11 @@ class _LinearReluBN(torch.autograd.Function):
         tb = tabs + [None] * (3 - len(tabs))
         ids = list(idx) + [None] * (3 - len(idx))
         R = lib().mdl_bn_sums_rows()
-        buf = _zeros_step((R + 2, M), x.device)
-        sums, save = buf[:R], buf[R:]
+        buf = _zeros_step((R + 3, M), x.device)                       # sums | the epilogue's shift row | save
+        sums, save = buf[:R], buf[R + 1:]
         nd = _true_rows_for(N)
-        # the statistics of the BatchNorm ride in the dense layer's epilogue (plain per-column sums of the rounded outputs) —
+        # the statistics of the BatchNorm ride in the dense layer's epilogue (per-column sums of the rounded outputs about output
+        # row 0, which the kernel evaluates for itself and leaves in the shift row) —
         # except in deterministic mode, where the one-workgroup statistics kernel gives the run-to-run reproducible sums
         in_epilogue = not _DET and len(tabs) in (0, 2) and K <= 160
         if in_epilogue:
@@ -1516,7 +1546,7 @@ class _LinearReluBN(torch.autograd.Function):
         if not in_epilogue:
             check(lib().mdl_bn_stats_n(ptr(y), ptr(sums), N, M, ptr(nd), dt | _dflag(), stream()), "mdl_bn_stats")
         check(lib().mdl_bn_apply_n(ptr(y), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(rm), ptr(rv), ptr(z), N, M, float(eps),
-                                   float(momentum), ptr(nd), dt | (_lib.MDL_BN_UNSHIFTED if in_epilogue else 0), stream()),
+                                   float(momentum), ptr(nd), dt | (_lib.MDL_BN_SHIFT_ROW if in_epilogue else 0), stream()),
               "mdl_bn_apply")
         ctx.save_for_backward(x, w, y, save, gw)
         ctx.n_dev, ctx.idx, ctx.rows, ctx.ntab = nd, list(idx), [None if t is None else t.shape[0] for t in tabs], len(tabs)

@@ -246,7 +246,7 @@ def test_cgconv_deterministic_mode_is_bit_reproducible_and_matches_the_default()
 
 
 def test_cgconv_balanced_ranges_through_the_c_abi():
-    """mdl_cgconv_balance against numpy (integer work: exact) and mdl_cgconv_bwd_hb — kernel 2 (MDL_K3_EDGE_LANE in `dtype`)
+    """mdl_cgconv_balance against numpy (integer work: exact) and mdl_cgconv_bwd_ex with the prefix — kernel 2 (MDL_K3_EDGE_LANE in `flags`)
     with node ranges of equal cost — against the same kernel on its default partition: the partition changes which workgroup
     sums what, not the sums (bf16 by-source sums: atomic order and window cuts differ).  The oracle check of the balanced
     kernel is test_cgconv_default_dispatch_on_a_large_batch_matches_oracle."""
@@ -286,8 +286,10 @@ def test_cgconv_balanced_ranges_through_the_c_abi():
         r_tgt = torch.empty(n_pad, 2 * C, device=d, dtype=torch.bfloat16)
         r_src = torch.zeros(n_pad, 2 * C, device=d, dtype=torch.bfloat16)
         dwe, db = torch.zeros(2 * C, 64, device=d), torch.zeros(2 * C, device=d)
-        _lib.check(L.mdl_cgconv_bwd_hb(P(x), P(ea), P(csr.rowptr), P(csr.src), P(csr.tgt), P(wpack), P(bpack), P(gout), P(r_tgt),
-                                       P(r_src), P(dwe), P(db), n_pad, E, C, G, 1, dt | _lib.MDL_K3_EDGE_LANE, None, 0, P(bal), st()), "bwd_hb")
+        a = _lib.cg_args(dtype=dt, flags=_lib.MDL_K3_EDGE_LANE, aggr=1, N=n_pad, E=E, C=C, G=G, x=x, edge_attr=ea, rowptr=csr.rowptr,
+                         src=csr.src, tgt=csr.tgt, wpack=wpack, bpack=bpack, grad_out=gout, r_tgt=r_tgt, r_src=r_src,
+                         r_src_dtype=_lib.MDL_BF16, dwe=dwe, db=db, balance=bal)
+        _lib.check(L.mdl_cgconv_bwd_ex(a, st()), "bwd_ex")
         assert L.mdl_debug_last_k3() == 2
         res.append((r_tgt, r_src, dwe, db))
     (rt0, rs0, dwe0, db0), (rt1, rs1, dwe1, db1) = res
@@ -345,9 +347,10 @@ def test_cgconv_c_abi_eperm_and_workspace_paths():
         dwe = torch.zeros(2 * C, 64, device=d)
         db = torch.zeros(2 * C, device=d)
         wsb = torch.full((ws_bytes,), 0xAB, dtype=torch.uint8, device=d) if use_ws else None      # garbage: the library zeroes it
-        _lib.check(L.mdl_cgconv_bwd(P(x), P(ea_sorted), P(csr.rowptr), P(csr.src), P(csr.tgt), None, P(wpack), P(bpack), P(gout),
-                                    P(r_tgt), P(r_src), P(dwe), P(db), n, E, C, G, 1, dt, P(wsb), ws_bytes if use_ws else 0,
-                                    st()), "bwd")
+        a = _lib.cg_args(dtype=dt, aggr=1, N=n, E=E, C=C, G=G, x=x, edge_attr=ea_sorted, rowptr=csr.rowptr, src=csr.src, tgt=csr.tgt,
+                         wpack=wpack, bpack=bpack, grad_out=gout, r_tgt=r_tgt, r_src=r_src, r_src_dtype=_lib.MDL_F32, dwe=dwe, db=db,
+                         workspace=wsb, workspace_bytes=ws_bytes if use_ws else 0)
+        _lib.check(L.mdl_cgconv_bwd_ex(a, st()), "bwd_ex")
         res.append((r_tgt, r_src, dwe, db))
     (rt0, rs0, dwe0, db0), (rt1, rs1, dwe1, db1) = res
     close(rt0, rt1, 8e-3, 1e-3)          # by-target sums: fp32 accumulation, stored in bf16 (one ulp of slack)
@@ -487,7 +490,8 @@ def test_buffer_stores_past_the_last_row_are_dropped():
     _lib.check(L.mdl_cgconv_pack_node_weights(P(wf), P(ws), C, G, P(wn_t), dt, st()), "pack_node")
     da, dx = carve(n, C)
     dwn = torch.zeros(4 * C, C, device=d)
-    _lib.check(L.mdl_cgconv_bwd_node(P(xx), P(gout), P(r_tgt), P(r_src), P(wn_t), P(dx), P(dwn), n, C, dt, st()), "bwd_node")
+    _lib.check(L.mdl_cgconv_bwd_node_ex(_lib.cg_node_args(dtype=dt, N=n, C=C, r_src_dtype=_lib.MDL_F32, x=xx, grad_out=gout, r_tgt=r_tgt,
+                                                          r_src=r_src, wn_t=wn_t, dx=dx, dwn=dwn), st()), "bwd_node_ex")
     torch.cuda.synchronize()
     assert guard_ok(da, n, C)
     R = torch.cat([r_tgt.float(), r_src.to(torch.bfloat16).float()], dim=1)
@@ -1097,3 +1101,93 @@ def test_fused_post_fc_head_matches_the_layer_by_layer_path(shape):
     for a, b, c in zip(dwf + dbf, dwl + dbl, dwr + dbr):
         close(a, b, 3e-2, 3e-2)
         assert frob(a, c) <= max(3e-2, 1.2 * frob(b, c))
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm statistics formed by the PRODUCER of the rows (round 5): the CGConv forward's epilogue (mdl_cgconv_fwd_ex) and
+# the dense layer's (mdl_linear_act_stats), about a per-column shift, normalised by mdl_bn_apply_n(MDL_BN_SHIFT_ROW)
+# ---------------------------------------------------------------------------------------------
+def _bn_fp64(y, gamma, beta, eps=1e-5):
+    y = y.double()
+    m, v = y.mean(0), y.var(0, unbiased=False)
+    return ((y - m) / torch.sqrt(v + eps) * gamma.double() + beta.double()), m, y.var(0, unbiased=True)
+
+
+@pytest.mark.parametrize("C,n,shift_kind", [(64, 3000, "beta"), (64, 517, "none"), (32, 1200, "beta"), (64, 2000, "far")])
+def test_cgconv_forward_forms_the_batchnorm_statistics_in_its_epilogue(C, n, shift_kind):
+    """nn.CGConv(x, ..., bn=BatchNorm1d) (cgcnn.py:136-145: conv -> bn) with the statistics out of the conv kernel's epilogue,
+    against (a) the same layer followed by the separate statistics kernel and (b) an fp64 BatchNorm of the conv kernel's own
+    (bf16) output: normalised rows, running statistics, every gradient.  Isolated nodes (their rows are copied, not computed)
+    are part of the statistics; `far`: columns whose mean sits 300 standard deviations from zero — the cancellation case the
+    shifted sums exist for (with the previous layer's beta as the shift the sums stay well conditioned)."""
+    from matdeeplearn_amd import nn as mnn, ops
+    d = dev()
+    G = 50
+    g = torch.Generator().manual_seed(n + C)
+    ei = rand_graph(n, n, sort=True, empty_frac=0.1)
+    E = ei.shape[1]
+    off = 30.0 if shift_kind == "far" else 0.0
+    x = (torch.randn(n, C, generator=g) * 0.1 + off).to(torch.bfloat16)
+    ea = torch.rand(E, G, generator=g).to(torch.bfloat16)
+    gout = torch.randn(n, C, generator=g)
+    conv = mnn.CGConv(C, G, aggr="mean").to(d)
+    csr = ops.build_csr(ei.to(d), n, assume_sorted=True)
+    shift = None if shift_kind == "none" else torch.full((C,), off, device=d) + (0.0 if shift_kind == "far" else 0.05)
+
+    def run(fused):
+        bn = mnn.BatchNorm1d(C).to(d)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.2, 0.2, C))
+        conv.zero_grad(set_to_none=True)
+        xd = x.to(d).requires_grad_(True)
+        if fused:
+            assert ops.cgconv_bn_stats_ok(xd, ea.to(d), csr)
+            z = conv(xd, None, ea.to(d), csr=csr, bn=bn, bn_shift=shift)
+        else:
+            z = bn(conv(xd, None, ea.to(d), csr=csr))
+        (z.float() * gout.to(d)).sum().backward()
+        return z.detach(), xd.grad, conv.lin_f.weight.grad.clone(), conv.lin_s.weight.grad.clone(), bn.weight.grad, bn.bias.grad, \
+            bn.running_mean.clone(), bn.running_var.clone(), bn
+
+    fu, se = run(True), run(False)
+    with torch.no_grad():
+        y = conv(x.to(d), None, ea.to(d), csr=csr)                      # the conv kernel's own bf16 output
+    ref, m64, v64 = _bn_fp64(y.float().cpu(), fu[8].weight.detach().cpu(), fu[8].bias.detach().cpu())
+    for res, what in ((fu, "epilogue sums"), (se, "statistics kernel")):
+        close(res[0], ref.float(), 2e-2, 1e-2)                                        # bf16 output of an fp32 normalisation
+        rm = res[6].cpu().double() / 0.1                                              # momentum 0.1 from running_mean 0
+        assert float((rm - m64).abs().max()) <= 1e-5 * (1.0 + float(m64.abs().max())), what
+        rv = (res[7].cpu().double() - 0.9) / 0.1
+        assert float((rv - v64).abs().max()) <= 2e-3 * float(v64.abs().max()) + 1e-7, (what, float((rv - v64).abs().max()), float(v64.abs().max()))
+    for k, nm in enumerate(["out", "dx", "dW_f", "dW_s", "dgamma", "dbeta"]):
+        close(fu[k], se[k], 3e-2, 3e-2)
+
+
+def test_producer_side_batchnorm_sums_survive_a_large_mean_small_variance_column():
+    """(advisor, round 4) a post-ReLU column whose mean is far above its spread over 2e5 rows: plain sum x / sum x^2 in fp32
+    cancel (E[x^2] - mean^2), the sums about the producer's shift row do not.  Linear -> ReLU -> BatchNorm with the statistics in
+    the dense layer's epilogue against an fp64 BatchNorm of the same (bf16) activations."""
+    from matdeeplearn_amd import nn as mnn, ops
+    d = dev()
+    N, K, M = 200000, 64, 64
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16)
+    W = (torch.randn(M, K, generator=g) * 0.05)
+    b = torch.full((M,), 40.0)                            # relu(x W^T + b) = 40 +- 0.01: mean / std ~ 4000
+    b[::2] = 0.1                                          # ... next to ordinary columns
+    bn = mnn.BatchNorm1d(M).to(d)
+    xd = x.to(d).requires_grad_(True)
+    Wd, bd = W.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    z = bn.after_linear_relu(xd, Wd, bd, None, None)
+    assert z is not None
+    with torch.no_grad():
+        y = ops.linear_act(x.to(d), W.to(d), b.to(d), "relu")          # the same activations, as stored (bf16)
+    ref, m64, v64 = _bn_fp64(y.float().cpu(), torch.ones(M), torch.zeros(M))
+    rm = bn.running_mean.cpu().double() / 0.1
+    rv = (bn.running_var.cpu().double() - 0.9) / 0.1
+    assert float((rm - m64).abs().max()) <= 1e-5 * (1.0 + float(m64.abs().max()))
+    # the variance of the large-mean columns is ~1e-3 (bf16 steps of 0.25 at 40): it must come out to a few per cent, not as
+    # rounding noise of a 1600-sized square
+    rel = ((rv - v64).abs() / (v64 + 1e-12))
+    assert float(rel.max()) <= 5e-2, (float(rel.max()), v64[:4].tolist(), rv[:4].tolist())
+    close(z, ref.float(), 5e-2, 2e-2)

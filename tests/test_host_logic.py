@@ -517,9 +517,13 @@ def test_conv_kernels_register_budget():
         return hits[0]
     scratch, occ = find("cgconv_bwd_kernelItLi64ELi50ELi9ELi2ELi1ELi0E")          # per-wave backward, bf16 C=64 G=50
     assert scratch == 0 and occ == 1
-    scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb0ELi0E")      # all-slices forward
+    scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb0ELi0ELb0E")  # all-slices forward
     assert scratch == 0 and occ == 2
-    scratch, occ = find("cgconv_fwd_kernelItLi128ELi50ELi9ELi2ELi1ELb0ELi0E")     # 128-channel forward (padded C = 100): one
+    # ... with the BatchNorm statistics in its epilogue (an instantiation of its own so that the plain one keeps its allocation):
+    # a few 64-bit base pointers may spill, stored in the prologue and reloaded in the group epilogue — never in the tile loop
+    scratch, occ = find("cgconv_fwd_kernelItLi64ELi50ELi9ELi2ELi1ELb0ELi0ELb1E")
+    assert scratch <= 32 and occ == 2
+    scratch, occ = find("cgconv_fwd_kernelItLi128ELi50ELi9ELi2ELi1ELb0ELi0ELb0E") # 128-channel forward (padded C = 100): one
     assert scratch == 0 and occ == 2                                              # slice per wave
     scratch, occ = find("cgconv_bwd_kernelItLi128ELi50ELi9ELi2ELi1ELi0E")         # 128-channel backward: a few loop-invariant
     assert scratch <= 64 and occ == 1                                             # dwords spill
@@ -897,3 +901,32 @@ def test_checkpointed_optimizer_state_holds_float_learning_rates():
     sd["param_groups"][0]["lr"] = 0.001
     load_optimizer_state(opt, sd)
     assert opt.param_groups[0]["lr"] is lr_t and abs(float(lr_t) - 0.001) < 1e-9
+
+
+def test_struct_entry_points_have_the_layout_the_header_declares(tmp_path):
+    """MdlCgConv / MdlCgNode: the ctypes mirrors in _lib.py against sizeof / offsetof of include/mdl_hip.h as gcc lays them out
+    (a field added on one side only would shift every pointer behind it)."""
+    import ctypes
+    import shutil
+    import subprocess
+    from matdeeplearn_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    lines = []
+    for cls in (_lib.MdlCgConv, _lib.MdlCgNode):
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cls.__name__, cls.__name__))
+        for name, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cls.__name__, name, cls.__name__, name))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mdl_hip.h"\nint main(void) {\n%s\nreturn 0; }\n' % "\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True, capture_output=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cls in (_lib.MdlCgConv, _lib.MdlCgNode):
+        assert int(got[cls.__name__]) == ctypes.sizeof(cls)
+        for name, _ in cls._fields_:
+            assert int(got["%s.%s" % (cls.__name__, name)]) == getattr(cls, name).offset, (cls.__name__, name)
+    hdr = open(os.path.join(ROOT, "include", "mdl_hip.h")).read()
+    for gone in ("mdl_cgconv_bwd_h", "mdl_cgconv_bwd_hb", "mdl_cgconv_bwd_node_z", "mdl_cgconv_bwd_node_h"):
+        assert not re.search(r"\b%s\s*\(" % gone, hdr), gone

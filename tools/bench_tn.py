@@ -22,4 +22,5 @@ C = 64
 x = torch.randn(N, C, device=d).to(torch.bfloat16); g = torch.randn(N, C, device=d).to(torch.bfloat16)
 rt = torch.randn(N, 2 * C, device=d).to(torch.bfloat16); rs = torch.randn(N, 2 * C, device=d)
 wn = torch.randn(C, 4 * C, device=d).to(torch.bfloat16); dx = torch.empty_like(x); dwn = torch.zeros(4 * C, C, device=d)
-t("cgconv_bwd_node", lambda: L.mdl_cgconv_bwd_node(P(x), P(g), P(rt), P(rs), P(wn), P(dx), P(dwn), N, C, _lib.MDL_BF16, st()))
+t("cgconv_bwd_node", lambda: L.mdl_cgconv_bwd_node_ex(_lib.cg_node_args(dtype=_lib.MDL_BF16, N=N, C=C, r_src_dtype=_lib.MDL_F32, x=x, grad_out=g,
+                                                                        r_tgt=rt, r_src=rs, wn_t=wn, dx=dx, dwn=dwn), st()))
