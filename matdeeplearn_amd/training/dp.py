@@ -114,6 +114,24 @@ class FlatDataParallel:
                     t.copy_(flat[off:off + t.numel()].view_as(t))
                     off += t.numel()
 
+    def broadcast_buffers(self, src=0):
+        """The model's buffers (BatchNorm running statistics, which stay rank-local during training) from rank `src`, one flat
+        message per dtype: what DDP's broadcast_buffers=True does before EVERY forward (the reference's default,
+        training.py:263-266) is needed here only where ranks must evaluate the same model — the sharded validation."""
+        if self.world_size <= 1:
+            return
+        with torch.no_grad():
+            by_dtype = {}
+            for b in self.model.buffers():
+                by_dtype.setdefault(b.dtype, []).append(b.data)
+            for dt, ts in by_dtype.items():
+                flat = torch.cat([t.reshape(-1) for t in ts])
+                dist.broadcast(flat, src=src, group=self.group)
+                off = 0
+                for t in ts:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+
     def zero_grad(self):
         for p in self.params:
             p.grad = None

@@ -72,13 +72,15 @@ def resolve_seed(seed, sync=None):
     return seed or int(np.random.randint(1, 1e6))
 
 
-def _loaders(dataset, splits, batch_size, seed, rank, world_size, edge_dtype, rbf):
+def _loaders(dataset, splits, batch_size, seed, rank, world_size, edge_dtype, rbf, shard_val=False):
     tr, va, te = splits
     r = rank if isinstance(rank, int) else 0
     mk = lambda idx, sh, ws=1, rk=0: DeviceLoader(dataset, idx, batch_size, shuffle=sh, seed=seed, rank=rk,
                                                      world_size=ws, edge_dtype=edge_dtype, rbf=rbf) if len(idx) else None
-    # training.py:291-325 — DistributedSampler on train only; val/test on rank 0
-    return mk(tr, True, world_size, r), (mk(va, False) if r == 0 else None), (mk(te, False) if r == 0 else None)
+    # training.py:291-325 — DistributedSampler on train only; val/test on rank 0.  shard_val: every rank validates ITS slice
+    # va[r::world] (an exact partition: no padding duplicates as in the training partition, the error is a plain sum over ranks)
+    val = mk(np.asarray(va)[r::world_size], False) if (shard_val and world_size > 1) else (mk(va, False) if r == 0 else None)
+    return mk(tr, True, world_size, r), val, (mk(te, False) if r == 0 else None)
 
 
 def train_regular(rank, world_size, dataset, job, training, model_params, splits=None, model_factory=None,
@@ -94,8 +96,11 @@ def train_regular(rank, world_size, dataset, job, training, model_params, splits
     seed = resolve_seed(job.get("seed", 0), sync=distributed)                 # one seed for split, loader, init on all ranks
     if splits is None:
         splits = split_data(len(dataset), training["train_ratio"], training["val_ratio"], training["test_ratio"], seed)
+    # validation of a distributed run: sharded over the ranks + one scalar all-reduce per epoch unless the job asks
+    # for the reference's rank-0 form (training.py:132-134) with `shard_validation: "False"`; same error either way
+    shard_val = distributed and str(training.get("shard_validation", "True")) != "False"
     train_loader, val_loader, test_loader = _loaders(dataset, splits, params.get("batch_size", 100), seed, rank,
-                                                     world_size if distributed else 1, edge_dtype, rbf)
+                                                     world_size if distributed else 1, edge_dtype, rbf, shard_val=shard_val)
     torch.manual_seed(seed)
     model = model_factory(params["model"])(data=dataset, **params)
     dev = dataset.device if dataset.device is not None else torch.device("cpu")
@@ -107,7 +112,7 @@ def train_regular(rank, world_size, dataset, job, training, model_params, splits
     sch = make_scheduler(opt, params.get("scheduler", "ReduceLROnPlateau"), **params.get("scheduler_args", {}))
     t0 = time.time()
     model, history = trainer(rank, world_size, model, opt, sch, training["loss"], train_loader, val_loader,
-                             params.get("epochs", 1), training.get("verbosity", 5), dp=dp, log=log)
+                             params.get("epochs", 1), training.get("verbosity", 5), dp=dp, log=log, shard_val=shard_val)
     out = dict(history=history, model=model, seed=seed, train_time=time.time() - t0)
     is_root = (not distributed) or rank == 0
     if is_root:

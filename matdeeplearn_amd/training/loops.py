@@ -99,13 +99,17 @@ def train(model, optimizer, loader, loss_method, rank=None, dp=None, stats=None)
     return loss_all / max(count, 1)
 
 
-def evaluate(loader, model, loss_method, rank=None, out=False):
-    """Eval-mode pass; with out=True also returns rows (id, target, prediction) like training.py:68-90."""
+def evaluate(loader, model, loss_method, rank=None, out=False, sharded=False):
+    """Eval-mode pass; with out=True also returns rows (id, target, prediction) like training.py:68-90.
+    sharded=True (every rank of the process group calls it on ITS shard of the split, loader may be None for an empty shard):
+    the sample-weighted loss sum and the sample count are added up over the ranks with ONE two-element all-reduce, so every
+    rank returns the error of the whole split — the same number the reference's rank-0 evaluation (training.py:132-134) gives,
+    in 1 / world_size of the time."""
     model.eval()
     loss_all, count = 0, 0
     ids, preds, targets = [], [], []
     with torch.no_grad():
-        for data in loader:
+        for data in (loader if loader is not None else ()):
             data = data.to(rank)
             output = model(data)
             loss = getattr(F, loss_method)(output, data.y)
@@ -115,6 +119,16 @@ def evaluate(loader, model, loss_method, rank=None, out=False):
                 preds.append(output.detach().cpu().numpy())
                 targets.append(data.y.detach().cpu().numpy())
             count += output.size(0)
+    if sharded:
+        import torch.distributed as dist
+        dev = loss_all.device if torch.is_tensor(loss_all) else next(model.parameters()).device
+        t = torch.zeros(2, dtype=torch.float64, device=dev)
+        t[0] = loss_all if not torch.is_tensor(loss_all) else loss_all.double()
+        t[1] = float(count)
+        if dist.get_backend() == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return (t[0] / t[1].clamp(min=1.0)).float()
     loss_all = loss_all / max(count, 1)
     if out:
         return loss_all, np.column_stack((np.array(ids, dtype=object), np.concatenate(targets), np.concatenate(preds)))
@@ -122,9 +136,11 @@ def evaluate(loader, model, loss_method, rank=None, out=False):
 
 
 def trainer(rank, world_size, model, optimizer, scheduler, loss, train_loader, val_loader, epochs, verbosity=5,
-            dp=None, log=print):
+            dp=None, log=print, shard_val=False):
     """Epoch driver (training.py:96-207).  Returns (model with the best-validation weights loaded,
-    history list of dicts)."""
+    history list of dicts).  shard_val (distributed runs): `val_loader` is this rank's SHARD of the validation split (None
+    for an empty one) and the error comes from evaluate(sharded=True) — every rank then knows it, so every rank keeps the same
+    best-validation weights (with the reference's rank-0 form only rank 0 does)."""
     import torch.distributed as dist
 
     distributed = dp is not None and dp.world_size > 1
@@ -141,8 +157,15 @@ def trainer(rank, world_size, model, optimizer, scheduler, loss, train_loader, v
             dist.all_reduce(train_error, op=dist.ReduceOp.SUM)
             train_error = train_error / world_size
         val_error = None
-        if val_loader is not None and (not distributed or dist.get_rank() == 0):
+        if distributed and shard_val:
+            for m in model.modules():                           # (host-side BatchNorm step counters -> their buffers)
+                if hasattr(m, "_sync_counter"):
+                    m._sync_counter()
+            dp.broadcast_buffers()                              # every rank validates rank 0's model, as the reference does
+            val_error = float(evaluate(val_loader, model, loss, rank=rank, sharded=True))
+        elif val_loader is not None and (not distributed or dist.get_rank() == 0):
             val_error = float(evaluate(val_loader, model, loss, rank=rank))
+        if val_error is not None:
             if val_error < best_val:                            # training.py:144-166 (NaN never passes)
                 best_val = val_error
                 best_state = copy.deepcopy(model.state_dict())

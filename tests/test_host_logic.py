@@ -371,6 +371,59 @@ def test_seed_agreement_and_replica_drivers_world_size_2_gloo(tmp_path):
     assert open(out).read() == "ok"
 
 
+def _train_regular_worker(rank, world, port, out_path):
+    """The reference's DDP training job (training.py:377-539: ddp_setup, DistributedSampler partition, lr x world size, one
+    gradient exchange per step, per-epoch error reduction) through train_regular on two gloo ranks, with the validation
+    sharded over the ranks and with the reference's rank-0 validation: same validation errors, ranks in lock step."""
+    import torch.distributed as dist
+    from matdeeplearn_amd.process import from_structures
+    from matdeeplearn_amd.training import ddp_cleanup, ddp_setup, train_regular
+    from oracle import models as omodels, ops as oops
+    os.environ["MASTER_PORT"] = str(port)
+    ddp_setup(rank, world, backend="gloo", master_port=port)
+    z = np.load(os.path.join(G, "pt10_dataset.npz"))
+    n = 90
+    structs = [dict(positions=z["positions"][s], numbers=z["numbers"][s], cell=z["cell"][s], pbc=z["pbc"][s]) for s in range(n)]
+    ds = from_structures(structs, z["y"][:n], [str(v) for v in z["ids"][:n]]).to("cpu")
+    job = dict(job_name="d", seed=11, save_model="False", write_output="False")
+    mp_ = dict(model="CGCNN", dim1=8, dim2=8, gc_count=2, post_fc_count=1, epochs=3, lr=0.005, batch_size=16,
+               optimizer="AdamW", optimizer_args={}, scheduler="ReduceLROnPlateau", scheduler_args={"mode": "min"})
+    kw = dict(model_factory=lambda name: omodels.REGISTRY[name], rbf=lambda d: oops.rbf_expand(d), log=lambda *a: None)
+    res = {}
+    for tag, shard in (("sharded", "True"), ("rank0", "False")):
+        training = dict(target_index=0, loss="l1_loss", train_ratio=0.6, val_ratio=0.25, test_ratio=0.15, verbosity=0,
+                        shard_validation=shard)
+        r = train_regular(rank, world, ds, job, training, mp_, **kw)
+        res[tag] = ([h["val"] for h in r["history"]], [h["train"] for h in r["history"]],
+                    torch.cat([p.detach().reshape(-1) for p in r["model"].parameters()]),
+                    torch.cat([b.detach().double().reshape(-1) for b in r["model"].buffers()]))
+    both = [None, None]
+    dist.all_gather_object(both, {k: (v[0], v[1], v[2].tolist(), v[3].tolist()) for k, v in res.items()})
+    a, b = both
+    # sharded: every rank knows every epoch's validation error, keeps the same best weights and (after the broadcast in front of
+    # the validation) the same buffers
+    assert a["sharded"][0] == b["sharded"][0] and all(v is not None for v in a["sharded"][0])
+    assert a["sharded"][2] == b["sharded"][2] and a["sharded"][3] == b["sharded"][3]
+    # the reference's form: rank 0 validates alone, rank 1 never learns the number
+    assert all(v is not None for v in a["rank0"][0]) and all(v is None for v in b["rank0"][0])
+    # same job, same seeds: the training errors agree across the two forms and the validation errors are the same numbers
+    assert a["sharded"][1] == a["rank0"][1]
+    assert np.allclose(a["sharded"][0], a["rank0"][0], rtol=1e-5, atol=1e-7), (a["sharded"][0], a["rank0"][0])
+    if rank == 0:
+        open(out_path, "w").write("ok")
+    ddp_cleanup()
+
+
+def test_distributed_training_job_with_sharded_validation_world_size_2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = 33500 + (os.getpid() % 2000)
+    out = str(tmp_path / "tr.txt")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    mp.spawn(_train_regular_worker, args=(2, port, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
 def test_flat_on_disk_dataset_round_trip(tmp_path):
     """GraphDataset.save_flat / load_flat (the own on-disk format): every array bit-identical, memory-mapped or
     read; the reloaded dataset assembles the same batches (same x, CSR, distances, targets) as the original."""
