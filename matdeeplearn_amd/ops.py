@@ -780,7 +780,11 @@ def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None, 
     return _CGConvFn.apply(x, edge_attr, w_f, b_f, w_s, b_s, csr, _lib.REDUCE[aggr], bn_stats)
 
 
-_CG_BN_STATS = os.environ.get("MDL_CG_BN_STATS", "1") != "0"      # BatchNorm statistics in the CGConv forward's epilogue (A/B switch)
+# BatchNorm statistics in the CGConv forward's epilogue (mdl_cgconv_fwd_ex, bn_sums): OPT-IN.  Measured on the bench batch
+# (profiles/r05_k2_bn_stats_ab.txt, kernel traces of alternating runs): the statistics kernel it removes costs 7.7 us per layer,
+# the forward instantiation that carries the epilogue is 12.5 us per layer slower than the plain one (188.0 vs 175.8 us: it
+# sits at 256 VGPRs with 28 bytes of scratch, the plain kernel at 252 and none) — time-neutral at 8192 graphs and at 100.
+_CG_BN_STATS = os.environ.get("MDL_CG_BN_STATS", "0") == "1"
 
 
 def cgconv_bn_stats_ok(x, edge_attr, csr):

@@ -1114,13 +1114,14 @@ def _bn_fp64(y, gamma, beta, eps=1e-5):
 
 
 @pytest.mark.parametrize("C,n,shift_kind", [(64, 3000, "beta"), (64, 517, "none"), (32, 1200, "beta"), (64, 2000, "far")])
-def test_cgconv_forward_forms_the_batchnorm_statistics_in_its_epilogue(C, n, shift_kind):
+def test_cgconv_forward_forms_the_batchnorm_statistics_in_its_epilogue(C, n, shift_kind, monkeypatch):
     """nn.CGConv(x, ..., bn=BatchNorm1d) (cgcnn.py:136-145: conv -> bn) with the statistics out of the conv kernel's epilogue,
     against (a) the same layer followed by the separate statistics kernel and (b) an fp64 BatchNorm of the conv kernel's own
     (bf16) output: normalised rows, running statistics, every gradient.  Isolated nodes (their rows are copied, not computed)
     are part of the statistics; `far`: columns whose mean sits 300 standard deviations from zero — the cancellation case the
     shifted sums exist for (with the previous layer's beta as the shift the sums stay well conditioned)."""
     from matdeeplearn_amd import nn as mnn, ops
+    monkeypatch.setattr(ops, "_CG_BN_STATS", True)          # (opt-in: measured time-neutral on the bench batch, DESIGN section 4)
     d = dev()
     G = 50
     g = torch.Generator().manual_seed(n + C)
@@ -1191,4 +1192,6 @@ def test_producer_side_batchnorm_sums_survive_a_large_mean_small_variance_column
     assert float(v64[1]) > 1e-4 and float(m64[1]) ** 2 / float(v64[1]) > 3e4           # (the case is what it claims to be)
     err = (rv - v64).abs() - 5e-2 * v64
     assert float(err.max()) <= 1e-6, (float(err.max()), v64[:4].tolist(), rv[:4].tolist())
-    close(z, ref.float(), 5e-2, 2e-2)
+    # (normalised rows: the ordinary columns; in the large-mean columns one bf16 step of the activation — 0.25 at 40 — is two
+    # standard deviations, so two launches that round one pre-activation differently are not comparable element by element)
+    close(z[:, ::2], ref[:, ::2].float(), 5e-2, 2e-2)
