@@ -180,7 +180,9 @@ typedef struct MdlCgConv {
     void* r_src;
     int32_t r_src_dtype;      /* MDL_F32; or MDL_BF16 (dtype MDL_BF16, C in {32, 64, 128}, G = 50, no eperm): packed bf16 atomics,
                                * half the atomic operations and bytes; what the balance prefix and the MDL_K3_* flags go with */
-    int32_t reserved;
+    int32_t ld_dwe;           /* leading dimension of dwe in floats; 0 = Gp.  With ld_dwe = 2C + G and dwe = dW + 2C the rows land
+                               * straight in the two Linears' stacked weight gradient dW [2C, 2C + G] (rows f | s, columns target |
+                               * source | edge; C == Cp) and mdl_cgconv_assemble_grads is not needed */
     float* dwe;
     float* db;
     void* workspace;          /* optional scratch, mdl_cgconv_workspace_bytes (dynamic group scheduling of the per-wave kernel) */
@@ -217,6 +219,9 @@ typedef struct MdlCgNode {
     int64_t N;
     int32_t C;
     int32_t r_src_dtype;      /* MDL_F32 | MDL_BF16: what the edge pass accumulated */
+    int32_t ld_dwn;           /* 0: dwn is [4Cp, C] as above.  > 0: dwn IS the stacked weight gradient dW [2C, ld_dwn] of the two Linears
+                               * (ld_dwn = 2C + G): block b of the product's rows is added to rows (b & 1) C + c, columns (b >> 1) C + k */
+    int32_t reserved;
     const void* x;            /* [N, C] */
     const void* grad_out;     /* [N, C] */
     const void* r_tgt;        /* [N, 2Cp] in dtype */

@@ -25,14 +25,14 @@ class MdlCgConv(ctypes.Structure):
     _fields_ = [("size", _u32), ("dtype", _i32), ("flags", _u32), ("aggr", _i32), ("N", _i64), ("E", _i64), ("C", _i32), ("G", _i32),
                 ("x", _vp), ("edge_attr", _vp), ("rowptr", _vp), ("src", _vp), ("tgt", _vp), ("eperm", _vp), ("wpack", _vp),
                 ("bpack", _vp), ("out", _vp), ("bn_sums", _vp), ("bn_shift", _vp), ("bn_rows", _vp), ("grad_out", _vp),
-                ("r_tgt", _vp), ("r_src", _vp), ("r_src_dtype", _i32), ("reserved", _i32), ("dwe", _vp), ("db", _vp),
+                ("r_tgt", _vp), ("r_src", _vp), ("r_src_dtype", _i32), ("ld_dwe", _i32), ("dwe", _vp), ("db", _vp),
                 ("workspace", _vp), ("workspace_bytes", _sz), ("balance", _vp)]
 
 
 class MdlCgNode(ctypes.Structure):
     """include/mdl_hip.h: arguments of mdl_cgconv_bwd_node_ex"""
     _fields_ = [("size", _u32), ("dtype", _i32), ("flags", _u32), ("zero_src", _i32), ("N", _i64), ("C", _i32), ("r_src_dtype", _i32),
-                ("x", _vp), ("grad_out", _vp), ("r_tgt", _vp), ("r_src", _vp), ("wn_t", _vp), ("dx", _vp), ("dwn", _vp)]
+                ("ld_dwn", _i32), ("reserved", _i32), ("x", _vp), ("grad_out", _vp), ("r_tgt", _vp), ("r_src", _vp), ("wn_t", _vp), ("dx", _vp), ("dwn", _vp)]
 
 
 def _dp(t):

@@ -153,6 +153,7 @@ struct CgParams {
                         // the saved-gate backward (cgconv_bwd_ab_kernel)
     const int32_t* balance;   // bwd, optional: [N + 1] non-decreasing cost prefix the workgroups' node ranges are balanced on
                               // (mdl_cgconv_balance); null: edges + nodes in front of a node
+    int ldwe;           // bwd: leading dimension of dwe in floats (0: GP) — MdlCgConv.ld_dwe
     int rs16;           // bwd, bf16: r_src is a bf16 array accumulated with packed bf16 atomics (mdl_cgconv_bwd_h)
     int flags;          // host side: MDL_DETERMINISTIC / MDL_K3_* bits the caller OR-ed into `dtype`
     // fwd, optional (mdl_cgconv_fwd_ex): statistics of the layer's OUTPUT for the training-mode BatchNorm1d behind it (cgcnn.py:143)
@@ -1781,6 +1782,9 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
         }
     }
     // flush the wave's dwe partial sums: D rows = channel slot d_row(r,h) of slice s, cols = feature
+#ifdef MDL_ABL_NODWEFLUSH      // (timing experiments: wrong results)
+    if (p.N >= 0) return;
+#endif
 #pragma unroll
     for (int nt = 0; nt < GNT; ++nt) {
         const int gcol = nt * 32 + i;
@@ -1995,6 +1999,7 @@ template <typename T>
 static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const char* name) {
     const CgDims d = cg_dims(p.C, p.G, dtype);
     p.Cp = d.Cp; p.KE = d.KE; p.KT = d.KT; p.WS = d.WS; p.EKS = d.EKS; p.NS = d.NS; p.GP = d.GP;
+    if (p.ldwe > 0) p.GP = p.ldwe;      // dwe rows straight into the caller's [2C, 2C + G] weight-gradient matrix (MdlCgConv.ld_dwe)
     p.w_elems = 2 * d.Cp * d.WS;
     const bool wsp = p.pt != nullptr;  // W-split entry points: packed weights = edge-feature part only
     if (wsp) { p.WS = d.EKS; p.w_elems = 2 * d.Cp * d.EKS; }
@@ -2530,6 +2535,8 @@ extern "C" int mdl_cgconv_bwd_ex(const MdlCgConv* a, mdlStream_t stream) {
     p.wpack = a->wpack; p.bpack = a->bpack; p.gout = a->grad_out; p.r_tgt = a->r_tgt; p.r_src = static_cast<float*>(a->r_src);
     p.dwe = a->dwe; p.db = a->db;
     p.N = a->N; p.E = a->E; p.C = a->C; p.G = a->G; p.aggr = a->aggr;
+    MDL_REQUIRE(a->ld_dwe == 0 || a->ld_dwe >= a->G, MDL_E_ARG, "mdl_cgconv_bwd_ex: ld_dwe (%d) below G", a->ld_dwe);
+    p.ldwe = a->ld_dwe;
     // optional caller workspace: work counters for dynamic group scheduling (zeroed here, on the stream)
     p.ctr = (a->workspace && a->workspace_bytes >= mdl_cgconv_workspace_bytes(a->N, a->E, a->C, a->G, dtype))
                 ? static_cast<unsigned*>(a->workspace) : nullptr;

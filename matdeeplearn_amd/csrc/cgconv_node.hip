@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64 * NW, 2) void cgconv_node_stream_kernel(const bf
                                                                     const bf16_t* __restrict__ r_tgt,
                                                                     const float* __restrict__ r_src,
                                                                     const bf16_t* __restrict__ wn_t, bf16_t* __restrict__ dx,
-                                                                    float* __restrict__ dwn, int64_t N, int zero_src) {
+                                                                    float* __restrict__ dwn, int64_t N, int zero_src, int ld_out) {
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     typedef __attribute__((address_space(3))) s16x4* lds4_t;
     constexpr int TN = 64;               // nodes per tile
@@ -200,7 +200,13 @@ __global__ __launch_bounds__(64 * NW, 2) void cgconv_node_stream_kernel(const bf
     for (int j = 0; j < MJ; ++j) {
         const int blk = wv * MJ + j, mt = blk / NT, nt = blk - mt * NT;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) unsafeAtomicAdd(dwn + (int64_t)(mt * 32 + d_row(r, h)) * CP + nt * 32 + i, dw[j][r]);
+        for (int r = 0; r < 16; ++r) {
+            const int R = mt * 32 + d_row(r, h), K = nt * 32 + i;           // row of [r_tgt | r_src]^T x (blocks f_tgt, s_tgt, f_src, s_src), column of x
+            // ld_out > 0 (MdlCgNode.ld_dwn): straight into the two Linears' stacked weight gradient [2C][ld_out] (rows f | s, columns
+            // target | source | edge): block b of rows goes to rows (b & 1) C + c, columns (b >> 1) C + K — no assembly pass
+            const int64_t at = ld_out > 0 ? (int64_t)(((R / CP) & 1) * CP + R % CP) * ld_out + ((R / CP) >> 1) * CP + K : (int64_t)R * CP + K;
+            unsafeAtomicAdd(dwn + at, dw[j][r]);
+        }
     }
 }
 
@@ -264,7 +270,7 @@ extern "C" int mdl_cgconv_assemble_grads(const float* dwn, const float* dwe, con
 }
 
 static int bwd_node_launch(const void* x, const void* grad_out, const void* r_tgt, float* r_src, const void* wn_t, void* dx,
-                           float* dwn, int64_t N, int C, int dtype, int zero_src, bool rs16, mdlStream_t stream);
+                           float* dwn, int64_t N, int C, int dtype, int zero_src, bool rs16, int ld_out, mdlStream_t stream);
 
 extern "C" int mdl_cgconv_bwd_node_ex(const MdlCgNode* a, mdlStream_t stream) {
     MDL_REQUIRE(a && a->size == sizeof(MdlCgNode), MDL_E_ARG, "mdl_cgconv_bwd_node_ex: argument struct of another layout (size %u, expected %u)",
@@ -272,11 +278,11 @@ extern "C" int mdl_cgconv_bwd_node_ex(const MdlCgNode* a, mdlStream_t stream) {
     MDL_REQUIRE((a->flags & ~(uint32_t)MDL_DETERMINISTIC) == 0, MDL_E_ARG, "mdl_cgconv_bwd_node_ex: unknown flag bits %#x", a->flags);
     MDL_REQUIRE(a->r_src_dtype == MDL_F32 || a->r_src_dtype == MDL_BF16, MDL_E_ARG, "mdl_cgconv_bwd_node_ex: r_src_dtype must be MDL_F32 or MDL_BF16");
     return bwd_node_launch(a->x, a->grad_out, a->r_tgt, static_cast<float*>(a->r_src), a->wn_t, a->dx, a->dwn, a->N, a->C,
-                           a->dtype | (int)a->flags, a->zero_src, a->r_src_dtype == MDL_BF16, stream);
+                           a->dtype | (int)a->flags, a->zero_src, a->r_src_dtype == MDL_BF16, a->ld_dwn, stream);
 }
 
 static int bwd_node_launch(const void* x, const void* grad_out, const void* r_tgt, float* r_src, const void* wn_t, void* dx,
-                           float* dwn, int64_t N, int C, int dtype, int zero_src, bool rs16, mdlStream_t stream) {
+                           float* dwn, int64_t N, int C, int dtype, int zero_src, bool rs16, int ld_out, mdlStream_t stream) {
     using namespace mdl;
     const bool det = (dtype & MDL_DETERMINISTIC) != 0;      // one workgroup: every dwn element gets one add from one wave
     dtype &= MDL_DTYPE_MASK;
@@ -286,6 +292,7 @@ static int bwd_node_launch(const void* x, const void* grad_out, const void* r_tg
                 "mdl_cgconv_bwd_node: bad arguments");
     MDL_REQUIRE(reinterpret_cast<uintptr_t>(wn_t) % 16 == 0 && reinterpret_cast<uintptr_t>(r_tgt) % 16 == 0 &&
                     reinterpret_cast<uintptr_t>(r_src) % 16 == 0, MDL_E_ARG, "mdl_cgconv_bwd_node: 16-byte alignment required");
+    MDL_REQUIRE(ld_out == 0 || ld_out >= 2 * C, MDL_E_ARG, "mdl_cgconv_bwd_node_ex: ld_dwn (%d) below 2 C", ld_out);
     if (N == 0) return MDL_OK;
     hipStream_t st = (hipStream_t)stream;
     int64_t sgrid = cdiv(N, 64);
@@ -297,12 +304,12 @@ static int bwd_node_launch(const void* x, const void* grad_out, const void* r_tg
         auto kf = rs16 ? cgconv_node_stream_kernel<64, true, MDL_K3C_NW> : cgconv_node_stream_kernel<64, false, MDL_K3C_NW>;
         set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
         hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(64 * MDL_K3C_NW), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
-                           (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N, zero_src);
+                           (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N, zero_src, ld_out);
     } else {
         const int lds = (32 * (128 + 8) + 64 * (128 + 8) + 64 * (32 + 8)) * 2;
         auto kf = rs16 ? cgconv_node_stream_kernel<32, true> : cgconv_node_stream_kernel<32, false>;
         hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)grad_out,
-                           (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N, zero_src);
+                           (const bf16_t*)r_tgt, r_src, (const bf16_t*)wn_t, (bf16_t*)dx, dwn, N, zero_src, ld_out);
     }
     return check_launch("mdl_cgconv_bwd_node");
 }

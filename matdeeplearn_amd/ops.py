@@ -696,18 +696,29 @@ class _CGConvFn(torch.autograd.Function):
             r_src = r_src.view(torch.bfloat16).view(N, 2 * Cp) if rs16 else r_src.view(N, 2 * Cp)
         else:
             r_src = torch.zeros((N, 2 * Cp), dtype=torch.bfloat16 if rs16 else torch.float32, device=x.device)
-        small = _zeros_step((2 * Cp * GP + 2 * Cp + 4 * Cp * C,), x.device)
-        dwe = small[:2 * Cp * GP].view(2 * Cp, GP)
-        db = small[2 * Cp * GP:2 * Cp * GP + 2 * Cp]
-        dwn = small[2 * Cp * GP + 2 * Cp:].view(4 * Cp, C)
+        ldw = 2 * C + G
+        if node_hip:
+            # K3 and K3c add their partial sums straight into the two Linears' STACKED weight gradient dW [2C, 2C + G] (rows f | s,
+            # columns target | source | edge: MdlCgConv.ld_dwe, MdlCgNode.ld_dwn) and into db [2C]: no assembly kernel, no staging
+            # buffers.  One zero-filled slice of the step's gradient arena; dW_f / dW_s / db_f / db_s are views of it.
+            gbuf = _zeros_grad(2 * C * ldw + 2 * C, x.device)
+            dW = gbuf[:2 * C * ldw].view(2 * C, ldw)
+            db = gbuf[2 * C * ldw:]
+            dwe, dwn, ld_dwe = dW[:, 2 * C:], dW, ldw
+        else:
+            small = _zeros_step((2 * Cp * GP + 2 * Cp + 4 * Cp * C,), x.device)
+            dwe = small[:2 * Cp * GP].view(2 * Cp, GP)
+            db = small[2 * Cp * GP:2 * Cp * GP + 2 * Cp]
+            dwn = small[2 * Cp * GP + 2 * Cp:].view(4 * Cp, C)
+            ld_dwe = 0
         ws = _workspace(x.device, lib().mdl_cgconv_workspace_bytes(N, E, C, G, dt))
         fl = _dflag()
         # node ranges of equal COST (far sources make a tile dearer): one prefix per batch, shared by all layers
         bal = csr.balance() if (rs16 and _BALANCE and E >= 400000 and not fl) else None
         eargs = _lib.cg_args(dtype=dt, flags=fl | (_k3flag() if rs16 else 0), aggr=ctx.aggr, N=N, E=E, C=Ck, G=G, x=xk, edge_attr=edge_attr,
                              rowptr=csr.rowptr, src=csr.src, tgt=csr.tgt, wpack=wpack, bpack=bpack, grad_out=gk, r_tgt=r_tgt, r_src=r_src,
-                             r_src_dtype=_lib.MDL_BF16 if rs16 else _lib.MDL_F32, dwe=dwe, db=db, workspace=ws, workspace_bytes=ws.numel(),
-                             balance=bal)
+                             r_src_dtype=_lib.MDL_BF16 if rs16 else _lib.MDL_F32, dwe=dwe, ld_dwe=ld_dwe, db=db, workspace=ws,
+                             workspace_bytes=ws.numel(), balance=bal)
         check(_launch_timed("bwd", lambda: lib().mdl_cgconv_bwd_ex(eargs, stream())), "mdl_cgconv_bwd_ex")
         # node-level dense part: rows of Wn / dWn = (f_tgt, s_tgt, f_src, s_src)
         if node_hip:
@@ -718,18 +729,13 @@ class _CGConvFn(torch.autograd.Function):
                       "mdl_cgconv_pack_node_weights")
             dx = torch.empty_like(x)
             nargs = _lib.cg_node_args(dtype=dt, flags=fl, zero_src=1 if keep is not None else 0, N=N, C=C,
-                                      r_src_dtype=_lib.MDL_BF16 if rs16 else _lib.MDL_F32, x=x, grad_out=g, r_tgt=r_tgt, r_src=r_src,
-                                      wn_t=wn_t, dx=dx, dwn=dwn)
+                                      r_src_dtype=_lib.MDL_BF16 if rs16 else _lib.MDL_F32, ld_dwn=ldw, x=x, grad_out=g, r_tgt=r_tgt,
+                                      r_src=r_src, wn_t=wn_t, dx=dx, dwn=dwn)
             check(_launch_timed("bwd_node", lambda: lib().mdl_cgconv_bwd_node_ex(nargs, stream())), "mdl_cgconv_bwd_node_ex")
             if keep is not None:
                 keep[1] = False                                                                     # handed back zeroed
-            dW_f = torch.empty((C, 2 * C + G), dtype=torch.float32, device=x.device)
-            dW_s = torch.empty_like(dW_f)
-            db_f = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[0] else None
-            db_s = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[1] else None
-            check(_launch_timed("bwd_grads", lambda: lib().mdl_cgconv_assemble_grads(
-                ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s), stream())), "mdl_cgconv_assemble_grads")
-            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None, None
+            return (dx, None, dW[:C].to(ctx.wdtypes[0]), db[:C].to(ctx.wdtypes[0]) if ctx.has_bias[0] else None,
+                    dW[C:].to(ctx.wdtypes[1]), db[C:].to(ctx.wdtypes[1]) if ctx.has_bias[1] else None, None, None, None)
         if dt == _lib.MDL_BF16 and Cp == 128 and C % 2 == 0 and N > 0:
             # wide layers (C = 100 / 128): the same products on the streaming kernels.  r_tgt / r_src keep their padded
             # [N, 2 Cp] layout (padded columns are exact zeros), so  dx = g + r_tgt Wn_t + r_src Wn_s  is two library GEMMs on
