@@ -88,11 +88,9 @@ PROTOTYPES = {
     "mdl_bn_apply_n": (_i32, [_vp] * 8 + [_i64, _i32, _f32, _f32, _vp, _i32, _vp]),
     "mdl_bn_bwd_stats_n": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "mdl_bn_bwd_apply_n": (_i32, [_vp] * 6 + [_i64, _i32, _vp, _i32, _vp]),
+    "mdl_bn_fwd_n": (_i32, [_vp] * 8 + [_i64, _i32, _f32, _f32, _vp, _i32, _vp]),
+    "mdl_bn_bwd_n": (_i32, [_vp] * 6 + [_i64, _i32, _vp, _i32, _i32, _vp]),
     "mdl_bn_bwd_apply_relu_n": (_i32, [_vp] * 6 + [_i64, _i32, _vp, _i32, _vp]),
-    "mdl_bn_stats": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp]),
-    "mdl_bn_apply": (_i32, [_vp] * 8 + [_i64, _i32, _f32, _f32, _i32, _vp]),
-    "mdl_bn_bwd_stats": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
-    "mdl_bn_bwd_apply": (_i32, [_vp] * 6 + [_i64, _i32, _i32, _vp]),
     "mdl_linear_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_dense_bwd": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mdl_linear_act_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),

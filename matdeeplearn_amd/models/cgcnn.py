@@ -8,6 +8,10 @@ from ._base import GraphModel
 
 
 class CGCNN(GraphModel):
+    # nothing in this model walks the edges by SOURCE (the CGConv backward reaches the source rows from the by-target walk):
+    # a static batch built for it skips the by-source CSR (process.StaticBatch(by_source=False), training.GraphedStep)
+    needs_by_source = False
+
     def __init__(self, data, dim1=64, dim2=64, pre_fc_count=1, gc_count=3, post_fc_count=1,
                  pool="global_mean_pool", pool_order="early", batch_norm="True", batch_track_stats="True",
                  act="relu", dropout_rate=0.0, compute_dtype="fp32", **kwargs):

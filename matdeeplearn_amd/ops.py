@@ -697,7 +697,8 @@ class _CGConvFn(torch.autograd.Function):
         else:
             r_src = torch.zeros((N, 2 * Cp), dtype=torch.bfloat16 if rs16 else torch.float32, device=x.device)
         ldw = 2 * C + G
-        if node_hip:
+        direct = node_hip and _DIRECT_GRADS
+        if direct:
             # K3 and K3c add their partial sums straight into the two Linears' STACKED weight gradient dW [2C, 2C + G] (rows f | s,
             # columns target | source | edge: MdlCgConv.ld_dwe, MdlCgNode.ld_dwn) and into db [2C]: no assembly kernel, no staging
             # buffers.  One zero-filled slice of the step's gradient arena; dW_f / dW_s / db_f / db_s are views of it.
@@ -729,13 +730,21 @@ class _CGConvFn(torch.autograd.Function):
                       "mdl_cgconv_pack_node_weights")
             dx = torch.empty_like(x)
             nargs = _lib.cg_node_args(dtype=dt, flags=fl, zero_src=1 if keep is not None else 0, N=N, C=C,
-                                      r_src_dtype=_lib.MDL_BF16 if rs16 else _lib.MDL_F32, ld_dwn=ldw, x=x, grad_out=g, r_tgt=r_tgt,
-                                      r_src=r_src, wn_t=wn_t, dx=dx, dwn=dwn)
+                                      r_src_dtype=_lib.MDL_BF16 if rs16 else _lib.MDL_F32, ld_dwn=ldw if direct else 0, x=x, grad_out=g,
+                                      r_tgt=r_tgt, r_src=r_src, wn_t=wn_t, dx=dx, dwn=dwn)
             check(_launch_timed("bwd_node", lambda: lib().mdl_cgconv_bwd_node_ex(nargs, stream())), "mdl_cgconv_bwd_node_ex")
             if keep is not None:
                 keep[1] = False                                                                     # handed back zeroed
-            return (dx, None, dW[:C].to(ctx.wdtypes[0]), db[:C].to(ctx.wdtypes[0]) if ctx.has_bias[0] else None,
-                    dW[C:].to(ctx.wdtypes[1]), db[C:].to(ctx.wdtypes[1]) if ctx.has_bias[1] else None, None, None, None)
+            if direct:
+                return (dx, None, dW[:C].to(ctx.wdtypes[0]), db[:C].to(ctx.wdtypes[0]) if ctx.has_bias[0] else None,
+                        dW[C:].to(ctx.wdtypes[1]), db[C:].to(ctx.wdtypes[1]) if ctx.has_bias[1] else None, None, None, None)
+            dW_f = torch.empty((C, 2 * C + G), dtype=torch.float32, device=x.device)
+            dW_s = torch.empty_like(dW_f)
+            db_f = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[0] else None
+            db_s = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[1] else None
+            check(_launch_timed("bwd_grads", lambda: lib().mdl_cgconv_assemble_grads(
+                ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s), stream())), "mdl_cgconv_assemble_grads")
+            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None, None
         if dt == _lib.MDL_BF16 and Cp == 128 and C % 2 == 0 and N > 0:
             # wide layers (C = 100 / 128): the same products on the streaming kernels.  r_tgt / r_src keep their padded
             # [N, 2 Cp] layout (padded columns are exact zeros), so  dx = g + r_tgt Wn_t + r_src Wn_s  is two library GEMMs on
@@ -791,6 +800,8 @@ def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None, 
 # the forward instantiation that carries the epilogue is 12.5 us per layer slower than the plain one (188.0 vs 175.8 us: it
 # sits at 256 VGPRs with 28 bytes of scratch, the plain kernel at 252 and none) — time-neutral at 8192 graphs and at 100.
 _CG_BN_STATS = os.environ.get("MDL_CG_BN_STATS", "0") == "1"
+# K3 / K3c add their weight-gradient partial sums straight into the stacked dW [2C, 2C + G] (no mdl_cgconv_assemble_grads launch)
+_DIRECT_GRADS = os.environ.get("MDL_CG_DIRECT_GRADS", "1") == "1"
 
 
 def cgconv_bn_stats_ok(x, edge_attr, csr):
@@ -1482,10 +1493,13 @@ class _BatchNormTrain(torch.autograd.Function):
         y = torch.empty_like(x)
         nd = _true_rows_for(N)
         if pre is None:
-            check(lib().mdl_bn_stats_n(ptr(x), ptr(sums), N, C, ptr(nd), dt | _dflag(), stream()), "mdl_bn_stats")
-        check(lib().mdl_bn_apply_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
-                                   ptr(y), N, C, float(eps), float(momentum), ptr(nd),
-                                   dt | (_lib.MDL_BN_SHIFT_ROW if pre is not None else 0), stream()), "mdl_bn_apply")
+            # statistics + apply: one launch for few rows (the reference's batch size), the pair of passes otherwise
+            check(lib().mdl_bn_fwd_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
+                                     ptr(y), N, C, float(eps), float(momentum), ptr(nd), dt | _dflag(), stream()), "mdl_bn_fwd_n")
+        else:
+            check(lib().mdl_bn_apply_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
+                                       ptr(y), N, C, float(eps), float(momentum), ptr(nd), dt | _lib.MDL_BN_SHIFT_ROW, stream()),
+                  "mdl_bn_apply")
         ctx.n_dev = nd
         ctx.save_for_backward(x, save, gw)
         ctx.has = (weight is not None, bias is not None)
@@ -1502,9 +1516,8 @@ class _BatchNormTrain(torch.autograd.Function):
         sums = _zeros_grad(R * C, x.device).view(R, C)                       # (the step's GRADIENT arena, never reused: the totals
         dx = torch.empty_like(x)                                              # rows are returned as parameter gradients)
         nd = ctx.n_dev
-        check(lib().mdl_bn_bwd_stats_n(ptr(dy), ptr(x), ptr(save), ptr(sums), N, C, ptr(nd), dt | _dflag(), stream()), "mdl_bn_bwd_stats")
-        check(lib().mdl_bn_bwd_apply_n(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, ptr(nd), dt, stream()),
-              "mdl_bn_bwd_apply")
+        check(lib().mdl_bn_bwd_n(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, ptr(nd), 0, dt | _dflag(), stream()),
+              "mdl_bn_bwd_n")
         dgamma = sums[R - 1].to(ctx.wdt) if ctx.has[0] else None          # totals row pair published by bwd_apply
         dbeta = sums[R - 2].to(ctx.wdt) if ctx.has[1] else None
         return dx, dgamma, dbeta, None, None, None, None, None
@@ -1575,10 +1588,8 @@ class _LinearReluBN(torch.autograd.Function):
         R = lib().mdl_bn_sums_rows()
         sums = _zeros_grad(R * M, x.device).view(R, M)
         gp = torch.empty_like(y)                                                 # gradient w.r.t. the Linear's output (pre-activation)
-        check(lib().mdl_bn_bwd_stats_n(ptr(gz), ptr(y), ptr(save), ptr(sums), N, M, ptr(ctx.n_dev), dt | _dflag(), stream()),
-              "mdl_bn_bwd_stats")
-        check(lib().mdl_bn_bwd_apply_relu_n(ptr(gz), ptr(y), ptr(save), ptr(sums), ptr(gw), ptr(gp), N, M, ptr(ctx.n_dev), dt,
-                                            stream()), "mdl_bn_bwd_apply_relu")
+        check(lib().mdl_bn_bwd_n(ptr(gz), ptr(y), ptr(save), ptr(sums), ptr(gw), ptr(gp), N, M, ptr(ctx.n_dev), 1, dt | _dflag(),
+                                 stream()), "mdl_bn_bwd_n")
         dgamma = sums[R - 1].to(ctx.bn_wdt) if ctx.bn_has[0] else None
         dbeta = sums[R - 2].to(ctx.bn_wdt) if ctx.bn_has[1] else None
         buf = _zeros_grad(M * K + M, x.device)

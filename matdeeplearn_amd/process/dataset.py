@@ -478,9 +478,13 @@ class StaticBatch:
     kernels (BatchNorm) read through ops.true_rows().  Edge slots past the batch's last edge are referenced by no rowptr
     range."""
 
-    def __init__(self, ds, batch_size, n_cap, e_cap, x_dtype=torch.float32, edge_dtype=torch.float32, ring=8):
+    def __init__(self, ds, batch_size, n_cap, e_cap, x_dtype=torch.float32, edge_dtype=torch.float32, ring=8, by_source=True):
+        """by_source=False: the model never walks the edges by source (CGCNN: its backward reaches the source rows with atomics), so
+        assemble() skips the by-source CSR of the batch — one launch per step less; a model that does ask for it then fails
+        loudly on a stale index instead of reading one."""
         if ds.device is None or ds.device.type != "cuda":
             raise ops.MdlError("StaticBatch: the dataset must be resident on a HIP device")
+        self.by_source = bool(by_source)
         dev = ds.device
         B, F, G = int(batch_size), ds.num_features, ds.num_edge_features
         self.ds, self.B, self.n_cap, self.e_cap = ds, B, int(n_cap), int(e_cap)
@@ -503,7 +507,13 @@ class StaticBatch:
         # by-source index (static buffers, filled inside the graph) and the int64 edge_index view some models read
         self.rowptr_s = torch.zeros(self.n_cap + 1, dtype=torch.int32, device=dev)
         self.col_s, self.eid_s, self.src_s = (torch.zeros(self.e_cap, dtype=torch.int32, device=dev) for _ in range(3))
-        csr.set_transposed((self.rowptr_s, self.col_s, self.eid_s, self.src_s))
+        if self.by_source:
+            csr.set_transposed((self.rowptr_s, self.col_s, self.eid_s, self.src_s))
+        else:
+            def _no_by_source():
+                raise ops.MdlError("this StaticBatch was built with by_source=False (the model declared needs_by_source = False): "
+                                   "the by-source CSR of the batch is not maintained")
+            csr.set_transposed_builder(_no_by_source)
         csr.partial = True                                     # rows past n_dev / e_dev belong to no segment
         self.edge_index = torch.zeros((2, self.e_cap), dtype=torch.int64, device=dev)
         self.b_dev = torch.full((1,), B, dtype=torch.int64, device=dev)
@@ -529,9 +539,10 @@ class StaticBatch:
         ops.register_csr(self.edge_index, csr)
         # every index tensor a model may hand to scatter() maps to the loader's segment index: no sorts inside the graph,
         # and the unused tail of the buffers stays outside every segment
-        ops.register_seg_index(self.edge_index[0], csr.seg_src(), owner=self.edge_index)
+        if self.by_source:
+            ops.register_seg_index(self.edge_index[0], csr.seg_src(), owner=self.edge_index)
+            ops.register_seg_index(self.src, csr.seg_src())
         ops.register_seg_index(self.edge_index[1], csr.seg_tgt(), owner=self.edge_index)
-        ops.register_seg_index(self.src, csr.seg_src())
         ops.register_seg_index(self.tgt, csr.seg_tgt())
         ops.register_seg_index(self.batch_idx, self.batch.pool_index)
         self._pinned = [torch.zeros(self.pack_all.numel(), dtype=torch.int64).pin_memory() for _ in range(ring)]
@@ -584,11 +595,12 @@ class StaticBatch:
             int(ds.target_index), _lib.dtype_code(self.x), _lib.stream()), "mdl_assemble_batch")
         _lib.check(_lib.lib().mdl_pad_batch_tail(p(noff_d), p(eoff_d), B, self.n_cap, p(self.rowptr), p(self.batch_idx),
                                                  _lib.stream()), "mdl_pad_batch_tail")
-        eperm_s, lrowptr_s = ds.by_source()
-        _lib.check(_lib.lib().mdl_assemble_transposed(
-            p(ids_d), p(noff_d), p(eoff_d), p(d["node_ptr"]), p(d["edge_ptr"]), p(d["src"]), p(d["tgt"]), p(eperm_s),
-            p(lrowptr_s), p(self.rowptr_s), p(self.col_s), p(self.eid_s), p(self.src_s), B, self.n_cap, _lib.stream()),
-            "mdl_assemble_transposed")
+        if self.by_source:
+            eperm_s, lrowptr_s = ds.by_source()
+            _lib.check(_lib.lib().mdl_assemble_transposed(
+                p(ids_d), p(noff_d), p(eoff_d), p(d["node_ptr"]), p(d["edge_ptr"]), p(d["src"]), p(d["tgt"]), p(eperm_s),
+                p(lrowptr_s), p(self.rowptr_s), p(self.col_s), p(self.eid_s), p(self.src_s), B, self.n_cap, _lib.stream()),
+                "mdl_assemble_transposed")
         _lib.check(_lib.lib().mdl_pad_edge_tail(p(noff_d), p(eoff_d), B, self.n_cap, self.e_cap, p(self.src), p(self.tgt),
                                                 p(self.col_s), p(self.eid_s), p(self.src_s), _lib.stream()), "mdl_pad_edge_tail")
         self.batch._edge_index_stale = True       # the int64 [2, e_cap] view: refilled when (and if) a model reads batch.edge_index

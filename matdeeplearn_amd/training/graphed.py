@@ -37,7 +37,8 @@ class GraphedStep:
         # mean + 3.5 sigma: one batch in a few thousand takes the eager path (same arithmetic, ~2.5x the time at the reference's
         # batch size) — against 6 sigma that is 2-3 % less padded work per replay at 8192 graphs and a third less at 100
         n_cap, e_cap = capacity if capacity is not None else static_capacity(dataset, batch_size, indices, slack=3.5)
-        self.sb = StaticBatch(dataset, batch_size, n_cap, e_cap, x_dtype=compute_dtype, edge_dtype=compute_dtype)
+        self.sb = StaticBatch(dataset, batch_size, n_cap, e_cap, x_dtype=compute_dtype, edge_dtype=compute_dtype,
+                              by_source=getattr(model, "needs_by_source", True))
         self.dev = dataset.device
         distributed = dp is not None and (dp.world_size > 1 or getattr(dp, "active", False))
         if dp is not None and hasattr(dp, "single_collective"):

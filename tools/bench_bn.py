@@ -22,9 +22,9 @@ def t(name, fn, iters=50):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     print("%-14s %.1f us" % (name, e0.elapsed_time(e1) * 1e3 / iters))
-t("bn_stats", lambda: L.mdl_bn_stats(P(x), P(sums), N, C, _lib.MDL_BF16, st()))
-t("bn_apply", lambda: L.mdl_bn_apply(P(x), P(sums), P(gw), P(gb), P(save), None, None, P(y), N, C, 1e-5, 0.1, _lib.MDL_BF16, st()))
-t("bn_bwd_stats", lambda: L.mdl_bn_bwd_stats(P(dy), P(x), P(save), P(sums), N, C, _lib.MDL_BF16, st()))
-t("bn_bwd_apply", lambda: L.mdl_bn_bwd_apply(P(dy), P(x), P(save), P(sums), P(gw), P(dx), N, C, _lib.MDL_BF16, st()))
+t("bn_stats", lambda: L.mdl_bn_stats_n(P(x), P(sums), N, C, None, _lib.MDL_BF16, st()))
+t("bn_apply", lambda: L.mdl_bn_apply_n(P(x), P(sums), P(gw), P(gb), P(save), None, None, P(y), N, C, 1e-5, 0.1, None, _lib.MDL_BF16, st()))
+t("bn_bwd_stats", lambda: L.mdl_bn_bwd_stats_n(P(dy), P(x), P(save), P(sums), N, C, None, _lib.MDL_BF16, st()))
+t("bn_bwd_apply", lambda: L.mdl_bn_bwd_apply_n(P(dy), P(x), P(save), P(sums), P(gw), P(dx), N, C, None, _lib.MDL_BF16, st()))
 t("fill 27MB", lambda: y.zero_())
 t("copy 27MB", lambda: y.copy_(x))
