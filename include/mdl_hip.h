@@ -131,6 +131,13 @@ int mdl_cgconv_pack_weights(const float* w_f, const float* b_f, const float* w_s
 int mdl_cgconv_pack_weights_node(const float* w_f, const float* b_f, const float* w_s, const float* b_s, int C,
                                  int G, void* wpack, float* bpack, void* wn_t, int dtype, mdlStream_t stream);
 
+/* The same for every conv layer of a model in ONE launch: host tables of L <= 16 device pointers (b_f / b_s / wn_t tables or
+ * single entries may be NULL); all layers share C, G, dtype.  A model's weights are all known before its first layer runs, and
+ * at the reference's batch size (config.yml:136) a pack launch per layer is 5 us of a launch-bound step. */
+int mdl_cgconv_pack_weights_multi(int L, const float* const* w_f, const float* const* b_f, const float* const* w_s,
+                                  const float* const* b_s, int C, int G, void* const* wpack, float* const* bpack,
+                                  void* const* wn_t, int dtype, mdlStream_t stream);
+
 /* x: [N, C]; edge_attr: [E, G] (leading dim G); out: [N, C]; all in `dtype`. */
 int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,
                    const int32_t* tgt, const int32_t* eperm, const void* wpack, const float* bpack,

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "mdl_cgconv_wpack_bytes": (_sz, [_i32, _i32, _i32]),
     "mdl_cgconv_pack_weights": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mdl_cgconv_pack_weights_node": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "mdl_cgconv_pack_weights_multi": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "mdl_cgconv_fwd": (_i32, [_vp] * 9 + [_i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_cgconv_fwd_ex": (_i32, [ctypes.POINTER(MdlCgConv), _vp]),
     "mdl_cgconv_bwd_ex": (_i32, [ctypes.POINTER(MdlCgConv), _vp]),

@@ -1869,11 +1869,11 @@ int launch2(CgParams& p, hipStream_t st, int wgs, const char* name);     // cgco
 // Weight packing: nn.Linear [C, 2C+G] (target|source|edge) -> [2Cp][WS] with K order [e|x_tgt|x_src]
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void cgconv_pack_kernel(const float* __restrict__ wf, const float* __restrict__ bfv,
-                                                          const float* __restrict__ ws, const float* __restrict__ bsv,
-                                                          int C, int G, CgDims d, T* __restrict__ wpack,
-                                                          float* __restrict__ bpack, float scale, int bias_col,
-                                                          bf16_t* __restrict__ wn_t = nullptr) {
+__device__ __forceinline__ void cgconv_pack_body(const float* __restrict__ wf, const float* __restrict__ bfv,
+                                                 const float* __restrict__ ws, const float* __restrict__ bsv,
+                                                 int C, int G, const CgDims& d, T* __restrict__ wpack,
+                                                 float* __restrict__ bpack, float scale, int bias_col,
+                                                 bf16_t* __restrict__ wn_t) {
     const int total = 2 * d.Cp * d.WS;
     const int ldw = 2 * C + G;
     if (wn_t) {
@@ -1912,6 +1912,28 @@ __global__ __launch_bounds__(256) void cgconv_pack_kernel(const float* __restric
         const float* b = part ? bsv : bfv;
         bpack[q] = (c < C && b) ? b[c] * scale : 0.0f;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cgconv_pack_kernel(const float* __restrict__ wf, const float* __restrict__ bfv,
+                                                          const float* __restrict__ ws, const float* __restrict__ bsv,
+                                                          int C, int G, CgDims d, T* __restrict__ wpack,
+                                                          float* __restrict__ bpack, float scale, int bias_col,
+                                                          bf16_t* __restrict__ wn_t = nullptr) {
+    cgconv_pack_body<T>(wf, bfv, ws, bsv, C, G, d, wpack, bpack, scale, bias_col, wn_t);
+}
+
+// every conv layer of a model in ONE launch (blockIdx.y = layer): the layers' weights are all known before the first one runs,
+// and a pack launch per layer is 5 us of a step that is launch-bound at the reference's batch size (mdl_cgconv_pack_weights_multi)
+constexpr int PACK_MAXL = 16;
+struct PackMulti {
+    const float* wf[PACK_MAXL]; const float* bf[PACK_MAXL]; const float* ws[PACK_MAXL]; const float* bs[PACK_MAXL];
+    void* wpack[PACK_MAXL]; float* bpack[PACK_MAXL]; bf16_t* wn_t[PACK_MAXL];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void cgconv_pack_multi_kernel(PackMulti a, int C, int G, CgDims d, float scale, int bias_col) {
+    const int l = blockIdx.y;
+    cgconv_pack_body<T>(a.wf[l], a.bf[l], a.ws[l], a.bs[l], C, G, d, static_cast<T*>(a.wpack[l]), a.bpack[l], scale, bias_col, a.wn_t[l]);
 }
 
 #if MDL_EXPERIMENTS
@@ -2330,6 +2352,28 @@ static int cg_pack_weights(const float* w_f, const float* b_f, const float* w_s,
         return MDL_E_UNSUPP;
     }
     return check_launch("mdl_cgconv_pack_weights");
+}
+
+extern "C" int mdl_cgconv_pack_weights_multi(int L, const float* const* w_f, const float* const* b_f, const float* const* w_s,
+                                             const float* const* b_s, int C, int G, void* const* wpack, float* const* bpack,
+                                             void* const* wn_t, int dtype, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(L >= 1 && L <= PACK_MAXL && w_f && w_s && wpack && bpack, MDL_E_ARG, "mdl_cgconv_pack_weights_multi: 1..%d layers, non-null tables", PACK_MAXL);
+    MDL_REQUIRE(C >= 1 && C <= 256 && G >= 1 && G <= 64, MDL_E_UNSUPP, "mdl_cgconv_pack_weights_multi: unsupported C=%d G=%d", C, G);
+    MDL_REQUIRE(dtype == MDL_BF16 || dtype == MDL_F32, MDL_E_UNSUPP, "mdl_cgconv_pack_weights_multi: unsupported dtype %d", dtype);
+    MDL_REQUIRE(!wn_t || dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_cgconv_pack_weights_multi: wn_t is bf16 only");
+    PackMulti a = {};
+    for (int l = 0; l < L; ++l) {
+        MDL_REQUIRE(w_f[l] && w_s[l] && wpack[l] && bpack[l], MDL_E_ARG, "mdl_cgconv_pack_weights_multi: null pointer (layer %d)", l);
+        a.wf[l] = w_f[l]; a.bf[l] = b_f ? b_f[l] : nullptr; a.ws[l] = w_s[l]; a.bs[l] = b_s ? b_s[l] : nullptr;
+        a.wpack[l] = wpack[l]; a.bpack[l] = bpack[l]; a.wn_t[l] = wn_t ? static_cast<bf16_t*>(wn_t[l]) : nullptr;
+    }
+    const CgDims d = cg_dims(C, G, dtype);
+    dim3 grid((unsigned)cdiv(2 * d.Cp * d.WS, 256), (unsigned)L), block(256);
+    const int bias_col = (G % 16) != 0;
+    if (dtype == MDL_BF16) hipLaunchKernelGGL((cgconv_pack_multi_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a, C, G, d, Gate<true>::W_SCALE, bias_col);
+    else hipLaunchKernelGGL((cgconv_pack_multi_kernel<float>), grid, block, 0, (hipStream_t)stream, a, C, G, d, Gate<false>::W_SCALE, bias_col);
+    return check_launch("mdl_cgconv_pack_weights_multi");
 }
 
 extern "C" int mdl_cgconv_fwd(const void* x, const void* edge_attr, const int32_t* rowptr, const int32_t* src,

@@ -3,6 +3,7 @@ conv_list.i = CGConv(gc_dim, num_edge_features, aggr="mean", batch_norm=False) (
 conv -> bn_list.i -> dropout, NO activation between layers (:146 is commented out in the reference)."""
 from torch import nn
 
+from .. import ops
 from ..nn import CGConv
 from ._base import GraphModel
 
@@ -27,9 +28,13 @@ class CGCNN(GraphModel):
         x, edge_attr, csr = self._inputs(data)
         out = self._pre(x)
         bn_on = self.batch_norm == "True"
+        # every layer's weights are packed for the kernels in ONE launch (they are all known here): at the reference's batch size a
+        # pack launch per layer is 5 us of a launch-bound step
+        packs = ops.cgconv_prepack(list(self.conv_list), out.dtype, out.device, want_node=torch.is_grad_enabled()) if out.is_cuda else None
         for i, conv in enumerate(self.conv_list):
             # conv -> bn as one call: the BatchNorm's statistics are formed in the conv kernel's epilogue where the layer has the
             # shape for it (nn.CGConv.forward); the sums' shift = the beta of the BatchNorm whose output this layer reads
             prev = self.bn_list[i - 1].bias if (bn_on and i > 0) else None
-            out = self._drop(conv(out, None, edge_attr, csr=csr, bn=self.bn_list[i] if bn_on else None, bn_shift=prev))
+            out = self._drop(conv(out, None, edge_attr, csr=csr, bn=self.bn_list[i] if bn_on else None, bn_shift=prev,
+                                  packed=None if packs is None else packs[i]))
         return self._head(out, data)

@@ -31,21 +31,22 @@ class CGConv(nn.Module):
         self.lin_f.reset_parameters()
         self.lin_s.reset_parameters()
 
-    def forward(self, x, edge_index, edge_attr=None, csr=None, bn=None, bn_shift=None):
+    def forward(self, x, edge_index, edge_attr=None, csr=None, bn=None, bn_shift=None, packed=None):
         """PyG's forward(x, edge_index, edge_attr).  Extra keywords of this build: `csr` (the batch's ops.EdgeCSR; no lookup by
         edge_index), and `bn` — the BatchNorm1d the caller applies to the result (cgcnn.py:143): when it normalises with batch
         statistics and the layer runs on the static bf16 kernels, bn(conv(x)) is returned with the statistics formed in the
-        conv kernel's epilogue (`bn_shift`: [C] values near the column means, e.g. the beta of the BatchNorm in front)."""
+        conv kernel's epilogue (`bn_shift`: [C] values near the column means, e.g. the beta of the BatchNorm in front);
+        `packed`: this layer's entry of ops.cgconv_prepack (its weights packed with the model's other layers in one launch)."""
         if edge_attr is None:
             edge_attr = x.new_zeros((edge_index.shape[1], 0))
         if bn is not None:
             if csr is None:
                 csr = ops.csr_for(edge_index, x.shape[0])
-            y = bn.after_cgconv(self, x, edge_index, edge_attr, csr, bn_shift)
+            y = bn.after_cgconv(self, x, edge_index, edge_attr, csr, bn_shift, packed)
             if y is not None:
                 return y
         y = ops.cgconv(x, edge_index, edge_attr, self.lin_f.weight, self.lin_f.bias, self.lin_s.weight,
-                       self.lin_s.bias, self.aggr, csr=csr)
+                       self.lin_s.bias, self.aggr, csr=csr, packed=packed)
         return y if bn is None else bn(y)
 
     def extra_repr(self):
@@ -365,7 +366,7 @@ class BatchNorm1d(nn.BatchNorm1d):
         self._sync_counter()
         return super().forward(x)
 
-    def after_cgconv(self, conv, x, edge_index, edge_attr, csr, shift=None):
+    def after_cgconv(self, conv, x, edge_index, edge_attr, csr, shift=None, packed=None):
         """self(conv(x, ...)) with the statistics in the conv kernel's epilogue (ops.cgconv_bn) when this module normalises with
         batch statistics and the layer has the shape for it; None otherwise (the caller composes)."""
         use_batch_stats = self.training or not self.track_running_stats
@@ -377,7 +378,7 @@ class BatchNorm1d(nn.BatchNorm1d):
             rm, rv = self.running_mean, self.running_var
             self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1
         return ops.cgconv_bn(x, edge_index, edge_attr, conv.lin_f.weight, conv.lin_f.bias, conv.lin_s.weight, conv.lin_s.bias,
-                             conv.aggr, csr, self.weight, self.bias, rm, rv, self.eps, self.momentum, shift)
+                             conv.aggr, csr, self.weight, self.bias, rm, rv, self.eps, self.momentum, shift, packed)
 
     def after_linear_relu(self, h, weight, bias, lowp=None, gathered=None):
         """self(relu(F.linear(h, weight, bias) + gathered rows)) as one fused autograd node (ops.linear_relu_bn) when this

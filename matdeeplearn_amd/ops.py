@@ -617,7 +617,7 @@ def _take_rsrc(nfloats, device):
 
 class _CGConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, edge_attr, w_f, b_f, w_s, b_s, csr, aggr, bn=None):
+    def forward(ctx, x, edge_attr, w_f, b_f, w_s, b_s, csr, aggr, bn=None, packed=None):
         require_hip(x, edge_attr, w_f, w_s)
         if edge_attr.requires_grad:
             raise MdlError("cgconv: gradients w.r.t. edge_attr are not implemented (the reference's edge features are "
@@ -644,11 +644,16 @@ class _CGConvFn(torch.autograd.Function):
         if _PAD128 and dt == _lib.MDL_BF16 and G == 50 and 96 < C < 128 and csr.eperm is None and E > 0:
             Ck = 128
             x = torch.nn.functional.pad(x, (0, Ck - C))
-        wpack = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        bpack = torch.empty(2 * _rup(C, 32), dtype=torch.float32, device=x.device)
-        # a training step on the K3c shapes packs the backward node kernel's operand in the same launch
         wn_t = None
-        if dt == _lib.MDL_BF16 and C in (32, 64) and any(ctx.needs_input_grad):
+        if packed is not None and packed[3] == (C, G, dt) and Ck == C:
+            wpack, bpack, wn_t = packed[:3]               # packed with the model's other layers (cgconv_prepack): no launch here
+        else:
+            wpack = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            bpack = torch.empty(2 * _rup(C, 32), dtype=torch.float32, device=x.device)
+        # a training step on the K3c shapes packs the backward node kernel's operand in the same launch
+        if packed is not None and packed[3] == (C, G, dt) and Ck == C:
+            pass
+        elif dt == _lib.MDL_BF16 and C in (32, 64) and any(ctx.needs_input_grad):
             wn_t = torch.empty((C, 4 * C), dtype=torch.bfloat16, device=x.device)
             check(L.mdl_cgconv_pack_weights_node(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpack), ptr(bpack),
                                                  ptr(wn_t), dt, stream()), "mdl_cgconv_pack_weights_node")
@@ -737,14 +742,14 @@ class _CGConvFn(torch.autograd.Function):
                 keep[1] = False                                                                     # handed back zeroed
             if direct:
                 return (dx, None, dW[:C].to(ctx.wdtypes[0]), db[:C].to(ctx.wdtypes[0]) if ctx.has_bias[0] else None,
-                        dW[C:].to(ctx.wdtypes[1]), db[C:].to(ctx.wdtypes[1]) if ctx.has_bias[1] else None, None, None, None)
+                        dW[C:].to(ctx.wdtypes[1]), db[C:].to(ctx.wdtypes[1]) if ctx.has_bias[1] else None, None, None, None, None)
             dW_f = torch.empty((C, 2 * C + G), dtype=torch.float32, device=x.device)
             dW_s = torch.empty_like(dW_f)
             db_f = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[0] else None
             db_s = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[1] else None
             check(_launch_timed("bwd_grads", lambda: lib().mdl_cgconv_assemble_grads(
                 ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s), stream())), "mdl_cgconv_assemble_grads")
-            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None, None
+            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None, None, None
         if dt == _lib.MDL_BF16 and Cp == 128 and C % 2 == 0 and N > 0:
             # wide layers (C = 100 / 128): the same products on the streaming kernels.  r_tgt / r_src keep their padded
             # [N, 2 Cp] layout (padded columns are exact zeros), so  dx = g + r_tgt Wn_t + r_src Wn_s  is two library GEMMs on
@@ -768,7 +773,7 @@ class _CGConvFn(torch.autograd.Function):
             db_s = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[1] else None
             check(lib().mdl_cgconv_assemble_grads(ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s),
                                                   stream()), "mdl_cgconv_assemble_grads")
-            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None, None
+            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None, None, None
         Wn = torch.cat([wf32[:, :C], ws32[:, :C], wf32[:, C:2 * C], ws32[:, C:2 * C]], dim=0)      # [4C, C]
         rt = r_tgt.view(N, 2, Cp)[:, :, :C]                                                        # library GEMMs
         rs = r_src.view(N, 2, Cp)[:, :, :C]
@@ -781,10 +786,41 @@ class _CGConvFn(torch.autograd.Function):
         dW_s = torch.cat([dWn[C:2 * C], dWn[3 * C:4 * C], dwe_s], dim=1).to(ctx.wdtypes[1])
         db_f = db[:C].clone() if ctx.has_bias[0] else None
         db_s = db[Cp:Cp + C].clone() if ctx.has_bias[1] else None
-        return dx, None, dW_f, db_f, dW_s, db_s, None, None, None
+        return dx, None, dW_f, db_f, dW_s, db_s, None, None, None, None
 
 
-def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None, bn_stats=None):
+def cgconv_prepack(convs, x_dtype, device, want_node=True):
+    """The packed weights of several CGConv layers of equal shape in ONE launch (mdl_cgconv_pack_weights_multi): a list of
+    (wpack, bpack, wn_t, key) to hand to cgconv(..., packed=...), or None when the layers do not share a shape / the fast
+    path does not apply.  A model calls it once per forward: the layers' weights are all known before the first one runs."""
+    import ctypes
+    if len(convs) < 2 or len(convs) > 16 or device.type != "cuda":
+        return None
+    C, G = convs[0].channels, convs[0].dim
+    dt = _lib.MDL_BF16 if x_dtype == torch.bfloat16 else _lib.MDL_F32
+    if any(c.channels != C or c.dim != G or c.lin_f.weight.dtype != torch.float32 or not c.lin_f.weight.is_contiguous()
+           or not c.lin_s.weight.is_contiguous() or (c.lin_f.bias is None) != (convs[0].lin_f.bias is None) for c in convs):
+        return None
+    if not (dt == _lib.MDL_BF16 and C in (32, 64)):
+        return None
+    L = lib()
+    nbytes = L.mdl_cgconv_wpack_bytes(C, G, dt)
+    if nbytes == 0:
+        return None
+    n = len(convs)
+    wbuf = torch.empty((n, nbytes), dtype=torch.uint8, device=device)
+    bbuf = torch.empty((n, 2 * _rup(C, 32)), dtype=torch.float32, device=device)
+    nbuf = torch.empty((n, C, 4 * C), dtype=torch.bfloat16, device=device) if want_node else None
+    tab = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    has_b = convs[0].lin_f.bias is not None
+    check(L.mdl_cgconv_pack_weights_multi(
+        n, tab([c.lin_f.weight.detach() for c in convs]), tab([c.lin_f.bias.detach() for c in convs]) if has_b else None,
+        tab([c.lin_s.weight.detach() for c in convs]), tab([c.lin_s.bias.detach() for c in convs]) if has_b else None, C, G,
+        tab(list(wbuf)), tab(list(bbuf)), tab(list(nbuf)) if want_node else None, dt, stream()), "mdl_cgconv_pack_weights_multi")
+    return [(wbuf[k], bbuf[k], nbuf[k] if want_node else None, (C, G, dt)) for k in range(n)]
+
+
+def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None, bn_stats=None, packed=None):
     """CGConv forward.  x [N,C], edge_index [2,E], edge_attr [E,G]; returns [N,C].
     bn_stats = (sums [2 R + 3, C] fp32 zero-filled, shift [C] fp32 or None): the kernel's epilogue also forms the statistics
     of its output for the BatchNorm behind the layer (callers check cgconv_bn_stats_ok first)."""
@@ -792,7 +828,7 @@ def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None, 
         raise MdlError("cgconv: aggr must be mean or add")
     if csr is None:
         csr = csr_for(edge_index, x.shape[0])
-    return _CGConvFn.apply(x, edge_attr, w_f, b_f, w_s, b_s, csr, _lib.REDUCE[aggr], bn_stats)
+    return _CGConvFn.apply(x, edge_attr, w_f, b_f, w_s, b_s, csr, _lib.REDUCE[aggr], bn_stats, packed)
 
 
 # BatchNorm statistics in the CGConv forward's epilogue (mdl_cgconv_fwd_ex, bn_sums): OPT-IN.  Measured on the bench batch
@@ -800,8 +836,13 @@ def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None, 
 # the forward instantiation that carries the epilogue is 12.5 us per layer slower than the plain one (188.0 vs 175.8 us: it
 # sits at 256 VGPRs with 28 bytes of scratch, the plain kernel at 252 and none) — time-neutral at 8192 graphs and at 100.
 _CG_BN_STATS = os.environ.get("MDL_CG_BN_STATS", "0") == "1"
-# K3 / K3c add their weight-gradient partial sums straight into the stacked dW [2C, 2C + G] (no mdl_cgconv_assemble_grads launch)
-_DIRECT_GRADS = os.environ.get("MDL_CG_DIRECT_GRADS", "1") == "1"
+# K3 / K3c can add their weight-gradient partial sums straight into the stacked dW [2C, 2C + G] (MdlCgConv.ld_dwe, MdlCgNode.ld_dwn:
+# no mdl_cgconv_assemble_grads launch).  OPT-IN: measured in one box session (profiles/r05_direct_grads_ab.txt) the node kernel's
+# flush into 712-byte rows (every 128-byte atomic instruction straddles two cache lines) costs it +8.5 us at 8192 graphs — what the
+# 7-us assembly kernel cost — and +10 us per layer at the reference's batch size, where that flush IS the kernel: 0.59 vs 0.55 ms/step.
+_DIRECT_GRADS = os.environ.get("MDL_CG_DIRECT_GRADS", "0") == "1"
+# BatchNorm forward / backward through the whole-direction entry points (one launch for few rows); 0: always the statistics + apply pair
+_BN_WHOLE = os.environ.get("MDL_BN_WHOLE", "1") == "1"
 
 
 def cgconv_bn_stats_ok(x, edge_attr, csr):
@@ -814,7 +855,7 @@ def cgconv_bn_stats_ok(x, edge_attr, csr):
 
 
 def cgconv_bn(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr, csr, bn_weight, bn_bias, running_mean, running_var, eps, momentum,
-              shift=None):
+              shift=None, packed=None):
     """BatchNorm1d(train)(cgconv(...)) — cgcnn.py:136-145 — with the statistics pass over [N, C] folded into the conv kernel's
     epilogue: the sums are formed about `shift` ([C] fp32 near the column means: the beta of the BatchNorm in FRONT of the layer,
     None = 0) and normalised by mdl_bn_apply_n(MDL_BN_SHIFT_ROW)."""
@@ -822,7 +863,7 @@ def cgconv_bn(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr, csr, bn_weight
     R = lib().mdl_bn_sums_rows()
     buf = _zeros_step((R + 3, C), x.device)                  # sums (copies + totals) | shift row | save (mean, invstd)
     y = cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr, csr=csr,
-               bn_stats=(buf, None if shift is None else shift.detach().float().contiguous()))
+               bn_stats=(buf, None if shift is None else shift.detach().float().contiguous()), packed=packed)
     return _BatchNormTrain.apply(y, bn_weight, bn_bias, running_mean, running_var, eps, momentum, buf)
 
 
@@ -1492,7 +1533,11 @@ class _BatchNormTrain(torch.autograd.Function):
         gb = None if bias is None else bias.detach().float().contiguous()
         y = torch.empty_like(x)
         nd = _true_rows_for(N)
-        if pre is None:
+        if pre is None and not _BN_WHOLE:
+            check(lib().mdl_bn_stats_n(ptr(x), ptr(sums), N, C, ptr(nd), dt | _dflag(), stream()), "mdl_bn_stats")
+            check(lib().mdl_bn_apply_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
+                                       ptr(y), N, C, float(eps), float(momentum), ptr(nd), dt, stream()), "mdl_bn_apply")
+        elif pre is None:
             # statistics + apply: one launch for few rows (the reference's batch size), the pair of passes otherwise
             check(lib().mdl_bn_fwd_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
                                      ptr(y), N, C, float(eps), float(momentum), ptr(nd), dt | _dflag(), stream()), "mdl_bn_fwd_n")
@@ -1516,8 +1561,13 @@ class _BatchNormTrain(torch.autograd.Function):
         sums = _zeros_grad(R * C, x.device).view(R, C)                       # (the step's GRADIENT arena, never reused: the totals
         dx = torch.empty_like(x)                                              # rows are returned as parameter gradients)
         nd = ctx.n_dev
-        check(lib().mdl_bn_bwd_n(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, ptr(nd), 0, dt | _dflag(), stream()),
-              "mdl_bn_bwd_n")
+        if _BN_WHOLE:
+            check(lib().mdl_bn_bwd_n(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, ptr(nd), 0, dt | _dflag(), stream()),
+                  "mdl_bn_bwd_n")
+        else:
+            check(lib().mdl_bn_bwd_stats_n(ptr(dy), ptr(x), ptr(save), ptr(sums), N, C, ptr(nd), dt | _dflag(), stream()), "mdl_bn_bwd_stats")
+            check(lib().mdl_bn_bwd_apply_n(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, ptr(nd), dt, stream()),
+                  "mdl_bn_bwd_apply")
         dgamma = sums[R - 1].to(ctx.wdt) if ctx.has[0] else None          # totals row pair published by bwd_apply
         dbeta = sums[R - 2].to(ctx.wdt) if ctx.has[1] else None
         return dx, dgamma, dbeta, None, None, None, None, None
