@@ -1,6 +1,7 @@
 """CGCNN on the HIP message-passing engine — /root/reference/matdeeplearn/models/cgcnn.py:17-174.
 conv_list.i = CGConv(gc_dim, num_edge_features, aggr="mean", batch_norm=False) (:80-83); per layer
 conv -> bn_list.i -> dropout, NO activation between layers (:146 is commented out in the reference)."""
+import torch
 from torch import nn
 
 from .. import ops
