@@ -354,19 +354,6 @@ int mdl_bn_bwd_apply_n(const void* dy, const void* x, const float* save, float* 
  * behind it (mdl_dense_bwd with act = 0) needs neither the activation staging nor x's rows for the mask.  bf16 only. */
 int mdl_bn_bwd_apply_relu_n(const void* dy, const void* x, const float* save, float* sums, const float* gamma, void* dx,
                             int64_t N, int C, const int64_t* n_rows_dev, int dtype, mdlStream_t stream);
-/* The whole forward / backward of one BatchNorm1d call site as ONE entry point each (what a caller normally wants; the four
- * passes above remain for producers that form the statistics themselves).  Up to 6144 rows — the reference's batch size of 100
- * graphs is ~2.5 k node rows, config.yml:136 — statistics and apply run as ONE launch (one workgroup per 16 bytes of
- * channels forms its columns' sums over all rows, then re-reads and writes them: at that size the step is bound by the number of
- * launches, not by bytes); larger inputs, and MDL_DETERMINISTIC, run the statistics + apply pair.  Arguments as the passes
- * above; `sums` zero-filled by the caller as for them; mdl_bn_bwd_n leaves dbeta | dgamma in the totals rows of `sums` like
- * mdl_bn_bwd_apply_n; relu_mask != 0 = mdl_bn_bwd_apply_relu_n's form. */
-int mdl_bn_fwd_n(const void* x, float* sums, const float* gamma, const float* beta, float* save, float* running_mean,
-                 float* running_var, void* y, int64_t N, int C, float eps, float momentum, const int64_t* n_rows_dev, int dtype,
-                 mdlStream_t stream);
-int mdl_bn_bwd_n(const void* dy, const void* x, const float* save, float* sums, const float* gamma, void* dx, int64_t N, int C,
-                 const int64_t* n_rows_dev, int relu_mask, int dtype, mdlStream_t stream);
-
 /* ---- node-level dense layer forward, fused: out[N, M] = act(x[N, K] . w[M, K]^T + bias) ---------------
  * Replaces `getattr(F, act)(lin(out))` of the pre-FC / post-FC loops (matdeeplearn/models/cgcnn.py:124-130,155-166)
  * for the tall-skinny shapes of this path.  x: dense rows (leading dimension K), 16-byte aligned; w [M, K] and bias [M]

@@ -89,8 +89,6 @@ PROTOTYPES = {
     "mdl_bn_apply_n": (_i32, [_vp] * 8 + [_i64, _i32, _f32, _f32, _vp, _i32, _vp]),
     "mdl_bn_bwd_stats_n": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "mdl_bn_bwd_apply_n": (_i32, [_vp] * 6 + [_i64, _i32, _vp, _i32, _vp]),
-    "mdl_bn_fwd_n": (_i32, [_vp] * 8 + [_i64, _i32, _f32, _f32, _vp, _i32, _vp]),
-    "mdl_bn_bwd_n": (_i32, [_vp] * 6 + [_i64, _i32, _vp, _i32, _i32, _vp]),
     "mdl_bn_bwd_apply_relu_n": (_i32, [_vp] * 6 + [_i64, _i32, _vp, _i32, _vp]),
     "mdl_linear_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_dense_bwd": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),

@@ -238,158 +238,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 
-// ---- few rows (the reference's batch size: 100 graphs = ~2.5 k nodes, config.yml:136): statistics + apply in ONE launch ------
-// At that size each of the two kernels above is a launch of ~5 us that moves 0.4 MB: the step is bound by the NUMBER of
-// launches.  Here one workgroup owns W channels (16 bytes of every row): pass 1 forms the shifted sums of its columns over all
-// rows, an LDS reduction makes them the workgroup's totals — no other workgroup is involved, so no grid-wide hand-off — and
-// pass 2 re-reads the rows (L2 hits) and writes the result.  C / W workgroups only: right for N up to a few thousand rows.
-constexpr int BN_SMALL_T = 512;           // threads per workgroup (rows in flight)
-constexpr int64_t BN_SMALL_ROWS = 6144;   // row counts up to this take the one-launch form
-
-template <int W>
-__device__ __forceinline__ void bn_block_sum(float (&a)[W], float (&b)[W], float* red) {
-    // sum of a[], b[] over the workgroup; every thread returns with the totals
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int j = 0; j < W; ++j)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a[j] += __shfl_xor(a[j], o); b[j] += __shfl_xor(b[j], o); }
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < W; ++j) { red[wv * 2 * W + j] = a[j]; red[wv * 2 * W + W + j] = b[j]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-        float ta = 0.0f, tb = 0.0f;
-        for (int k = 0; k < BN_SMALL_T / 64; ++k) { ta += red[k * 2 * W + j]; tb += red[k * 2 * W + W + j]; }
-        a[j] = ta; b[j] = tb;
-    }
-}
-
-template <typename T, int W>
-__global__ __launch_bounds__(BN_SMALL_T) void bn_fwd_small_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
-                                                                   const float* __restrict__ beta, float* __restrict__ save,
-                                                                   float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                                   T* __restrict__ y, int64_t Ncap, int C, float eps, float momentum,
-                                                                   const int64_t* __restrict__ n_dev) {
-    typedef VecW<T, W> V;
-    const int64_t N = n_dev ? max((int64_t)1, min(*n_dev, Ncap)) : Ncap;
-    __shared__ float red[(BN_SMALL_T / 64) * 2 * W];
-    const int c0 = blockIdx.x * W;
-    float sh[W], s0[W], s1[W];
-    V::ld(x + c0, sh);                                           // shift = first row (as mdl_bn_stats)
-#pragma unroll
-    for (int j = 0; j < W; ++j) { s0[j] = 0.0f; s1[j] = 0.0f; }
-    constexpr int U = 4;
-    for (int64_t n0 = threadIdx.x; n0 < N; n0 += U * BN_SMALL_T) {
-        float v[U][W];
-#pragma unroll
-        for (int u = 0; u < U; ++u) V::ld(x + min(n0 + u * BN_SMALL_T, N - 1) * C + c0, v[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float m = (n0 + u * BN_SMALL_T < N) ? 1.0f : 0.0f;
-#pragma unroll
-            for (int j = 0; j < W; ++j) { const float d = (v[u][j] - sh[j]) * m; s0[j] += d; s1[j] = fmaf(d, d, s1[j]); }
-        }
-    }
-    bn_block_sum<W>(s0, s1, red);
-    const float invn = 1.0f / (float)N;
-    float scale[W], shiftv[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-        const int c = c0 + j;
-        const float m1 = s0[j] * invn;
-        const float var = fmaxf(s1[j] * invn - m1 * m1, 0.0f);
-        const float istd = rsqrtf(var + eps), mean = sh[j] + m1;
-        scale[j] = istd * (gamma ? gamma[c] : 1.0f);
-        shiftv[j] = (beta ? beta[c] : 0.0f) - mean * scale[j];
-        if (threadIdx.x == 0) {
-            save[c] = mean;
-            save[C + c] = istd;
-            if (run_mean) {
-                const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
-                run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean;
-                run_var[c] = (1.0f - momentum) * run_var[c] + momentum * unb;
-            }
-        }
-    }
-    for (int64_t n0 = threadIdx.x; n0 < Ncap; n0 += U * BN_SMALL_T) {
-        float v[U][W];
-#pragma unroll
-        for (int u = 0; u < U; ++u) V::ld(x + min(n0 + u * BN_SMALL_T, N - 1) * C + c0, v[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t n = n0 + u * BN_SMALL_T;
-#pragma unroll
-            for (int j = 0; j < W; ++j) v[u][j] = n < N ? v[u][j] * scale[j] + shiftv[j] : 0.0f;   // padding rows: exact zeros
-            if (n < Ncap) V::st(y + n * C + c0, v[u]);
-        }
-    }
-}
-
-template <typename T, int W, bool MASK>
-__global__ __launch_bounds__(BN_SMALL_T) void bn_bwd_small_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                                   const float* __restrict__ save, float* __restrict__ sums,
-                                                                   const float* __restrict__ gamma, T* __restrict__ dx, int64_t Ncap,
-                                                                   int C, const int64_t* __restrict__ n_dev) {
-    typedef VecW<T, W> V;
-    const int64_t N = n_dev ? max((int64_t)1, min(*n_dev, Ncap)) : Ncap;
-    __shared__ float red[(BN_SMALL_T / 64) * 2 * W];
-    const int c0 = blockIdx.x * W;
-    float mean[W], istd[W], s0[W], s1[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) { mean[j] = save[c0 + j]; istd[j] = save[C + c0 + j]; s0[j] = 0.0f; s1[j] = 0.0f; }
-    constexpr int U = 2;
-    for (int64_t n0 = threadIdx.x; n0 < N; n0 += U * BN_SMALL_T) {
-        float vd[U][W], vx[U][W];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t n = min(n0 + u * BN_SMALL_T, N - 1);
-            V::ld(dy + n * C + c0, vd[u]);
-            V::ld(x + n * C + c0, vx[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float m = (n0 + u * BN_SMALL_T < N) ? 1.0f : 0.0f;
-#pragma unroll
-            for (int j = 0; j < W; ++j) { const float v = vd[u][j] * m; s0[j] += v; s1[j] = fmaf(v, (vx[u][j] - mean[j]) * istd[j], s1[j]); }
-        }
-    }
-    bn_block_sum<W>(s0, s1, red);
-    const float invn = 1.0f / (float)N;
-    float k0[W], k1[W], gs[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-        gs[j] = (gamma ? gamma[c0 + j] : 1.0f) * istd[j];
-        k0[j] = s0[j] * invn;
-        k1[j] = s1[j] * invn;
-        if (threadIdx.x == 0) {                                  // dbeta | dgamma where mdl_bn_bwd_apply publishes them
-            sums[(size_t)BN_R * 2 * C + c0 + j] = s0[j];
-            sums[(size_t)BN_R * 2 * C + C + c0 + j] = s1[j];
-        }
-    }
-    for (int64_t n0 = threadIdx.x; n0 < Ncap; n0 += U * BN_SMALL_T) {
-        float vd[U][W], vx[U][W];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t n = min(n0 + u * BN_SMALL_T, N - 1);
-            V::ld(dy + n * C + c0, vd[u]);
-            V::ld(x + n * C + c0, vx[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t n = n0 + u * BN_SMALL_T;
-#pragma unroll
-            for (int j = 0; j < W; ++j) {
-                const float d = gs[j] * (vd[u][j] - k0[j] - (vx[u][j] - mean[j]) * istd[j] * k1[j]);
-                vd[u][j] = (n < N && (!MASK || vx[u][j] > 0.0f)) ? d : 0.0f;                  // padding rows: no gradient
-            }
-            if (n < Ncap) V::st(dx + n * C + c0, vd[u]);
-        }
-    }
-}
-
 // vector width: 16 bytes when the channel count allows it (bf16: C % 8), else 4 elements (bf16 C = 100, 150: 8 bytes)
 static int bn_width(int C, int dtype) { return (dtype == MDL_BF16 && C % 8 == 0) ? 8 : 4; }
 // threads per block: a whole number of rows, each CG = C / W lanes wide
@@ -494,54 +342,4 @@ extern "C" int mdl_bn_bwd_apply_n(const void* dy, const void* x, const float* sa
 extern "C" int mdl_bn_bwd_apply_relu_n(const void* dy, const void* x, const float* save, float* sums, const float* gamma,
                                        void* dx, int64_t N, int C, const int64_t* n_dev, int dtype, mdlStream_t stream) {
     return bn_bwd_apply_launch("mdl_bn_bwd_apply_relu", true, dy, x, save, sums, gamma, dx, N, C, n_dev, dtype, stream);
-}
-
-// The whole BatchNorm1d forward / backward of one call site as ONE entry point each: few rows (<= BN_SMALL_ROWS) run the
-// one-launch kernels above, anything else the statistics + apply pair; MDL_DETERMINISTIC always takes the pair (its
-// one-workgroup statistics kernel is the run-to-run reproducible form).
-extern "C" int mdl_bn_fwd_n(const void* x, float* sums, const float* gamma, const float* beta, float* save, float* running_mean,
-                            float* running_var, void* y, int64_t N, int C, float eps, float momentum, const int64_t* n_dev, int dtype,
-                            mdlStream_t stream) {
-    using namespace mdl;
-    const bool det = (dtype & MDL_DETERMINISTIC) != 0;
-    const int dt = dtype & MDL_DTYPE_MASK;
-    int rc = bn_check("mdl_bn_fwd_n", N, C, dt, x);
-    if (rc) return rc;
-    MDL_REQUIRE(sums && save && y, MDL_E_ARG, "mdl_bn_fwd_n: null pointer");
-    if (!det && N <= BN_SMALL_ROWS) {
-        hipStream_t st = (hipStream_t)stream;
-        const int W = bn_width(C, dt);
-        if (dt == MDL_BF16 && W == 8) hipLaunchKernelGGL((bn_fwd_small_kernel<bf16_t, 8>), dim3(C / 8), dim3(BN_SMALL_T), 0, st, (const bf16_t*)x, gamma, beta, save, running_mean, running_var, (bf16_t*)y, N, C, eps, momentum, n_dev);
-        else if (dt == MDL_BF16) hipLaunchKernelGGL((bn_fwd_small_kernel<bf16_t, 4>), dim3(C / 4), dim3(BN_SMALL_T), 0, st, (const bf16_t*)x, gamma, beta, save, running_mean, running_var, (bf16_t*)y, N, C, eps, momentum, n_dev);
-        else hipLaunchKernelGGL((bn_fwd_small_kernel<float, 4>), dim3(C / 4), dim3(BN_SMALL_T), 0, st, (const float*)x, gamma, beta, save, running_mean, running_var, (float*)y, N, C, eps, momentum, n_dev);
-        return check_launch("mdl_bn_fwd_n");
-    }
-    rc = mdl_bn_stats_n(x, sums, N, C, n_dev, dtype, stream);
-    if (rc) return rc;
-    return mdl_bn_apply_n(x, sums, gamma, beta, save, running_mean, running_var, y, N, C, eps, momentum, n_dev, dt, stream);
-}
-
-extern "C" int mdl_bn_bwd_n(const void* dy, const void* x, const float* save, float* sums, const float* gamma, void* dx, int64_t N,
-                            int C, const int64_t* n_dev, int relu_mask, int dtype, mdlStream_t stream) {
-    using namespace mdl;
-    const bool det = (dtype & MDL_DETERMINISTIC) != 0;
-    const int dt = dtype & MDL_DTYPE_MASK;
-    int rc = bn_check("mdl_bn_bwd_n", N, C, dt, x);
-    if (rc) return rc;
-    MDL_REQUIRE(dy && save && sums && dx, MDL_E_ARG, "mdl_bn_bwd_n: null pointer");
-    MDL_REQUIRE(!relu_mask || dt == MDL_BF16, MDL_E_UNSUPP, "mdl_bn_bwd_n: the ReLU mask is bf16 only");
-    if (!det && N <= BN_SMALL_ROWS) {
-        hipStream_t st = (hipStream_t)stream;
-        const int W = bn_width(C, dt);
-#define MDL_BN_BS(T_, W_, M_) hipLaunchKernelGGL((bn_bwd_small_kernel<T_, W_, M_>), dim3(C / W_), dim3(BN_SMALL_T), 0, st, (const T_*)dy, (const T_*)x, save, sums, gamma, (T_*)dx, N, C, n_dev)
-        if (dt == MDL_BF16 && W == 8) { if (relu_mask) MDL_BN_BS(bf16_t, 8, true); else MDL_BN_BS(bf16_t, 8, false); }
-        else if (dt == MDL_BF16) { if (relu_mask) MDL_BN_BS(bf16_t, 4, true); else MDL_BN_BS(bf16_t, 4, false); }
-        else MDL_BN_BS(float, 4, false);
-#undef MDL_BN_BS
-        return check_launch("mdl_bn_bwd_n");
-    }
-    rc = mdl_bn_bwd_stats_n(dy, x, save, sums, N, C, n_dev, dtype, stream);
-    if (rc) return rc;
-    return relu_mask ? mdl_bn_bwd_apply_relu_n(dy, x, save, sums, gamma, dx, N, C, n_dev, dt, stream)
-                     : mdl_bn_bwd_apply_n(dy, x, save, sums, gamma, dx, N, C, n_dev, dt, stream);
 }

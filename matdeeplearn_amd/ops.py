@@ -841,8 +841,6 @@ _CG_BN_STATS = os.environ.get("MDL_CG_BN_STATS", "0") == "1"
 # flush into 712-byte rows (every 128-byte atomic instruction straddles two cache lines) costs it +8.5 us at 8192 graphs — what the
 # 7-us assembly kernel cost — and +10 us per layer at the reference's batch size, where that flush IS the kernel: 0.59 vs 0.55 ms/step.
 _DIRECT_GRADS = os.environ.get("MDL_CG_DIRECT_GRADS", "0") == "1"
-# BatchNorm forward / backward through the whole-direction entry points (one launch for few rows); 0: always the statistics + apply pair
-_BN_WHOLE = os.environ.get("MDL_BN_WHOLE", "1") == "1"
 
 
 def cgconv_bn_stats_ok(x, edge_attr, csr):
@@ -1533,18 +1531,14 @@ class _BatchNormTrain(torch.autograd.Function):
         gb = None if bias is None else bias.detach().float().contiguous()
         y = torch.empty_like(x)
         nd = _true_rows_for(N)
-        if pre is None and not _BN_WHOLE:
+        # (statistics + apply as ONE launch for few rows was built and measured slower at the reference's batch size — 0.54 vs
+        # 0.49 ms/step: C / 8 workgroups walking all rows twice are a longer dependent chain than two wide launches;
+        # experiments/patches/bn_one_launch.patch)
+        if pre is None:
             check(lib().mdl_bn_stats_n(ptr(x), ptr(sums), N, C, ptr(nd), dt | _dflag(), stream()), "mdl_bn_stats")
-            check(lib().mdl_bn_apply_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
-                                       ptr(y), N, C, float(eps), float(momentum), ptr(nd), dt, stream()), "mdl_bn_apply")
-        elif pre is None:
-            # statistics + apply: one launch for few rows (the reference's batch size), the pair of passes otherwise
-            check(lib().mdl_bn_fwd_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
-                                     ptr(y), N, C, float(eps), float(momentum), ptr(nd), dt | _dflag(), stream()), "mdl_bn_fwd_n")
-        else:
-            check(lib().mdl_bn_apply_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
-                                       ptr(y), N, C, float(eps), float(momentum), ptr(nd), dt | _lib.MDL_BN_SHIFT_ROW, stream()),
-                  "mdl_bn_apply")
+        check(lib().mdl_bn_apply_n(ptr(x), ptr(sums), ptr(gw), ptr(gb), ptr(save), ptr(running_mean), ptr(running_var),
+                                   ptr(y), N, C, float(eps), float(momentum), ptr(nd),
+                                   dt | (_lib.MDL_BN_SHIFT_ROW if pre is not None else 0), stream()), "mdl_bn_apply")
         ctx.n_dev = nd
         ctx.save_for_backward(x, save, gw)
         ctx.has = (weight is not None, bias is not None)
@@ -1561,13 +1555,9 @@ class _BatchNormTrain(torch.autograd.Function):
         sums = _zeros_grad(R * C, x.device).view(R, C)                       # (the step's GRADIENT arena, never reused: the totals
         dx = torch.empty_like(x)                                              # rows are returned as parameter gradients)
         nd = ctx.n_dev
-        if _BN_WHOLE:
-            check(lib().mdl_bn_bwd_n(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, ptr(nd), 0, dt | _dflag(), stream()),
-                  "mdl_bn_bwd_n")
-        else:
-            check(lib().mdl_bn_bwd_stats_n(ptr(dy), ptr(x), ptr(save), ptr(sums), N, C, ptr(nd), dt | _dflag(), stream()), "mdl_bn_bwd_stats")
-            check(lib().mdl_bn_bwd_apply_n(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, ptr(nd), dt, stream()),
-                  "mdl_bn_bwd_apply")
+        check(lib().mdl_bn_bwd_stats_n(ptr(dy), ptr(x), ptr(save), ptr(sums), N, C, ptr(nd), dt | _dflag(), stream()), "mdl_bn_bwd_stats")
+        check(lib().mdl_bn_bwd_apply_n(ptr(dy), ptr(x), ptr(save), ptr(sums), ptr(gw), ptr(dx), N, C, ptr(nd), dt, stream()),
+              "mdl_bn_bwd_apply")
         dgamma = sums[R - 1].to(ctx.wdt) if ctx.has[0] else None          # totals row pair published by bwd_apply
         dbeta = sums[R - 2].to(ctx.wdt) if ctx.has[1] else None
         return dx, dgamma, dbeta, None, None, None, None, None
@@ -1638,8 +1628,10 @@ class _LinearReluBN(torch.autograd.Function):
         R = lib().mdl_bn_sums_rows()
         sums = _zeros_grad(R * M, x.device).view(R, M)
         gp = torch.empty_like(y)                                                 # gradient w.r.t. the Linear's output (pre-activation)
-        check(lib().mdl_bn_bwd_n(ptr(gz), ptr(y), ptr(save), ptr(sums), ptr(gw), ptr(gp), N, M, ptr(ctx.n_dev), 1, dt | _dflag(),
-                                 stream()), "mdl_bn_bwd_n")
+        check(lib().mdl_bn_bwd_stats_n(ptr(gz), ptr(y), ptr(save), ptr(sums), N, M, ptr(ctx.n_dev), dt | _dflag(), stream()),
+              "mdl_bn_bwd_stats")
+        check(lib().mdl_bn_bwd_apply_relu_n(ptr(gz), ptr(y), ptr(save), ptr(sums), ptr(gw), ptr(gp), N, M, ptr(ctx.n_dev), dt,
+                                            stream()), "mdl_bn_bwd_apply_relu")
         dgamma = sums[R - 1].to(ctx.bn_wdt) if ctx.bn_has[0] else None
         dbeta = sums[R - 2].to(ctx.bn_wdt) if ctx.bn_has[1] else None
         buf = _zeros_grad(M * K + M, x.device)

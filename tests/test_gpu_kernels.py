@@ -936,8 +936,8 @@ def test_linear_act_without_input_grad(act):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,C", [(1000, 64), (37, 64), (5000, 128), (1, 32), (999, 16), (6144, 100),      # one-launch forms (few rows)
-                                 (20000, 64), (6145, 100), (9000, 16)])                                      # statistics + apply pairs
+@pytest.mark.parametrize("N,C", [(1000, 64), (37, 64), (5000, 128), (1, 32), (999, 16), (6144, 100),
+                                 (20000, 64), (6145, 100), (9000, 16)])
 def test_batchnorm_train_matches_torch(dtype, N, C):
     """HIP BatchNorm1d (training mode) vs torch.nn.BatchNorm1d on CPU: output, running stats, all gradients."""
     from matdeeplearn_amd import nn as mnn
