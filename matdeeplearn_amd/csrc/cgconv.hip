@@ -86,7 +86,8 @@
 #define MDL_FWD_RANGE_EDGES 64   // edges per node range (= per wave) below which the launch shrinks instead: two 32-edge tiles
 #endif
 #ifndef MDL_BWD_RANGE_EDGES
-#define MDL_BWD_RANGE_EDGES 64
+#define MDL_BWD_RANGE_EDGES 128  // (64 -> 128: -7 of 45 us at the reference's batch size — half as many waves flush their weight-gradient sums;
+                                 // from 6.5e4 edges on the grid is capped at one workgroup per CU either way)
 #endif
 #ifndef MDL_BWD_WAVES
 #define MDL_BWD_WAVES 1   // waves per SIMD the backward kernel is register-allocated for
@@ -154,6 +155,7 @@ struct CgParams {
     const int32_t* balance;   // bwd, optional: [N + 1] non-decreasing cost prefix the workgroups' node ranges are balanced on
                               // (mdl_cgconv_balance); null: edges + nodes in front of a node
     int ldwe;           // bwd: leading dimension of dwe in floats (0: GP) — MdlCgConv.ld_dwe
+    int dwe_combine;    // bwd, per-wave kernel: the two waves of a workgroup that share a channel slice combine their dwe sums in LDS
     int rs16;           // bwd, bf16: r_src is a bf16 array accumulated with packed bf16 atomics (mdl_cgconv_bwd_h)
     int flags;          // host side: MDL_DETERMINISTIC / MDL_K3_* bits the caller OR-ed into `dtype`
     // fwd, optional (mdl_cgconv_fwd_ex): statistics of the layer's OUTPUT for the training-mode BatchNorm1d behind it (cgcnn.py:143)
@@ -1785,6 +1787,31 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 #ifdef MDL_ABL_NODWEFLUSH      // (timing experiments: wrong results)
     if (p.N >= 0) return;
 #endif
+    if (p.dwe_combine) {
+        // Two slices, four waves: waves w and w + 2 of a workgroup hold partial sums of the SAME slice.  The flush is 64 atomic
+        // instructions per wave on addresses every wave of the slice hits (12.5 of 45 us at the reference's batch size, where a
+        // wave has one or two tiles of work in front of it): wave w + 2 hands its sums over through the LDS area of the weights —
+        // free once every wave is out of its loop — and only wave w flushes.
+        const int wv4 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        float* const cb = reinterpret_cast<float*>(smem) + (wv4 & 1) * (2 * GNT * 16 * WAVE) + lane;
+        __syncthreads();
+        if (wv4 >= 2) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int nt = 0; nt < GNT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cb[((a * GNT + nt) * 16 + r) * WAVE] = dwe_acc[a][nt][r];
+        }
+        __syncthreads();
+        if (wv4 >= 2) return;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int nt = 0; nt < GNT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dwe_acc[a][nt][r] += cb[((a * GNT + nt) * 16 + r) * WAVE];
+    }
 #pragma unroll
     for (int nt = 0; nt < GNT; ++nt) {
         const int gcol = nt * 32 + i;
@@ -2101,6 +2128,8 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
         }
     }
     if (bwd) g_last_k3 = det ? 3 : 1;
+    // per-wave backward, 4 waves on 2 slices with the weights in LDS (>= 2 x 16 KB: the hand-over area): pair-wise dwe flush
+    p.dwe_combine = (bwd && !det && waves == 4 && d.NS == 2 && w_lds && !p.w_slice && w_bytes >= 2 * 2 * 2 * 16 * 64 * 4) ? 1 : 0;
     // total waves must be a multiple of NS so that every wave keeps one channel slice (w_slice: whole workgroups)
     while ((grid * waves) % d.NS) ++grid;
     if (p.w_slice) while (grid % d.NS) ++grid;
