@@ -116,13 +116,33 @@ __global__ __launch_bounds__(256, 1) void mlp_head_bwd_kernel(MlpArgs p) {
     bf16_t* dbuf = da + 64 * MLP_LD;                                   // [64][LD] dZ of the next (lower) layer
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = wv & 1, nt = wv >> 1, t16 = i & 15;
-    for (int l = 0; l < p.NL; ++l) {
-        const int K = l ? p.M[l - 1] : p.K0, M = p.M[l];
-        for (int q = tid; q < 64 * 64; q += 256) {
-            const int k = q >> 6, m = q & 63;                          // wt[l][k][m] = W_l[m][k]
-            bf16_t v = 0;
-            if (m < M && k < K) v = p.w[l][(int64_t)m * K + k];
-            wt[(l * 64 + k) * MLP_LD + m] = v;
+    // wt[l][k][m] = W_l[m][k]: the rows are READ as coalesced dwords — every load of every layer in flight before the first is
+    // used — and scattered into the transposed LDS copy with two-byte stores.  (The first version gathered element by element
+    // from global memory, 16 dependent two-byte loads per thread and layer: most of the kernel's 31 us at the reference's batch
+    // size, where a workgroup has two tiles of work, and a fixed ~15 us at 8192 rows.)
+    {
+        unsigned wv_[MLP_MAXL][8];
+#pragma unroll
+        for (int l = 0; l < MLP_MAXL; ++l) {
+            const int K = l < p.NL ? (l ? p.M[l - 1] : p.K0) : 0, M = l < p.NL ? p.M[l] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = tid + 256 * u, m = q >> 5, d = q & 31;
+                unsigned v = 0u;
+                if (m < M && 2 * d + 1 < K) v = *reinterpret_cast<const unsigned*>(p.w[l] + (int64_t)m * K + 2 * d);
+                else if (m < M && 2 * d < K) v = (unsigned)p.w[l][(int64_t)m * K + 2 * d];        // (odd K: the last column alone)
+                wv_[l][u] = v;
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < MLP_MAXL; ++l) {
+            if (l >= p.NL) break;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = tid + 256 * u, m = q >> 5, d = q & 31;
+                wt[(l * 64 + 2 * d) * MLP_LD + m] = (bf16_t)(wv_[l][u] & 0xffffu);
+                wt[(l * 64 + 2 * d + 1) * MLP_LD + m] = (bf16_t)(wv_[l][u] >> 16);
+            }
         }
     }
     f32x16 dwacc[MLP_MAXL];
@@ -130,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void mlp_head_bwd_kernel(MlpArgs p) {
     for (int l = 0; l < MLP_MAXL; ++l)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dwacc[l][r] = 0.0f;
-    float dbacc[MLP_MAXL] = {0.0f, 0.0f, 0.0f, 0.0f};               // threads 0..63: column sums of dZ_l
+    float dbacc[MLP_MAXL] = {0.0f, 0.0f, 0.0f, 0.0f};               // thread t: sum of column t & 63 of dZ_l over the 16 rows of row block t >> 6
     const int64_t n_tiles = (p.N + 63) / 64;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t r0 = tile * 64;
@@ -158,9 +178,10 @@ __global__ __launch_bounds__(256, 1) void mlp_head_bwd_kernel(MlpArgs p) {
                 const bf16x8 bf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
                 dwacc[lq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, dwacc[lq], 0, 0, 0);
             }
-            if (tid < 64) {
+            {
                 float s = 0.0f;
-                for (int r = 0; r < 64; ++r) s += bf2f(dcur[r * MLP_LD + tid]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += bf2f(dcur[(16 * (tid >> 6) + r) * MLP_LD + (tid & 63)]);
                 dbacc[lq] += s;
             }
             // dIn_l = dZ_l . W_l : lane = input column nt*32 + i, registers = rows
@@ -181,6 +202,18 @@ __global__ __launch_bounds__(256, 1) void mlp_head_bwd_kernel(MlpArgs p) {
             __syncthreads();
             bf16_t* t = dcur; dcur = dnext; dnext = t;
         }
+    }
+    // the four row blocks' bias sums -> one per column, added up in a fixed order (MDL_DETERMINISTIC runs one workgroup: every sum
+    // then receives its terms from one thread in program order)
+    {
+        float* red = reinterpret_cast<float*>(da);                     // [MLP_MAXL][4][64] floats = 4 KB of the dZ tile (9 KB)
+        __syncthreads();
+#pragma unroll
+        for (int lq = 0; lq < MLP_MAXL; ++lq) red[(lq * 4 + (tid >> 6)) * 64 + (tid & 63)] = dbacc[lq];
+        __syncthreads();
+#pragma unroll
+        for (int lq = 0; lq < MLP_MAXL; ++lq)
+            dbacc[lq] = tid < 64 ? ((red[(lq * 4 + 0) * 64 + tid] + red[(lq * 4 + 1) * 64 + tid]) + red[(lq * 4 + 2) * 64 + tid]) + red[(lq * 4 + 3) * 64 + tid] : 0.0f;
     }
     // flush: dW blocks (rows = m in registers, lane = input column) and the bias sums
 #pragma unroll
