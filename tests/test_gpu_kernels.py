@@ -1196,3 +1196,32 @@ def test_producer_side_batchnorm_sums_survive_a_large_mean_small_variance_column
     # (normalised rows: the ordinary columns; in the large-mean columns one bf16 step of the activation — 0.25 at 40 — is two
     # standard deviations, so two launches that round one pre-activation differently are not comparable element by element)
     close(z[:, ::2], ref[:, ::2].float(), 5e-2, 2e-2)
+
+
+def test_weight_gradients_written_in_place_match_the_assembled_ones(monkeypatch):
+    """MdlCgConv.ld_dwe / MdlCgNode.ld_dwn (opt-in, ops._DIRECT_GRADS): K3 and K3c add their partial sums straight into the two
+    Linears' stacked weight gradient [2C, 2C + G] instead of into staging buffers that mdl_cgconv_assemble_grads re-lays out —
+    same gradients up to the order of the fp32 atomic adds."""
+    from matdeeplearn_amd import ops
+    d = dev()
+    n, C, G = 1500, 64, 50
+    g = torch.Generator().manual_seed(77)
+    ei = rand_graph(n, 77, sort=True, empty_frac=0.05)
+    E = ei.shape[1]
+    x = torch.randn(n, C, generator=g).to(torch.bfloat16)
+    ea = torch.rand(E, G, generator=g).to(torch.bfloat16)
+    wf, ws = torch.randn(C, 2 * C + G, generator=g) * 0.1, torch.randn(C, 2 * C + G, generator=g) * 0.1
+    bf, bs = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    gout = torch.randn(n, C, generator=g)
+    csr = ops.build_csr(ei.to(d), n, assume_sorted=True)
+    res = []
+    for direct in (False, True):
+        monkeypatch.setattr(ops, "_DIRECT_GRADS", direct)
+        xd = x.to(d).requires_grad_(True)
+        ps = [t.to(d).clone().requires_grad_(True) for t in (wf, bf, ws, bs)]
+        out = ops.cgconv(xd, None, ea.to(d), ps[0], ps[1], ps[2], ps[3], "mean", csr=csr)
+        (out.float() * gout.to(d)).sum().backward()
+        res.append([xd.grad] + [p.grad for p in ps])
+    assert torch.equal(res[0][0], res[1][0])                   # dx does not go through the re-laid-out sums
+    for a, b in zip(res[0][1:], res[1][1:]):
+        close(b, a, 1e-4, 1e-5)
