@@ -1222,6 +1222,6 @@ def test_weight_gradients_written_in_place_match_the_assembled_ones(monkeypatch)
         out = ops.cgconv(xd, None, ea.to(d), ps[0], ps[1], ps[2], ps[3], "mean", csr=csr)
         (out.float() * gout.to(d)).sum().backward()
         res.append([xd.grad] + [p.grad for p in ps])
-    assert torch.equal(res[0][0], res[1][0])                   # dx does not go through the re-laid-out sums
+    close(res[1][0], res[0][0], 2e-2, 2e-2)                    # dx: the same kernels either way (by-source sums: bf16 atomics, order-dependent)
     for a, b in zip(res[0][1:], res[1][1:]):
         close(b, a, 1e-4, 1e-5)
