@@ -2298,7 +2298,7 @@ static int cg_launch_bwd_ab(CgParams& p, hipStream_t st, const char* name) {
     p.wave_lds_bytes = et_bytes + 32 + 128 + 32 + 16 + 128 * OHS * 2;
     const int waves = 4;
     const int lds = waves * p.wave_lds_bytes;
-    const int64_t ranges = std::max<int64_t>(1, std::min<int64_t>(cdiv(p.E, bwd ? MDL_BWD_RANGE_EDGES : MDL_FWD_RANGE_EDGES), p.N));
+    const int64_t ranges = std::max<int64_t>(1, std::min<int64_t>(cdiv(p.E, 64), p.N));
     int64_t grid = cdiv(ranges * d.NS, waves);
     const CgEnv& env = cg_env();
     const int64_t cap = 256 * (env.ab_wgs > 0 ? env.ab_wgs : 1);
