@@ -1223,5 +1223,7 @@ def test_weight_gradients_written_in_place_match_the_assembled_ones(monkeypatch)
         (out.float() * gout.to(d)).sum().backward()
         res.append([xd.grad] + [p.grad for p in ps])
     close(res[1][0], res[0][0], 2e-2, 2e-2)                    # dx: the same kernels either way (by-source sums: bf16 atomics, order-dependent)
+    # the weight gradients: the x_j columns are r_src^T x with r_src summed by bf16 atomics, so two runs of the SAME mode differ
+    # by ~1e-3 of the gradient scale (observed 1.0e-3 on a 282-pass box); a wrong row/column offset would be an O(1) error
     for a, b in zip(res[0][1:], res[1][1:]):
-        close(b, a, 1e-4, 1e-5)
+        close(b, a, 1e-3, 5e-3)

@@ -324,7 +324,7 @@ def test_cfg4_megnet_bf16_training_tracks_fp32():
     within 8 % on average (observed over a dozen runs: 12-20 % at the worst single step, 2-3 % on average; every step draws a
     fresh 64-graph batch, so the curve is the per-batch loss, and AdamW turns the order noise of fp32 atomics into +-lr steps
     of near-zero-gradient parameters: the worst step moves from run to run); (ii) at the bf16-TRAINED weights the bf16 and
-    fp32 compute modes predict the same on held-out graphs to 5 % of the prediction scale (observed 1 %); (iii) the held-out
+    fp32 compute modes predict the same on held-out graphs to 5 % of max(prediction scale, 0.1 of the target scale) (observed 1 %); (iii) the held-out
     MAE of the two trained models agrees to 15 %.  What is NOT asserted is equality of the two weight sets: AdamW turns rounding noise in near-zero gradients
     (BatchNorm biases) into +-lr steps, so two trainings drift apart in those parameters — in fp32 against fp32 as well."""
     from matdeeplearn_amd import models, ops
@@ -370,7 +370,13 @@ def test_cfg4_megnet_bf16_training_tracks_fp32():
     p_bb, mae_b = held_out("bf16", "bf16")
     p_bf, _ = held_out("bf16", "fp32")
     _, mae_f = held_out("fp32", "fp32")
-    _close(p_bb, p_bf, 5e-2, "bf16-trained weights: bf16 vs fp32 compute mode")
+    # 5 % of max(prediction scale, 0.1 of the target scale): after 24 steps at lr 5e-4 the model still predicts nearly the
+    # same small number for every graph on some runs (|p| <= 0.015 on standardised targets of scale 1), and 5 % of THAT is less
+    # than the bf16 rounding of the O(1) activations behind it (observed there: 1.2e-3 absolute)
+    y_scale = float(np.abs(np.asarray(ds.y)).max())           # standardised composition targets: ~2-3
+    scale = max(float(p_bf.abs().max()), 0.1 * y_scale)
+    err = float((p_bb - p_bf).abs().max())
+    assert err <= 5e-2 * scale, ("bf16-trained weights: bf16 vs fp32 compute mode", err, float(p_bf.abs().max()), y_scale)
     assert abs(mae_b - mae_f) < 0.15 * mae_f, (mae_b, mae_f)
 
 
