@@ -1,0 +1,346 @@
+// cfconv.hip — K4: the fused forward of SchNet's continuous-filter convolution (kernel list K4).
+//
+// Reference path: matdeeplearn/models/schnet.py:131-145 calls torch_geometric's InteractionBlock / CFConv (2.0.1):
+//     W_e  = Linear(F, F)( ssp( Linear(G, F)(rbf_e) ) )                 the filter network on the Gaussian expansion of d_e
+//     out_i = sum_{e: j -> i}  h_j * W_e * C(d_e)                       h = lin1(x), C = cosine cutoff
+// Unfused (nn.CFConv before this kernel) that is three passes over the edges: two dense layers (100 + 300 B read, 300 + 300 B
+// written per edge at F = 150) and the gather-multiply-reduce (300 B read + the h rows).  Here ONE kernel walks the edges in
+// CSR order: a wave stages the rbf rows of a 32-edge tile in LDS and chains, in registers,
+//     GEMM1  D1[unit][edge] = W1p . rbf^T          (4 k-steps, weights from LDS, bias in the constant-1 column of the tile)
+//     ssp, bf16 -> these registers ARE the B operand of
+//     GEMM2  D2[unit][edge] = W2p . a1             (10 k-steps; W2p's K columns packed in the order GEMM1 leaves the units in)
+//     msg = bf16(D2) * h[src] * C                  (lane = edge: the cutoff is one scalar per lane, h[src] arrives as 8-byte chunks)
+//     out[tgt] += one-hot(tgt) . msg               (32-unit block by block through a 2.3-KB LDS transpose, like kernel 2 of K3)
+// and writes the two activations the existing backward consumes (a1 = layer-1 output, W = filter) straight from the
+// accumulator layout (8-byte chunks: a 32-edge tile is one contiguous 9.6-KB run of either tensor).  Without them (inference:
+// a1 == w == nullptr) the edge pass reads 100 B and gathers 300 B per edge and writes nothing per edge.
+//
+// Lane = EDGE in both products (the MFMA computes the transposed layer, A = weights, B = activations), so GEMM1's D registers
+// feed GEMM2 without leaving the wave, and the reduction over the edges — the one step that needs the edges on the K axis — is
+// the only trip through LDS.  One-hot operands: two packed instructions per pair (value 2^-126, the messages travel scaled by
+// 2^64 folded into the cutoff factor; see cgconv_ep2.inc).
+#include <algorithm>
+
+#include "mdl_common.h"
+
+namespace mdl {
+namespace cf {
+
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds4_t;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int FP = 160, NBK = FP / 32;        // padded filter width; 32-unit blocks
+constexpr int G_ = 50, GH = G_ / 2;           // Gaussians per edge (the reference's edge features); dwords per rbf row
+constexpr int KE = 64, EKS = KE + 8;          // K of GEMM1 (G + bias column, padded); row stride of the rbf tile (halfwords)
+constexpr int W1S = KE + 8, W2S = FP + 8;     // row strides of the packed weights in LDS (halfwords)
+constexpr int DCS = 32 * 8 + 32;              // one chunk row of the message block: 32 edges x 8 bytes + pad
+constexpr int NWAVE = 8, NT = NWAVE * WAVE;
+constexpr int W1_BYTES = FP * W1S * 2, W2_BYTES = FP * W2S * 2;
+constexpr int OFF_ET = 0, OFF_DP = 32 * EKS * 2, OFF_TSL = OFF_DP + 8 * DCS, WAVE_BYTES = OFF_TSL + 64;
+constexpr int LDS = W1_BYTES + W2_BYTES + NWAVE * WAVE_BYTES;
+constexpr int NJ = (32 * GH + WAVE - 1) / WAVE;           // dwords of an rbf tile per lane
+constexpr float UP = 18446744073709551616.0f;             // 2^64: the messages travel scaled (folded into the cutoff factor)
+constexpr float RW = 4611686018427387904.0f;              // 2^62 = 2^126 / 2^64: scale of the one-hot sums
+static_assert(W1_BYTES % 16 == 0 && W2_BYTES % 16 == 0 && WAVE_BYTES % 16 == 0 && OFF_DP % 16 == 0 && OFF_TSL % 16 == 0, "alignment");
+static_assert(LDS <= 160 * 1024, "LDS budget");
+
+struct Params {
+    const bf16_t* rbf;       // [E, G] edge features, CSR order
+    const float* cut;        // [E] cutoff factor C(d_e)
+    const bf16_t* h;         // [N, F] lin1(x)
+    const int32_t* rowptr;   // [N + 1]
+    const int32_t* src;      // [E] source node per CSR position
+    const int32_t* tgt;      // [E] target node per CSR position
+    const bf16_t* wpack;     // W1p [FP][W1S] | W2p [FP][W2S] (mdl_cfconv_pack_weights)
+    bf16_t* out;             // [N, F]
+    bf16_t* a1;              // [E, F] layer-1 output (post ssp) or nullptr
+    bf16_t* w;               // [E, F] filter or nullptr
+    int N, E, F;
+};
+
+__device__ __forceinline__ bf16x8 ld_frag(const bf16_t* base, int row, int ld, int k0, int h) {
+    return *reinterpret_cast<const bf16x8*>(base + row * ld + k0 + 8 * h);
+}
+
+// two bf16 one-hot values (2^-126 where the halfword of x is zero): see cgconv_ep2.inc
+__device__ __forceinline__ unsigned oh2x(unsigned x) {
+    const u16x2 k = {0x0080, 0x0080};
+    return __builtin_bit_cast(unsigned, (u16x2)__builtin_elementwise_sub_sat(k, __builtin_bit_cast(u16x2, x)));
+}
+
+// smallest n in [0, N] with rowptr[n] + n >= b (the cost in front of node n: its edges and itself); 64 probes per round
+__device__ __forceinline__ int lower_bound_cost(const int32_t* __restrict__ rowptr, int N, int64_t b, int lane) {
+    int lo = 0, hi = N;
+    while (lo < hi) {
+        const int step = (hi - lo + 63) >> 6;
+        const int n = min(lo + lane * step, hi);
+        const bool ge = n >= hi ? true : ((int64_t)rowptr[n] + n >= b);
+        const unsigned long long m = __ballot(ge);
+        if (m == 0ull) { lo = min(lo + 63 * step, hi - 1) + 1; continue; }
+        const int fl = __builtin_ctzll(m);
+        if (fl == 0) { hi = lo; break; }
+        hi = min(lo + fl * step, hi);
+        lo = lo + (fl - 1) * step + 1;
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
+}
+
+__global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
+    typedef Gate<true> GT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, t16 = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int F = p.F, N = p.N;
+
+    // ---- one-time setup: packed weights -> LDS, the waves' regions zeroed, bias column of the rbf tiles = 1
+    {
+        const u32x4* g = reinterpret_cast<const u32x4*>(p.wpack);
+        u32x4* l = reinterpret_cast<u32x4*>(smem);
+        for (int q = tid; q < (W1_BYTES + W2_BYTES) / 16; q += NT) l[q] = g[q];
+        unsigned* z = reinterpret_cast<unsigned*>(smem + W1_BYTES + W2_BYTES);
+        for (int q = tid; q < NWAVE * WAVE_BYTES / 4; q += NT) z[q] = 0u;
+    }
+    __syncthreads();
+    char* const mybuf = smem + W1_BYTES + W2_BYTES + wv * WAVE_BYTES;
+    bf16_t* const et = reinterpret_cast<bf16_t*>(mybuf + OFF_ET);
+    char* const dp = mybuf + OFF_DP;
+    if (lane < 32) et[lane * EKS + G_] = 0x3F80;
+    const bf16_t* const w1l = reinterpret_cast<const bf16_t*>(smem);
+    const bf16_t* const w2l = reinterpret_cast<const bf16_t*>(smem + W1_BYTES);
+    wave_lds_fence();
+
+    const int Et = __builtin_amdgcn_readfirstlane(p.rowptr[N]);
+    // rows past the last edge (a padded static batch): the activations the backward reads must be finite there
+    if (p.a1 || p.w) {
+        const int64_t d0 = (int64_t)Et * F / 2, d1 = (int64_t)p.E * F / 2;
+        unsigned* a = reinterpret_cast<unsigned*>(p.a1);
+        unsigned* b = reinterpret_cast<unsigned*>(p.w);
+        for (int64_t q = d0 + (int64_t)blockIdx.x * NT + tid; q < d1; q += (int64_t)gridDim.x * NT) {
+            if (a) a[q] = 0u;
+            if (b) b[q] = 0u;
+        }
+    }
+
+    // ---- this wave's node range: equal cost (edges + nodes) per wave
+    const int gw = blockIdx.x * NWAVE + wv, Wn = gridDim.x * NWAVE;
+    const int64_t total = (int64_t)Et + N;
+    const int na = gw == 0 ? 0 : lower_bound_cost(p.rowptr, N, total * gw / Wn, lane);
+    const int nb = gw == Wn - 1 ? N : lower_bound_cost(p.rowptr, N, total * (gw + 1) / Wn, lane);
+
+    const unsigned rsplat = (unsigned)(i << 7) * 0x00010001u;
+    for (int n0 = na; n0 < nb;) {
+        const int n1 = min(n0 + 32, nb);
+        const int e0 = __builtin_amdgcn_readfirstlane(p.rowptr[n0]), e1 = __builtin_amdgcn_readfirstlane(p.rowptr[n1]);
+        f32x16 oacc[NBK];
+#pragma unroll
+        for (int b = 0; b < NBK; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[b][r] = 0.0f;
+
+        for (int eb = e0; eb < e1; eb += 32) {
+            const int nv = min(32, e1 - eb);
+            const bool valid_i = i < nv;
+            const int ec = min(eb + i, e1 - 1);                 // (slots past the group repeat its last edge: clamp, never guard)
+            const int srcn = p.src[ec];
+            const int tg = p.tgt[ec];
+            const float cu = valid_i ? p.cut[ec] * UP : 0.0f;
+            // ---- the tile's rbf rows: nv x 100 contiguous bytes -> LDS rows of EKS halfwords
+            {
+                const unsigned* g = reinterpret_cast<const unsigned*>(p.rbf + (int64_t)eb * G_);
+                const int nd = nv * GH;
+                unsigned v[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) v[j] = (lane + WAVE * j < nd) ? g[lane + WAVE * j] : 0u;
+                wave_lds_fence();
+                unsigned* etd = reinterpret_cast<unsigned*>(et);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int d = lane + WAVE * j;
+                    const int row = (d * 1311) >> 15;            // d / 25 for d < 2^15 / (26 * 25 - 1311 * 25 ...): exact below 1024
+                    const int col = d - row * GH;
+                    if (d < nd) etd[row * (EKS / 2) + col] = v[j];
+                }
+                if (h == 0) reinterpret_cast<unsigned short*>(mybuf + OFF_TSL)[i] = valid_i ? (unsigned short)((tg - n0) << 7) : (unsigned short)0xffff;
+            }
+            wave_lds_fence();
+
+            // one-hot operands of the by-target reduction (k-slot q of k-step ks = edge slot 16 ks + 8 (q >> 2) + 4 h + (q & 3))
+            bf16x8 tf[2];
+            {
+                const u32x2* tw = reinterpret_cast<const u32x2*>(mybuf + OFF_TSL) + h;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const u32x2 t0 = tw[4 * ks], t1 = tw[4 * ks + 2];
+                    tf[ks] = __builtin_bit_cast(bf16x8, u32x4{oh2x(t0[0] ^ rsplat), oh2x(t0[1] ^ rsplat), oh2x(t1[0] ^ rsplat), oh2x(t1[1] ^ rsplat)});
+                }
+            }
+
+            // ---- GEMM1 + ssp: a1 fragments (k-slot s of fragment 2 b + t = unit 32 b + 16 t + 8 (s >> 2) + 4 h + (s & 3))
+            bf16x8 zf[KE / 16];
+#pragma unroll
+            for (int k = 0; k < KE / 16; ++k) zf[k] = ld_frag(et, i, EKS, 16 * k, h);
+            bf16x8 af[2 * NBK];
+            const int64_t erow = (int64_t)(eb + i) * F;
+#pragma unroll
+            for (int b = 0; b < NBK; ++b) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KE / 16; ++k)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * b + i, W1S, 16 * k, h), zf[k], acc, 0, 0, 0);
+                float a[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[r] = LN2_F * (GT::softplus_u(acc[r]) - 1.0f);
+                unsigned dw[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    dw[2 * q] = pk_bf16(a[4 * q], a[4 * q + 1]);
+                    dw[2 * q + 1] = pk_bf16(a[4 * q + 2], a[4 * q + 3]);
+                    if (p.a1 && valid_i) {
+                        const int u0 = 32 * b + 8 * q + 4 * h;          // chunk 8 b + 2 q + h = units u0 .. u0 + 3
+                        if (b < NBK - 1 || u0 + 4 <= F) *reinterpret_cast<u32x2*>(p.a1 + erow + u0) = u32x2{dw[2 * q], dw[2 * q + 1]};
+                        else if (u0 + 2 <= F) *reinterpret_cast<unsigned*>(p.a1 + erow + u0) = dw[2 * q];
+                    }
+                }
+                // unit FP - 1 (lane half 1, register 15 of the last block) is the constant 1 that carries the bias of layer 2
+                if (b == NBK - 1 && h == 1) dw[7] = (dw[7] & 0x0000ffffu) | 0x3F800000u;
+                af[2 * b] = __builtin_bit_cast(bf16x8, u32x4{dw[0], dw[1], dw[2], dw[3]});
+                af[2 * b + 1] = __builtin_bit_cast(bf16x8, u32x4{dw[4], dw[5], dw[6], dw[7]});
+            }
+
+            // ---- GEMM2, messages, by-target reduction: one 32-unit block at a time
+            const bf16_t* const hrow = p.h + (int64_t)srcn * F;
+#pragma unroll
+            for (int b = 0; b < NBK; ++b) {
+                // the h[src] chunks of this block (requested first: they travel under the MFMAs)
+                u32x2 hv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int u0 = 32 * b + 8 * q + 4 * h;
+                    hv[q] = u32x2{0u, 0u};
+                    if (b < NBK - 1 || u0 + 4 <= F) hv[q] = *reinterpret_cast<const u32x2*>(hrow + u0);
+                    else if (u0 + 2 <= F) hv[q][0] = *reinterpret_cast<const unsigned*>(hrow + u0);
+                }
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < 2 * NBK; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w2l, 32 * b + i, W2S, 16 * ks, h), af[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned w0 = pk_bf16(acc[4 * q], acc[4 * q + 1]), w1 = pk_bf16(acc[4 * q + 2], acc[4 * q + 3]);
+                    const int u0 = 32 * b + 8 * q + 4 * h;
+                    if (p.w && valid_i) {
+                        if (b < NBK - 1 || u0 + 4 <= F) *reinterpret_cast<u32x2*>(p.w + erow + u0) = u32x2{w0, w1};
+                        else if (u0 + 2 <= F) *reinterpret_cast<unsigned*>(p.w + erow + u0) = w0;
+                    }
+                    // message = the ROUNDED filter (what the unfused path multiplies) * h[src] * cutoff, scaled by 2^64
+                    const float m0 = (__uint_as_float(w0 << 16) * __uint_as_float(hv[q][0] << 16)) * cu;
+                    const float m1 = (__uint_as_float(w0 & 0xffff0000u) * __uint_as_float(hv[q][0] & 0xffff0000u)) * cu;
+                    const float m2 = (__uint_as_float(w1 << 16) * __uint_as_float(hv[q][1] << 16)) * cu;
+                    const float m3 = (__uint_as_float(w1 & 0xffff0000u) * __uint_as_float(hv[q][1] & 0xffff0000u)) * cu;
+                    *reinterpret_cast<u32x2*>(dp + (2 * q + h) * DCS + i * 8) = u32x2{pk_bf16(m0, m1), pk_bf16(m2, m3)};
+                }
+                wave_lds_fence();
+                {
+                    const char* a = dp + (4 * (i >> 4) + (t16 & 3)) * DCS + (4 * h + (t16 >> 2)) * 8;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a + 128 * ks));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a + 128 * ks + 64));
+                        const bf16x8 mf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        oacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[ks], mf, oacc[b], 0, 0, 0);
+                    }
+                }
+                wave_lds_fence();
+            }
+        }
+        // ---- the group's rows: lane = unit, registers = node slots (D layout)
+#pragma unroll
+        for (int b = 0; b < NBK; ++b) {
+            const int unit = 32 * b + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + d_row(r, h);
+                if (n < n1 && (b < NBK - 1 || unit < F)) p.out[(int64_t)n * F + unit] = f2bf(oacc[b][r] * RW);
+            }
+        }
+        n0 = n1;
+    }
+}
+
+// W1 [F, G], b1 [F], W2 [F, F], b2 [F] (fp32 masters) -> W1p [FP][W1S] (scaled by log2 e for the base-2 softplus, bias in column
+// G) | W2p [FP][W2S] with the K columns in the order GEMM1's accumulators leave the units in and the bias in the slot of unit
+// FP - 1, which the kernel sets to 1
+__global__ __launch_bounds__(256) void cfconv_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2, int F,
+                                                          bf16_t* __restrict__ wpack) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < FP * W1S) {
+        const int row = idx / W1S, col = idx - row * W1S;
+        float v = 0.0f;
+        if (row < F) {
+            if (col < G_) v = w1[row * G_ + col];
+            else if (col == G_ && b1) v = b1[row];
+        }
+        wpack[idx] = f2bf(v * LOG2E_F);
+    } else if (idx < FP * W1S + FP * W2S) {
+        const int j = idx - FP * W1S;
+        const int n = j / W2S, pos = j - n * W2S;
+        float v = 0.0f;
+        if (n < F && pos < FP) {
+            const int ks = pos >> 4, hh = (pos >> 3) & 1, s = pos & 7;
+            const int unit = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (s >> 2) + 4 * hh + (s & 3);
+            if (unit < F) v = w2[n * F + unit];
+            else if (unit == FP - 1 && b2) v = b2[n];
+        }
+        wpack[idx] = f2bf(v);
+    }
+}
+
+}  // namespace cf
+}  // namespace mdl
+
+using namespace mdl;
+
+extern "C" size_t mdl_cfconv_wpack_bytes(void) { return (size_t)cf::W1_BYTES + cf::W2_BYTES; }
+
+extern "C" int mdl_cfconv_supported(int F, int G, int dtype) {
+    return dtype == MDL_BF16 && G == cf::G_ && F > 128 && F <= cf::FP - 2 && F % 2 == 0;
+}
+
+extern "C" int mdl_cfconv_pack_weights(const float* w1, const float* b1, const float* w2, const float* b2, int F, int G, void* wpack,
+                                       mdlStream_t stream) {
+    MDL_REQUIRE(mdl_cfconv_supported(F, G, MDL_BF16), MDL_E_UNSUPP, "mdl_cfconv_pack_weights: F = %d, G = %d (supported: G = 50, even F in (128, 158])", F, G);
+    MDL_REQUIRE(w1 && w2 && wpack, MDL_E_ARG, "mdl_cfconv_pack_weights: null weights");
+    const int total = cf::FP * cf::W1S + cf::FP * cf::W2S;
+    hipLaunchKernelGGL(cf::cfconv_pack_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, F,
+                       static_cast<bf16_t*>(wpack));
+    return check_launch("mdl_cfconv_pack_weights");
+}
+
+extern "C" int mdl_cfconv_fwd(const void* rbf, const float* cut, const void* h, const int32_t* rowptr, const int32_t* src,
+                              const int32_t* tgt, const void* wpack, void* out, void* a1, void* w, int64_t N, int64_t E, int F, int G,
+                              int dtype, mdlStream_t stream) {
+    MDL_REQUIRE(mdl_cfconv_supported(F, G, dtype), MDL_E_UNSUPP, "mdl_cfconv_fwd: bf16, G = 50 and even F in (128, 158] only (F = %d, G = %d, dtype %d)", F, G, dtype);
+    MDL_REQUIRE(N >= 0 && E >= 0 && N < (1ll << 31) && E * (int64_t)F < (1ll << 40) && E < (1ll << 31), MDL_E_ARG, "mdl_cfconv_fwd: sizes out of range");
+    if (N == 0) return MDL_OK;
+    MDL_REQUIRE(rowptr && out && wpack && h, MDL_E_ARG, "mdl_cfconv_fwd: null argument");
+    MDL_REQUIRE(E == 0 || (rbf && cut && src && tgt), MDL_E_ARG, "mdl_cfconv_fwd: null edge arrays");
+    MDL_REQUIRE(((uintptr_t)rbf % 4) == 0 && ((uintptr_t)h % 4) == 0 && ((uintptr_t)a1 % 4) == 0 && ((uintptr_t)w % 4) == 0 && ((uintptr_t)wpack % 16) == 0,
+                MDL_E_ARG, "mdl_cfconv_fwd: misaligned tensor");
+    cf::Params p{static_cast<const bf16_t*>(rbf), cut, static_cast<const bf16_t*>(h), rowptr, src, tgt, static_cast<const bf16_t*>(wpack),
+                 static_cast<bf16_t*>(out), static_cast<bf16_t*>(a1), static_cast<bf16_t*>(w), (int)N, (int)E, F};
+    // one 8-wave workgroup per CU; small problems: about two tiles per wave at least
+    const int64_t grid = std::min<int64_t>(256, std::max<int64_t>(1, cdiv(E + N, 32 * cf::NWAVE * 2)));
+    auto kf = cf::cfconv_fwd_kernel;
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), cf::LDS);
+    if (e != hipSuccess) { set_error("mdl_cfconv_fwd: LDS attribute (%d B): %s", cf::LDS, hipGetErrorString(e)); return MDL_E_LAUNCH; }
+    hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(cf::NT), cf::LDS, (hipStream_t)stream, p);
+    return check_launch("mdl_cfconv_fwd");
+}

@@ -73,9 +73,10 @@ try:
         print("bwd per-tile cycles (wave 0, %d tiles, total %d cyc/tile):" % (n, v[30] / n), {names[k]: round(v[16 + k] / n) for k in range(13)}, "sum", round(sum(v[16:29]) / n), "| shader clock %.2f GHz, wave-0 lifetime %.1f us/launch" % (v[30] / max(v[29], 1) * 0.1, v[29] / 100.0 / max(1, a.iters + 2)))
         if os.environ.get("MDL_CG_EP", "0") == "2":   # kernel 2: producer wave 0 above (first five slots), reducer wave 4 here; per ROUND
             n = max(v[47], 1)
-            names = ["meta + group test", "group change (flush, roll)", "operand reads + tf + R", "e reads + dwe", "window blocks", "round tail", "barrier"]
+            names = ["meta + group test", "group change (rest)", "operand reads + tf + R", "e reads + dwe", "window blocks", "round tail", "barrier",
+                     "gc: before flush_r", "gc: flush_r", "gc: flush_w", "gc: roll", "round top: take", "round top: header + first request"]
             print("ep2 producer per-round cycles:", dict(zip(["wait top", "take+commit+slots", "issue ids/e", "mfma+gate+oow", "barrier"], [round(v[16 + k] / max(v[31], 1)) for k in range(5)])))
-            print("ep2 reducer per-round cycles (%d rounds, total %d):" % (n, v[46] / n), {names[k]: round(v[32 + k] / n) for k in range(7)})
+            print("ep2 reducer per-round cycles (%d rounds, total %d):" % (n, v[46] / n), {names[k]: round(v[32 + k] / n) for k in range(len(names))})
     if hasattr(L, "mdl_debug_life"):
         import numpy as np
         for which, nm in ((0, "fwd"), (1, "bwd")):
