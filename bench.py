@@ -209,7 +209,7 @@ def main():
     dp = FlatDataParallel(model)
     opt = make_optimizer(model.parameters(), "AdamW", lr=0.002 * world)   # lr x world_size, training.py:388-389
 
-    ktimes = {"cgcnn": {"fwd": [], "bwd": [], "bwd_node": [], "bwd_grads": []}, "schnet": {"gmr_fwd": []}, "megnet": {"edge_linear": []},
+    ktimes = {"cgcnn": {"fwd": [], "bwd": [], "bwd_node": [], "bwd_grads": []}, "schnet": {"gmr_fwd": [], "cfconv_fwd": []}, "megnet": {"edge_linear": []},
               "gcn": {"gmr_fwd": []}, "mpnn": {"nnconv_fwd": []}}[args.model]
 
     prefetch = not args.no_prefetch
@@ -375,8 +375,11 @@ def main():
                                                "bwd_grads": "mdl_cgconv_assemble_grads"}[k] for k in parts)}
     elif args.model == "schnet":                     # K4a (aggregation only): E(2 F s + 8) + N(F s + 4)   (csrc/gather.hip)
         F_ = mkw["dim3"]
-        ab = {"gmr_fwd": e_ev * (2 * F_ * s + 8) + n_ev * (F_ * s + 4)}
-        kname = {"gmr_fwd": "mdl_gather_mul_reduce"}
+        ab = {"gmr_fwd": e_ev * (2 * F_ * s + 8) + n_ev * (F_ * s + 4),
+              # K4 (fused forward, csrc/cfconv.hip), SURVEY 8d: E(G s + 4 + F s + 4) + N(2 F s + 4) — the training form also WRITES the two
+              # activations the backward reads (2 E F s), which SURVEY's figure (filter recomputed in the backward) does not count
+              "cfconv_fwd": e_ev * (G * s + 4 + F_ * s + 4) + n_ev * (2 * F_ * s + 4)}
+        kname = {"gmr_fwd": "mdl_gather_mul_reduce", "cfconv_fwd": "mdl_cfconv_fwd (K4: filter network + cutoff + h[src] * W + segmented sum)"}
     elif args.model == "gcn":                        # K4a with a scalar edge weight: E(F s + 8) + N(F s + 4)
         F_ = mkw["dim1"]
         ab = {"gmr_fwd": e_ev * (F_ * s + 8) + n_ev * (F_ * s + 4)}

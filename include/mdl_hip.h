@@ -439,6 +439,26 @@ int mdl_gather_mul_reduce(const void* h, const void* w, const float* scale, cons
 int mdl_gather_mul_reduce_dw(const void* g, const void* w, const float* scale, const int32_t* rowptr_s,
                              const int32_t* col_s, const int32_t* eid_s, void* dh, const void* h, void* dw,
                              int64_t N, int64_t F, int dtype, mdlStream_t stream);
+/* ---- K4: the fused forward of SchNet's continuous-filter convolution -----------------------------
+ * Replaces, in ONE pass over the CSR-ordered edges, what torch_geometric's InteractionBlock / CFConv run at
+ * matdeeplearn/models/schnet.py:131-145 (constructed at schnet.py:81) as filter network + propagate:
+ *     a1[e, :]  = ssp(rbf[e, :] W1^T + b1)            ssp(v) = softplus(v) - ln 2          (mlp[0], mlp[1])
+ *     w[e, :]   = a1[e, :] W2^T + b2                                                       (mlp[2]: the filter)
+ *     out[i, :] = sum_{e in [rowptr[i], rowptr[i+1])} h[src[e], :] * w[e, :] * cut[e]      (CFConv.message + aggr = add)
+ * rbf: [E, G] edge features in CSR order; cut: [E] fp32 cosine cutoff; h: [N, F] = lin1(x); src / tgt: [E] int32 node per
+ * CSR slot; out: [N, F].  a1 / w: [E, F] — the two activations the backward consumes (mdl_gather_mul_reduce_dw, the dense
+ * backward of the two layers) — or NULL for inference; rows past rowptr[N] (padded static batch) are zeroed.  The product uses
+ * the bf16-ROUNDED filter, like the unfused sequence mdl_linear_act x 2 -> mdl_gather_mul_reduce.  bf16, G = 50, even F in
+ * (128, 158] (SchNet_demo: 150); other shapes: MDL_E_UNSUPP (callers keep the unfused sequence).  wpack: the weights packed by
+ * mdl_cfconv_pack_weights (mdl_cfconv_wpack_bytes() bytes, 16-byte aligned) from the fp32 masters W1 [F, G], b1 [F] or NULL,
+ * W2 [F, F], b2 [F] or NULL. */
+int mdl_cfconv_supported(int F, int G, int dtype);
+size_t mdl_cfconv_wpack_bytes(void);
+int mdl_cfconv_pack_weights(const float* w1, const float* b1, const float* w2, const float* b2, int F, int G, void* wpack,
+                            mdlStream_t stream);
+int mdl_cfconv_fwd(const void* rbf, const float* cut, const void* h, const int32_t* rowptr, const int32_t* src,
+                   const int32_t* tgt, const void* wpack, void* out, void* a1, void* w, int64_t N, int64_t E, int F, int G,
+                   int dtype, mdlStream_t stream);
 /* out[e, :] = a[ia[e], :] * b[ib[e], :] * scale[e]   (gradient w.r.t. the per-edge filter w) */
 int mdl_edge_mul(const void* a, const int32_t* ia, const void* b, const int32_t* ib, const float* scale, void* out,
                  int64_t E, int64_t F, int dtype, mdlStream_t stream);

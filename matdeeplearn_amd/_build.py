@@ -16,7 +16,7 @@ OBJDIR = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libmdl_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 # per-file extras: the edge-per-lane CGConv backward wants its MFMA results in VGPRs (see csrc/cgconv.hip)
-FILE_FLAGS = {"cgconv_ep.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+FILE_FLAGS = {"cgconv_ep.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "cfconv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 # translation units that #include another .hip file
 FILE_DEPS = {"cgconv_ep.hip": ["cgconv.hip"]}
 

@@ -106,6 +106,10 @@ PROTOTYPES = {
     "mdl_gather_mul_reduce": (_i32, [_vp] * 7 + [_i64, _i64, _i32, _i32, _vp]),
     "mdl_gather_mul_reduce_dw": (_i32, [_vp] * 9 + [_i64, _i64, _i32, _vp]),
     "mdl_edge_mul": (_i32, [_vp] * 6 + [_i64, _i64, _i32, _vp]),
+    "mdl_cfconv_supported": (_i32, [_i32, _i32, _i32]),
+    "mdl_cfconv_wpack_bytes": (_sz, []),
+    "mdl_cfconv_pack_weights": (_i32, [_vp] * 4 + [_i32, _i32, _vp, _vp]),
+    "mdl_cfconv_fwd": (_i32, [_vp] * 10 + [_i64, _i64, _i32, _i32, _i32, _vp]),
 }
 
 _lib = None

@@ -131,9 +131,33 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
     const int nb = gw == Wn - 1 ? N : lower_bound_cost(p.rowptr, N, total * (gw + 1) / Wn, lane);
 
     const unsigned rsplat = (unsigned)(i << 7) * 0x00010001u;
+    if (na >= nb) return;
+
+    // ---- software pipeline: the operands a tile needs from memory (its indices, cutoff factors and rbf dwords) are requested ONE
+    // TILE AHEAD, and its h[src] rows at its top; everything is waited for ONCE per tile, behind GEMM1 (20 MFMAs + 80 softplus
+    // values: ~2 us of cover) and in front of the tile's first global store — from there to the end of the tile the wave only
+    // stores.  (Loads and stores share one counter that the compiler can only drain completely once both kinds are in flight:
+    // a load wait anywhere else would also wait for the stores issued just before it.)  The edges of consecutive tiles are
+    // contiguous in CSR order whatever the group boundaries, so "the next tile" starts at eb + nv before its length is known.
+    struct Pre { int src, tg; float cu; unsigned v[NJ]; };
+    auto request = [&](Pre& q, int eb) {
+        const int ec = min(eb + i, Et - 1);
+        q.src = p.src[ec];
+        q.tg = p.tgt[ec];
+        q.cu = p.cut[ec];
+        const unsigned* g = reinterpret_cast<const unsigned*>(p.rbf + (int64_t)eb * G_);
+        const int64_t lim = ((int64_t)Et - eb) * GH;                  // dwords left in the array
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) q.v[j] = g[min((int64_t)(lane + WAVE * j), lim - 1)];
+    };
+    Pre cur, nxt;
+    int e0 = __builtin_amdgcn_readfirstlane(p.rowptr[na]);
+    if (e0 < Et) request(cur, e0); else { cur.src = 0; cur.tg = 0; cur.cu = 0.0f; for (int j = 0; j < NJ; ++j) cur.v[j] = 0u; }
+    nxt = cur;
+
     for (int n0 = na; n0 < nb;) {
         const int n1 = min(n0 + 32, nb);
-        const int e0 = __builtin_amdgcn_readfirstlane(p.rowptr[n0]), e1 = __builtin_amdgcn_readfirstlane(p.rowptr[n1]);
+        const int e1 = __builtin_amdgcn_readfirstlane(p.rowptr[n1]);
         f32x16 oacc[NBK];
 #pragma unroll
         for (int b = 0; b < NBK; ++b)
@@ -143,27 +167,33 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
         for (int eb = e0; eb < e1; eb += 32) {
             const int nv = min(32, e1 - eb);
             const bool valid_i = i < nv;
-            const int ec = min(eb + i, e1 - 1);                 // (slots past the group repeat its last edge: clamp, never guard)
-            const int srcn = p.src[ec];
-            const int tg = p.tgt[ec];
-            const float cu = valid_i ? p.cut[ec] * UP : 0.0f;
-            // ---- the tile's rbf rows: nv x 100 contiguous bytes -> LDS rows of EKS halfwords
-            {
-                const unsigned* g = reinterpret_cast<const unsigned*>(p.rbf + (int64_t)eb * G_);
-                const int nd = nv * GH;
-                unsigned v[NJ];
+            const int srcn = cur.src;
+            const float cu = valid_i ? cur.cu * UP : 0.0f;
+            // ---- this tile's h[src] chunks, then the next tile's operands: all in flight under GEMM1
+            const bf16_t* const hrow = p.h + (int64_t)srcn * F;
+            u32x2 hv[NBK][4];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) v[j] = (lane + WAVE * j < nd) ? g[lane + WAVE * j] : 0u;
-                wave_lds_fence();
+            for (int b = 0; b < NBK; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int u0 = 32 * b + 8 * q + 4 * h;
+                    hv[b][q] = u32x2{0u, 0u};
+                    if (b < NBK - 1 || u0 + 4 <= F) hv[b][q] = *reinterpret_cast<const u32x2*>(hrow + u0);
+                    else if (u0 + 2 <= F) hv[b][q][0] = *reinterpret_cast<const unsigned*>(hrow + u0);
+                }
+            if (eb + nv < Et) request(nxt, eb + nv);
+            // ---- the tile's rbf rows (nv x 100 contiguous bytes, in registers since the last tile) -> LDS rows of EKS halfwords
+            {
+                const int nd = nv * GH;
                 unsigned* etd = reinterpret_cast<unsigned*>(et);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int d = lane + WAVE * j;
-                    const int row = (d * 1311) >> 15;            // d / 25 for d < 2^15 / (26 * 25 - 1311 * 25 ...): exact below 1024
+                    const int row = (d * 1311) >> 15;            // d / 25, exact below 800
                     const int col = d - row * GH;
-                    if (d < nd) etd[row * (EKS / 2) + col] = v[j];
+                    if (d < nd) etd[row * (EKS / 2) + col] = cur.v[j];
                 }
-                if (h == 0) reinterpret_cast<unsigned short*>(mybuf + OFF_TSL)[i] = valid_i ? (unsigned short)((tg - n0) << 7) : (unsigned short)0xffff;
+                if (h == 0) reinterpret_cast<unsigned short*>(mybuf + OFF_TSL)[i] = valid_i ? (unsigned short)((cur.tg - n0) << 7) : (unsigned short)0xffff;
             }
             wave_lds_fence();
 
@@ -178,12 +208,9 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                 }
             }
 
-            // ---- GEMM1 + ssp: a1 fragments (k-slot s of fragment 2 b + t = unit 32 b + 16 t + 8 (s >> 2) + 4 h + (s & 3))
-            bf16x8 zf[KE / 16];
-#pragma unroll
-            for (int k = 0; k < KE / 16; ++k) zf[k] = ld_frag(et, i, EKS, 16 * k, h);
-            bf16x8 af[2 * NBK];
-            const int64_t erow = (int64_t)(eb + i) * F;
+            // ---- GEMM1 + ssp: a1 fragments (k-slot s of fragment 2 b + t = unit 32 b + 16 t + 8 (s >> 2) + 4 h + (s & 3)); a
+            // fragment's dwords are also the 8-byte chunks of the a1 row (chunk 8 b + 2 q + h = dwords 2 q, 2 q + 1 of the pair)
+            unsigned ad[NBK][8];
 #pragma unroll
             for (int b = 0; b < NBK; ++b) {
                 f32x16 acc;
@@ -191,59 +218,92 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
                 for (int k = 0; k < KE / 16; ++k)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * b + i, W1S, 16 * k, h), zf[k], acc, 0, 0, 0);
-                float a[16];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * b + i, W1S, 16 * k, h), ld_frag(et, i, EKS, 16 * k, h), acc, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a[r] = LN2_F * (GT::softplus_u(acc[r]) - 1.0f);
-                unsigned dw[8];
+                for (int q = 0; q < 8; ++q)
+                    ad[b][q] = pk_bf16(LN2_F * (GT::softplus_u(acc[2 * q]) - 1.0f), LN2_F * (GT::softplus_u(acc[2 * q + 1]) - 1.0f));
+            }
+            // every load of this tile (and the next tile's operands) has had GEMM1 to arrive; from here on the tile only stores
+#ifndef MDL_CF_NOWAIT
+            __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+#endif
+            // The activations leave through the 2.3-KB chunk buffer: a lane owns an EDGE, so stores from the accumulator layout
+            // are 8-byte pieces of 32 different rows per instruction (37 L2 transactions per edge and tensor: measured +245 us
+            // for the two tensors).  Staged as chunks and read back row-wise, a lane writes 16 bytes and four neighbouring lanes
+            // one 64-byte run of a row: a quarter of the transactions.
+            auto store_block = [&](bf16_t* dst, int b) {
+                const int pc = lane & 3;
+                const int u0 = 32 * b + 8 * pc;                        // first unit of my 16-byte piece
+                const int ndw = min(4, max(0, (F - u0) >> 1));         // dwords of it that exist
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    dw[2 * q] = pk_bf16(a[4 * q], a[4 * q + 1]);
-                    dw[2 * q + 1] = pk_bf16(a[4 * q + 2], a[4 * q + 3]);
-                    if (p.a1 && valid_i) {
-                        const int u0 = 32 * b + 8 * q + 4 * h;          // chunk 8 b + 2 q + h = units u0 .. u0 + 3
-                        if (b < NBK - 1 || u0 + 4 <= F) *reinterpret_cast<u32x2*>(p.a1 + erow + u0) = u32x2{dw[2 * q], dw[2 * q + 1]};
-                        else if (u0 + 2 <= F) *reinterpret_cast<unsigned*>(p.a1 + erow + u0) = dw[2 * q];
+                for (int half = 0; half < 2; ++half) {
+                    const int r = (lane >> 2) + 16 * half;
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(dp + (2 * pc) * DCS + r * 8);
+                    const u32x2 hi = *reinterpret_cast<const u32x2*>(dp + (2 * pc + 1) * DCS + r * 8);
+                    if (r < nv) {
+#ifdef MDL_CF_SMALLDST
+                        unsigned* g = reinterpret_cast<unsigned*>(dst + (int64_t)((eb + r) & 4095) * F + u0);   // (A/B: stores that stay in L2)
+#else
+                        unsigned* g = reinterpret_cast<unsigned*>(dst + (int64_t)(eb + r) * F + u0);
+#endif
+                        if (b < NBK - 1 || ndw == 4) {
+                            *reinterpret_cast<u32x4*>(g) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                        } else {
+                            if (ndw >= 1) g[0] = lo[0];
+                            if (ndw >= 2) g[1] = lo[1];
+                            if (ndw >= 3) g[2] = hi[0];
+                        }
                     }
                 }
-                // unit FP - 1 (lane half 1, register 15 of the last block) is the constant 1 that carries the bias of layer 2
-                if (b == NBK - 1 && h == 1) dw[7] = (dw[7] & 0x0000ffffu) | 0x3F800000u;
-                af[2 * b] = __builtin_bit_cast(bf16x8, u32x4{dw[0], dw[1], dw[2], dw[3]});
-                af[2 * b + 1] = __builtin_bit_cast(bf16x8, u32x4{dw[4], dw[5], dw[6], dw[7]});
+            };
+            if (p.a1) {
+#pragma unroll
+                for (int b = 0; b < NBK; ++b) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<u32x2*>(dp + (2 * q + h) * DCS + i * 8) = u32x2{ad[b][2 * q], ad[b][2 * q + 1]};
+                    wave_lds_fence();
+                    store_block(p.a1, b);
+                    wave_lds_fence();
+                }
+            }
+            // unit FP - 1 (lane half 1, register 15 of the last block) is the constant 1 that carries the bias of layer 2
+            if (h == 1) ad[NBK - 1][7] = (ad[NBK - 1][7] & 0x0000ffffu) | 0x3F800000u;
+            bf16x8 af[2 * NBK];
+#pragma unroll
+            for (int b = 0; b < NBK; ++b) {
+                af[2 * b] = __builtin_bit_cast(bf16x8, u32x4{ad[b][0], ad[b][1], ad[b][2], ad[b][3]});
+                af[2 * b + 1] = __builtin_bit_cast(bf16x8, u32x4{ad[b][4], ad[b][5], ad[b][6], ad[b][7]});
             }
 
             // ---- GEMM2, messages, by-target reduction: one 32-unit block at a time
-            const bf16_t* const hrow = p.h + (int64_t)srcn * F;
 #pragma unroll
             for (int b = 0; b < NBK; ++b) {
-                // the h[src] chunks of this block (requested first: they travel under the MFMAs)
-                u32x2 hv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int u0 = 32 * b + 8 * q + 4 * h;
-                    hv[q] = u32x2{0u, 0u};
-                    if (b < NBK - 1 || u0 + 4 <= F) hv[q] = *reinterpret_cast<const u32x2*>(hrow + u0);
-                    else if (u0 + 2 <= F) hv[q][0] = *reinterpret_cast<const unsigned*>(hrow + u0);
-                }
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
                 for (int ks = 0; ks < 2 * NBK; ++ks)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w2l, 32 * b + i, W2S, 16 * ks, h), af[ks], acc, 0, 0, 0);
+                unsigned wd[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) wd[q] = pk_bf16(acc[2 * q], acc[2 * q + 1]);
+                if (p.w) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<u32x2*>(dp + (2 * q + h) * DCS + i * 8) = u32x2{wd[2 * q], wd[2 * q + 1]};
+                    wave_lds_fence();
+                    store_block(p.w, b);
+                    wave_lds_fence();
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const unsigned w0 = pk_bf16(acc[4 * q], acc[4 * q + 1]), w1 = pk_bf16(acc[4 * q + 2], acc[4 * q + 3]);
-                    const int u0 = 32 * b + 8 * q + 4 * h;
-                    if (p.w && valid_i) {
-                        if (b < NBK - 1 || u0 + 4 <= F) *reinterpret_cast<u32x2*>(p.w + erow + u0) = u32x2{w0, w1};
-                        else if (u0 + 2 <= F) *reinterpret_cast<unsigned*>(p.w + erow + u0) = w0;
-                    }
+                    const unsigned w0 = wd[2 * q], w1 = wd[2 * q + 1];
                     // message = the ROUNDED filter (what the unfused path multiplies) * h[src] * cutoff, scaled by 2^64
-                    const float m0 = (__uint_as_float(w0 << 16) * __uint_as_float(hv[q][0] << 16)) * cu;
-                    const float m1 = (__uint_as_float(w0 & 0xffff0000u) * __uint_as_float(hv[q][0] & 0xffff0000u)) * cu;
-                    const float m2 = (__uint_as_float(w1 << 16) * __uint_as_float(hv[q][1] << 16)) * cu;
-                    const float m3 = (__uint_as_float(w1 & 0xffff0000u) * __uint_as_float(hv[q][1] & 0xffff0000u)) * cu;
+                    const float m0 = (__uint_as_float(w0 << 16) * __uint_as_float(hv[b][q][0] << 16)) * cu;
+                    const float m1 = (__uint_as_float(w0 & 0xffff0000u) * __uint_as_float(hv[b][q][0] & 0xffff0000u)) * cu;
+                    const float m2 = (__uint_as_float(w1 << 16) * __uint_as_float(hv[b][q][1] << 16)) * cu;
+                    const float m3 = (__uint_as_float(w1 & 0xffff0000u) * __uint_as_float(hv[b][q][1] & 0xffff0000u)) * cu;
                     *reinterpret_cast<u32x2*>(dp + (2 * q + h) * DCS + i * 8) = u32x2{pk_bf16(m0, m1), pk_bf16(m2, m3)};
                 }
                 wave_lds_fence();
@@ -259,6 +319,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                 }
                 wave_lds_fence();
             }
+            cur = nxt;
         }
         // ---- the group's rows: lane = unit, registers = node slots (D layout)
 #pragma unroll
@@ -271,6 +332,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
             }
         }
         n0 = n1;
+        e0 = e1;
     }
 }
 

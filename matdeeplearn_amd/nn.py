@@ -74,7 +74,7 @@ def lowp_copies(lin):
     return sh[0], sh[1]
 
 
-def _lin(lin, h, act=None, in_act=None, out_pre=False):
+def _lin(lin, h, act=None, in_act=None, out_pre=False, pre=None):
     """nn.Linear (+ activation) applied in the dtype of h (fp32 master weights, bf16 activations): the streaming HIP dense
     layer for bf16 rows, the library otherwise."""
     if h.dtype == lin.weight.dtype:
@@ -82,14 +82,16 @@ def _lin(lin, h, act=None, in_act=None, out_pre=False):
         if act is None:
             return y
         return F.softplus(y) - math.log(2.0) if act == "ssp" else getattr(F, act)(y)
-    return ops.linear_act(h, lin.weight, lin.bias, act, lowp_copies(lin), in_act, out_pre)
+    return ops.linear_act(h, lin.weight, lin.bias, act, lowp_copies(lin), in_act, out_pre, pre)
 
 
-def _seq(seq, h):
+def _seq(seq, h, pre=None):
     """Sequential of Linear / activation modules; a Linear followed by ShiftedSoftplus / ReLU runs as ONE fused dense layer.
     Between two fused layers of the chain the intermediate tensor is private to this function, so the activation derivative
     is handed down the chain (ops._LinearActTN: the later layer's backward returns the gradient w.r.t. the earlier layer's
-    pre-activation, the earlier layer's backward reads neither its output nor applies a derivative)."""
+    pre-activation, the earlier layer's backward reads neither its output nor applies a derivative).
+    pre: the outputs of the chain's Linear layers, already formed by a fused forward (CFConv: ops.cfconv_fused) — every layer
+    must then take the fused dense path, whose autograd node only records the graph."""
     mods = list(seq)
     layers, k = [], 0                                   # (module, act) per step; act is None for non-Linear modules
     while k < len(mods):
@@ -103,8 +105,10 @@ def _seq(seq, h):
             layers.append((m, False))
             k += 1
     handed = False                                      # the previous step was a fused layer told to expect a pre-activation gradient
+    pre = list(pre) if pre is not None else None
     for j, (m, act) in enumerate(layers):
         if act is False:
+            assert pre is None
             h, handed = m(h), False
             continue
         nxt = layers[j + 1] if j + 1 < len(layers) else None
@@ -116,9 +120,9 @@ def _seq(seq, h):
                 and (nxt[1] != "ssp" or nxt[0].out_features % 2 == 0) and h.shape[0] >= 1024)
         prev_act = layers[j - 1][1] if handed else None
         if fused:
-            h = _lin(m, h, act, in_act=prev_act, out_pre=give)
+            h = _lin(m, h, act, in_act=prev_act, out_pre=give, pre=pre.pop(0) if pre else None)
         else:
-            assert not handed
+            assert not handed and pre is None
             h = _lin(m, h, act)
         handed = give
     return h
@@ -159,8 +163,20 @@ class CFConv(nn.Module):
         if csr is None:
             csr = ops.csr_for(edge_index, x.shape[0])
         c = cosine_cutoff(edge_weight, self.cutoff) if cut is None else cut           # [E] fp32
-        w = _seq(self.nn, edge_attr)                                                  # filter  [E, F]
         h = _lin(self.lin1, x)
+        mods = list(self.nn)
+        if (len(mods) == 3 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], ShiftedSoftplus) and isinstance(mods[2], nn.Linear)
+                and ops.cfconv_fused_ok(edge_attr, h, csr, mods[0], mods[2])):
+            # K4: filter network, cutoff, h[src] * W and the segmented sum in ONE pass over the edges.  Under autograd the two
+            # dense layers and the gather-multiply-reduce keep their nodes (the backward is theirs) — they receive the
+            # activations the fused pass wrote instead of launching their own forward kernels.
+            train = torch.is_grad_enabled() and (h.requires_grad or mods[0].weight.requires_grad)
+            agg, a1, w = ops.cfconv_fused(edge_attr, c, h.detach(), csr, mods[0], mods[2], want_acts=train)
+            if train:
+                w = _seq(self.nn, edge_attr, pre=[a1, w])
+                agg = ops.gather_mul_reduce(h, csr, w=w, scale=c, reduce="sum", pre=agg)
+            return _lin(self.lin2, agg)
+        w = _seq(self.nn, edge_attr)                                                  # filter  [E, F]
         agg = ops.gather_mul_reduce(h, csr, w=w.to(h.dtype), scale=c, reduce="sum")
         return _lin(self.lin2, agg)
 

@@ -893,7 +893,8 @@ def gather(src, index):
 
 class _GatherMulReduce(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, w, scale, csr, reduce):
+    def forward(ctx, h, w, scale, csr, reduce, pre=None):
+        # pre: the result, already formed by the fused CFConv forward (cfconv_fused) — this node then only records the graph
         require_hip(h)
         if scale is not None and scale.requires_grad:
             raise MdlError("gather_mul_reduce: gradients w.r.t. the per-edge scale are not implemented (cutoff / GCN "
@@ -906,10 +907,13 @@ class _GatherMulReduce(torch.autograd.Function):
                 raise MdlError("gather_mul_reduce: h and w must share a dtype")
         if scale is not None:
             scale = scale.float().contiguous()
-        out = torch.empty((N, F), dtype=h.dtype, device=h.device)
-        check(_launch_timed("gmr_fwd", lambda: lib().mdl_gather_mul_reduce(
-            ptr(h), ptr(w), ptr(scale), ptr(csr.rowptr), ptr(csr.src), ptr(csr.eperm), ptr(out), N, F, reduce, dtype_code(h),
-            stream())), "mdl_gather_mul_reduce")
+        if pre is not None:
+            out = pre.view_as(pre)
+        else:
+            out = torch.empty((N, F), dtype=h.dtype, device=h.device)
+            check(_launch_timed("gmr_fwd", lambda: lib().mdl_gather_mul_reduce(
+                ptr(h), ptr(w), ptr(scale), ptr(csr.rowptr), ptr(csr.src), ptr(csr.eperm), ptr(out), N, F, reduce, dtype_code(h),
+                stream())), "mdl_gather_mul_reduce")
         ctx.csr, ctx.reduce = csr, reduce
         ctx.save_for_backward(h, w, scale)
         return out
@@ -932,7 +936,7 @@ class _GatherMulReduce(torch.autograd.Function):
             dw = (torch.zeros_like if _true_rows_for(w.shape[0]) is not None else torch.empty_like)(w)
             check(lib().mdl_gather_mul_reduce_dw(ptr(g), ptr(w), ptr(scale), ptr(rowptr_s), ptr(col_s), ptr(eid_s), ptr(dh), ptr(h),
                                                  ptr(dw), csr.N, h.shape[1], dtype_code(h), stream()), "mdl_gather_mul_reduce_dw")
-            return dh, dw, None, None, None
+            return dh, dw, None, None, None, None
         if ctx.needs_input_grad[0]:
             rowptr_s, col_s, eid_s, _ = csr.transposed()
             dh = torch.empty_like(h)
@@ -943,12 +947,56 @@ class _GatherMulReduce(torch.autograd.Function):
             dw = torch.empty_like(w)
             check(lib().mdl_edge_mul(ptr(h), ptr(csr.row), ptr(g), ptr(csr.col), ptr(scale), ptr(dw), csr.E,
                                      h.shape[1], dtype_code(h), stream()), "mdl_edge_mul")
-        return dh, dw, None, None, None
+        return dh, dw, None, None, None, None
 
 
-def gather_mul_reduce(h, csr, w=None, scale=None, reduce="sum"):
+def gather_mul_reduce(h, csr, w=None, scale=None, reduce="sum", pre=None):
     """out[i] = reduce_{edges k -> i} h[src_k] * w[k] * scale[k]  (w: [E,F], scale: [E], caller's edge order)."""
-    return _GatherMulReduce.apply(h, w, scale, csr, _lib.REDUCE[reduce])
+    return _GatherMulReduce.apply(h, w, scale, csr, _lib.REDUCE[reduce], pre)
+
+
+# ------------------------------------------------------------------------------------------------
+# K4 — the fused CFConv forward (csrc/cfconv.hip): filter network + cutoff + h[src] * W -> segmented sum in one pass
+# ------------------------------------------------------------------------------------------------
+_CFCONV_FUSED = os.environ.get("MDL_CFCONV_FUSED", "1") == "1"
+
+
+def cfconv_fused_ok(rbf, h, csr, lin_a, lin_b):
+    """the fused forward takes (edge features [E, 50] bf16 in CSR order, h [N, F] bf16, the two Linears of the filter network):
+    shapes mdl_cfconv_fwd supports AND for which both dense layers would take the fused dense path (the backward is theirs)."""
+    if not (_CFCONV_FUSED and rbf.is_cuda and rbf.dtype == torch.bfloat16 and h.dtype == torch.bfloat16 and rbf.dim() == 2
+            and h.dim() == 2 and rbf.is_contiguous() and csr.eperm is None and rbf.shape[0] == csr.E):
+        return False
+    F, G = h.shape[1], rbf.shape[1]
+    if tuple(lin_a.weight.shape) != (F, G) or tuple(lin_b.weight.shape) != (F, F) or lin_a.weight.dtype != torch.float32:
+        return False
+    if not lib().mdl_cfconv_supported(F, G, dtype_code(h)):
+        return False
+    if torch.is_grad_enabled() and (lin_a.weight.requires_grad or lin_b.weight.requires_grad or h.requires_grad):
+        # the autograd nodes this forward stands in for: _LinearActTN (ssp, derivative handed down) -> _LinearActTN -> K4a
+        return (linear_act_fused_ok(rbf, lin_a.weight, "ssp") and _hip_shape_ok(F, F) and rbf.shape[0] >= 1024
+                and lin_a.weight.requires_grad and lin_b.weight.requires_grad)
+    return True
+
+
+def cfconv_fused(rbf, cut, h, csr, lin_a, lin_b, want_acts):
+    """One launch (plus the weight packing): out [N, F] and, with want_acts, the layer-1 output a1 [E, F] and the filter w [E, F]."""
+    require_hip(rbf, h)
+    F, G = h.shape[1], rbf.shape[1]
+    E, N = csr.E, csr.N
+    dev = h.device
+    wpack = torch.empty(lib().mdl_cfconv_wpack_bytes(), dtype=torch.uint8, device=dev)
+    check(lib().mdl_cfconv_pack_weights(ptr(lin_a.weight), ptr(lin_a.bias), ptr(lin_b.weight), ptr(lin_b.bias), F, G, ptr(wpack),
+                                        stream()), "mdl_cfconv_pack_weights")
+    out = torch.empty((N, F), dtype=h.dtype, device=dev)
+    a1 = torch.empty((E, F), dtype=h.dtype, device=dev) if want_acts else None
+    w = torch.empty((E, F), dtype=h.dtype, device=dev) if want_acts else None
+    h = h.contiguous()
+    cut = cut.float().contiguous()
+    check(_launch_timed("cfconv_fwd", lambda: lib().mdl_cfconv_fwd(
+        ptr(rbf), ptr(cut), ptr(h), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(out), ptr(a1), ptr(w), N, E, F, G,
+        dtype_code(h), stream())), "mdl_cfconv_fwd")
+    return out, a1, w
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1196,14 +1244,18 @@ class _LinearActTN(torch.autograd.Function):
     already is w.r.t. this layer's pre-activation (the layer behind applied in_act), so no derivative, no read of the output."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w_lp, b_lp, act, in_act=0, out_pre=False):
+    def forward(ctx, x, weight, bias, w_lp, b_lp, act, in_act=0, out_pre=False, pre=None):
+        # pre: this layer's output, already formed by a fused forward (cfconv_fused) — the node then only records the graph
         w = weight.to(x.dtype) if w_lp is None else w_lp
         b = None if bias is None else (bias.to(x.dtype) if b_lp is None else b_lp)
         N, K = x.shape
         M = weight.shape[0]
-        out = torch.empty((N, M), dtype=x.dtype, device=x.device)
-        check(lib().mdl_linear_act(ptr(x), ptr(w), ptr(b), ptr(out), N, K, M, {"relu": 1, "ssp": 2}.get(act, 0), dtype_code(x),
-                                   stream()), "mdl_linear_act")
+        if pre is not None:
+            out = pre.view_as(pre)
+        else:
+            out = torch.empty((N, M), dtype=x.dtype, device=x.device)
+            check(lib().mdl_linear_act(ptr(x), ptr(w), ptr(b), ptr(out), N, K, M, {"relu": 1, "ssp": 2}.get(act, 0), dtype_code(x),
+                                       stream()), "mdl_linear_act")
         ctx.save_for_backward(x, w, out if act in ("relu", "ssp") and not out_pre else None)
         ctx.wdtype, ctx.has_bias, ctx.shape, ctx.act = weight.dtype, bias is not None, tuple(weight.shape), act
         ctx.in_act, ctx.out_pre = int(in_act), bool(out_pre)
@@ -1213,7 +1265,7 @@ class _LinearActTN(torch.autograd.Function):
     def backward(ctx, g):
         x, w, out = ctx.saved_tensors
         code = 0 if ctx.out_pre else {"relu": 1, "ssp": 2}.get(ctx.act, 0)
-        tail = (None, None, None, None, None)
+        tail = (None, None, None, None, None, None)
         if _dense_bwd_ok(ctx, g, x, w, out if code else None):
             return _dense_bwd(ctx, g, x, w, (code, out) if code else None, xout=ctx.in_act) + tail
         if code and _tn_act_ok(ctx, g, x, out, w):
@@ -1408,15 +1460,15 @@ def linear_act_fused_ok(x, weight, act):
             and x.data_ptr() % 16 == 0 and weight.requires_grad)
 
 
-def linear_act(x, weight, bias, act, lowp=None, in_act=None, out_pre=False):
+def linear_act(x, weight, bias, act, lowp=None, in_act=None, out_pre=False, pre=None):
     """getattr(F, act)(F.linear(x, weight, bias)) — fused forward for bf16 inputs with dense rows, even in <= 256,
     out <= 128 and act in (relu, ssp, none); anything else composes `linear` with the library activation.
     in_act / out_pre: the activation hand-over of a private chain (see _LinearActTN; callers check linear_act_fused_ok for
     both layers first)."""
     if linear_act_fused_ok(x, weight, act):
         w_lp, b_lp = (lowp if lowp is not None and lowp[0].dtype == x.dtype else (None, None))
-        return _LinearActTN.apply(x, weight, bias, w_lp, b_lp, act, {"relu": 1, "ssp": 2}.get(in_act, 0), out_pre)
-    assert not in_act and not out_pre, "linear_act: activation hand-over on a layer that is not fused"
+        return _LinearActTN.apply(x, weight, bias, w_lp, b_lp, act, {"relu": 1, "ssp": 2}.get(in_act, 0), out_pre, pre)
+    assert not in_act and not out_pre and pre is None, "linear_act: activation hand-over on a layer that is not fused"
     y = linear(x, weight, bias, lowp)
     if act is None:
         return y

@@ -1227,3 +1227,105 @@ def test_weight_gradients_written_in_place_match_the_assembled_ones(monkeypatch)
     # by ~1e-3 of the gradient scale (observed 1.0e-3 on a 282-pass box); a wrong row/column offset would be an O(1) error
     for a, b in zip(res[0][1:], res[1][1:]):
         close(b, a, 1e-3, 5e-3)
+
+
+def _cfconv_case(n, F, seed, empty_frac=0.1, max_in=20):
+    from matdeeplearn_amd import nn as mnn, ops
+    d = dev()
+    g = torch.Generator().manual_seed(seed)
+    ei = rand_graph(n, seed, sort=True, empty_frac=empty_frac, max_in=max_in)
+    E = ei.shape[1]
+    csr = ops.build_csr(ei.to(d), n, assume_sorted=True)
+    dist = torch.rand(E, generator=g) * 7.5
+    rbf = torch.exp(-((dist.view(-1, 1) / 8.0 - torch.linspace(0, 1, 50).view(1, -1)) ** 2) / 0.2 ** 2)
+    conv = mnn.InteractionBlock(100, 50, F, 8.0)
+    with torch.no_grad():
+        for m in (conv.mlp[0], conv.mlp[2]):
+            m.bias.copy_(torch.randn(F, generator=g) * 0.2)
+    conv = conv.to(d)
+    x = (torch.randn(n, 100, generator=g) * 0.5).to(torch.bfloat16).to(d)
+    return conv, x, ei.to(d), dist.to(d), rbf.to(torch.bfloat16).to(d), csr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3000, 150, 0.1, 20), (1500, 150, 0.5, 3), (2500, 130, 0.0, 40), (2000, 158, 0.1, 12)])
+def test_fused_cfconv_forward_matches_the_three_pass_sequence_and_trains_through_it(shape, monkeypatch):
+    """K4 (mdl_cfconv_fwd: filter network -> cutoff -> h[src] * W -> segmented sum in one pass, csrc/cfconv.hip) against the
+    sequence it replaces (mdl_linear_act x 2 -> mdl_gather_mul_reduce) on the same bf16 operands: the InteractionBlock's output,
+    the two stored activations through the gradients they produce (x and every parameter of the block), in train and in
+    no-grad mode; many isolated nodes, in-degrees above one tile, the filter widths at both ends of the supported range.
+    Tolerances: the fused pass rounds each MESSAGE to bf16 before the one-hot product (the three-pass kernel sums fp32
+    products): 2e-2 of the output scale; gradients 3e-2 of their scale (bf16 activations either way)."""
+    from matdeeplearn_amd import ops
+    n, F, empty, max_in = shape
+    conv, x, ei, dist, rbf, csr = _cfconv_case(n, F, 100 + n, empty, max_in)
+    assert csr.E >= 1024
+    gy = torch.randn(n, 100, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).to(dev())
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(ops, "_CFCONV_FUSED", fused)
+        ev = {"cfconv_fwd": [], "gmr_fwd": []}
+        ops.KERNEL_EVENTS = ev
+        xr = x.clone().requires_grad_(True)
+        conv.zero_grad(set_to_none=True)
+        y = conv(xr, ei, dist, rbf, csr=csr)
+        ops.KERNEL_EVENTS = None
+        assert bool(ev["cfconv_fwd"]) == fused and bool(ev["gmr_fwd"]) != fused, ev      # the path under test is the one that ran
+        (y.float() * gy.float()).sum().backward()
+        with torch.no_grad():
+            y_ng = conv(x, ei, dist, rbf, csr=csr)
+        res[fused] = [y, y_ng, xr.grad] + [p.grad for p in conv.parameters()]
+    close(res[True][0], res[False][0], 2e-2, 2e-2)
+    close(res[True][1], res[False][1], 2e-2, 2e-2)
+    assert torch.equal(res[True][0], res[True][1])                    # with and without the stored activations: the same sums
+    for a, b in zip(res[True][2:], res[False][2:]):
+        close(a, b, 3e-2, 3e-2)
+
+
+@pytest.mark.gpu
+def test_fused_cfconv_matches_the_fp64_loop_oracle_and_zeroes_padded_rows():
+    """mdl_cfconv_fwd through the raw C-ABI against the literal per-edge loop of the oracle (fp64, on the bf16-rounded operands)
+    — out, and the two activations it stores — on an edge array LONGER than the CSR covers (a padded static batch): the rows
+    past rowptr[N] of both activations are written as zeros.  Tolerance 2e-2 of the output scale (bf16 activations between
+    the two layers, bf16 messages)."""
+    from matdeeplearn_amd import _lib, ops
+    d = dev()
+    L, P, st = _lib.lib(), _lib.ptr, _lib.stream
+    n, F, G, pad = 400, 150, 50, 77
+    g = torch.Generator().manual_seed(3)
+    ei = rand_graph(n, 21, sort=True, empty_frac=0.2, max_in=40)
+    E = ei.shape[1]
+    csr = ops.build_csr(ei.to(d), n, assume_sorted=True)
+    rbf = torch.rand(E + pad, G, generator=g).to(torch.bfloat16)
+    cut = torch.rand(E + pad, generator=g)
+    h = torch.randn(n, F, generator=g).to(torch.bfloat16)
+    w1, b1 = torch.randn(F, G, generator=g) * 0.3, torch.randn(F, generator=g) * 0.2
+    w2, b2 = torch.randn(F, F, generator=g) * 0.1, torch.randn(F, generator=g) * 0.2
+    src = torch.cat([csr.src, torch.zeros(pad, dtype=torch.int32, device=d)])
+    tgt = torch.cat([csr.tgt, torch.zeros(pad, dtype=torch.int32, device=d)])
+    wpack = torch.empty(L.mdl_cfconv_wpack_bytes(), dtype=torch.uint8, device=d)
+    dv = [t.to(d).contiguous() for t in (rbf, cut, h, w1, b1, w2, b2)]
+    _lib.check(L.mdl_cfconv_pack_weights(P(dv[3]), P(dv[4]), P(dv[5]), P(dv[6]), F, G, P(wpack), st()), "pack")
+    out = torch.full((n, F), float("nan"), dtype=torch.bfloat16, device=d)
+    a1 = torch.full((E + pad, F), float("nan"), dtype=torch.bfloat16, device=d)
+    w = torch.full((E + pad, F), float("nan"), dtype=torch.bfloat16, device=d)
+    _lib.check(L.mdl_cfconv_fwd(P(dv[0]), P(dv[1]), P(dv[2]), P(csr.rowptr), P(src), P(tgt), P(wpack), P(out), P(a1), P(w), n, E + pad,
+                                F, G, _lib.MDL_BF16, st()), "cfconv")
+    # the oracle on the operands the kernel multiplies: bf16 inputs and weights, a1 rounded before layer 2, the filter before the product
+    bfr = lambda t: t.to(torch.bfloat16).double()
+    a1_ref = torch.nn.functional.softplus(bfr(rbf[:E]) @ bfr(w1).t() + bfr(b1)) - np.log(2.0)
+    w_ref = bfr(a1_ref) @ bfr(w2).t() + bfr(b2)
+    out_ref = torch.zeros(n, F, dtype=torch.float64)
+    s_cpu, t_cpu = csr.src.cpu().long(), csr.tgt.cpu().long()
+    for e in range(E):
+        out_ref[t_cpu[e]] += h[s_cpu[e]].double() * bfr(w_ref[e]) * cut[e].double()
+    close(a1[:E], a1_ref, 1e-2, 1e-2)
+    close(w[:E], w_ref, 2e-2, 2e-2)
+    close(out, out_ref, 2e-2, 2e-2)
+    assert float(a1[E:].float().abs().max()) == 0.0 and float(w[E:].float().abs().max()) == 0.0
+    # inference form: no activations, the same sums
+    out2 = torch.full_like(out, float("nan"))
+    _lib.check(L.mdl_cfconv_fwd(P(dv[0]), P(dv[1]), P(dv[2]), P(csr.rowptr), P(src), P(tgt), P(wpack), P(out2), None, None, n, E + pad,
+                                F, G, _lib.MDL_BF16, st()), "cfconv")
+    assert torch.equal(out, out2)
+    assert L.mdl_cfconv_supported(128, 50, _lib.MDL_BF16) == 0 and L.mdl_cfconv_supported(150, 50, _lib.MDL_F32) == 0

@@ -758,7 +758,7 @@ def test_sequential_chains_fuse_each_dense_layer_with_its_activation(monkeypatch
     from matdeeplearn_amd import nn as mnn
     calls = []
 
-    def fake_linear_act(h, weight, bias, act, lowp=None, in_act=None, out_pre=False):
+    def fake_linear_act(h, weight, bias, act, lowp=None, in_act=None, out_pre=False, pre=None):
         calls.append((tuple(weight.shape), act, in_act, out_pre))
         return torch.zeros(h.shape[0], weight.shape[0], dtype=h.dtype)
     monkeypatch.setattr(mnn.ops, "linear_act", fake_linear_act)

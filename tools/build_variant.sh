@@ -8,7 +8,7 @@ cd /root/repo/matdeeplearn_amd
 mkdir -p lib/variants lib/obj_$name
 for f in csrc/*.hip; do
   b=$(basename $f .hip)
-  extra=""; [ "$b" = "cgconv_ep" ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
+  extra=""; { [ "$b" = "cgconv_ep" ] || [ "$b" = "cfconv" ]; } && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
   for vf in ${VAR_FILES:-cgconv cgconv_ep}; do [ "$b" = "$vf" ] && extra="$extra $@"; done
   [ -n "${NO_VGPR_FORM:-}" ] && [ "$b" = "cgconv_ep" ] && extra="$@"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $extra -c $f -o lib/obj_$name/$b.o &
