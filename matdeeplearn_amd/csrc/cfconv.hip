@@ -47,6 +47,19 @@ constexpr float RW = 4611686018427387904.0f;              // 2^62 = 2^126 / 2^64
 static_assert(W1_BYTES % 16 == 0 && W2_BYTES % 16 == 0 && WAVE_BYTES % 16 == 0 && OFF_DP % 16 == 0 && OFF_TSL % 16 == 0, "alignment");
 static_assert(LDS <= 160 * 1024, "LDS budget");
 
+#ifdef MDL_CF_TIMING      // experiment builds only: per-phase cycle counters of wave 0 of workgroup 0 (tools/bench_cfconv.py prints them)
+__device__ long long g_cf_dbg[16];
+#define CF_TDECL long long tprev = clock64(), tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tcount = 0
+#define CF_TMARK(k) do { __builtin_amdgcn_sched_barrier(0); const long long _t = clock64(); tacc[k] += _t - tprev; tprev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CF_TTILE() (tcount += 1)
+#define CF_TFLUSH() do { if (gw == 0 && lane == 0) { for (int _k = 0; _k < 8; ++_k) g_cf_dbg[_k] += tacc[_k]; g_cf_dbg[8] += tcount; } } while (0)
+#else
+#define CF_TDECL do { } while (0)
+#define CF_TMARK(k) do { } while (0)
+#define CF_TTILE() do { } while (0)
+#define CF_TFLUSH() do { } while (0)
+#endif
+
 struct Params {
     const bf16_t* rbf;       // [E, G] edge features, CSR order
     const float* cut;        // [E] cutoff factor C(d_e)
@@ -155,9 +168,11 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
     if (e0 < Et) request(cur, e0); else { cur.src = 0; cur.tg = 0; cur.cu = 0.0f; for (int j = 0; j < NJ; ++j) cur.v[j] = 0u; }
     nxt = cur;
 
+    CF_TDECL;
     for (int n0 = na; n0 < nb;) {
         const int n1 = min(n0 + 32, nb);
         const int e1 = __builtin_amdgcn_readfirstlane(p.rowptr[n1]);
+        CF_TMARK(6);
         f32x16 oacc[NBK];
 #pragma unroll
         for (int b = 0; b < NBK; ++b)
@@ -171,15 +186,25 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
             const float cu = valid_i ? cur.cu * UP : 0.0f;
             // ---- this tile's h[src] chunks, then the next tile's operands: all in flight under GEMM1
             const bf16_t* const hrow = p.h + (int64_t)srcn * F;
+            // (lane half h holds units 8 h .. 8 h + 7 and 16 + 8 h .. 16 + 8 h + 7 of every 32-unit block — see the row order of the
+            // packed weights — so a lane's share of its h row is TWO 16-byte pieces per block: half the L2 requests of 8-byte chunks)
             u32x2 hv[NBK][4];
 #pragma unroll
             for (int b = 0; b < NBK; ++b)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int u0 = 32 * b + 8 * q + 4 * h;
-                    hv[b][q] = u32x2{0u, 0u};
-                    if (b < NBK - 1 || u0 + 4 <= F) hv[b][q] = *reinterpret_cast<const u32x2*>(hrow + u0);
-                    else if (u0 + 2 <= F) hv[b][q][0] = *reinterpret_cast<const unsigned*>(hrow + u0);
+                for (int t = 0; t < 2; ++t) {
+                    const int u0 = 32 * b + 16 * t + 8 * h;
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (b < NBK - 1 || u0 + 8 <= F) {
+                        v = *reinterpret_cast<const u32x4*>(hrow + u0);
+                    } else {
+                        const int ndw = max(0, (F - u0) >> 1);          // (F even: whole dwords)
+                        if (ndw >= 1) v[0] = *reinterpret_cast<const unsigned*>(hrow + u0);
+                        if (ndw >= 2) v[1] = *reinterpret_cast<const unsigned*>(hrow + u0 + 2);
+                        if (ndw >= 3) v[2] = *reinterpret_cast<const unsigned*>(hrow + u0 + 4);
+                    }
+                    hv[b][2 * t] = u32x2{v[0], v[1]};
+                    hv[b][2 * t + 1] = u32x2{v[2], v[3]};
                 }
             if (eb + nv < Et) request(nxt, eb + nv);
             // ---- the tile's rbf rows (nv x 100 contiguous bytes, in registers since the last tile) -> LDS rows of EKS halfwords
@@ -196,6 +221,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                 if (h == 0) reinterpret_cast<unsigned short*>(mybuf + OFF_TSL)[i] = valid_i ? (unsigned short)((cur.tg - n0) << 7) : (unsigned short)0xffff;
             }
             wave_lds_fence();
+            CF_TMARK(0);
 
             // one-hot operands of the by-target reduction (k-slot q of k-step ks = edge slot 16 ks + 8 (q >> 2) + 4 h + (q & 3))
             bf16x8 tf[2];
@@ -208,8 +234,10 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                 }
             }
 
-            // ---- GEMM1 + ssp: a1 fragments (k-slot s of fragment 2 b + t = unit 32 b + 16 t + 8 (s >> 2) + 4 h + (s & 3)); a
-            // fragment's dwords are also the 8-byte chunks of the a1 row (chunk 8 b + 2 q + h = dwords 2 q, 2 q + 1 of the pair)
+            // ---- GEMM1 + ssp.  Row rho of a weight block holds unit pi(rho) = rho with bits 2 and 3 exchanged, so accumulator
+            // register r of lane half h (row (r & 3) + 8 (r >> 2) + 4 h) is unit 16 (r >> 3) + 8 h + (r & 7) of the block: the packed
+            // registers are k-slots 8 h .. 8 h + 7 of fragments 2 b and 2 b + 1 in NATURAL unit order (W2p's K columns need no
+            // permutation) and, as 8-byte chunks (registers 4 q .. 4 q + 3), rows 4 (q >> 1) + 2 h + (q & 1) of the chunk buffer
             unsigned ad[NBK][8];
 #pragma unroll
             for (int b = 0; b < NBK; ++b) {
@@ -224,9 +252,11 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                     ad[b][q] = pk_bf16(LN2_F * (GT::softplus_u(acc[2 * q]) - 1.0f), LN2_F * (GT::softplus_u(acc[2 * q + 1]) - 1.0f));
             }
             // every load of this tile (and the next tile's operands) has had GEMM1 to arrive; from here on the tile only stores
+            CF_TMARK(1);
 #ifndef MDL_CF_NOWAIT
             __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
 #endif
+            CF_TMARK(2);
             // The activations leave through the 2.3-KB chunk buffer: a lane owns an EDGE, so stores from the accumulator layout
             // are 8-byte pieces of 32 different rows per instruction (37 L2 transactions per edge and tensor: measured +245 us
             // for the two tensors).  Staged as chunks and read back row-wise, a lane writes 16 bytes and four neighbouring lanes
@@ -261,13 +291,14 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                 for (int b = 0; b < NBK; ++b) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<u32x2*>(dp + (2 * q + h) * DCS + i * 8) = u32x2{ad[b][2 * q], ad[b][2 * q + 1]};
+                        *reinterpret_cast<u32x2*>(dp + (4 * (q >> 1) + 2 * h + (q & 1)) * DCS + i * 8) = u32x2{ad[b][2 * q], ad[b][2 * q + 1]};
                     wave_lds_fence();
                     store_block(p.a1, b);
                     wave_lds_fence();
                 }
             }
-            // unit FP - 1 (lane half 1, register 15 of the last block) is the constant 1 that carries the bias of layer 2
+            CF_TMARK(3);
+            // unit FP - 1 (= 16 + 8 + 7 of the last block: lane half 1, register 15) is the constant 1 that carries the bias of layer 2
             if (h == 1) ad[NBK - 1][7] = (ad[NBK - 1][7] & 0x0000ffffu) | 0x3F800000u;
             bf16x8 af[2 * NBK];
 #pragma unroll
@@ -291,7 +322,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                 if (p.w) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<u32x2*>(dp + (2 * q + h) * DCS + i * 8) = u32x2{wd[2 * q], wd[2 * q + 1]};
+                        *reinterpret_cast<u32x2*>(dp + (4 * (q >> 1) + 2 * h + (q & 1)) * DCS + i * 8) = u32x2{wd[2 * q], wd[2 * q + 1]};
                     wave_lds_fence();
                     store_block(p.w, b);
                     wave_lds_fence();
@@ -304,7 +335,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                     const float m1 = (__uint_as_float(w0 & 0xffff0000u) * __uint_as_float(hv[b][q][0] & 0xffff0000u)) * cu;
                     const float m2 = (__uint_as_float(w1 << 16) * __uint_as_float(hv[b][q][1] << 16)) * cu;
                     const float m3 = (__uint_as_float(w1 & 0xffff0000u) * __uint_as_float(hv[b][q][1] & 0xffff0000u)) * cu;
-                    *reinterpret_cast<u32x2*>(dp + (2 * q + h) * DCS + i * 8) = u32x2{pk_bf16(m0, m1), pk_bf16(m2, m3)};
+                    *reinterpret_cast<u32x2*>(dp + (4 * (q >> 1) + 2 * h + (q & 1)) * DCS + i * 8) = u32x2{pk_bf16(m0, m1), pk_bf16(m2, m3)};
                 }
                 wave_lds_fence();
                 {
@@ -320,6 +351,8 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                 wave_lds_fence();
             }
             cur = nxt;
+            CF_TMARK(4);
+            CF_TTILE();
         }
         // ---- the group's rows: lane = unit, registers = node slots (D layout)
 #pragma unroll
@@ -333,18 +366,22 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
         }
         n0 = n1;
         e0 = e1;
+        CF_TMARK(5);
     }
+    CF_TFLUSH();
 }
 
 // W1 [F, G], b1 [F], W2 [F, F], b2 [F] (fp32 masters) -> W1p [FP][W1S] (scaled by log2 e for the base-2 softplus, bias in column
-// G) | W2p [FP][W2S] with the K columns in the order GEMM1's accumulators leave the units in and the bias in the slot of unit
-// FP - 1, which the kernel sets to 1
+// G) | W2p [FP][W2S], the bias in the K slot of unit FP - 1, which the kernel sets to 1.  ROWS of both: row rho of a 32-row block
+// holds unit pi(rho) (bits 2 and 3 exchanged) — a lane half of the accumulator then owns 8 + 8 consecutive units per block
 __global__ __launch_bounds__(256) void cfconv_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
                                                           const float* __restrict__ w2, const float* __restrict__ b2, int F,
                                                           bf16_t* __restrict__ wpack) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    auto pi = [](int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); };     // row of a 32-row block -> unit of the block
     if (idx < FP * W1S) {
-        const int row = idx / W1S, col = idx - row * W1S;
+        const int prow = idx / W1S, col = idx - prow * W1S;
+        const int row = pi(prow);
         float v = 0.0f;
         if (row < F) {
             if (col < G_) v = w1[row * G_ + col];
@@ -353,11 +390,11 @@ __global__ __launch_bounds__(256) void cfconv_pack_kernel(const float* __restric
         wpack[idx] = f2bf(v * LOG2E_F);
     } else if (idx < FP * W1S + FP * W2S) {
         const int j = idx - FP * W1S;
-        const int n = j / W2S, pos = j - n * W2S;
+        const int prow = j / W2S, pos = j - prow * W2S;
+        const int n = pi(prow);
         float v = 0.0f;
         if (n < F && pos < FP) {
-            const int ks = pos >> 4, hh = (pos >> 3) & 1, s = pos & 7;
-            const int unit = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (s >> 2) + 4 * hh + (s & 3);
+            const int unit = pos;                                   // GEMM1 leaves the units in natural order (row permutation pi)
             if (unit < F) v = w2[n * F + unit];
             else if (unit == FP - 1 && b2) v = b2[n];
         }
@@ -370,6 +407,14 @@ __global__ __launch_bounds__(256) void cfconv_pack_kernel(const float* __restric
 
 using namespace mdl;
 
+#ifdef MDL_CF_TIMING
+extern "C" int mdl_debug_read_cf(long long* host16) {
+    const hipError_t e = hipMemcpyFromSymbol(host16, HIP_SYMBOL(cf::g_cf_dbg), 16 * sizeof(long long));
+    static const long long zero[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(cf::g_cf_dbg), zero, sizeof(zero));
+    return e == hipSuccess ? 0 : 1;
+}
+#endif
 extern "C" size_t mdl_cfconv_wpack_bytes(void) { return (size_t)cf::W1_BYTES + cf::W2_BYTES; }
 
 extern "C" int mdl_cfconv_supported(int F, int G, int dtype) {

@@ -73,3 +73,11 @@ for name, pa, pw in (("none", None, None), ("a1", a1, None), ("w", None, w), ("b
     torch.cuda.synchronize()
     u = sorted(s.elapsed_time(e) * 1e3 for s, e in ts)
     print("mdl_cfconv_fwd stores=%-5s median %.1f us  min %.1f us" % (name, u[len(u) // 2], u[0]))
+    if hasattr(L, "mdl_debug_read_cf"):
+        import ctypes
+        buf = (ctypes.c_longlong * 16)()
+        L.mdl_debug_read_cf(buf)
+        v = list(buf)
+        n = max(v[8], 1)
+        names = ["top: issue gathers + prefetch, commit rbf", "one-hot + GEMM1 + ssp", "vmcnt(0)", "a1 staging + stores", "GEMM2 blocks", "group epilogue", "group top (rowptr)"]
+        print("   per tile (wave 0, %d tiles, %d cycles/tile):" % (n, sum(v[:7]) / n), {names[k]: round(v[k] / n) for k in range(7)})
