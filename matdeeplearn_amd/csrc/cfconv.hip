@@ -277,6 +277,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                         unsigned* g = reinterpret_cast<unsigned*>(dst + (int64_t)(eb + r) * F + u0);
 #endif
                         if (b < NBK - 1 || ndw == 4) {
+                            // (non-temporal stores measured: 522 -> 950 us — the 64-byte runs need the L2 to merge them into lines)
                             *reinterpret_cast<u32x4*>(g) = u32x4{lo[0], lo[1], hi[0], hi[1]};
                         } else {
                             if (ndw >= 1) g[0] = lo[0];
