@@ -37,7 +37,10 @@ constexpr int G_ = 50, GH = G_ / 2;           // Gaussians per edge (the referen
 constexpr int KE = 64, EKS = KE + 8;          // K of GEMM1 (G + bias column, padded); row stride of the rbf tile (halfwords)
 constexpr int W1S = KE + 8, W2S = FP + 8;     // row strides of the packed weights in LDS (halfwords)
 constexpr int DCS = 32 * 8 + 32;              // one chunk row of the message block: 32 edges x 8 bytes + pad
-constexpr int NWAVE = 8, NT = NWAVE * WAVE;
+#ifndef MDL_CF_NWAVE
+#define MDL_CF_NWAVE 8
+#endif
+constexpr int NWAVE = MDL_CF_NWAVE, NT = NWAVE * WAVE;
 constexpr int W1_BYTES = FP * W1S * 2, W2_BYTES = FP * W2S * 2;
 constexpr int OFF_ET = 0, OFF_DP = 32 * EKS * 2, OFF_TSL = OFF_DP + 8 * DCS, WAVE_BYTES = OFF_TSL + 64;
 constexpr int LDS = W1_BYTES + W2_BYTES + NWAVE * WAVE_BYTES;
