@@ -42,9 +42,10 @@ constexpr int DCS = 32 * 8 + 32;              // one chunk row of the message bl
 #endif
 constexpr int NWAVE = MDL_CF_NWAVE, NT = NWAVE * WAVE;
 constexpr int W1_BYTES = FP * W1S * 2, W2_BYTES = FP * W2S * 2;
-constexpr int OFF_ET = 0, OFF_DP = 32 * EKS * 2, OFF_TSL = OFF_DP + 8 * DCS, WAVE_BYTES = OFF_TSL + 64;
-constexpr int LDS = W1_BYTES + W2_BYTES + NWAVE * WAVE_BYTES;
 constexpr int NJ = (32 * GH + WAVE - 1) / WAVE;           // dwords of an rbf tile per lane
+constexpr int OFF_ET = 0, OFF_DP = 32 * EKS * 2, OFF_TSL = OFF_DP + 8 * DCS, OFF_STASH = OFF_TSL + 64;
+constexpr int WAVE_BYTES = OFF_STASH + NJ * WAVE * 4;     // (the stash: the NEXT tile's rbf dwords, parked in LDS once they have arrived)
+constexpr int LDS = W1_BYTES + W2_BYTES + NWAVE * WAVE_BYTES;
 constexpr float UP = 18446744073709551616.0f;             // 2^64: the messages travel scaled (folded into the cutoff factor)
 constexpr float RW = 4611686018427387904.0f;              // 2^62 = 2^126 / 2^64: scale of the one-hot sums
 static_assert(W1_BYTES % 16 == 0 && W2_BYTES % 16 == 0 && WAVE_BYTES % 16 == 0 && OFF_DP % 16 == 0 && OFF_TSL % 16 == 0, "alignment");
@@ -155,7 +156,15 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
     // stores.  (Loads and stores share one counter that the compiler can only drain completely once both kinds are in flight:
     // a load wait anywhere else would also wait for the stores issued just before it.)  The edges of consecutive tiles are
     // contiguous in CSR order whatever the group boundaries, so "the next tile" starts at eb + nv before its length is known.
+    // The rbf dwords of the next tile are 13 registers that would stay live through the whole tile (with the 80 persistent
+    // accumulators, 40 a1 and 40 h registers that is past 256: the compiler spilled, and a spill RELOAD is a scratch load —
+    // it shares the vector memory counter and its wait drains every load just issued): once arrived they are parked in LDS.
     struct Pre { int src, tg; float cu; unsigned v[NJ]; };
+    unsigned* const stash = reinterpret_cast<unsigned*>(mybuf + OFF_STASH);
+    auto park = [&](const Pre& q) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) stash[j * WAVE + lane] = q.v[j];
+    };
     auto request = [&](Pre& q, int eb) {
         const int ec = min(eb + i, Et - 1);
         q.src = p.src[ec];
@@ -166,10 +175,20 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) q.v[j] = g[min((int64_t)(lane + WAVE * j), lim - 1)];
     };
-    Pre cur, nxt;
     int e0 = __builtin_amdgcn_readfirstlane(p.rowptr[na]);
-    if (e0 < Et) request(cur, e0); else { cur.src = 0; cur.tg = 0; cur.cu = 0.0f; for (int j = 0; j < NJ; ++j) cur.v[j] = 0u; }
-    nxt = cur;
+    if (Et <= 0) {                                                   // no edges at all: every row of out is zero
+        for (int n = na + (lane >> 5); n < nb; n += 2)
+            for (int u = i; u < F; u += 32) p.out[(int64_t)n * F + u] = 0;
+        return;
+    }
+    int c_src, c_tg;
+    float c_cu;
+    {
+        Pre first;
+        request(first, min(e0, Et - 1));
+        park(first);
+        c_src = first.src; c_tg = first.tg; c_cu = first.cu;
+    }
 
     CF_TDECL;
     for (int n0 = na; n0 < nb;) {
@@ -185,57 +204,46 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
         for (int eb = e0; eb < e1; eb += 32) {
             const int nv = min(32, e1 - eb);
             const bool valid_i = i < nv;
-            const int srcn = cur.src;
-            const float cu = valid_i ? cur.cu * UP : 0.0f;
-            // ---- this tile's h[src] chunks, then the next tile's operands: all in flight under GEMM1
-            const bf16_t* const hrow = p.h + (int64_t)srcn * F;
-            // (lane half h holds units 8 h .. 8 h + 7 and 16 + 8 h .. 16 + 8 h + 7 of every 32-unit block — see the row order of the
-            // packed weights — so a lane's share of its h row is TWO 16-byte pieces per block: half the L2 requests of 8-byte chunks)
-            u32x2 hv[NBK][4];
-#pragma unroll
-            for (int b = 0; b < NBK; ++b)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int u0 = 32 * b + 16 * t + 8 * h;
-                    u32x4 v = {0u, 0u, 0u, 0u};
-                    if (b < NBK - 1 || u0 + 8 <= F) {
-                        v = *reinterpret_cast<const u32x4*>(hrow + u0);
-                    } else {
-                        const int ndw = max(0, (F - u0) >> 1);          // (F even: whole dwords)
-                        if (ndw >= 1) v[0] = *reinterpret_cast<const unsigned*>(hrow + u0);
-                        if (ndw >= 2) v[1] = *reinterpret_cast<const unsigned*>(hrow + u0 + 2);
-                        if (ndw >= 3) v[2] = *reinterpret_cast<const unsigned*>(hrow + u0 + 4);
-                    }
-                    hv[b][2 * t] = u32x2{v[0], v[1]};
-                    hv[b][2 * t + 1] = u32x2{v[2], v[3]};
-                }
-            if (eb + nv < Et) request(nxt, eb + nv);
+            const int srcn = c_src;
+            const float cu = valid_i ? c_cu * UP : 0.0f;
             // ---- the tile's rbf rows (nv x 100 contiguous bytes, in registers since the last tile) -> LDS rows of EKS halfwords
             {
                 const int nd = nv * GH;
                 unsigned* etd = reinterpret_cast<unsigned*>(et);
+                // (the 13 row / column pairs depend on the lane only: hoisted out of the tile loop they were 13 more registers
+                // for a kernel that has none — spilled, and reloaded here behind a vmcnt(0) each; the empty asm makes them per-tile)
+                int lane_t = lane;
+                asm volatile("" : "+v"(lane_t));
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int d = lane + WAVE * j;
+                    const int d = lane_t + WAVE * j;
                     const int row = (d * 1311) >> 15;            // d / 25, exact below 800
                     const int col = d - row * GH;
-                    if (d < nd) etd[row * (EKS / 2) + col] = cur.v[j];
+                    const unsigned v = stash[j * WAVE + lane_t];
+                    if (d < nd) etd[row * (EKS / 2) + col] = v;
                 }
-                if (h == 0) reinterpret_cast<unsigned short*>(mybuf + OFF_TSL)[i] = valid_i ? (unsigned short)((cur.tg - n0) << 7) : (unsigned short)0xffff;
+                if (lane_t < 32) reinterpret_cast<unsigned short*>(mybuf + OFF_TSL)[lane_t] = valid_i ? (unsigned short)((c_tg - n0) << 7) : (unsigned short)0xffff;
             }
+            // ---- this tile's h[src] chunks, then the next tile's operands: all in flight under GEMM1
+            const bf16_t* const hrow = p.h + (int64_t)srcn * F;
+            // (lane half h holds units 8 h .. 8 h + 7 and 16 + 8 h .. 16 + 8 h + 7 of every 32-unit block — see the row order of the
+            // packed weights — so a lane's share of its h row is TWO 16-byte pieces per block: half the L2 requests of 8-byte chunks)
+            // (last block: the 16 bytes are read where they END no later than the row; the shift that puts the piece's dwords in
+            // place is applied at the use, behind the wait — anything that touches a loaded register here would wait for it)
+            u32x4 hq[NBK][2];
+            int h_t = h;                                            // (per-tile copy: lane-only values hoisted out of the tile loop get
+            asm volatile("" : "+v"(h_t));                           // spilled, and a spill reload waits for every load in flight)
+#pragma unroll
+            for (int b = 0; b < NBK; ++b)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int u0 = 32 * b + 16 * t + 8 * h_t;
+                    hq[b][t] = *reinterpret_cast<const u32x4*>(hrow + (b < NBK - 1 ? u0 : min(u0, F - 8)));
+                }
+            Pre nxt;
+            request(nxt, min(eb + nv, Et - 1));                          // (unconditional: past the last edge it re-reads the last row)
             wave_lds_fence();
             CF_TMARK(0);
-
-            // one-hot operands of the by-target reduction (k-slot q of k-step ks = edge slot 16 ks + 8 (q >> 2) + 4 h + (q & 3))
-            bf16x8 tf[2];
-            {
-                const u32x2* tw = reinterpret_cast<const u32x2*>(mybuf + OFF_TSL) + h;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const u32x2 t0 = tw[4 * ks], t1 = tw[4 * ks + 2];
-                    tf[ks] = __builtin_bit_cast(bf16x8, u32x4{oh2x(t0[0] ^ rsplat), oh2x(t0[1] ^ rsplat), oh2x(t1[0] ^ rsplat), oh2x(t1[1] ^ rsplat)});
-                }
-            }
 
             // ---- GEMM1 + ssp.  Row rho of a weight block holds unit pi(rho) = rho with bits 2 and 3 exchanged, so accumulator
             // register r of lane half h (row (r & 3) + 8 (r >> 2) + 4 h) is unit 16 (r >> 3) + 8 h + (r & 7) of the block: the packed
@@ -260,6 +268,19 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
 #endif
             CF_TMARK(2);
+            park(nxt);
+            // one-hot operands of the by-target reduction (k-slot q of k-step ks = edge slot 16 ks + 8 (q >> 2) + 4 h + (q & 3))
+            bf16x8 tf[2];
+            {
+                const u32x2* tw = reinterpret_cast<const u32x2*>(mybuf + OFF_TSL) + h;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const u32x2 t0 = tw[4 * ks], t1 = tw[4 * ks + 2];
+                    tf[ks] = __builtin_bit_cast(bf16x8, u32x4{oh2x(t0[0] ^ rsplat), oh2x(t0[1] ^ rsplat), oh2x(t1[0] ^ rsplat), oh2x(t1[1] ^ rsplat)});
+                }
+            }
+
+
             // The activations leave through the 2.3-KB chunk buffer: a lane owns an EDGE, so stores from the accumulator layout
             // are 8-byte pieces of 32 different rows per instruction (37 L2 transactions per edge and tensor: measured +245 us
             // for the two tensors).  Staged as chunks and read back row-wise, a lane writes 16 bytes and four neighbouring lanes
@@ -331,14 +352,32 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                     store_block(p.w, b);
                     wave_lds_fence();
                 }
+                u32x2 hv[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    u32x4 v = hq[b][t];
+                    if (b == NBK - 1) {
+                        // the piece's dword k is dword k + sh of what was read; sh is one scalar per lane half (0 inside the row, 4: none)
+                        const int U0 = 32 * b + 16 * t;
+                        const int sh0 = min(4, (U0 - min(U0, F - 8)) >> 1), sh1 = min(4, (U0 + 8 - min(U0 + 8, F - 8)) >> 1);
+                        auto pick = [&](int idx) -> unsigned { return idx == 0 ? v[0] : idx == 1 ? v[1] : idx == 2 ? v[2] : idx == 3 ? v[3] : 0u; };
+                        u32x4 a, c;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { a[k] = pick(k + sh0); c[k] = pick(k + sh1); }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = h ? c[k] : a[k];
+                    }
+                    hv[2 * t] = u32x2{v[0], v[1]};
+                    hv[2 * t + 1] = u32x2{v[2], v[3]};
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const unsigned w0 = wd[2 * q], w1 = wd[2 * q + 1];
                     // message = the ROUNDED filter (what the unfused path multiplies) * h[src] * cutoff, scaled by 2^64
-                    const float m0 = (__uint_as_float(w0 << 16) * __uint_as_float(hv[b][q][0] << 16)) * cu;
-                    const float m1 = (__uint_as_float(w0 & 0xffff0000u) * __uint_as_float(hv[b][q][0] & 0xffff0000u)) * cu;
-                    const float m2 = (__uint_as_float(w1 << 16) * __uint_as_float(hv[b][q][1] << 16)) * cu;
-                    const float m3 = (__uint_as_float(w1 & 0xffff0000u) * __uint_as_float(hv[b][q][1] & 0xffff0000u)) * cu;
+                    const float m0 = (__uint_as_float(w0 << 16) * __uint_as_float(hv[q][0] << 16)) * cu;
+                    const float m1 = (__uint_as_float(w0 & 0xffff0000u) * __uint_as_float(hv[q][0] & 0xffff0000u)) * cu;
+                    const float m2 = (__uint_as_float(w1 << 16) * __uint_as_float(hv[q][1] << 16)) * cu;
+                    const float m3 = (__uint_as_float(w1 & 0xffff0000u) * __uint_as_float(hv[q][1] & 0xffff0000u)) * cu;
                     *reinterpret_cast<u32x2*>(dp + (4 * (q >> 1) + 2 * h + (q & 1)) * DCS + i * 8) = u32x2{pk_bf16(m0, m1), pk_bf16(m2, m3)};
                 }
                 wave_lds_fence();
@@ -354,7 +393,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                 }
                 wave_lds_fence();
             }
-            cur = nxt;
+            c_src = nxt.src; c_tg = nxt.tg; c_cu = nxt.cu;
             CF_TMARK(4);
             CF_TTILE();
         }
