@@ -162,8 +162,10 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
     struct Pre { int src, tg; float cu; unsigned v[NJ]; };
     unsigned* const stash = reinterpret_cast<unsigned*>(mybuf + OFF_STASH);
     auto park = [&](const Pre& q) {
+        int lane_p = lane;                                           // (per call: the address is not kept across the tile)
+        asm volatile("" : "+v"(lane_p));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) stash[j * WAVE + lane] = q.v[j];
+        for (int j = 0; j < NJ; ++j) stash[j * WAVE + lane_p] = q.v[j];
     };
     auto request = [&](Pre& q, int eb) {
         const int ec = min(eb + i, Et - 1);
@@ -220,7 +222,16 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                     const int row = (d * 1311) >> 15;            // d / 25, exact below 800
                     const int col = d - row * GH;
                     const unsigned v = stash[j * WAVE + lane_t];
-                    if (d < nd) etd[row * (EKS / 2) + col] = v;
+                    if (d < 32 * GH) etd[row * (EKS / 2) + col] = d < nd ? v : 0u;    // (rows past the tile: zeros, never stale staging bytes)
+                }
+                // columns G (the constant 1 of the bias), G + 1 .. 63 (zeros): the e-tile region is the activations' staging area
+                // in the second half of the tile, so they are rewritten with every tile — dwords 25 .. 31 of the 32 rows
+#pragma unroll
+                for (int j = 0; j < (32 * 7 + WAVE - 1) / WAVE; ++j) {
+                    const int d = lane_t + WAVE * j;
+                    const int row = (d * 9363) >> 16;            // d / 7, exact below 224
+                    const int c = d - row * 7;
+                    if (d < 32 * 7) etd[row * (EKS / 2) + GH + c] = c == 0 ? 0x00003F80u : 0u;
                 }
                 if (lane_t < 32) reinterpret_cast<unsigned short*>(mybuf + OFF_TSL)[lane_t] = valid_i ? (unsigned short)((c_tg - n0) << 7) : (unsigned short)0xffff;
             }
@@ -285,15 +296,15 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
             // are 8-byte pieces of 32 different rows per instruction (37 L2 transactions per edge and tensor: measured +245 us
             // for the two tensors).  Staged as chunks and read back row-wise, a lane writes 16 bytes and four neighbouring lanes
             // one 64-byte run of a row: a quarter of the transactions.
-            auto store_block = [&](bf16_t* dst, int b) {
+            auto store_block = [&](const char* buf, bf16_t* dst, int b) {
                 const int pc = lane & 3;
                 const int u0 = 32 * b + 8 * pc;                        // first unit of my 16-byte piece
                 const int ndw = min(4, max(0, (F - u0) >> 1));         // dwords of it that exist
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int r = (lane >> 2) + 16 * half;
-                    const u32x2 lo = *reinterpret_cast<const u32x2*>(dp + (2 * pc) * DCS + r * 8);
-                    const u32x2 hi = *reinterpret_cast<const u32x2*>(dp + (2 * pc + 1) * DCS + r * 8);
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(buf + (2 * pc) * DCS + r * 8);
+                    const u32x2 hi = *reinterpret_cast<const u32x2*>(buf + (2 * pc + 1) * DCS + r * 8);
                     if (r < nv) {
 #ifdef MDL_CF_SMALLDST
                         unsigned* g = reinterpret_cast<unsigned*>(dst + (int64_t)((eb + r) & 4095) * F + u0);   // (A/B: stores that stay in L2)
@@ -311,16 +322,24 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                     }
                 }
             };
+            // Staging buffers: the e-tile region (GEMM1 has read it; the next tile's commit rewrites it) holds TWO chunk buffers, so
+            // a block's chunks are written while the block before it is still being read back and stored, and in the GEMM2 loop the
+            // filter's staging does not share a buffer with the message transpose.  One compiler fence between a buffer's writes and
+            // its reads; the wave's LDS queue is in order, so a later write never passes an earlier read.
+            char* const sb0 = mybuf + OFF_ET;
+            char* const sb1 = mybuf + OFF_ET + 8 * DCS;
+            static_assert(2 * 8 * DCS <= 32 * EKS * 2, "two staging buffers fit the e-tile region");
             if (p.a1) {
 #pragma unroll
                 for (int b = 0; b < NBK; ++b) {
+                    char* const sb = (b & 1) ? sb1 : sb0;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<u32x2*>(dp + (4 * (q >> 1) + 2 * h + (q & 1)) * DCS + i * 8) = u32x2{ad[b][2 * q], ad[b][2 * q + 1]};
+                        *reinterpret_cast<u32x2*>(sb + (4 * (q >> 1) + 2 * h + (q & 1)) * DCS + i * 8) = u32x2{ad[b][2 * q], ad[b][2 * q + 1]};
                     wave_lds_fence();
-                    store_block(p.a1, b);
-                    wave_lds_fence();
+                    store_block(sb, p.a1, b);
                 }
+                wave_lds_fence();
             }
             CF_TMARK(3);
             // unit FP - 1 (= 16 + 8 + 7 of the last block: lane half 1, register 15) is the constant 1 that carries the bias of layer 2
@@ -344,13 +363,11 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                 unsigned wd[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) wd[q] = pk_bf16(acc[2 * q], acc[2 * q + 1]);
+                char* const sbw = (b & 1) ? sb1 : sb0;
                 if (p.w) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<u32x2*>(dp + (4 * (q >> 1) + 2 * h + (q & 1)) * DCS + i * 8) = u32x2{wd[2 * q], wd[2 * q + 1]};
-                    wave_lds_fence();
-                    store_block(p.w, b);
-                    wave_lds_fence();
+                        *reinterpret_cast<u32x2*>(sbw + (4 * (q >> 1) + 2 * h + (q & 1)) * DCS + i * 8) = u32x2{wd[2 * q], wd[2 * q + 1]};
                 }
                 u32x2 hv[4];
 #pragma unroll
@@ -391,6 +408,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
                         oacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[ks], mf, oacc[b], 0, 0, 0);
                     }
                 }
+                if (p.w) store_block(sbw, p.w, b);                 // (behind the same fence as the transposed reads: they travel together)
                 wave_lds_fence();
             }
             c_src = nxt.src; c_tg = nxt.tg; c_cu = nxt.cu;
