@@ -291,6 +291,12 @@ def main():
     for i in range(args.warmup):
         step(step_ids[i], False, step_ids[i + 1])
     barrier()
+    # (no cyclic-garbage collection inside the timed region, like `timeit`: the host enqueues a step in about the time the device
+    # needs for it, so a generation-2 pass over the process's objects — tens of ms — shows as ONE slow group of four steps)
+    import gc
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()
     ms_t0 = torch.cuda.memory_stats(dev)
     marks = [torch.cuda.Event(enable_timing=True)]
     marks[0].record()
@@ -314,6 +320,8 @@ def main():
             marks[-1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
     ms_t1 = torch.cuda.memory_stats(dev)
     by4, done = [], 0
     for a, b in zip(marks[:-1], marks[1:]):
