@@ -282,6 +282,14 @@ def main():
     # batch has more edges than every earlier one allocates that step's [E, F] activations anew (hipMalloc: 40-60 ms for the eight
     # 438-MB tensors of a SchNet step — seen as ONE group of four at 15-22 ms in a leg of 8.0).  The largest of the batches that
     # are about to be timed runs once, untimed, in front of the warm-up steps.
+    # No cyclic-garbage collection inside the timed region (like `timeit`): the host enqueues a step in about the time the device
+    # needs for it, so a generation-2 pass over the process's objects — tens of ms — shows as ONE slow group of four steps (seen
+    # in the SchNet leg at a fixed step index, in four of nine runs).  The collection runs HERE, in front of the warm-up steps: a
+    # host pause right in front of the timed region would let the device drop to its idle clocks.
+    import gc
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()
     if args.settle_s > 0 and hasattr(ds, "edge_ptr"):
         epg = np.diff(np.asarray(ds.edge_ptr))
         step(max(step_ids, key=lambda ids: int(epg[np.asarray(ids)].sum())), False)
@@ -291,12 +299,6 @@ def main():
     for i in range(args.warmup):
         step(step_ids[i], False, step_ids[i + 1])
     barrier()
-    # (no cyclic-garbage collection inside the timed region, like `timeit`: the host enqueues a step in about the time the device
-    # needs for it, so a generation-2 pass over the process's objects — tens of ms — shows as ONE slow group of four steps)
-    import gc
-    gc.collect()
-    gc_was = gc.isenabled()
-    gc.disable()
     ms_t0 = torch.cuda.memory_stats(dev)
     marks = [torch.cuda.Event(enable_timing=True)]
     marks[0].record()
