@@ -791,6 +791,39 @@ def test_sequential_chains_fuse_each_dense_layer_with_its_activation(monkeypatch
     with torch.no_grad():
         mnn._seq(chain, big)
     assert [c[2:] for c in calls] == [(None, False)] * 3
+    # outputs already formed by a fused forward (K4, ops.cfconv_fused) travel to the layers in order — the hand-over is unchanged
+    seen = []
+
+    def fake_with_pre(h, weight, bias, act, lowp=None, in_act=None, out_pre=False, pre=None):
+        seen.append((tuple(weight.shape), act, in_act, out_pre, None if pre is None else tuple(pre.shape)))
+        return torch.zeros(h.shape[0], weight.shape[0], dtype=h.dtype) if pre is None else pre
+    monkeypatch.setattr(mnn.ops, "linear_act", fake_with_pre)
+    filt = torch.nn.Sequential(torch.nn.Linear(50, 150), mnn.ShiftedSoftplus(), torch.nn.Linear(150, 150))
+    a1, w = torch.ones(2048, 150, dtype=torch.bfloat16), torch.full((2048, 150), 2.0, dtype=torch.bfloat16)
+    out = mnn._seq(filt, big, pre=[a1, w])
+    assert seen == [((150, 50), "ssp", None, True, (2048, 150)), ((150, 150), None, "ssp", False, (2048, 150))] and out is w
+
+
+def test_k4_unit_order_of_the_packed_weight_rows():
+    """csrc/cfconv.hip packs row rho of every 32-row weight block with unit pi(rho) = rho with bits 2 and 3 exchanged.  What the
+    kernel relies on (restated here in integers): accumulator register r of lane half h sits in MFMA row (r & 3) + 8 (r >> 2) + 4 h
+    and therefore holds unit 16 (r >> 3) + 8 h + (r & 7) of the block — a lane half owns two runs of eight consecutive units
+    (its 16-byte pieces of an h row), the packed registers of a block are k-slots 8 h .. 8 h + 7 of two fragments in NATURAL unit
+    order (W2p needs no column permutation), 8-byte chunk q (registers 4 q .. 4 q + 3) is row 4 (q >> 1) + 2 h + (q & 1) of the
+    chunk buffer = units 4 row .. 4 row + 3, and the layer-2 bias slot (unit 159) is register 15 of lane half 1 of the last block."""
+    pi = lambda r: (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)
+    d_row = lambda r, h: (r & 3) + 8 * (r >> 2) + 4 * h
+    assert sorted(pi(r) for r in range(160)) == list(range(160)) and all(pi(pi(r)) == r for r in range(160))
+    for b in range(5):
+        for h in (0, 1):
+            units = [pi(32 * b + d_row(r, h)) for r in range(16)]
+            assert units == [32 * b + 16 * (r >> 3) + 8 * h + (r & 7) for r in range(16)]
+            for t in (0, 1):                      # fragment 2 b + t, k-slot s of this lane half = position 16 (2 b + t) + 8 h + s
+                assert [units[8 * t + s] for s in range(8)] == [16 * (2 * b + t) + 8 * h + s for s in range(8)]
+            for q in range(4):                    # chunk q -> chunk-buffer row (in unit order)
+                row = 4 * (q >> 1) + 2 * h + (q & 1)
+                assert units[4 * q:4 * q + 4] == [32 * b + 4 * row + j for j in range(4)]
+    assert pi(32 * 4 + d_row(15, 1)) == 159
 
 
 def test_dense_layer_dispatch_predicates():
