@@ -583,6 +583,24 @@ def test_conv_kernels_register_budget():
     for frag in ("cgconv_node_stream_kernelILi64", "cgconv_node_stream_kernelILi32"):    # node-level dense half
         scratch, occ = find(frag)
         assert scratch == 0 and occ >= 2
+    # kernel 2 of K3 and K4 (the fused CFConv forward): their translation units are built with the VGPR form of the MFMA results
+    # (matdeeplearn_amd/_build.py FILE_FLAGS).  K4 is the kernel that paid for the lesson in round 5: 28 spilled registers, each
+    # reloaded behind a vmcnt(0) in its tile loop, were a third of its time ("Round 5" item 8)
+    text = ""
+    with tempfile.TemporaryDirectory() as td:
+        for name in ("cgconv_ep.hip", "cfconv.hip"):
+            src = os.path.join(ROOT, "matdeeplearn_amd", "csrc", name)
+            out = os.path.join(td, name + ".s")
+            subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result",
+                            "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only", "-o", out, src],
+                           check=True, capture_output=True, timeout=600)
+            text += open(out).read()
+    stats.clear()
+    for m in re.finditer(r"^(_ZN3mdl[0-9A-Za-z_]+):.*?; ScratchSize: (\d+).*?; Occupancy: (\d+)", text, re.S | re.M):
+        stats[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    for frag in ("2ep11bwd2_kernelILi64E", "2cf17cfconv_fwd_kernel"):
+        scratch, occ = find(frag)
+        assert scratch == 0 and occ == 2, (frag, scratch, occ)
 
 
 # ---------------------------------------------------------------------------------------------
