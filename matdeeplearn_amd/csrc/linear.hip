@@ -108,6 +108,12 @@ __global__ __launch_bounds__(64 * MDL_LIN_NW(KP, GATHER), 2) void linear_act_ker
     const int64_t n_tiles = (N + TN - 1) / TN;
     unsigned xr[NLX], yr[XACT ? NLX : 1];
     auto load_tile = [&](int64_t tile) {
+        // (per call: the dword offsets below depend on the lane only — hoisted out of the tile loop they are registers the wider
+        // forms of this kernel do not have, and a spilled offset comes back through a scratch load whose wait drains the prefetch)
+        // Only the forms with gathered addends / BatchNorm statistics need it (they are the ones that spilled: 3-42 registers,
+        // every reload inside the tile loop); on the plain forms the recomputation costs up to 2 % (150 -> 150: 218 -> 222 us).
+        int lane = threadIdx.x & 63;
+        if constexpr (GATHER != 0 || STATS) asm volatile("" : "+v"(lane));
         const int64_t nb = tile * TN;
         const int64_t bytes = (N - nb) * (int64_t)K * 2, cap = (int64_t)TN * K * 2;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x + nb * (int64_t)K), 0,
