@@ -89,10 +89,17 @@ def parse():
     ap.add_argument("--force-strong", action="store_true",
                     help="run the strong-scaling leg at world size 1 too, as if the global batch were shared by two ranks (B / 2 "
                          "graphs per step): executes the N > 1 code path on a one-GPU box (tests)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the gradient exchange at world size 1 too (tests)")
+    ap.add_argument("--ops", action="append", default=[], metavar="NAME=0|1",
+                    help="dispatch option of matdeeplearn_amd.ops (ops.OPTIONS) for A/B runs; repeatable")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="assemble every batch on the compute stream at the start of its step instead of one step ahead on a side stream")
     ap.add_argument("--event-stride", type=int, default=0,
                     help="HIP events around the roofline kernels on every n-th timed step (0 = 4 for >= 8 steps, else every step)")
+    ap.add_argument("--run-in", type=int, default=0,
+                    help="diagnosis: this many of the warm-up steps are enqueued behind the barrier that opens the timed region "
+                         "(config.device_ms_per_step then shows the K steps with a non-empty launch queue at the start)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--dataset-cache", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "mdl_bench_data"),
                     help="directory for the flat on-disk copy of the synthetic dataset ('' = always regenerate)")
@@ -130,6 +137,143 @@ def batch_stream(loader, B):
         buf = buf[B:]
 
 
+class _HostMark:
+    """stand-in for a device event on a CPU 'device' (the gloo world-size-2 test of the N > 1 plumbing)"""
+    def __init__(self):
+        self.t = None
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def _mark(dev):
+    return torch.cuda.Event(enable_timing=True) if dev.type == "cuda" else _HostMark()
+
+
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
+def make_barrier(dev, use_dist):
+    import torch.distributed as dist
+
+    def _barrier():
+        if use_dist:
+            dist.barrier()
+        _sync(dev)
+    return _barrier
+
+
+def all_reduce_scalars(vals, op, dev, use_dist):
+    """one fp64 all-reduce (MIN / MAX / SUM) of a short list of host scalars; returns python floats"""
+    import torch.distributed as dist
+    t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(t, op={"min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM}[op])
+    return [float(v) for v in t.tolist()]
+
+
+def settle_phase(step, stream, dev, use_dist, settle_s, cap_s):
+    """Untimed real steps until the step time has CONVERGED on every rank: >= settle_s seconds AND three consecutive 8-step groups
+    within 3 % of each other (cap cap_s).  The steps run through the SAME path as the timed ones — each assembles the batch that
+    follows on the side stream (round 6: the settle steps used to collate on the compute stream, so the side stream's allocator
+    pool had seen five batches when the timed region started and the driver's round-5 run paid three hipMalloc inside it)."""
+    n, groups = 0, []
+    if settle_s <= 0:
+        return n, groups
+    t_s = time.perf_counter()
+    nxt = next(stream)
+    while True:
+        t_g = time.perf_counter()
+        for _ in range(8):
+            cur, nxt = nxt, next(stream)
+            step(cur, False, nxt)
+        n += 8
+        _sync(dev)
+        now = time.perf_counter()
+        groups.append((now - t_g) / 8 * 1e3)
+        last = groups[-3:]
+        stable = len(last) == 3 and max(last) <= 1.03 * min(last)
+        el, st = all_reduce_scalars([now - t_s, 1.0 if stable else 0.0], "min", dev, use_dist)
+        if (el >= settle_s and st > 0) or el >= max(cap_s, settle_s):
+            break
+    return n, groups
+
+
+def timed_region(step, step_ids, warmup, steps, dev, use_dist, ev_stride, barrier, run_in=0):
+    """W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + device synchronisation on both sides; the
+    MAX over ranks of the host-clock time and the SUM over ranks of the edges.  Returns a dict.
+    `run_in` (diagnosis only, default 0): that many of the W warm-up steps are enqueued BEHIND the barrier, and the dict also
+    carries `elapsed_dev` = device-event time from the start mark (recorded behind them) to the end mark — the K steps as the
+    device sees them when its launch queue is not empty at the start."""
+    total = warmup + steps
+    run_in = max(0, min(run_in, warmup))
+    for i in range(warmup - run_in):
+        step(step_ids[i], False, step_ids[i + 1])
+    barrier()
+    for i in range(warmup - run_in, warmup):
+        step(step_ids[i], False, step_ids[i + 1])
+    on_gpu = dev.type == "cuda"
+    ms_t0 = torch.cuda.memory_stats(dev) if on_gpu else {}
+    marks = [_mark(dev)]
+    marks[0].record()
+    t0 = time.perf_counter()
+    edges = nodes = 0
+    ev_edges = ev_nodes = ev_steps = 0
+    host_ms = []
+    # HIP events around the roofline kernels on every `ev_stride`-th timed step: the event pairs are measurement overhead inside
+    # the timed region (35-55 us per instrumented step), so the default run pays it on a quarter of its steps — and never on
+    # the first one, which starts from an idle device and an empty launch queue (round 6)
+    ev_phase = 1 if (ev_stride > 1 and steps > 1) else 0
+    for i in range(warmup, total):
+        k = i - warmup
+        ev_on = k % ev_stride == ev_phase
+        th = time.perf_counter()
+        e, n = step(step_ids[i], ev_on, step_ids[i + 1] if i + 1 < total else step_ids[0])
+        host_ms.append(round((time.perf_counter() - th) * 1e3, 3))
+        edges += e
+        nodes += n
+        if ev_on:
+            ev_edges, ev_nodes, ev_steps = ev_edges + e, ev_nodes + n, ev_steps + 1
+        if k % 4 == 3 or i == total - 1:
+            marks.append(_mark(dev))                 # (one event record per four steps: device-side step times)
+            marks[-1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms_t1 = torch.cuda.memory_stats(dev) if on_gpu else {}
+    by4, done = [], 0
+    for a, b in zip(marks[:-1], marks[1:]):
+        k = min(4, steps - done)
+        by4.append(round(a.elapsed_time(b) / max(k, 1), 3))
+        done += k
+    elapsed_max, = all_reduce_scalars([elapsed], "max", dev, use_dist)
+    edges_all, = all_reduce_scalars([edges], "sum", dev, use_dist)
+    return {"elapsed": elapsed, "elapsed_max": elapsed_max, "edges": edges, "nodes": nodes, "edges_all": edges_all, "by4": by4,
+            "elapsed_dev": marks[0].elapsed_time(marks[-1]) * 1e-3, "run_in": run_in,
+            "ev_edges": ev_edges, "ev_nodes": ev_nodes, "ev_steps": ev_steps, "host_enqueue_ms": host_ms,
+            "device_mallocs": int(ms_t1.get("num_device_alloc", 0) - ms_t0.get("num_device_alloc", 0))}
+
+
+def strong_leg(step, s_ids, warmup, strong_steps, Bs, world, dev, use_dist, barrier):
+    """N > 1: the GLOBAL batch fixed at the one-GPU size (Bs = B / N graphs per GPU and step); max-over-ranks time, sum of edges."""
+    for i in range(warmup):
+        step(s_ids[i], False, s_ids[i + 1])
+    barrier()
+    t1 = time.perf_counter()
+    e_s = 0
+    for i in range(warmup, len(s_ids)):
+        e_s += step(s_ids[i], False, s_ids[i + 1] if i + 1 < len(s_ids) else None)[0]
+    barrier()
+    ts, = all_reduce_scalars([time.perf_counter() - t1], "max", dev, use_dist)
+    es, = all_reduce_scalars([e_s], "sum", dev, use_dist)
+    return {"value": round(es / ts, 1), "unit": "edges/s", "scaling": "strong", "steps": strong_steps,
+            "ms_per_step": round(ts / strong_steps * 1e3, 4), "global_batch_graphs": Bs * world, "batch_graphs_per_gpu": Bs}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -147,7 +291,9 @@ def main():
     from matdeeplearn_amd.process import DeviceLoader, split_data
     from matdeeplearn_amd.training import FlatDataParallel, make_optimizer
 
-    use_dist = world > 1 or os.environ.get("MDL_FORCE_DIST") == "1"   # the env var exercises the RCCL path on one GPU
+    if args.ops:
+        ops.configure(**{kv.split("=")[0]: kv.split("=")[1] not in ("0", "false", "False") for kv in args.ops})
+    use_dist = world > 1 or args.force_dist           # --force-dist exercises the RCCL path on one GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -206,7 +352,7 @@ def main():
     # ---- model ------------------------------------------------------------------------------------
     torch.manual_seed(args.seed)
     model = getattr(models, cls_name)(ds, compute_dtype=args.dtype, **mkw).to(dev)
-    dp = FlatDataParallel(model)
+    dp = FlatDataParallel(model, force=use_dist)
     opt = make_optimizer(model.parameters(), "AdamW", lr=0.002 * world)   # lr x world_size, training.py:388-389
 
     ktimes = {"cgcnn": {"fwd": [], "bwd": [], "bwd_node": [], "bwd_grads": []}, "schnet": {"gmr_fwd": [], "cfconv_fwd": []}, "megnet": {"edge_linear": []},
@@ -243,45 +389,19 @@ def main():
 
     step = make_step(model, dp, opt, cdt)
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = make_barrier(dev, use_dist)
 
     model.train()
     # Settle phase (untimed, before the W warm-up steps): a fresh process sees a window of 100-200 ms, a few dozen steps
-    # after its first launches, in which every kernel runs 2-4x slower (measured with the dataset read from the cache, i.e.
-    # when the step loop starts within a second of process start: steps 20-40 took 10-12 ms instead of 3.8; with the 5 s
-    # dataset generation in front the window falls into the CPU phase).  Real steps are run until `--settle-s` seconds have
-    # passed on every rank, so the W + K steps that follow measure the steady state.
-    settle_steps = 0
-    settle_groups = []
-    if args.settle_s > 0:
-        # ... and then until the step time has CONVERGED: three consecutive 8-step groups within 3 % of each other (cap
-        # --settle-cap-s).  A leg of 900 launches per step with varying batch sizes (MEGNet) spends its first dozens of steps
-        # on first-use costs — hipBLASLt heuristics per GEMM shape, hipMalloc until the caching allocator holds every size
-        # class — and a fixed 0.3 s ended after ONE group of eight such steps (round 4: the driver's fresh box timed those).
-        t_s = time.perf_counter()
-        while True:
-            t_g = time.perf_counter()
-            for _ in range(8):
-                step(next(stream), False)
-            settle_steps += 8
-            torch.cuda.synchronize()
-            now = time.perf_counter()
-            settle_groups.append((now - t_g) / 8 * 1e3)
-            last = settle_groups[-3:]
-            stable = len(last) == 3 and max(last) <= 1.03 * min(last)
-            st = torch.tensor([now - t_s, 1.0 if stable else 0.0], dtype=torch.float64, device=dev)
-            if use_dist:
-                dist.all_reduce(st, op=dist.ReduceOp.MIN)
-            el, stable = float(st[0]), bool(st[1] > 0)
-            if (el >= args.settle_s and stable) or el >= max(args.settle_cap_s, args.settle_s):
-                break
+    # after its first launches, in which every kernel runs 2-4x slower, and a leg of 900 launches per step with varying batch
+    # sizes (MEGNet) spends its first dozens of steps on first-use costs — hipBLASLt heuristics per GEMM shape, hipMalloc until
+    # the caching allocator holds every size class.  Real steps run until the step time has converged (settle_phase).
+    settle_steps, settle_groups = settle_phase(step, stream, dev, use_dist, args.settle_s, args.settle_cap_s)
     # Allocator high-water mark: the caching allocator reuses a block only for a request that fits it, so the first step whose
     # batch has more edges than every earlier one allocates that step's [E, F] activations anew (hipMalloc: 40-60 ms for the eight
     # 438-MB tensors of a SchNet step — seen as ONE group of four at 15-22 ms in a leg of 8.0).  The largest of the batches that
-    # are about to be timed runs once, untimed, in front of the warm-up steps.
+    # are about to be timed runs once, untimed, in front of the warm-up steps — assembled on the SIDE stream like every timed
+    # batch (each stream has its own pool of blocks), then consumed on the compute stream.
     # No cyclic-garbage collection inside the timed region (like `timeit`): the host enqueues a step in about the time the device
     # needs for it, so a generation-2 pass over the process's objects — tens of ms — shows as ONE slow group of four steps (seen
     # in the SchNet leg at a fixed step index, in four of nine runs).  The collection runs HERE, in front of the warm-up steps: a
@@ -292,51 +412,22 @@ def main():
     gc.disable()
     if args.settle_s > 0 and hasattr(ds, "edge_ptr"):
         epg = np.diff(np.asarray(ds.edge_ptr))
-        step(max(step_ids, key=lambda ids: int(epg[np.asarray(ids)].sum())), False)
-        settle_steps += 1
+        npg = np.diff(np.asarray(ds.node_ptr))
+        big = {max(range(len(step_ids)), key=lambda k: int(epg[np.asarray(step_ids[k])].sum())),
+               max(range(len(step_ids)), key=lambda k: int(npg[np.asarray(step_ids[k])].sum()))}
+        for k in sorted(big):
+            step(step_ids[0], False, step_ids[k])          # (assembles batch k on the side stream ...)
+            step(step_ids[k], False, step_ids[0])          # (... and steps on it)
+            settle_steps += 2
     # (prefetch: every step also starts the assembly of the batch that follows on a side stream — the first timed batch during
     # the last warm-up step, and the last timed step one more (unused) batch, so that the K timed steps contain K assemblies)
-    for i in range(args.warmup):
-        step(step_ids[i], False, step_ids[i + 1])
-    barrier()
-    ms_t0 = torch.cuda.memory_stats(dev)
-    marks = [torch.cuda.Event(enable_timing=True)]
-    marks[0].record()
-    t0 = time.perf_counter()
-    edges = nodes = 0
-    # HIP events around the roofline kernels on every `ev_stride`-th timed step (every step for short runs): the event pairs are
-    # measurement overhead inside the timed region (a record in front of and behind each of the 8 conv launches costs the
-    # default run 35-55 us per step, measured with and without them on one box), so the default run pays it on a quarter of
-    # its steps; the roofline still comes from launches of the timed region (`roofline.launches`, `roofline.events`)
     ev_stride = args.event_stride or (4 if args.steps >= 8 else 1)
-    ev_edges = ev_nodes = ev_steps = 0
-    for i in range(args.warmup, total_steps):
-        ev_on = (i - args.warmup) % ev_stride == 0
-        e, n = step(step_ids[i], ev_on, step_ids[i + 1] if i + 1 < total_steps else step_ids[0])
-        edges += e
-        nodes += n
-        if ev_on:
-            ev_edges, ev_nodes, ev_steps = ev_edges + e, ev_nodes + n, ev_steps + 1
-        if (i - args.warmup) % 4 == 3 or i == total_steps - 1:
-            marks.append(torch.cuda.Event(enable_timing=True))     # (one event record per four steps: device-side step times)
-            marks[-1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    tr = timed_region(step, step_ids, args.warmup, args.steps, dev, use_dist, ev_stride, barrier, run_in=args.run_in)
     if gc_was:
         gc.enable()
-    ms_t1 = torch.cuda.memory_stats(dev)
-    by4, done = [], 0
-    for a, b in zip(marks[:-1], marks[1:]):
-        k = min(4, args.steps - done)
-        by4.append(round(a.elapsed_time(b) / max(k, 1), 3))
-        done += k
-
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    etot = torch.tensor([float(edges)], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(etot, op=dist.ReduceOp.SUM)
-    elapsed_max, edges_all = float(tmax), float(etot)
+    elapsed, elapsed_max, edges_all = tr["elapsed"], tr["elapsed_max"], tr["edges_all"]
+    edges, nodes, by4 = tr["edges"], tr["nodes"], tr["by4"]
+    ev_edges, ev_nodes, ev_steps = tr["ev_edges"], tr["ev_nodes"], tr["ev_steps"]
 
     # ---- strong scaling beside it (N > 1): the GLOBAL batch fixed at the one-GPU size, B / N graphs per GPU ----
     strong = None
@@ -345,22 +436,7 @@ def main():
         Bs = max(1, B // div)
         s_stream = batch_stream(DeviceLoader(ds, tr_idx, Bs, shuffle=True, seed=args.seed + 1, rank=rank, world_size=world), Bs)
         s_ids = [next(s_stream) for _ in range(args.warmup + args.strong_steps)]
-        for i in range(args.warmup):
-            step(s_ids[i], False)
-        barrier()
-        t1 = time.perf_counter()
-        e_s = 0
-        for i in range(args.warmup, len(s_ids)):
-            e_s += step(s_ids[i], False, s_ids[i + 1] if i + 1 < len(s_ids) else None)[0]
-        barrier()
-        ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        es = torch.tensor([float(e_s)], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-            dist.all_reduce(es, op=dist.ReduceOp.SUM)
-        strong = {"value": round(float(es) / float(ts), 1), "unit": "edges/s", "scaling": "strong", "steps": args.strong_steps,
-                  "ms_per_step": round(float(ts) / args.strong_steps * 1e3, 4), "global_batch_graphs": Bs * world,
-                  "batch_graphs_per_gpu": Bs}
+        strong = strong_leg(step, s_ids, args.warmup, args.strong_steps, Bs, world, dev, use_dist, barrier)
 
     if rank != 0:
         if use_dist:
@@ -466,7 +542,8 @@ def main():
                    "parallelism": "dp%d" % world, "dataset_load_s": round(gen_s, 1), "dataset_source": data_src, "settle_steps": settle_steps,
                    "settle_ms_per_step_by_8": [round(g, 2) for g in settle_groups[-6:]], "targets": args.targets,
                    "ms_per_step_by_4": by4,
-                   "device_mallocs": int(ms_t1.get("num_device_alloc", 0) - ms_t0.get("num_device_alloc", 0)),
+                   "device_mallocs": tr["device_mallocs"], "host_enqueue_ms_per_step": tr["host_enqueue_ms"],
+                   "device_ms_per_step": round(tr["elapsed_dev"] / args.steps * 1e3, 4), "run_in": tr["run_in"],
                    "conv_kernel_share_of_step": round(sum(v for k, v in tot.items() if k != "k3") / max(ev_steps, 1) * args.steps / elapsed, 3)},
     }
     if strong is not None:
@@ -639,7 +716,7 @@ def other_models(args):
         # the MEGNet leg against 19.3 on a warm box)
         cmd = [sys.executable, os.path.abspath(__file__), "--model", model, "--steps", "20", "--warmup", "3", "--settle-s", "0.5",
                "--settle-cap-s", "3.0", "--no-extras", "--fp32-leg", "--graphs", str(int(B * 1.25 / 0.8) + 64), "--cpu-steps", "0",
-               "--dataset-cache", args.dataset_cache, "--seed", str(args.seed), "--no-other-models", "--targets", args.targets] + extra
+               "--dataset-cache", args.dataset_cache, "--seed", str(args.seed), "--no-other-models", "--targets", args.targets] + extra + [a for o in args.ops for a in ("--ops", o)]
         t0 = time.time()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)

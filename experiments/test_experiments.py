@@ -38,7 +38,12 @@ for name, (res, args) in {
 def _run(code, **env):
     if not os.path.exists(EXP_LIB):
         pytest.skip("experiments library not built (python experiments/build.py)")
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "MDL_HIP_LIB": EXP_LIB, **env}, cwd=ROOT,
+    # (the package reads no environment: the library path and the fp32 by-source buffer are explicit calls; the MDL_CG_* variables
+    # that remain are read by the EXPERIMENTS build of the C library, `#if MDL_EXPERIMENTS`)
+    pre = "from matdeeplearn_amd import _lib as _l, ops as _o\n_l.use_library(%r)\n" % EXP_LIB
+    if env.pop("MDL_CG_RSRC16", "1") == "0":
+        pre += "_o.configure(rsrc16=False)\n"
+    r = subprocess.run([sys.executable, "-c", pre + code], env={**os.environ, **env}, cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "EXP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 

@@ -6,7 +6,16 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MDL_HIP_LIB") or os.path.join(HERE, "lib", "libmdl_hip.so")  # env override: A/B builds
+LIB_PATH = os.path.join(HERE, "lib", "libmdl_hip.so")
+
+
+def use_library(path):
+    """Bind another build of libmdl_hip.so (A/B builds of tools/, the experiments library) — call before the first op.
+    The package reads no environment variable; tools/ and the test harness translate their own MDL_HIP_LIB into this call."""
+    global LIB_PATH, _lib
+    if _lib is not None and os.path.abspath(path) != os.path.abspath(LIB_PATH):
+        raise MdlError("use_library(%s): %s is already loaded in this process" % (path, LIB_PATH))
+    LIB_PATH = path
 
 MDL_F32, MDL_BF16 = 0, 1
 MDL_SUM, MDL_MEAN, MDL_MAX = 0, 1, 2

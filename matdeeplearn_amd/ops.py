@@ -534,8 +534,8 @@ def _workspace(device, nbytes):
 # floating-point atomics — the CGConv backward edge pass and node kernel, the TN GEMM, the BatchNorm sums, the fused head —
 # are launched in a shape in which every sum gets its terms from ONE wave in program order: bit-reproducible from run to run,
 # a few hundred times slower.  For HIP-vs-HIP regression checks (graph replay vs eager, padded rows, data-parallel exchange);
-# `with ops.deterministic():` or MDL_DETERMINISTIC=1 in the environment of the PYTHON process (the library reads none).
-_DET = os.environ.get("MDL_DETERMINISTIC", "0") == "1"
+# `with ops.deterministic():` or `ops.configure(deterministic=True)` (neither the library nor the package reads the environment).
+_DET = False
 
 
 def set_deterministic(on=True):
@@ -557,6 +557,44 @@ class deterministic:
         return False
 
 
+# Dispatch options.  Defaults are the measured-best paths; there is NO environment variable behind any of them (round 6): a
+# caller that wants another path says so with ops.configure(name=value, ...) — bench.py's `--ops name=value` for A/B runs.
+# name -> (module attribute, what it selects)
+OPTIONS = {
+    "deterministic": ("_DET", "bit-reproducible launch shapes of every atomically accumulating kernel (slow; HIP-vs-HIP tests)"),
+    "gmr_dw": ("_GMR_DW", "CFConv backward: dh and dw from one walk over the by-source CSR"),
+    "balance": ("_BALANCE", "cost-balanced node ranges for the edge-per-lane CGConv backward (E >= 4e5)"),
+    "pad128": ("_PAD128", "C in (96, 128): static 128-channel CGConv kernels on zero-padded rows"),
+    "rsrc16": ("_RSRC16", "by-source sums of the CGConv backward in bf16 (packed atomics)"),
+    "cg_bn_stats": ("_CG_BN_STATS", "BatchNorm statistics in the CGConv forward's epilogue (measured time-neutral: off)"),
+    "direct_grads": ("_DIRECT_GRADS", "K3 / K3c add into the final dW layout (measured slower at small batches: off)"),
+    "cfconv_fused": ("_CFCONV_FUSED", "K4: the fused CFConv forward"),
+    "tn_colsum": ("_TN_COLSUM", "bias gradients out of the TN GEMM"),
+    "dense_bwd": ("_DENSE_BWD", "dX + dW + db of a tall dense layer in one pass"),
+    "dense_bwd_wide": ("_DENSE_BWD_WIDE", "... also when both widths exceed 128"),
+    "mlp_head": ("_MLP_HEAD", "post-FC head as one launch per direction"),
+    "linear_wide": ("_LINEAR_WIDE", "NNConv's Y = x W2r on the streaming kernel"),
+}
+
+
+def configure(**kw):
+    """Set dispatch options (see OPTIONS); returns the previous values of the ones given.  Unknown names raise."""
+    prev = {}
+    g = globals()
+    for k, v in kw.items():
+        if k not in OPTIONS:
+            raise MdlError("ops.configure: unknown option %r (known: %s)" % (k, ", ".join(sorted(OPTIONS))))
+        attr = OPTIONS[k][0]
+        prev[k] = g[attr]
+        g[attr] = bool(v)
+    return prev
+
+
+def options():
+    """current value of every dispatch option"""
+    return {k: globals()[a] for k, (a, _) in OPTIONS.items()}
+
+
 def _dflag():
     return _lib.MDL_DETERMINISTIC if _DET else 0
 
@@ -575,13 +613,13 @@ def last_k3():
     return int(lib().mdl_debug_last_k3())
 
 
-_GMR_DW = os.environ.get("MDL_GMR_DW", "1") != "0"          # CFConv backward: dh and dw from one walk over the by-source CSR
-_BALANCE = os.environ.get("MDL_CG_BALANCE", "1") != "0"     # cost-balanced node ranges for the edge-per-lane backward
-_PAD128 = os.environ.get("MDL_CG_PAD128", "1") != "0"      # C in (96, 128): static 128-channel kernels on zero-padded rows
+_GMR_DW = True          # CFConv backward: dh and dw from one walk over the by-source CSR
+_BALANCE = True     # cost-balanced node ranges for the edge-per-lane backward
+_PAD128 = True      # C in (96, 128): static 128-channel kernels on zero-padded rows
 # By-source sums of the CGConv backward in bf16, accumulated with packed bf16 atomics (mdl_cgconv_bwd_h / mdl_cgconv_bwd_node_h;
 # bf16 mode, C in {32, 64, 128}, G = 50): half the atomic operations and bytes of the fp32 buffer; a source row is rounded to bf16
-# once per window flush (1-3 partial sums per node).  MDL_CG_RSRC16=0 restores the fp32 buffer.
-_RSRC16 = os.environ.get("MDL_CG_RSRC16", "1") == "1"
+# once per window flush (1-3 partial sums per node).  ops.configure(rsrc16=False) restores the fp32 buffer.
+_RSRC16 = True
 
 
 # r_src (by-source sums of the CGConv backward: fp32 [N, 2*Cp], accumulated with atomics) must start at zero: 107 MB per
@@ -601,12 +639,19 @@ def _take_rsrc(nfloats, device):
         # node kernel at the end of every layer — so every replay finds it zero, and the four zero fills per step
         # (53 MB each at the bench batch) that a fresh tensor per layer cost are gone.  The buffer leaves the eager table for
         # good (the graph owns its address); without a clean candidate the caller falls back to a fresh zero-filled tensor.
-        ent = _RSRC_CAP.get(device.index)
-        if ent is None or ent[0].numel() < nfloats:
-            cand = [k for k, v in _RSRC.items() if k[0] == device.index and not v[1] and v[0].numel() >= nfloats]
-            if not cand:
-                return None
-            ent = _RSRC_CAP[device.index] = _RSRC.pop(max(cand, key=lambda k: _RSRC[k][0].numel()))
+        # Every adopted buffer stays referenced for the life of the process (a LIST per device): its address is baked into the
+        # graph that adopted it, so a later, larger capture must not drop the last reference to it (the allocator would hand the
+        # memory out again and a replay of the earlier graph would zero-fill and add into somebody else's tensor).  A buffer
+        # whose dirty flag is set (an exception between an edge pass and its node kernel) is never handed to a capture.
+        owned = _RSRC_CAP.setdefault(device.index, [])
+        for ent in owned:
+            if ent[0].numel() >= nfloats and not ent[1]:
+                return ent
+        cand = [k for k, v in _RSRC.items() if k[0] == device.index and not v[1] and v[0].numel() >= nfloats]
+        if not cand:
+            return None
+        ent = _RSRC.pop(max(cand, key=lambda k: _RSRC[k][0].numel()))
+        owned.append(ent)
         return ent
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ent = _RSRC.get(key)
@@ -835,12 +880,12 @@ def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None, 
 # (profiles/r05_k2_bn_stats_ab.txt, kernel traces of alternating runs): the statistics kernel it removes costs 7.7 us per layer,
 # the forward instantiation that carries the epilogue is 12.5 us per layer slower than the plain one (188.0 vs 175.8 us: it
 # sits at 256 VGPRs with 28 bytes of scratch, the plain kernel at 252 and none) — time-neutral at 8192 graphs and at 100.
-_CG_BN_STATS = os.environ.get("MDL_CG_BN_STATS", "0") == "1"
+_CG_BN_STATS = False
 # K3 / K3c can add their weight-gradient partial sums straight into the stacked dW [2C, 2C + G] (MdlCgConv.ld_dwe, MdlCgNode.ld_dwn:
 # no mdl_cgconv_assemble_grads launch).  OPT-IN: measured in one box session (profiles/r05_direct_grads_ab.txt) the node kernel's
 # flush into 712-byte rows (every 128-byte atomic instruction straddles two cache lines) costs it +8.5 us at 8192 graphs — what the
 # 7-us assembly kernel cost — and +10 us per layer at the reference's batch size, where that flush IS the kernel: 0.59 vs 0.55 ms/step.
-_DIRECT_GRADS = os.environ.get("MDL_CG_DIRECT_GRADS", "0") == "1"
+_DIRECT_GRADS = False
 
 
 def cgconv_bn_stats_ok(x, edge_attr, csr):
@@ -958,7 +1003,7 @@ def gather_mul_reduce(h, csr, w=None, scale=None, reduce="sum", pre=None):
 # ------------------------------------------------------------------------------------------------
 # K4 — the fused CFConv forward (csrc/cfconv.hip): filter network + cutoff + h[src] * W -> segmented sum in one pass
 # ------------------------------------------------------------------------------------------------
-_CFCONV_FUSED = os.environ.get("MDL_CFCONV_FUSED", "1") == "1"
+_CFCONV_FUSED = True
 
 
 def cfconv_fused_ok(rbf, h, csr, lin_a, lin_b):
@@ -968,8 +1013,12 @@ def cfconv_fused_ok(rbf, h, csr, lin_a, lin_b):
             and h.dim() == 2 and rbf.is_contiguous() and csr.eperm is None and rbf.shape[0] == csr.E):
         return False
     F, G = h.shape[1], rbf.shape[1]
-    if tuple(lin_a.weight.shape) != (F, G) or tuple(lin_b.weight.shape) != (F, F) or lin_a.weight.dtype != torch.float32:
+    if tuple(lin_a.weight.shape) != (F, G) or tuple(lin_b.weight.shape) != (F, F):
         return False
+    # mdl_cfconv_pack_weights reads both weights and both biases as dense fp32 rows
+    for t in (lin_a.weight, lin_b.weight, lin_a.bias, lin_b.bias):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda):
+            return False
     if not lib().mdl_cfconv_supported(F, G, dtype_code(h)):
         return False
     if torch.is_grad_enabled() and (lin_a.weight.requires_grad or lin_b.weight.requires_grad or h.requires_grad):
@@ -1045,7 +1094,7 @@ def nnconv_msg(Y, h, csr, out_channels):
 # GEMM for the weight gradient — dW = g^T x contracts over the ROWS (2e5 nodes, 8192 graphs), a shape the
 # library handles badly (47 us for a 64 x 64 x 8192 product, 0.7 ms for 64 x 114 x 2e5)
 # ------------------------------------------------------------------------------------------------
-_TN_COLSUM = os.environ.get("MDL_TN_COLSUM", "1") == "1"
+_TN_COLSUM = True
 
 
 class _LinearTN(torch.autograd.Function):
@@ -1115,8 +1164,8 @@ def _dx_hip(g, w, act_y=None):
     return g @ w
 
 
-_DENSE_BWD_WIDE = os.environ.get("MDL_DENSE_BWD_WIDE", "1") != "0"   # ... also when both widths exceed 128 (SchNet's 150 x 150 filter layer)
-_DENSE_BWD = os.environ.get("MDL_DENSE_BWD", "1") != "0"     # dX + dW + db of a tall dense layer in one pass (csrc/dense_bwd.hip)
+_DENSE_BWD_WIDE = True   # ... also when both widths exceed 128 (SchNet's 150 x 150 filter layer)
+_DENSE_BWD = True     # dX + dW + db of a tall dense layer in one pass (csrc/dense_bwd.hip)
 
 
 def _dense_bwd_ok(ctx, g, x, w, y=None):
@@ -1216,7 +1265,7 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
     if M % 2:                               # the streaming kernel stages rows as dwords: pad an odd width (the model's
         ga, Ma = torch.nn.functional.pad(g, (0, 1)), M + 1             # 1-column output layer) with a zero column
     # db out of the same pass (mdl_gemm_tn_colsum: the column sums of g ride in a padding column of the B tile and are
-    # flushed with one gathered atomic instruction per block); MDL_TN_COLSUM=0 falls back to the library reduction
+    # flushed with one gathered atomic instruction per block); ops.configure(tn_colsum=False) falls back to the library reduction
     fused_db = (_TN_COLSUM and ctx.has_bias and K % 2 == 0 and K <= 158 and x.stride(0) % 2 == 0
                 and ga.stride(0) % 2 == 0 and x.data_ptr() % 4 == 0 and ga.data_ptr() % 4 == 0)
     buf = _zeros_grad(Ma * K + Ma, g.device)                                       # dW | db: zero-filled (one fill per step)
@@ -1230,8 +1279,8 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
     return dx, dw.to(ctx.wdtype), db
 
 
-_MLP_HEAD = os.environ.get("MDL_MLP_HEAD", "1") != "0"        # post-FC head (post_lin_list + lin_out) as one launch per direction
-_LINEAR_WIDE = os.environ.get("MDL_LINEAR_WIDE", "1") != "0"   # NNConv's Y = x W2r on the streaming kernel
+_MLP_HEAD = True        # post-FC head (post_lin_list + lin_out) as one launch per direction
+_LINEAR_WIDE = True   # NNConv's Y = x W2r on the streaming kernel
 
 
 class _LinearActTN(torch.autograd.Function):

@@ -580,6 +580,9 @@ class StaticBatch:
         ev.record()
         self._events[k] = ev
         self.true_nodes, self.true_edges = int(noff[-1]), int(eoff[-1])
+        # every load changes src / tgt on the next assembly (eager or replayed): the lazily filled int64 edge_index of the static
+        # batch is stale from here on, whether or not the Python body of assemble() runs again (it does not on replays)
+        self.batch._edge_index_stale = True
 
     def assemble(self):
         """Device side (part of the captured graph): K8 batch assembly, tail padding, K1 RBF expansion."""

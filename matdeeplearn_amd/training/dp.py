@@ -57,16 +57,16 @@ class FlatDataParallel:
     become ready; rank 0's order is broadcast (one agreed layout), the flat buffer is re-laid out in that order, and from the
     second step on the first-ready half is packed and all-reduced from the hook of its last member, under the rest of the
     backward.  Every step then issues exactly two collectives in the same order on every rank — a parameter that got no
-    gradient on this rank only delays its chunk to reduce_grads(), where it is packed as zeros."""
+    gradient on this rank only delays its chunk to reduce_grads(), where it is packed as zeros.  Gradient accumulation (two
+    backward passes before one exchange) is supported: the early chunk that left after the first backward is re-packed from
+    the accumulated gradients and reduced again by reduce_grads_async (three collectives in that step, on every rank)."""
 
-    def __init__(self, model, process_group=None, broadcast=True, force=None, chunk_bytes=0):
+    def __init__(self, model, process_group=None, broadcast=True, force=False, chunk_bytes=0):
         self.model = model
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force: run the exchange even at world size 1 (an initialised process group with one rank) — how the RCCL path is
-        # exercised on a one-GPU box (MDL_FORCE_DIST=1: bench.py, tests)
-        if force is None:
-            force = os.environ.get("MDL_FORCE_DIST", "0") == "1"
+        # exercised on a one-GPU box (bench.py --force-dist, tests); no environment variable is read
         self.force = bool(force) and dist.is_initialized()
         self.active = self.world_size > 1 or self.force
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -84,6 +84,7 @@ class FlatDataParallel:
         # (the first `numel` floats of the flat buffer) are the chunk whose exchange starts from a hook
         self.split = None
         self._ready, self._early_left = [], 0
+        self._early_stale = False
         if self.active and chunk_bytes and total * 4 > chunk_bytes and len(self.params) > 1:
             self.split = "observe"
             for p in self.params:
@@ -139,6 +140,7 @@ class FlatDataParallel:
         if self._early_work is not None:                  # a backward whose gradients were never reduced: drop its exchange
             self._early_work.wait()
             self._early_work = None
+        self._early_stale = False
         if isinstance(self.split, tuple):
             self._early_left = self.split[0]
 
@@ -157,6 +159,10 @@ class FlatDataParallel:
         if id(param) not in self._early_ids:
             return
         self._early_left -= 1
+        if self._early_left < 0:
+            # a SECOND backward before the exchange (gradient accumulation): the early chunk left after the first one with that
+            # micro-batch's gradients only — reduce_grads_async re-packs and re-reduces it from the accumulated .grad tensors
+            self._early_stale = True
         if self._early_left == 0 and self._early_work is None:
             # (not inside a stream capture: a captured step issues its collectives outside the graph)
             if self.flat_grad.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -232,8 +238,12 @@ class FlatDataParallel:
             return False
         lo = 0
         if isinstance(self.split, tuple):
+            if self._early_work is not None and self._early_stale:
+                self._early_work.wait()                   # (accumulation: every rank fires its hooks twice, so every rank is here)
+                self._early_work = None
             if self._early_work is None:                  # a member got no gradient on this rank: same two collectives, now
                 self._early_work = self._launch(0, self.split[0])
+            self._early_stale = False
             lo = self.split[0]
         self._work = self._launch(lo, len(self.params))
         return True
@@ -259,6 +269,7 @@ class FlatDataParallel:
         # the exchange is over: the next backward counts its early chunk from the start, whoever clears the gradients
         # (dp.zero_grad() or the optimizer's zero_grad())
         self._ready = []
+        self._early_stale = False
         if isinstance(self.split, tuple):
             self._early_left = self.split[0]
 

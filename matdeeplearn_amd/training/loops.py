@@ -104,7 +104,8 @@ def evaluate(loader, model, loss_method, rank=None, out=False, sharded=False):
     sharded=True (every rank of the process group calls it on ITS shard of the split, loader may be None for an empty shard):
     the sample-weighted loss sum and the sample count are added up over the ranks with ONE two-element all-reduce, so every
     rank returns the error of the whole split — the same number the reference's rank-0 evaluation (training.py:132-134) gives,
-    in 1 / world_size of the time."""
+    in 1 / world_size of the time.  Returns None when the split is empty on EVERY rank: the trainer then keeps the
+    latest weights, as the reference does without a validation loader (training.py:130-170)."""
     model.eval()
     loss_all, count = 0, 0
     ids, preds, targets = [], [], []
@@ -128,7 +129,9 @@ def evaluate(loader, model, loss_method, rank=None, out=False, sharded=False):
         if dist.get_backend() == "gloo":
             t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return (t[0] / t[1].clamp(min=1.0)).float()
+        if float(t[1]) == 0.0:
+            return None                       # the whole split is empty (val_ratio = 0): "no validation", not an error of 0
+        return (t[0] / t[1]).float()
     loss_all = loss_all / max(count, 1)
     if out:
         return loss_all, np.column_stack((np.array(ids, dtype=object), np.concatenate(targets), np.concatenate(preds)))
@@ -162,7 +165,8 @@ def trainer(rank, world_size, model, optimizer, scheduler, loss, train_loader, v
                 if hasattr(m, "_sync_counter"):
                     m._sync_counter()
             dp.broadcast_buffers()                              # every rank validates rank 0's model, as the reference does
-            val_error = float(evaluate(val_loader, model, loss, rank=rank, sharded=True))
+            val_error = evaluate(val_loader, model, loss, rank=rank, sharded=True)
+            val_error = None if val_error is None else float(val_error)
         elif val_loader is not None and (not distributed or dist.get_rank() == 0):
             val_error = float(evaluate(val_loader, model, loss, rank=rank))
         if val_error is not None:

@@ -16,6 +16,11 @@ _FILE_ORDER = ["test_gpu_kernels.py", "test_gpu_model.py", "test_gpu_workloads.p
 
 
 def pytest_configure(config):
+    # A/B runs of the tools (tools/gpu_k3ab.sh ...) point the SUITE at another build with MDL_HIP_LIB; the package itself reads
+    # no environment variable, so the harness makes the explicit call
+    if os.environ.get("MDL_HIP_LIB"):
+        from matdeeplearn_amd import _lib
+        _lib.use_library(os.environ["MDL_HIP_LIB"])
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
     config.addinivalue_line("markers", "last: spawns processes / uses RCCL — collected after every other test")
 

@@ -143,11 +143,11 @@ def test_rccl_backend_executes_on_one_gpu():
 
 
 def test_bench_distributed_path_executes_on_one_gpu():
-    """bench.py with MDL_FORCE_DIST=1 (process group of one rank: RCCL init, flat exchange on the side stream, the reductions of
+    """bench.py with --force-dist (process group of one rank: RCCL init, flat exchange on the side stream, the reductions of
     the timing) and --force-strong (the strong-scaling leg, which otherwise only runs for N > 1)."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MDL_FORCE_DIST="1", MASTER_PORT="29534")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29534")
     r = subprocess.run([sys.executable, "bench.py", "--graphs", "640", "--batch", "256", "--steps", "3", "--warmup", "2",
-                        "--no-cpu-baseline", "--no-extras", "--force-strong", "--strong-steps", "3"], cwd=ROOT, env=env,
+                        "--no-cpu-baseline", "--no-extras", "--force-dist", "--force-strong", "--strong-steps", "3"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert line, r.stdout[-2000:] + r.stderr[-2000:]
@@ -159,13 +159,13 @@ def test_bench_distributed_path_executes_on_one_gpu():
 
 def test_bench_under_the_driver_launcher_on_one_gpu():
     """The command line the driver uses for N > 1 — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
-    127.0.0.1 --master-port P bench.py --gpus N ...` — with N = 1 and MDL_FORCE_DIST=1: the launcher's environment (RANK,
+    127.0.0.1 --master-port P bench.py --gpus N ...` — with N = 1 and --force-dist: the launcher's environment (RANK,
     LOCAL_RANK, WORLD_SIZE, MASTER_*) is what initialises the RCCL process group, and rank 0 prints the one JSON line."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MDL_FORCE_DIST="1")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("MASTER_PORT", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                         "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "1", "--graphs", "640", "--batch", "256",
-                        "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-extras"], cwd=ROOT, env=env,
+                        "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--force-dist"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, r.stdout[-2000:] + r.stderr[-2000:]

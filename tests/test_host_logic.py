@@ -409,6 +409,16 @@ def _train_regular_worker(rank, world, port, out_path):
     # same job, same seeds: the training errors agree across the two forms and the validation errors are the same numbers
     assert a["sharded"][1] == a["rank0"][1]
     assert np.allclose(a["sharded"][0], a["rank0"][0], rtol=1e-5, atol=1e-7), (a["sharded"][0], a["rank0"][0])
+    # an EMPTY validation split (val_ratio = 0): "no validation" in both forms — every epoch's val is None and the LATEST weights
+    # are kept (training.py:130-170 without a val loader), not the epoch-1 weights a best-of-zero-errors rule would reload
+    nov = {}
+    for tag, shard in (("sharded", "True"), ("rank0", "False")):
+        training = dict(target_index=0, loss="l1_loss", train_ratio=0.8, val_ratio=0.0, test_ratio=0.2, verbosity=0,
+                        shard_validation=shard)
+        r = train_regular(rank, world, ds, job, training, mp_, **kw)
+        assert [h["val"] for h in r["history"]] == [None] * 3, (tag, [h["val"] for h in r["history"]])
+        nov[tag] = torch.cat([p.detach().reshape(-1) for p in r["model"].parameters()])
+    assert torch.equal(nov["sharded"], nov["rank0"])
     if rank == 0:
         open(out_path, "w").write("ok")
     ddp_cleanup()
@@ -980,6 +990,22 @@ def test_two_chunk_exchange_survives_accumulation_and_foreign_zero_grad(tmp_path
                 assert calls == [0], "the first-ready chunk leaves from its hook without dp.zero_grad()"
                 dp.reduce_grads()
                 assert calls == [0, dp.split[1]]
+            # (advisor, round 5) accumulation in the two-chunk steady state: the early chunk leaves after the FIRST backward with
+            # that micro-batch's gradients only; the exchange must re-pack and re-reduce it from the accumulated gradients
+            calls.clear()
+            opt.zero_grad(set_to_none=True)
+            m(x).sum().backward()
+            m(2 * x).sum().backward()
+            want = {id(p): p.grad.clone() for p in m.parameters()}
+            dp.reduce_grads()
+            assert calls == [0, 0, dp.split[1]], calls
+            for p in m.parameters():
+                assert torch.equal(p.grad, want[id(p)]), "second micro-batch's gradient of an early parameter was lost"
+            calls.clear()                                       # ... and the step after it is an ordinary two-collective step
+            opt.zero_grad(set_to_none=True)
+            m(x).sum().backward()
+            dp.reduce_grads()
+            assert calls == [0, dp.split[1]]
         finally:
             dist.all_reduce = real
     finally:
@@ -1034,3 +1060,99 @@ def test_struct_entry_points_have_the_layout_the_header_declares(tmp_path):
     hdr = open(os.path.join(ROOT, "include", "mdl_hip.h")).read()
     for gone in ("mdl_cgconv_bwd_h", "mdl_cgconv_bwd_hb", "mdl_cgconv_bwd_node_z", "mdl_cgconv_bwd_node_h"):
         assert not re.search(r"\b%s\s*\(" % gone, hdr), gone
+
+
+def _bench_plumbing_worker(rank, world, port, out_path):
+    """bench.py's own N > 1 branch — settle phase (MIN reduce), timed region (MAX of the times, SUM of the edges), strong-scaling
+    leg — on a world_size-2 gloo group with CPU tensors behind a stub step: the first 8-GPU run of the driver cannot die in the
+    bench's reductions (training.py:227-237, 291-294 is the reference's multi-process launch these stand beside)."""
+    import importlib.util
+    import time
+    import torch.distributed as dist
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    barrier = bench.make_barrier(dev, True)
+    calls = []
+
+    def step(ids, timed, next_ids=None):                       # rank 1 is the slow rank; every batch "has" 10 edges per graph
+        calls.append((int(ids[0]), bool(timed), None if next_ids is None else int(next_ids[0])))
+        time.sleep(0.002 * (1 + rank))
+        return 10 * len(ids) + rank, len(ids)
+
+    def stream():
+        k = 0
+        while True:
+            yield np.arange(k, k + 4)
+            k += 4
+
+    n, groups = bench.settle_phase(step, stream(), dev, True, 0.05, 0.5)
+    assert n >= 8 and n % 8 == 0 and len(groups) == n // 8
+    ns = [None, None]
+    dist.all_gather_object(ns, n)
+    assert ns[0] == ns[1], "ranks must leave the settle phase after the same number of steps (MIN-reduced clock and flag)"
+    assert all(c[2] is not None for c in calls), "settle steps assemble the next batch ahead, like the timed ones"
+    calls.clear()
+
+    W, K = 2, 9
+    ids = [np.arange(100 * i, 100 * i + 4) for i in range(W + K)]
+    tr = bench.timed_region(step, ids, W, K, dev, True, 4, barrier)
+    assert len(calls) == W + K and [c[0] for c in calls] == [100 * i for i in range(W + K)]
+    assert [c[1] for c in calls[:W]] == [False] * W
+    assert [c[1] for c in calls[W:]] == [k % 4 == 1 for k in range(K)], "event steps: every 4th, never the first timed step"
+    assert calls[-1][2] == 0 and calls[W - 1][2] == 100 * W    # the K timed steps contain K assemblies
+    assert tr["edges"] == K * (40 + rank) and tr["edges_all"] == K * (40 + 40 + 1)
+    assert tr["ev_steps"] == 2 and len(tr["by4"]) == 3 and len(tr["host_enqueue_ms"]) == K
+    both = [None, None]
+    dist.all_gather_object(both, (tr["elapsed"], tr["elapsed_max"]))
+    assert both[0][1] == both[1][1] == max(both[0][0], both[1][0]) and both[1][0] >= K * 0.004
+    calls.clear()
+    tr2 = bench.timed_region(step, ids, W, K, dev, True, 1, barrier, run_in=1)
+    assert tr2["run_in"] == 1 and len(calls) == W + K and all(c[1] for c in calls[W:])
+
+    s_ids = [np.arange(7 * i, 7 * i + 2) for i in range(W + 3)]
+    st = bench.strong_leg(step, s_ids, W, 3, 2, world, dev, True, barrier)
+    assert st["scaling"] == "strong" and st["global_batch_graphs"] == 4 and st["steps"] == 3
+    assert abs(st["value"] * st["ms_per_step"] * 1e-3 * 3 - 3 * (20 + 21)) < 0.5     # SUM of edges / MAX of times
+    assert st["ms_per_step"] >= 4.0                                                   # the slow rank's 4 ms per step
+    r0, r1, r2 = bench.all_reduce_scalars([rank + 1.0, 5.0], "sum", dev, True), bench.all_reduce_scalars([rank], "max", dev, True), \
+        bench.all_reduce_scalars([rank], "min", dev, True)
+    assert r0 == [3.0, 10.0] and r1 == [1.0] and r2 == [0.0]
+    if rank == 0:
+        open(out_path, "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_bench_multi_gpu_plumbing_world_size_2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = 33500 + (os.getpid() % 2000)
+    out = str(tmp_path / "bench.txt")
+    mp.spawn(_bench_plumbing_worker, args=(2, port, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_package_reads_no_mode_environment():
+    """No import-time (or any) A/B switch behind an environment variable in the product: the only names the package may read are
+    the rendezvous variables of torch.distributed and the build's HIPCC; dispatch options go through ops.configure()."""
+    from matdeeplearn_amd import ops
+    allowed = {"MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK", "HIPCC"}
+    pkg = os.path.join(ROOT, "matdeeplearn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                for name in re.findall(r"os\.environ(?:\.get|\.setdefault)?\(\s*[\"']([A-Za-z0-9_]+)[\"']", src) + \
+                        re.findall(r"os\.environ\[\s*[\"']([A-Za-z0-9_]+)[\"']", src) + re.findall(r"getenv\(\s*[\"']([A-Za-z0-9_]+)", src):
+                    assert name in allowed, "%s reads the environment variable %s" % (f, name)
+    prev = ops.configure(rsrc16=False, balance=False)
+    try:
+        assert prev == {"rsrc16": True, "balance": True} and ops.options()["rsrc16"] is False and ops._BALANCE is False
+    finally:
+        ops.configure(**prev)
+    assert ops.options()["rsrc16"] is True
+    with pytest.raises(ops.MdlError):
+        ops.configure(no_such_option=True)

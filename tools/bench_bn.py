@@ -3,6 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from matdeeplearn_amd import _lib
+import _ab; _ab.apply()      # (tools/_ab.py: MDL_HIP_LIB / MDL_OPS of the A/B scripts -> explicit calls)
 L = _lib.lib(); P = _lib.ptr; st = _lib.stream
 d = torch.device("cuda:0")
 N, C = 209768, 64

@@ -50,6 +50,7 @@ for fused in (True, False, True, False):
 
 # raw C-ABI timings: which of the two activation tensors are written
 from matdeeplearn_amd import _lib
+import _ab; _ab.apply()      # (tools/_ab.py: MDL_HIP_LIB / MDL_OPS of the A/B scripts -> explicit calls)
 L, P, st = _lib.lib(), _lib.ptr, _lib.stream
 E, N, F = b.num_edges, b.num_nodes, a.F
 h = (torch.randn(N, F, device=dev) * 0.5).to(torch.bfloat16)

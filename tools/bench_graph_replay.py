@@ -3,6 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from matdeeplearn_amd import models, ops
 from matdeeplearn_amd.process import synthetic_bulk
 from matdeeplearn_amd.training import GraphedStep, make_optimizer
+import _ab; _ab.apply()      # (tools/_ab.py: MDL_HIP_LIB / MDL_OPS of the A/B scripts -> explicit calls)
 dev = torch.device("cuda:0")
 ds = synthetic_bulk(int(os.environ.get("GRAPHS", "20000")), seed=0).to(dev)
 rng = np.random.default_rng(0)

@@ -5,6 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from matdeeplearn_amd import ops, _lib
 from matdeeplearn_amd.process import synthetic_bulk
+import _ab; _ab.apply()      # (tools/_ab.py: MDL_HIP_LIB / MDL_OPS of the A/B scripts -> explicit calls)
 
 # the library reads no environment any more: MDL_CG_EP = 0 / 2 here selects the backward edge pass through ops.K3_VARIANT
 _ep = os.environ.get("MDL_CG_EP")

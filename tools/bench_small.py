@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from matdeeplearn_amd import models
 from matdeeplearn_amd.process import synthetic_bulk
 from matdeeplearn_amd.training import GraphedStep, make_optimizer
+import _ab; _ab.apply()      # (tools/_ab.py: MDL_HIP_LIB / MDL_OPS of the A/B scripts -> explicit calls)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=100)

@@ -5,6 +5,7 @@ import numpy as np, torch
 from matdeeplearn_amd import models, ops
 from matdeeplearn_amd.process import synthetic_bulk, DeviceLoader, split_data
 from matdeeplearn_amd.training import FlatDataParallel, make_optimizer
+import _ab; _ab.apply()      # (tools/_ab.py: MDL_HIP_LIB / MDL_OPS of the A/B scripts -> explicit calls)
 from bench import batch_stream
 dev = torch.device("cuda:0")
 ds = synthetic_bulk(int(os.environ.get("GRAPHS", "46744")), seed=0).to(dev)
