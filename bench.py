@@ -80,6 +80,10 @@ def parse():
                     help="composition: the standardised mean atomic number of a graph (a target the models can fit, so that val-MAE "
                          "deltas discriminate); noise: the N(0,1) targets of the SURVEY 8d recipe")
     ap.add_argument("--cpu-steps", type=int, default=1, help="timed oracle steps on the GPU run's own batches")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="cpu_baseline on torch.set_num_threads(os.cpu_count()) as SURVEY 8d words it (default: the faster of 16 / 64 "
+                         "threads on a probe batch — the intra-op pool degrades far beyond the useful parallelism of these sizes); "
+                         "with --cpu-steps 50 this is SURVEY 8d's protocol (minutes of CPU time: not the default)")
     ap.add_argument("--cpu-graphs", type=int, default=0,
                     help="graphs of each timed batch the oracle steps on (0 = whole batch; MPNN defaults to 16: the oracle "
                          "materialises the reference's E x C x C edge tensor)")
@@ -97,6 +101,9 @@ def parse():
                     help="assemble every batch on the compute stream at the start of its step instead of one step ahead on a side stream")
     ap.add_argument("--event-stride", type=int, default=0,
                     help="HIP events around the roofline kernels on every n-th timed step (0 = 4 for >= 8 steps, else every step)")
+    ap.add_argument("--collector", default="off", choices=["off", "freeze", "on"],
+                    help="cyclic collector inside the timed region: off (round 5), freeze (gc.freeze() in front of the warm-up steps: "
+                         "collections stay on but only walk objects created since), on (untouched)")
     ap.add_argument("--run-in", type=int, default=0,
                     help="diagnosis: this many of the warm-up steps are enqueued behind the barrier that opens the timed region "
                          "(config.device_ms_per_step then shows the K steps with a non-empty launch queue at the start)")
@@ -409,7 +416,13 @@ def main():
     import gc
     gc.collect()
     gc_was = gc.isenabled()
-    gc.disable()
+    if args.collector == "off":
+        gc.disable()
+    elif args.collector == "freeze":
+        # everything alive now moves to the permanent generation: later collections only walk the objects created since, so a
+        # full pass is microseconds — and cyclic garbage that holds device tensors still gets freed (with the collector OFF
+        # such tensors pile up and the caching allocator calls hipMalloc inside the timed region: `device_mallocs`)
+        gc.freeze()
     if args.settle_s > 0 and hasattr(ds, "edge_ptr"):
         epg = np.diff(np.asarray(ds.edge_ptr))
         npg = np.diff(np.asarray(ds.node_ptr))
@@ -423,6 +436,8 @@ def main():
     # the last warm-up step, and the last timed step one more (unused) batch, so that the K timed steps contain K assemblies)
     ev_stride = args.event_stride or (4 if args.steps >= 8 else 1)
     tr = timed_region(step, step_ids, args.warmup, args.steps, dev, use_dist, ev_stride, barrier, run_in=args.run_in)
+    if args.collector == "freeze":
+        gc.unfreeze()
     if gc_was:
         gc.enable()
     elapsed, elapsed_max, edges_all = tr["elapsed"], tr["elapsed_max"], tr["edges_all"]
@@ -795,7 +810,9 @@ def cpu_baseline(args, ds, gpu_model, cls_name, mkw, timed_ids, va_idx):
     out = {}
     probe = cds.collate(timed_ids[0][:512], rbf=rbf) if args.cpu_steps > 0 else None
     best_nt, best_t = min(cores, 16), None
-    for nt in (sorted({min(cores, t) for t in (16, 64)}) if args.cpu_steps > 0 else []):
+    if args.cpu_all_cores:
+        best_nt = cores
+    for nt in (sorted({min(cores, t) for t in (16, 64)}) if (args.cpu_steps > 0 and not args.cpu_all_cores) else []):
         torch.set_num_threads(nt)
         om = oracle()
         om.train()
@@ -817,9 +834,12 @@ def cpu_baseline(args, ds, gpu_model, cls_name, mkw, timed_ids, va_idx):
             t_total += one_step(om, opt, b)
             edges += b.num_edges
         out = {"value": round(edges / t_total, 1), "unit": "edges/s", "cores": best_nt, "host_cores": cores, "kind": "port",
-               "sample": "%d fp32 training step(s) of the oracle %s on %s of the GPU run's own timed batch(es) (%d graphs, %d edges) "
-                         "after 1 warm-up step, %.1f s" % (nsteps, cls_name, ("the first %d graphs" % cap) if cap else "all graphs",
-                                                           len(timed_ids[1]), edges, t_total)}
+               "sample": "%s: %d fp32 training step(s) of the oracle %s on %s of the GPU run's own timed batch(es) (%d graphs, %d edges) "
+                         "after 1 warm-up step, %.1f s; threads: %s"
+                         % ("1-step sample" if nsteps == 1 else "%d-step sample" % nsteps, nsteps, cls_name,
+                            ("the first %d graphs" % cap) if cap else "all graphs", len(timed_ids[1]), edges, t_total,
+                            "all %d host cores (--cpu-all-cores)" % cores if args.cpu_all_cores else
+                            "%d of %d (the faster of 16 / 64 on a probe batch)" % (best_nt, cores))}
 
     # parity at the trained weights on held-out graphs: oracle (CPU fp32) vs HIP fp32 vs HIP bf16
     om = oracle()

@@ -208,10 +208,11 @@ def test_product_matches_reference_wrapper_goldens(case):
             continue
         g = torch.from_numpy(g)
         s = float(g.abs().max()) + 1e-9
-        # 1e-2 of the tensor's own scale plus 1e-4 of the model's largest gradient (a bias in front of BatchNorm has a
-        # mathematically zero gradient: both sides hold rounding noise); the tight gradient checks are the kernel-level
-        # ones in test_gpu_kernels.py
-        assert float((p.grad.cpu() - g).abs().max()) <= 1e-2 * s + 1e-4 * gmax, (k, float((p.grad.cpu() - g).abs().max()), s, gmax)
+        # measured x 10 (round 6, tools/dbg/golden_grad_errors.py over all 23 cases on the device: worst error of a tensor that
+        # carries signal 5.8e-5 of its own scale, worst error of any tensor 2.3e-6 of the model's largest gradient — a bias in
+        # front of BatchNorm has a mathematically zero gradient, both sides hold rounding noise): 6e-4 of the tensor's scale plus
+        # 3e-5 of the model's largest gradient.  (Rounds 2-5 allowed 1e-2 + 1e-4.)
+        assert float((p.grad.cpu() - g).abs().max()) <= 6e-4 * s + 3e-5 * gmax, (k, float((p.grad.cpu() - g).abs().max()), s, gmax)
     for k, v in model.state_dict().items():
         if "running_" in k or "num_batches" in k:
             r = torch.from_numpy(z["%s/post/%s" % (case, k)]).float()
@@ -268,10 +269,11 @@ def test_product_megnet_matches_reference_goldens(tag, kw):
             continue
         g = torch.from_numpy(g)
         s = float(g.abs().max()) + 1e-9
-        # same bound as the wrapper goldens: 1e-2 of the tensor's own scale + 1e-4 of the model's largest gradient (ReLU mask
-        # flips between two fp32 summation orders; biases in front of a BatchNorm hold rounding noise on both sides)
+        # measured x 10 / x 5 (round 6, tools/dbg/golden_grad_errors.py, four configurations: worst 4.9e-5 of a signal tensor's
+        # own scale, 2.0e-5 of the model's largest gradient over all tensors — ReLU mask flips between two fp32 summation orders,
+        # biases in front of a BatchNorm hold rounding noise on both sides): 6e-4 of the tensor's scale + 1e-4 of the largest gradient
         err = float((p.grad.cpu() - g).abs().max())
-        assert err <= 1e-2 * s + 1e-4 * gmax, (k, err, s, gmax)
+        assert err <= 6e-4 * s + 1e-4 * gmax, (k, err, s, gmax)
     for k, v in model.state_dict().items():
         if "running_" in k or "num_batches" in k:
             r = sd[k].float()
