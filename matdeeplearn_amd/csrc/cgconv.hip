@@ -852,7 +852,12 @@ struct GroupInfo {
 // BN_: the instantiation whose epilogue also forms the BatchNorm statistics of the output (p.bn_sums) — a variant of its own, so
 // that the plain forward keeps its register allocation (it sits at 252 of 256 VGPRs)
 template <typename T, int CP_, int G_, int VEC, int EW, int WM, bool AB_ = false, int WSP = 0, bool BN_ = false>   // WM: 0 global, 1 LDS, 2 registers
-__global__ __launch_bounds__(MDL_FWD_THREADS, MDL_FWD_WAVES) void cgconv_fwd_kernel(CgParams p) {
+// (fp32: the packed weights alone are 99 KB of LDS, so one 4-wave workgroup fits a CU whatever the register count — the fp32
+// STATIC instantiation is allocated for ONE wave per SIMD (512 registers) instead of spilling 102 registers at 256: round 6)
+#ifndef MDL_FWD_WAVES_F32
+#define MDL_FWD_WAVES_F32 1
+#endif
+__global__ __launch_bounds__(MDL_FWD_THREADS, ((sizeof(T) == 4 && CP_ != 0) ? MDL_FWD_WAVES_F32 : MDL_FWD_WAVES)) void cgconv_fwd_kernel(CgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Mma<T> M;
     typedef Gate<M::FAST> GT;
