@@ -63,7 +63,9 @@ def parse():
     ap.add_argument("--model", default="cgcnn", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="graphs per GPU per step (default per workload; reference default is 100)")
     ap.add_argument("--graphs", type=int, default=0, help="synthetic dataset size (default: the workload's recipe)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"],
+                    help="compute mode: bf16 (headline), fp32 (exact parity mode), bf16x3 (fp32 storage, the CGConv products as three "
+                         "bf16 MFMAs on split operands)")
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--gc", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -681,26 +683,29 @@ def main():
                                          "ms_per_step": res["ref_batch_100"]["eager"]["ms_per_step"], "mode": "eager",
                                          "graph_error": repr(exc)[:300]})
 
-    # ---- fp32 (parity) mode: same model, same batches, compute_dtype fp32 ----------------------------------
-    if world == 1 and args.dtype != "fp32" and (args.fp32_leg or not args.no_extras):
-        torch.manual_seed(args.seed)
-        m32 = getattr(models, cls_name)(ds, compute_dtype="fp32", **mkw).to(dev)
-        m32.train()
-        dp32 = FlatDataParallel(m32)
-        opt32 = make_optimizer(m32.parameters(), "AdamW", lr=0.002)
-        step32 = make_step(m32, dp32, opt32, torch.float32)
-        n32 = max(3, min(args.steps, 10))
-        for i in range(2):
-            step32(step_ids[i], False)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        e32 = 0
-        for i in range(n32):
-            e32 += step32(step_ids[args.warmup + i % args.steps], False)[0]
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        res["fp32_mode"] = {"value": round(e32 / dt, 1), "unit": "edges/s", "ms_per_step": round(dt / n32 * 1e3, 4), "steps": n32}
-        del m32, dp32, opt32
+    # ---- the parity modes: same model, same batches, compute_dtype fp32 (exact products) and — CGCNN, whose conv kernels have
+    # the form — bf16x3 (fp32 storage, the conv products as three bf16 MFMAs on (hi, lo)-split operands) ---------------------
+    if world == 1 and args.dtype == "bf16" and (args.fp32_leg or not args.no_extras):
+        for mode in (("fp32", "bf16x3") if (cls_name == "CGCNN" and mkw.get("dim1") == 64) else ("fp32",)):
+            torch.manual_seed(args.seed)
+            m32 = getattr(models, cls_name)(ds, compute_dtype=mode, **mkw).to(dev)
+            m32.train()
+            dp32 = FlatDataParallel(m32)
+            opt32 = make_optimizer(m32.parameters(), "AdamW", lr=0.002)
+            step32 = make_step(m32, dp32, opt32, torch.float32)
+            n32 = max(3, min(args.steps, 10))
+            for i in range(2):
+                step32(step_ids[i], False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            e32 = 0
+            for i in range(n32):
+                e32 += step32(step_ids[args.warmup + i % args.steps], False)[0]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            res[mode + "_mode"] = {"value": round(e32 / dt, 1), "unit": "edges/s", "ms_per_step": round(dt / n32 * 1e3, 4), "steps": n32,
+                                   "vs_bf16_step": round(dt / n32 / (elapsed_max / args.steps), 2)}
+            del m32, dp32, opt32
 
 
     # ---- the other BASELINE configurations as short legs of the same run (cfg3 SchNet_demo, cfg4 MEGNet_demo, the cfg5 members):
@@ -850,7 +855,10 @@ def cpu_baseline(args, ds, gpu_model, cls_name, mkw, timed_ids, va_idx):
         p_cpu = om(bc)
         mae_cpu = float(torch.nn.functional.l1_loss(p_cpu, bc.y))
         scale = float(p_cpu.abs().max()) + 1e-12
-        for tag, cd, dt in (("fp32", "fp32", torch.float32), ("bf16", "bf16", torch.bfloat16)):
+        modes = [("fp32", "fp32", torch.float32), ("bf16", "bf16", torch.bfloat16)]
+        if cls_name == "CGCNN" and mkw.get("dim1") == 64:      # (the split-product kernels exist for C = 64, G = 50)
+            modes.insert(1, ("bf16x3", "bf16x3", torch.float32))
+        for tag, cd, dt in modes:
             gm = getattr(models, cls_name)(ds, compute_dtype=cd, **mkw).to(ds.device)
             gm.load_state_dict(gpu_model.state_dict())
             gm.eval()
@@ -858,7 +866,7 @@ def cpu_baseline(args, ds, gpu_model, cls_name, mkw, timed_ids, va_idx):
             p = gm(bg)
             mae = float(torch.nn.functional.l1_loss(p, bg.y))
             out["val_mae_hip_" + tag] = mae
-            out["val_mae_delta" + ("" if tag == "fp32" else "_bf16")] = abs(mae - mae_cpu)
+            out["val_mae_delta" + ("" if tag == "fp32" else "_" + tag)] = abs(mae - mae_cpu)
             out["pred_max_rel_delta_" + tag] = float((p.cpu() - p_cpu).abs().max()) / scale
     out["val_mae_oracle_cpu"] = mae_cpu
     out["val_graphs"] = int(len(ids))

@@ -58,6 +58,13 @@ enum {
  *   MDL_BN_SHIFT_ROW   mdl_bn_apply_n only: the sums were formed by the PRODUCER of the rows (mdl_linear_act_stats,
  *                      mdl_cgconv_fwd_ex) about the per-column shift it stored behind the totals rows of the sums buffer
  *                      (row 2 MDL_BN_REPLICAS + 2), instead of about the first row as mdl_bn_stats forms them.
+ *   MDL_SPLIT_BF16     CGConv kernels with MDL_F32 storage (MdlCgConv.flags of mdl_cgconv_fwd_ex / mdl_cgconv_bwd_ex; OR-ed
+ *                      into `dtype` for mdl_cgconv_wpack_bytes / mdl_cgconv_pack_weights[_multi], whose packed layout it
+ *                      changes): the K = 2C + G product z W^T runs as THREE bf16 MFMAs on operands split into (hi, lo) bf16
+ *                      pairs (hi hi + lo hi + hi lo: operands to 16 significant bits, fp32 accumulation) instead of the
+ *                      exact-fp32 MFMA, which has 1/16 of the bf16 rate.  Relative error 2^-16 per product: a PARITY
+ *                      mode between bf16 (2^-9) and exact fp32 — the reference computes fp32 throughout
+ *                      (training.py:34-54).  C = 64, G = 50, edge features in CSR order only.
  * The struct entry points (MdlCgConv, MdlCgNode) carry their flags in a field of their own; the positional entry points of
  * the dense / BatchNorm kernels take them OR-ed into `dtype`. */
 #define MDL_DTYPE_MASK 0xff
@@ -65,6 +72,7 @@ enum {
 #define MDL_K3_PER_WAVE 0x200
 #define MDL_K3_EDGE_LANE 0x400
 #define MDL_BN_SHIFT_ROW 0x800
+#define MDL_SPLIT_BF16 0x1000
 
 typedef void* mdlStream_t; /* hipStream_t */
 

@@ -21,6 +21,7 @@ MDL_F32, MDL_BF16 = 0, 1
 MDL_SUM, MDL_MEAN, MDL_MAX = 0, 1, 2
 # execution flags (include/mdl_hip.h): the `flags` field of the struct entry points, OR-ed into `dtype` for the positional ones
 MDL_DTYPE_MASK, MDL_DETERMINISTIC, MDL_K3_PER_WAVE, MDL_K3_EDGE_LANE = 0xFF, 0x100, 0x200, 0x400
+MDL_SPLIT_BF16 = 0x1000        # CGConv kernels on fp32 storage: the K = 2C + G product as three bf16 MFMAs on (hi, lo) operands
 MDL_BN_SHIFT_ROW = 0x800       # mdl_bn_apply_n: sums about the shift row their producer stored behind the totals rows
 MDL_BN_REPLICAS = 16
 REDUCE = {"sum": MDL_SUM, "add": MDL_SUM, "mean": MDL_MEAN, "max": MDL_MAX}

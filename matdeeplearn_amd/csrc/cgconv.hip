@@ -186,13 +186,16 @@ struct CgDims {
 
 static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 
-static CgDims cg_dims(int C, int G, int dtype) {
+// x3 (MDL_SPLIT_BF16, fp32 storage): the K = 2C + G product runs as three bf16 MFMAs on split operands, whose fragments are
+// 16-byte LDS reads — rows padded by FOUR dwords (an odd number of 16-byte slots) instead of one
+static CgDims cg_dims(int C, int G, int dtype, bool x3 = false) {
     CgDims d;
     d.Cp = rup(C, 32);
     d.KE = rup(G, 16);
     d.KT = d.KE + 2 * d.Cp;
-    d.WS = d.KT + (dtype == MDL_BF16 ? 8 : 1);   // bf16: odd number of 16-B slots; f32: odd dword stride
-    d.EKS = d.KE + (dtype == MDL_BF16 ? 8 : 1);
+    const int pad = dtype == MDL_BF16 ? 8 : (x3 ? 4 : 1);   // bf16: odd number of 16-B slots; f32: odd dword stride
+    d.WS = d.KT + pad;
+    d.EKS = d.KE + pad;
     d.NS = d.Cp / 32;
     d.GP = rup(G, 64);
     return d;
@@ -265,15 +268,52 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const float* v) {
 }
 
 // ------------------------------------------------------------------------------------------
+// x3: fp32 values as (hi, lo) bf16 pairs — v = hi + lo to 16 significant bits (both parts rounded to nearest), so that
+// a * b ~ a_hi b_hi + a_lo b_hi + a_hi b_lo on the bf16 matrix core at 1/5 of the cost of the exact-fp32 MFMA
+// (3 x 32 cycles per 16 k-values against 8 x 64): relative error 2^-16 per product, fp32 accumulation.
+// ------------------------------------------------------------------------------------------
+struct SplitFrag { bf16x8 hi, lo; };
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
+    hi = pk_bf16(v0, v1);
+    const float r0 = v0 - __builtin_bit_cast(float, hi << 16);
+    const float r1 = v1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = pk_bf16(r0, r1);
+}
+__device__ __forceinline__ SplitFrag split8(const f32x4& a, const f32x4& b) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split_pair(a[0], a[1], h0, l0);
+    split_pair(a[2], a[3], h1, l1);
+    split_pair(b[0], b[1], h2, l2);
+    split_pair(b[2], b[3], h3, l3);
+    return SplitFrag{__builtin_bit_cast(bf16x8, u32x4{h0, h1, h2, h3}), __builtin_bit_cast(bf16x8, u32x4{l0, l1, l2, l3})};
+}
+// eight consecutive fp32 values of a row (16-byte aligned: LDS tile rows of EKS = KE + 4 dwords, or a global x row)
+__device__ __forceinline__ SplitFrag split8_at(const float* p) {
+    return split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
+}
+__device__ __forceinline__ f32x16 mma_x3(const SplitFrag& a, const SplitFrag& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+}
+// B fragment of the x3 weight pack: a row holds, per group of eight k-values, [8 x hi bf16 | 8 x lo bf16] (32 bytes, the
+// footprint of the eight floats it replaces); lane half h of k-step k0 / 16 takes group k0 / 8 + h
+__device__ __forceinline__ SplitFrag ld_wfrag_x3(const float* wbase, int row, int ld, int k0, int h) {
+    const char* g = reinterpret_cast<const char*>(wbase + row * ld) + (k0 / 8 + h) * 32;
+    return SplitFrag{*reinterpret_cast<const bf16x8*>(g), *reinterpret_cast<const bf16x8*>(g + 16)};
+}
+
+// ------------------------------------------------------------------------------------------
 // Shared per-tile machinery
 // ------------------------------------------------------------------------------------------
 // Problem dimensions: compile-time when the kernel is instantiated for a fixed (CP_, G_) — loops
 // unroll fully, so all loads of a tile are issued before the first MFMA that needs them — or
 // run-time (CP_ = 0 / G_ = 0) for the generic fallback.
-template <typename T, int CP_, int G_, int EW, int WSP = 0>
+template <typename T, int CP_, int G_, int EW, int WSP = 0, bool X3 = false>
 struct Dims {
     static constexpr bool STATIC = (CP_ != 0) && (G_ != 0);
-    static constexpr int PADW = std::is_same<T, bf16_t>::value ? 8 : 1;
+    static constexpr int PADW = std::is_same<T, bf16_t>::value ? 8 : (X3 ? 4 : 1);
+    static_assert(!X3 || (std::is_same<T, float>::value && STATIC && WSP == 0), "x3: fp32 storage, static shapes");
     int C, Cp, G, KE, WS, EKS, GW;
     __device__ __forceinline__ Dims(const CgParams& p) {
         C = p.C;
@@ -370,7 +410,7 @@ struct EWords {
 
 // x-row A fragments of one tile (target rows and source rows), all issued up front when the
 // channel count is static.
-template <typename T, int CP_, int VEC>
+template <typename T, int CP_, int VEC, bool X3 = false>
 struct XFrags {
     typedef Mma<T> M;
     static constexpr int NF = CP_ ? CP_ / M::KSTEP : 1;
@@ -382,6 +422,21 @@ struct XFrags {
         for (int f = 0; f < NF; ++f) t[f] = ld_xfrag<VEC>(xt, f * M::KSTEP, h, C);
 #pragma unroll
         for (int f = 0; f < NF; ++f) s[f] = ld_xfrag<VEC>(xs, f * M::KSTEP, h, C);
+    }
+};
+// x3: the raw fp32 chunks of the two rows (16-byte loads; same 2 x CP_ / 2 registers as the k-pair fragments of the exact
+// form): chunk f of a row = columns 16 f + 8 h .. + 7, split into (hi, lo) where it is used
+template <int CP_, int VEC>
+struct XFrags<float, CP_, VEC, true> {
+    static constexpr int NF = CP_ / 16;
+    f32x4 t[NF][2], s[NF][2];
+    __device__ __forceinline__ void load(const float* x, int C, int my_tgt, int my_src, int h) {
+        const float* xt = x + (int64_t)my_tgt * C + 8 * h;
+        const float* xs = x + (int64_t)my_src * C + 8 * h;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { t[f][0] = *reinterpret_cast<const f32x4*>(xt + 16 * f); t[f][1] = *reinterpret_cast<const f32x4*>(xt + 16 * f + 4); }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { s[f][0] = *reinterpret_cast<const f32x4*>(xs + 16 * f); s[f][1] = *reinterpret_cast<const f32x4*>(xs + 16 * f + 4); }
     }
 };
 
@@ -463,14 +518,39 @@ struct WRegs {
 };
 
 // pre-activation tile: accf/accs (32 edge slots x 32 channels of slice s), bias pre-loaded.
-template <typename T, int CP_, int VEC, int WM, int NKW, int DEPTH = 0, typename D>
+template <typename T, int CP_, int VEC, int WM, int NKW, int DEPTH = 0, bool X3 = false, typename D>
 __device__ __forceinline__ void pre_tile(const CgParams& p, const D& dm, const WaveCtx<T>& w, int lane, int s,
-                                         int my_tgt, int my_src, const XFrags<T, CP_, VEC>& xf,
+                                         int my_tgt, int my_src, const XFrags<T, CP_, VEC, X3>& xf,
                                          const WRegs<T, NKW>& wr, f32x16& accf, f32x16& accs) {
     typedef Mma<T> M;
     const int i = lane & 31, h = lane >> 5;
     const bool wsl = (CP_ == 0 || CP_ > 64) && p.w_slice;    // (never for the static shapes whose W fits LDS: folds away there)
     const int rowf = (wsl ? 0 : s * 32) + i, rows = (wsl ? 32 : dm.Cp + s * 32) + i;
+    if constexpr (X3) {
+        // fp32 storage, split-bf16 products: z fragments split where they are read (e tile: 2 ds_read_b128 per fragment; x
+        // chunks: registers), weight fragments pre-split by the pack kernel (no arithmetic here)
+        static_assert(WM == 1 && CP_ != 0, "x3: static shapes, W in LDS");
+#pragma unroll
+        for (int k0 = 0; k0 < dm.KE; k0 += 16) {
+            const SplitFrag a = split8_at(w.et + i * dm.EKS + k0 + 8 * h);
+            accf = mma_x3(a, ld_wfrag_x3(w.wbase, rowf, dm.WS, k0, h), accf);
+            accs = mma_x3(a, ld_wfrag_x3(w.wbase, rows, dm.WS, k0, h), accs);
+        }
+        constexpr int NF = CP_ / 16;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const SplitFrag a = split8(xf.t[f][0], xf.t[f][1]);
+            accf = mma_x3(a, ld_wfrag_x3(w.wbase, rowf, dm.WS, dm.KE + 16 * f, h), accf);
+            accs = mma_x3(a, ld_wfrag_x3(w.wbase, rows, dm.WS, dm.KE + 16 * f, h), accs);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const SplitFrag a = split8(xf.s[f][0], xf.s[f][1]);
+            accf = mma_x3(a, ld_wfrag_x3(w.wbase, rowf, dm.WS, dm.KE + dm.Cp + 16 * f, h), accf);
+            accs = mma_x3(a, ld_wfrag_x3(w.wbase, rows, dm.WS, dm.KE + dm.Cp + 16 * f, h), accs);
+        }
+        return;
+    } else {
     if constexpr (CP_ != 0 && (WM == 2 || WM == 3)) {
         // static shapes.  WM 2: all B fragments live in registers.  WM 3: the x-part of W lives in
         // registers, the e-part is read from the LDS copy (those reads depend on nothing and are
@@ -573,6 +653,7 @@ __device__ __forceinline__ void pre_tile(const CgParams& p, const D& dm, const W
             accs = M::mma(a, ld_frag(w.wbase, rows, dm.WS, dm.KE + dm.Cp + k0, h), accs);
         }
     }
+    }   // (!X3)
 }
 
 // acc[node slot][ch] += sum over the tile's edge slots of onehot(slot -> node slot) * v[edge slot][ch]
@@ -600,6 +681,25 @@ __device__ __forceinline__ void seg_reduce_mma(const f32x16& v, const unsigned t
             const unsigned slot = (t4[r >> 2] >> (8 * (r & 3))) & 0xffu;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32((slot == (unsigned)ns) ? 1.0f : 0.0f, v[r], acc, 0, 0, 0);
         }
+    }
+}
+
+// x3: the same reduction on the bf16 matrix core with the values split into (hi, lo) — the one-hot operand is exact in bf16, so
+// the sums carry the values' 16 bits: 4 MFMAs of 32 cycles instead of 16 exact-fp32 MFMAs of 64
+__device__ __forceinline__ void seg_reduce_mma_x3(const f32x16& v, const unsigned t4[4], int ns, f32x16& acc) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = 8 * ks + q;
+            const unsigned slot = (t4[r >> 2] >> (8 * (r & 3))) & 0xffu;
+            a[q] = (slot == (unsigned)ns) ? (short)0x3F80 : (short)0;
+        }
+        const SplitFrag b = split8(f32x4{v[8 * ks], v[8 * ks + 1], v[8 * ks + 2], v[8 * ks + 3]},
+                                   f32x4{v[8 * ks + 4], v[8 * ks + 5], v[8 * ks + 6], v[8 * ks + 7]});
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b.lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b.hi, acc, 0, 0, 0);
     }
 }
 
@@ -646,6 +746,36 @@ template <> struct DFrags<float> {
     f32x16 f, s;
     __device__ __forceinline__ void pack(const f32x16& af, const f32x16& as) { f = af; s = as; }
 };
+
+// x3: dpre of one tile as (hi, lo) bf16 fragments, split ONCE and used by the three segmented reductions and the dwe product
+struct DFragsX3 {
+    SplitFrag f[2], s[2];
+    __device__ __forceinline__ void pack(const f32x16& af, const f32x16& as) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f[ks] = split8(f32x4{af[8 * ks], af[8 * ks + 1], af[8 * ks + 2], af[8 * ks + 3]},
+                           f32x4{af[8 * ks + 4], af[8 * ks + 5], af[8 * ks + 6], af[8 * ks + 7]});
+            s[ks] = split8(f32x4{as[8 * ks], as[8 * ks + 1], as[8 * ks + 2], as[8 * ks + 3]},
+                           f32x4{as[8 * ks + 4], as[8 * ks + 5], as[8 * ks + 6], as[8 * ks + 7]});
+        }
+    }
+};
+__device__ __forceinline__ void seg_reduce2_x3(const DFragsX3& d, const unsigned b4[4], unsigned row_id, f32x16& accF, f32x16& accS) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = 8 * ks + q;
+            const unsigned slot = (b4[r >> 2] >> (8 * (r & 3))) & 0xffu;
+            a[q] = (slot == row_id) ? (short)0x3F80 : (short)0;
+        }
+        accF = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, d.f[ks].lo, accF, 0, 0, 0);
+        accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, d.s[ks].lo, accS, 0, 0, 0);
+        accF = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, d.f[ks].hi, accF, 0, 0, 0);
+        accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, d.s[ks].hi, accS, 0, 0, 0);
+    }
+}
 
 // accF/accS[slot row][ch] += onehot(byte(edge slot) == row_id) x dpre   (see seg_reduce_mma)
 template <typename T>
@@ -851,7 +981,7 @@ struct GroupInfo {
 #endif
 // BN_: the instantiation whose epilogue also forms the BatchNorm statistics of the output (p.bn_sums) — a variant of its own, so
 // that the plain forward keeps its register allocation (it sits at 252 of 256 VGPRs)
-template <typename T, int CP_, int G_, int VEC, int EW, int WM, bool AB_ = false, int WSP = 0, bool BN_ = false>   // WM: 0 global, 1 LDS, 2 registers
+template <typename T, int CP_, int G_, int VEC, int EW, int WM, bool AB_ = false, int WSP = 0, bool BN_ = false, bool X3 = false>   // WM: 0 global, 1 LDS, 2 registers; X3: split-bf16 products on fp32 storage
 // (fp32: the packed weights alone are 99 KB of LDS, so one 4-wave workgroup fits a CU whatever the register count — the fp32
 // STATIC instantiation is allocated for ONE wave per SIMD (512 registers) instead of spilling 102 registers at 256: round 6)
 #ifndef MDL_FWD_WAVES_F32
@@ -860,8 +990,8 @@ template <typename T, int CP_, int G_, int VEC, int EW, int WM, bool AB_ = false
 __global__ __launch_bounds__(MDL_FWD_THREADS, ((sizeof(T) == 4 && CP_ != 0) ? MDL_FWD_WAVES_F32 : MDL_FWD_WAVES)) void cgconv_fwd_kernel(CgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Mma<T> M;
-    typedef Gate<M::FAST> GT;
-    typedef Dims<T, CP_, G_, EW, WSP> D;
+    typedef Gate<M::FAST || X3> GT;   // x3: hardware exp2 / log2 / rcp (1 ulp) on base-2 pre-activations, like the bf16 kernels
+    typedef Dims<T, CP_, G_, EW, WSP, X3> D;
     constexpr bool ST = D::STATIC;
     const D dm(p);
     WaveCtx<T> w;
@@ -964,7 +1094,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, ((sizeof(T) == 4 && CP_ != 0) ? MD
         GN = G;
         TileIdx cur, nxt;
         EWords<T, G_, EW> ew;
-        XFrags<T, WSP ? 0 : CP_, VEC> xf;
+        XFrags<T, WSP ? 0 : CP_, VEC, X3> xf;
         // W-split: projection rows instead of x rows, ONE slice's fragments at a time (32 registers, like the x rows): the
         // rows of slice sl + 1 — or of the next tile's slice 0 — are requested right after slice sl's MFMAs have consumed
         // the registers, and arrive under that slice's gate arithmetic and aggregation
@@ -1097,7 +1227,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, ((sizeof(T) == 4 && CP_ != 0) ? MD
                         pre_tile_wsp<CP_, 1, MDL_FWD_PRE_DEPTH>(dm, w, lane, sl, 0, pf, idf, accf, accs);
                         pf.load(p.pt, p.ps, sl == NSL - 1 ? nxt.tgt : cur.tgt, sl == NSL - 1 ? nxt.src : cur.src, h, (sl + 1) % NSL);
                     } else {
-                        pre_tile<T, CP_, VEC, WM, NKW, MDL_FWD_PRE_DEPTH>(p, dm, w, lane, sl, cur.tgt, cur.src, xf, wr, accf, accs);
+                        pre_tile<T, CP_, VEC, WM, NKW, MDL_FWD_PRE_DEPTH, X3>(p, dm, w, lane, sl, cur.tgt, cur.src, xf, wr, accf, accs);
                     }
                     TPIN16(accf); TPIN16(accs);
                     TMARK(3 + 3 * sl);
@@ -1143,7 +1273,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, ((sizeof(T) == 4 && CP_ != 0) ? MD
                     }
                     TPIN16(m);
                     TMARK(4 + 3 * sl);
-                    seg_reduce_mma<T>(m, t4, i, acc_out[sl]);
+                    if constexpr (X3) seg_reduce_mma_x3(m, t4, i, acc_out[sl]); else seg_reduce_mma<T>(m, t4, i, acc_out[sl]);
                     TPIN16(acc_out[sl]);
                     TMARK(5 + 3 * sl);
                     __builtin_amdgcn_sched_barrier(0);      // keep the slices' register footprints apart
@@ -1172,7 +1302,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, ((sizeof(T) == 4 && CP_ != 0) ? MD
                         const int n = min(G.n0 + d_row(r, h), G.n1 - 1);
                         xr[sl][r] = Elem<T>::ld(x + (int64_t)n * dm.C + sl * 32 + i);
                     }
-                const float invd = M::FAST ? __builtin_amdgcn_rcpf((float)max(dg1 - dg0, 1)) : 1.0f / (float)max(dg1 - dg0, 1);
+                const float invd = (M::FAST && !X3) ? __builtin_amdgcn_rcpf((float)max(dg1 - dg0, 1)) : 1.0f / (float)max(dg1 - dg0, 1);
                 float invr[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) invr[r] = __shfl(invd, d_row(r, h));
@@ -1224,7 +1354,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, ((sizeof(T) == 4 && CP_ != 0) ? MD
     for (int r = 0; r < 16; ++r) { acc_out[r] = 0.0f; cnt[r] = 0.0f; }
     TileIdx cur, nxt;
     EWords<T, G_, EW> ew;
-    XFrags<T, CP_, VEC> xf;
+    XFrags<T, CP_, VEC, X3> xf;
     float xr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) xr[r] = 0.0f;
@@ -1298,7 +1428,7 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, ((sizeof(T) == 4 && CP_ != 0) ? MD
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
 #ifndef MDL_ABL_NOPRE
-        pre_tile<T, CP_, VEC, WM, NKW>(p, dm, w, lane, s, cur.tgt, cur.src, xf, wr, accf, accs);
+        pre_tile<T, CP_, VEC, WM, NKW, 0, X3>(p, dm, w, lane, s, cur.tgt, cur.src, xf, wr, accf, accs);
 #else
         if constexpr (std::is_same<T, bf16_t>::value) {
 #pragma unroll
@@ -1377,12 +1507,12 @@ __device__ __forceinline__ void rsrc16_add2(bf16_t* base_even_col, int64_t rowa_
 // ------------------------------------------------------------------------------------------
 // Backward edge pass
 // ------------------------------------------------------------------------------------------
-template <typename T, int CP_, int G_, int VEC, int EW, int WM, int WSP = 0>
+template <typename T, int CP_, int G_, int VEC, int EW, int WM, int WSP = 0, bool X3 = false>
 __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Mma<T> M;
-    typedef Gate<M::FAST> GT;
-    typedef Dims<T, CP_, G_, EW, WSP> D;
+    typedef Gate<M::FAST || X3> GT;   // x3: hardware exp2 / log2 / rcp (1 ulp) on base-2 pre-activations, like the bf16 kernels
+    typedef Dims<T, CP_, G_, EW, WSP, X3> D;
     constexpr bool ST = D::STATIC;
     constexpr bool BF = std::is_same<T, bf16_t>::value;
     const D dm(p);
@@ -1448,7 +1578,8 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
         const int nd = min(n0 + i, n1 - 1);
         const int dg0 = p.rowptr[nd], dg1 = p.rowptr[nd + 1];
         // (2) grad_out columns of this lane's channel for the B fragments of the one-hot expansion to edges
-        constexpr int NFg = BF ? 2 : 16, PERg = BF ? 8 : 1;
+        constexpr bool PK = BF || X3;                // k-slots of a fragment: eight node slots per lane half (bf16 MFMA shapes)
+        constexpr int NFg = PK ? 2 : 16, PERg = PK ? 8 : 1;
         float graw[NFg][PERg];
         {
             const int chc = min(ch, dm.C - 1);
@@ -1456,7 +1587,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             for (int f = 0; f < NFg; ++f)
 #pragma unroll
                 for (int q = 0; q < PERg; ++q) {
-                    const int ns = BF ? (16 * f + 8 * h + q) : (2 * f + h);
+                    const int ns = PK ? (16 * f + 8 * h + q) : (2 * f + h);
                     graw[f][q] = Elem<T>::ld(go + (int64_t)min(n0 + ns, n1 - 1) * dm.C + chc);
                 }
         }
@@ -1475,7 +1606,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
         // (4) first tiles of the edge stream
         TileIdx cur, nxt, nn;
         EWords<T, G_, EW> ew;
-        XFrags<T, WSP ? 0 : CP_, VEC> xf, xn;
+        XFrags<T, WSP ? 0 : CP_, VEC, X3> xf, xn;
         PFrags<CP_, 1> pf, pn;                      // W-split: the projection rows of this wave's slice instead of x rows
         bf16x8 idf[2];
         if constexpr (WSP != 0) identity_frags(i, h, idf);
@@ -1490,16 +1621,19 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 
         const float invd = (p.aggr == MDL_MEAN) ? 1.0f / (float)max(dg1 - dg0, 1) : 1.0f;
         typename M::frag_t gB[NFg];
+        SplitFrag gBx[2];                            // x3: grad_out / deg as (hi, lo) fragments
 #pragma unroll
         for (int f = 0; f < NFg; ++f) {
             float v[PERg];
 #pragma unroll
             for (int q = 0; q < PERg; ++q) {
-                const int ns = BF ? (16 * f + 8 * h + q) : (2 * f + h);
+                const int ns = PK ? (16 * f + 8 * h + q) : (2 * f + h);
                 const float sc = __shfl(invd, ns);
                 v[q] = (n0 + ns < n1 && ch < dm.C) ? graw[f][q] * sc : 0.0f;
             }
-            if constexpr (BF) gB[f] = pack_bf16x8(v); else gB[f] = v[0];
+            if constexpr (BF) gB[f] = pack_bf16x8(v);
+            else if constexpr (X3) gBx[f] = split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+            else gB[f] = v[0];
         }
 
         TMARK(12);           // (timing builds: prologue up to here = loads + their wait + the gB shuffles)
@@ -1570,7 +1704,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
             if constexpr (WSP != 0) pre_tile_wsp<CP_, 1, 0>(dm, w, lane, s, 0, pf, idf, accf, accs);
-            else pre_tile<T, CP_, VEC, WM, NKW>(p, dm, w, lane, s, cur.tgt, cur.src, xf, wr, accf, accs);
+            else pre_tile<T, CP_, VEC, WM, NKW, 0, X3>(p, dm, w, lane, s, cur.tgt, cur.src, xf, wr, accf, accs);
             TPIN16(accf); TPIN16(accs);
             TMARK(3);
 
@@ -1582,6 +1716,15 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
                     dmv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh_frag(w.oh_e, i, ks, h), gB[ks], dmv, 0, 0, 0);
+            } else if constexpr (X3) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 a;                        // one-hot(edge slot i -> node slot 16 ks + 8 h + q), exact in bf16
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = (my_ts == 16 * ks + 8 * h + q) ? (short)0x3F80 : (short)0;
+                    dmv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, gBx[ks].lo, dmv, 0, 0, 0);
+                    dmv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, gBx[ks].hi, dmv, 0, 0, 0);
+                }
             } else {
 #pragma unroll
                 for (int f = 0; f < 16; ++f)
@@ -1648,7 +1791,8 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
             TPIN16(accf); TPIN16(accs);
             TMARK(5);
             DFrags<T> dp;
-            dp.pack(accf, accs);
+            DFragsX3 dpx;
+            if constexpr (X3) dpx.pack(accf, accs); else dp.pack(accf, accs);
             TMARK(6);
             if constexpr (BF) {
                 seg_reduce2_tab(dp, w.oh_t, i, h, Rf, Rs);                  // by target  -> r_tgt
@@ -1662,9 +1806,15 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                 unsigned t4[4], s4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { t4[j] = w.tsl[2 * j + h]; s4[j] = w.ssl[2 * j + h]; }
-                seg_reduce2<T>(dp, t4, (unsigned)i, Rf, Rs);
+                if constexpr (X3) {
+                    seg_reduce2_x3(dpx, t4, (unsigned)i, Rf, Rs);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) seg_reduce2<T>(dp, s4, (unsigned)(i + 32 * mt), Wf[mt], Ws[mt]);
+                    for (int mt = 0; mt < 2; ++mt) seg_reduce2_x3(dpx, s4, (unsigned)(i + 32 * mt), Wf[mt], Ws[mt]);
+                } else {
+                    seg_reduce2<T>(dp, t4, (unsigned)i, Rf, Rs);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) seg_reduce2<T>(dp, s4, (unsigned)(i + 32 * mt), Wf[mt], Ws[mt]);
+                }
             }
 
             TMARK(8);
@@ -1699,6 +1849,17 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
                             }
                             dwe_acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp.f[ks], b, dwe_acc[0][nt], 0, 0, 0);
                             dwe_acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp.s[ks], b, dwe_acc[1][nt], 0, 0, 0);
+                        }
+                    } else if constexpr (X3) {
+                        // both operands split: dpre_hi e_hi + dpre_lo e_hi + dpre_hi e_lo (k = the tile's 32 edge slots)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            float ev[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) ev[q] = w.et[d_row(8 * ks + q, h) * dm.EKS + gcol];
+                            const SplitFrag b = split8(f32x4{ev[0], ev[1], ev[2], ev[3]}, f32x4{ev[4], ev[5], ev[6], ev[7]});
+                            dwe_acc[0][nt] = mma_x3(dpx.f[ks], b, dwe_acc[0][nt]);
+                            dwe_acc[1][nt] = mma_x3(dpx.s[ks], b, dwe_acc[1][nt]);
                         }
                     } else {
 #pragma unroll
@@ -1905,7 +2066,7 @@ __device__ __forceinline__ void cgconv_pack_body(const float* __restrict__ wf, c
                                                  const float* __restrict__ ws, const float* __restrict__ bsv,
                                                  int C, int G, const CgDims& d, T* __restrict__ wpack,
                                                  float* __restrict__ bpack, float scale, int bias_col,
-                                                 bf16_t* __restrict__ wn_t) {
+                                                 bf16_t* __restrict__ wn_t, int x3 = 0) {
     const int total = 2 * d.Cp * d.WS;
     const int ldw = 2 * C + G;
     if (wn_t) {
@@ -1937,6 +2098,22 @@ __device__ __forceinline__ void cgconv_pack_body(const float* __restrict__ wf, c
                 if (kc < C) v = W[c * ldw + C + kc];
             }
         }
+        if constexpr (std::is_same<T, float>::value) {
+            if (x3) {
+                // x3 layout (ld_wfrag_x3): per group of eight k-values [8 x hi bf16 | 8 x lo bf16] in the 32 bytes of the eight
+                // floats; the row's padding dwords are never read
+                if (k < d.KT) {
+                    unsigned hi, lo;
+                    split_pair(v * scale, 0.0f, hi, lo);
+                    bf16_t* g = reinterpret_cast<bf16_t*>(wpack + row * d.WS) + (k >> 3) * 16 + (k & 7);
+                    g[0] = (bf16_t)(hi & 0xffffu);
+                    g[8] = (bf16_t)(lo & 0xffffu);
+                } else {
+                    wpack[q] = 0.0f;
+                }
+                continue;
+            }
+        }
         Elem<T>::st(wpack + q, v * scale);
     }
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < 2 * d.Cp; q += gridDim.x * blockDim.x) {
@@ -1951,8 +2128,8 @@ __global__ __launch_bounds__(256) void cgconv_pack_kernel(const float* __restric
                                                           const float* __restrict__ ws, const float* __restrict__ bsv,
                                                           int C, int G, CgDims d, T* __restrict__ wpack,
                                                           float* __restrict__ bpack, float scale, int bias_col,
-                                                          bf16_t* __restrict__ wn_t = nullptr) {
-    cgconv_pack_body<T>(wf, bfv, ws, bsv, C, G, d, wpack, bpack, scale, bias_col, wn_t);
+                                                          bf16_t* __restrict__ wn_t = nullptr, int x3 = 0) {
+    cgconv_pack_body<T>(wf, bfv, ws, bsv, C, G, d, wpack, bpack, scale, bias_col, wn_t, x3);
 }
 
 // every conv layer of a model in ONE launch (blockIdx.y = layer): the layers' weights are all known before the first one runs,
@@ -1963,9 +2140,9 @@ struct PackMulti {
     void* wpack[PACK_MAXL]; float* bpack[PACK_MAXL]; bf16_t* wn_t[PACK_MAXL];
 };
 template <typename T>
-__global__ __launch_bounds__(256) void cgconv_pack_multi_kernel(PackMulti a, int C, int G, CgDims d, float scale, int bias_col) {
+__global__ __launch_bounds__(256) void cgconv_pack_multi_kernel(PackMulti a, int C, int G, CgDims d, float scale, int bias_col, int x3 = 0) {
     const int l = blockIdx.y;
-    cgconv_pack_body<T>(a.wf[l], a.bf[l], a.ws[l], a.bs[l], C, G, d, static_cast<T*>(a.wpack[l]), a.bpack[l], scale, bias_col, a.wn_t[l]);
+    cgconv_pack_body<T>(a.wf[l], a.bf[l], a.ws[l], a.bs[l], C, G, d, static_cast<T*>(a.wpack[l]), a.bpack[l], scale, bias_col, a.wn_t[l], x3);
 }
 
 #if MDL_EXPERIMENTS
@@ -2051,7 +2228,8 @@ static volatile int g_last_k3 = 0;
 
 template <typename T>
 static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const char* name) {
-    const CgDims d = cg_dims(p.C, p.G, dtype);
+    const bool x3 = (p.flags & MDL_SPLIT_BF16) != 0;
+    const CgDims d = cg_dims(p.C, p.G, dtype, x3);
     p.Cp = d.Cp; p.KE = d.KE; p.KT = d.KT; p.WS = d.WS; p.EKS = d.EKS; p.NS = d.NS; p.GP = d.GP;
     if (p.ldwe > 0) p.GP = p.ldwe;      // dwe rows straight into the caller's [2C, 2C + G] weight-gradient matrix (MdlCgConv.ld_dwe)
     p.w_elems = 2 * d.Cp * d.WS;
@@ -2278,7 +2456,25 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
         else if (vec == 4) MDL_CG_BY_EW(4);
         else MDL_CG_BY_EW(1);
     } else {
-        if (fast && w_lds) MDL_CG_LAUNCH(64, 50, 9, 1, 1);
+        if (x3) {
+            // fp32 storage, split-bf16 products (MDL_SPLIT_BF16): the static C = 64, G = 50 kernels with the weights in LDS only
+            if (!(fast && w_lds && p.bias_col && !wsp && !det && reinterpret_cast<uintptr_t>(p.x) % 16 == 0)) {
+                set_error("%s: MDL_SPLIT_BF16 needs fp32, C = 64, G = 50, edge features in CSR order, 16-byte aligned x", name);
+                return MDL_E_UNSUPP;
+            }
+            hipError_t e;
+            if (bwd) {
+                auto kf = cgconv_bwd_kernel<T, 64, 50, 9, 1, 1, 0, true>;
+                e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
+                if (e == hipSuccess) hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
+            } else {
+                auto kf = cgconv_fwd_kernel<T, 64, 50, 9, 1, 1, false, 0, false, true>;
+                e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
+                if (e == hipSuccess) hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
+            }
+            if (e != hipSuccess) { set_error("%s: LDS attribute (%d B): %s", name, lds, hipGetErrorString(e)); return MDL_E_LAUNCH; }
+        }
+        else if (fast && w_lds) MDL_CG_LAUNCH(64, 50, 9, 1, 1);
         else MDL_CG_BY_WL(1, 1);
     }
 #endif
@@ -2346,10 +2542,15 @@ static int cg_check(const char* name, const void* x, const void* ea, const int32
 
 }  // namespace mdl
 
+// x3 (MDL_SPLIT_BF16 OR-ed into dtype, fp32 only): the static shape the split-product kernels exist for
+static bool cg_x3_ok(int C, int G, int dtype) { return dtype == MDL_F32 && C == 64 && G == 50; }
+
 extern "C" size_t mdl_cgconv_wpack_bytes(int C, int G, int dtype) {
     using namespace mdl;
-    if (C < 1 || G < 1 || (dtype != MDL_F32 && dtype != MDL_BF16)) return 0;
-    const CgDims d = cg_dims(C, G, dtype);
+    const bool x3 = (dtype & MDL_SPLIT_BF16) != 0;
+    dtype &= ~MDL_SPLIT_BF16;
+    if (C < 1 || G < 1 || (dtype != MDL_F32 && dtype != MDL_BF16) || (x3 && !cg_x3_ok(C, G, dtype))) return 0;
+    const CgDims d = cg_dims(C, G, dtype, x3);
     const size_t b = (size_t)2 * d.Cp * d.WS * (dtype == MDL_BF16 ? 2 : 4);
     return (b + 15) & ~(size_t)15;
 }
@@ -2370,7 +2571,10 @@ static int cg_pack_weights(const float* w_f, const float* b_f, const float* w_s,
     using namespace mdl;
     MDL_REQUIRE(w_f && w_s && wpack && bpack, MDL_E_ARG, "mdl_cgconv_pack_weights: null pointer");
     MDL_REQUIRE(C >= 1 && C <= 256 && G >= 1 && G <= 64, MDL_E_UNSUPP, "mdl_cgconv_pack_weights: unsupported C=%d G=%d", C, G);
-    const CgDims d = cg_dims(C, G, dtype);
+    const bool x3 = (dtype & MDL_SPLIT_BF16) != 0;
+    dtype &= ~MDL_SPLIT_BF16;
+    MDL_REQUIRE(!x3 || cg_x3_ok(C, G, dtype), MDL_E_UNSUPP, "mdl_cgconv_pack_weights: MDL_SPLIT_BF16 needs fp32, C = 64, G = 50 (C=%d G=%d dtype=%d)", C, G, dtype);
+    const CgDims d = cg_dims(C, G, dtype, x3);
     const int total = 2 * d.Cp * d.WS;
     dim3 grid((unsigned)cdiv(total, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
@@ -2380,7 +2584,7 @@ static int cg_pack_weights(const float* w_f, const float* b_f, const float* w_s,
                            Gate<true>::W_SCALE, bias_col, (bf16_t*)wn_t);
     else if (dtype == MDL_F32)
         hipLaunchKernelGGL((cgconv_pack_kernel<float>), grid, block, 0, st, w_f, b_f, w_s, b_s, C, G, d, (float*)wpack, bpack,
-                           Gate<false>::W_SCALE, bias_col, (bf16_t*)nullptr);
+                           x3 ? Gate<true>::W_SCALE : Gate<false>::W_SCALE, bias_col, (bf16_t*)nullptr, x3 ? 1 : 0);
     else {
         set_error("mdl_cgconv_pack_weights: unsupported dtype %d", dtype);
         return MDL_E_UNSUPP;
@@ -2394,7 +2598,10 @@ extern "C" int mdl_cgconv_pack_weights_multi(int L, const float* const* w_f, con
     using namespace mdl;
     MDL_REQUIRE(L >= 1 && L <= PACK_MAXL && w_f && w_s && wpack && bpack, MDL_E_ARG, "mdl_cgconv_pack_weights_multi: 1..%d layers, non-null tables", PACK_MAXL);
     MDL_REQUIRE(C >= 1 && C <= 256 && G >= 1 && G <= 64, MDL_E_UNSUPP, "mdl_cgconv_pack_weights_multi: unsupported C=%d G=%d", C, G);
+    const bool x3 = (dtype & MDL_SPLIT_BF16) != 0;
+    dtype &= ~MDL_SPLIT_BF16;
     MDL_REQUIRE(dtype == MDL_BF16 || dtype == MDL_F32, MDL_E_UNSUPP, "mdl_cgconv_pack_weights_multi: unsupported dtype %d", dtype);
+    MDL_REQUIRE(!x3 || cg_x3_ok(C, G, dtype), MDL_E_UNSUPP, "mdl_cgconv_pack_weights_multi: MDL_SPLIT_BF16 needs fp32, C = 64, G = 50");
     MDL_REQUIRE(!wn_t || dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_cgconv_pack_weights_multi: wn_t is bf16 only");
     PackMulti a = {};
     for (int l = 0; l < L; ++l) {
@@ -2402,11 +2609,11 @@ extern "C" int mdl_cgconv_pack_weights_multi(int L, const float* const* w_f, con
         a.wf[l] = w_f[l]; a.bf[l] = b_f ? b_f[l] : nullptr; a.ws[l] = w_s[l]; a.bs[l] = b_s ? b_s[l] : nullptr;
         a.wpack[l] = wpack[l]; a.bpack[l] = bpack[l]; a.wn_t[l] = wn_t ? static_cast<bf16_t*>(wn_t[l]) : nullptr;
     }
-    const CgDims d = cg_dims(C, G, dtype);
+    const CgDims d = cg_dims(C, G, dtype, x3);
     dim3 grid((unsigned)cdiv(2 * d.Cp * d.WS, 256), (unsigned)L), block(256);
     const int bias_col = (G % 16) != 0;
     if (dtype == MDL_BF16) hipLaunchKernelGGL((cgconv_pack_multi_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a, C, G, d, Gate<true>::W_SCALE, bias_col);
-    else hipLaunchKernelGGL((cgconv_pack_multi_kernel<float>), grid, block, 0, (hipStream_t)stream, a, C, G, d, Gate<false>::W_SCALE, bias_col);
+    else hipLaunchKernelGGL((cgconv_pack_multi_kernel<float>), grid, block, 0, (hipStream_t)stream, a, C, G, d, x3 ? Gate<true>::W_SCALE : Gate<false>::W_SCALE, bias_col, x3 ? 1 : 0);
     return check_launch("mdl_cgconv_pack_weights_multi");
 }
 
@@ -2432,7 +2639,8 @@ extern "C" int mdl_cgconv_fwd_ex(const MdlCgConv* a, mdlStream_t stream) {
     using namespace mdl;
     MDL_REQUIRE(a && a->size == sizeof(MdlCgConv), MDL_E_ARG, "mdl_cgconv_fwd_ex: argument struct of another layout (size %u, expected %u)",
                 a ? a->size : 0u, (unsigned)sizeof(MdlCgConv));
-    MDL_REQUIRE((a->flags & ~(uint32_t)MDL_DETERMINISTIC) == 0, MDL_E_ARG, "mdl_cgconv_fwd_ex: unknown flag bits %#x", a->flags);
+    MDL_REQUIRE((a->flags & ~(uint32_t)(MDL_DETERMINISTIC | MDL_SPLIT_BF16)) == 0, MDL_E_ARG, "mdl_cgconv_fwd_ex: unknown flag bits %#x", a->flags);
+    MDL_REQUIRE(!(a->flags & MDL_SPLIT_BF16) || (a->dtype == MDL_F32 && !a->bn_sums), MDL_E_UNSUPP, "mdl_cgconv_fwd_ex: MDL_SPLIT_BF16 goes with MDL_F32 storage");
     int rc = cg_check("mdl_cgconv_fwd_ex", a->x, a->edge_attr, a->rowptr, a->src, a->tgt, a->wpack, a->bpack, a->N, a->E, a->C, a->G,
                       a->aggr, a->dtype);
     if (rc) return rc;
@@ -2440,6 +2648,7 @@ extern "C" int mdl_cgconv_fwd_ex(const MdlCgConv* a, mdlStream_t stream) {
     CgParams p = {};
     p.x = a->x; p.ea = a->edge_attr; p.rowptr = a->rowptr; p.src = a->src; p.tgt = a->tgt; p.eperm = a->eperm;
     p.wpack = a->wpack; p.bpack = a->bpack; p.out = a->out; p.N = a->N; p.E = a->E; p.C = a->C; p.G = a->G; p.aggr = a->aggr;
+    p.flags = (int)(a->flags & MDL_SPLIT_BF16);
     if (a->bn_sums) {
         // BatchNorm statistics in the epilogue: the static all-slices kernel only (bf16, C in {32, 64}, G = 50, CSR-ordered edge features)
         MDL_REQUIRE(cg_fwd_stats_ok(a->C, a->G, a->dtype) && !a->eperm && a->E > 0 &&
@@ -2599,8 +2808,10 @@ extern "C" int mdl_cgconv_bwd_ex(const MdlCgConv* a, mdlStream_t stream) {
     using namespace mdl;
     MDL_REQUIRE(a && a->size == sizeof(MdlCgConv), MDL_E_ARG, "mdl_cgconv_bwd_ex: argument struct of another layout (size %u, expected %u)",
                 a ? a->size : 0u, (unsigned)sizeof(MdlCgConv));
-    MDL_REQUIRE((a->flags & ~(uint32_t)(MDL_DETERMINISTIC | MDL_K3_PER_WAVE | MDL_K3_EDGE_LANE)) == 0, MDL_E_ARG,
+    MDL_REQUIRE((a->flags & ~(uint32_t)(MDL_DETERMINISTIC | MDL_K3_PER_WAVE | MDL_K3_EDGE_LANE | MDL_SPLIT_BF16)) == 0, MDL_E_ARG,
                 "mdl_cgconv_bwd_ex: unknown flag bits %#x", a->flags);
+    MDL_REQUIRE(!(a->flags & MDL_SPLIT_BF16) || (a->dtype == MDL_F32 && !(a->flags & MDL_DETERMINISTIC)), MDL_E_UNSUPP,
+                "mdl_cgconv_bwd_ex: MDL_SPLIT_BF16 goes with MDL_F32 storage (and not with MDL_DETERMINISTIC)");
     const int dtype = a->dtype;
     int rc = cg_check("mdl_cgconv_bwd_ex", a->x, a->edge_attr, a->rowptr, a->src, a->tgt, a->wpack, a->bpack, a->N, a->E, a->C, a->G,
                       a->aggr, dtype);

@@ -5,7 +5,7 @@ e.g. /root/reference/matdeeplearn/models/cgcnn.py:35-119,121-174):
 
 Constructor keywords (string booleans "True"/"False", unknown keys swallowed by **kwargs), the
 forward(batch) contract (`out.view(-1)` when the output dimension is 1) and the state_dict key names
-are the reference's.  Extra keyword: compute_dtype = "fp32" (parity mode) | "bf16".
+are the reference's.  Extra keyword: compute_dtype = "fp32" (parity mode) | "bf16x3" (fp32 storage, split-bf16 products) | "bf16".
 Dense layers are library GEMMs with fp32 master weights; everything indexed by edge_index / batch
 runs on the HIP kernels of libmdl_hip.so (matdeeplearn_amd.ops / matdeeplearn_amd.nn).
 """
@@ -43,7 +43,11 @@ class GraphModel(nn.Module):
         self.batch_track_stats = batch_track_stats != "False"
         self.batch_norm, self.pool, self.act = batch_norm, pool, act
         self.pool_order, self.dropout_rate = pool_order, dropout_rate
-        self.compute_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[compute_dtype]
+        # "bf16x3" (round 6): fp32 storage everywhere; the CGConv kernels form their K = 2C + G product as three bf16 MFMAs on
+        # (hi, lo)-split operands (ops.cgconv(split=True), MDL_SPLIT_BF16) — 16-bit operands instead of bf16's 8, 1/5 of the
+        # matrix-core time of exact fp32.  Blocks without a split form (SchNet / MEGNet / MPNN / GCN) run exact fp32 under it.
+        self.compute_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "bf16x3": torch.float32}[compute_dtype]
+        self.split_products = compute_dtype == "bf16x3"
         self.gc_dim = data.num_features if pre_fc_count == 0 else dim1
         y0 = data[0].y
         self.output_dim = 1 if y0.ndim == 0 else len(y0[0])

@@ -37,5 +37,5 @@ class CGCNN(GraphModel):
             # shape for it (nn.CGConv.forward); the sums' shift = the beta of the BatchNorm whose output this layer reads
             prev = self.bn_list[i - 1].bias if (bn_on and i > 0) else None
             out = self._drop(conv(out, None, edge_attr, csr=csr, bn=self.bn_list[i] if bn_on else None, bn_shift=prev,
-                                  packed=None if packs is None else packs[i]))
+                                  packed=None if packs is None else packs[i], split=self.split_products))
         return self._head(out, data)

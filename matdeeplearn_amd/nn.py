@@ -31,12 +31,13 @@ class CGConv(nn.Module):
         self.lin_f.reset_parameters()
         self.lin_s.reset_parameters()
 
-    def forward(self, x, edge_index, edge_attr=None, csr=None, bn=None, bn_shift=None, packed=None):
+    def forward(self, x, edge_index, edge_attr=None, csr=None, bn=None, bn_shift=None, packed=None, split=False):
         """PyG's forward(x, edge_index, edge_attr).  Extra keywords of this build: `csr` (the batch's ops.EdgeCSR; no lookup by
         edge_index), and `bn` — the BatchNorm1d the caller applies to the result (cgcnn.py:143): when it normalises with batch
         statistics and the layer runs on the static bf16 kernels, bn(conv(x)) is returned with the statistics formed in the
         conv kernel's epilogue (`bn_shift`: [C] values near the column means, e.g. the beta of the BatchNorm in front);
-        `packed`: this layer's entry of ops.cgconv_prepack (its weights packed with the model's other layers in one launch)."""
+        `packed`: this layer's entry of ops.cgconv_prepack (its weights packed with the model's other layers in one launch);
+        `split`: fp32 tensors only — the kernels' products on (hi, lo)-split bf16 operands (MDL_SPLIT_BF16, "bf16x3")."""
         if edge_attr is None:
             edge_attr = x.new_zeros((edge_index.shape[1], 0))
         if bn is not None:
@@ -46,7 +47,7 @@ class CGConv(nn.Module):
             if y is not None:
                 return y
         y = ops.cgconv(x, edge_index, edge_attr, self.lin_f.weight, self.lin_f.bias, self.lin_s.weight,
-                       self.lin_s.bias, self.aggr, csr=csr, packed=packed)
+                       self.lin_s.bias, self.aggr, csr=csr, packed=packed, split=split)
         return y if bn is None else bn(y)
 
     def extra_repr(self):

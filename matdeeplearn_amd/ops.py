@@ -662,7 +662,7 @@ def _take_rsrc(nfloats, device):
 
 class _CGConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, edge_attr, w_f, b_f, w_s, b_s, csr, aggr, bn=None, packed=None):
+    def forward(ctx, x, edge_attr, w_f, b_f, w_s, b_s, csr, aggr, bn=None, packed=None, split=False):
         require_hip(x, edge_attr, w_f, w_s)
         if edge_attr.requires_grad:
             raise MdlError("cgconv: gradients w.r.t. edge_attr are not implemented (the reference's edge features are "
@@ -676,10 +676,15 @@ class _CGConvFn(torch.autograd.Function):
             raise MdlError("cgconv: CSR (%d nodes, %d edges) does not match x/edge_attr (%d, %d)" % (csr.N, csr.E, N, E))
         dt = dtype_code(x)
         L = lib()
+        # split-bf16 products on fp32 storage (MDL_SPLIT_BF16, the "bf16x3" parity mode): where the kernels have the shape
+        # for it (C = 64, G = 50, CSR-ordered edge features); everything else of an fp32 tensor runs the exact form
+        sp = _lib.MDL_SPLIT_BF16 if (split and dt == _lib.MDL_F32 and C == 64 and G == 50 and E > 0 and not _DET
+                                     and x.data_ptr() % 16 == 0) else 0
+        ctx.split = sp
         wf32, ws32 = w_f.detach().float().contiguous(), w_s.detach().float().contiguous()
         bf32 = None if b_f is None else b_f.detach().float().contiguous()
         bs32 = None if b_s is None else b_s.detach().float().contiguous()
-        nbytes = L.mdl_cgconv_wpack_bytes(C, G, dt)
+        nbytes = L.mdl_cgconv_wpack_bytes(C, G, dt | sp)
         if nbytes == 0:
             raise MdlError("cgconv: unsupported C=%d G=%d" % (C, G))
         # widths between 97 and 127 (the reference's default dim1 = 100, config.yml:123) run the static 128-channel kernels on
@@ -703,7 +708,7 @@ class _CGConvFn(torch.autograd.Function):
             check(L.mdl_cgconv_pack_weights_node(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpack), ptr(bpack),
                                                  ptr(wn_t), dt, stream()), "mdl_cgconv_pack_weights_node")
         else:
-            check(L.mdl_cgconv_pack_weights(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpack), ptr(bpack), dt,
+            check(L.mdl_cgconv_pack_weights(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpack), ptr(bpack), dt | sp,
                                             stream()), "mdl_cgconv_pack_weights")
         ctx.wn_t = wn_t
         out = torch.empty_like(x)
@@ -711,7 +716,7 @@ class _CGConvFn(torch.autograd.Function):
         # statistics of the output for the BatchNorm behind the layer, in the kernel's epilogue (bn = (sums buffer, shift)): the
         # static bf16 kernels only — the caller (cgconv_bn_stats_ok) has checked
         bn_sums, bn_shift = bn if bn is not None else (None, None)
-        args = _lib.cg_args(dtype=dt, aggr=aggr, N=N, E=E, C=Ck, G=G, x=x, edge_attr=edge_attr, rowptr=csr.rowptr, src=csr.src,
+        args = _lib.cg_args(dtype=dt, flags=sp, aggr=aggr, N=N, E=E, C=Ck, G=G, x=x, edge_attr=edge_attr, rowptr=csr.rowptr, src=csr.src,
                             tgt=csr.tgt, wpack=wpack, bpack=bpack, out=out, bn_sums=bn_sums, bn_shift=bn_shift,
                             bn_rows=_true_rows_for(N) if bn_sums is not None else None)
         check(_launch_timed("fwd", lambda: L.mdl_cgconv_fwd_ex(args, stream())), "mdl_cgconv_fwd_ex")
@@ -766,7 +771,7 @@ class _CGConvFn(torch.autograd.Function):
         fl = _dflag()
         # node ranges of equal COST (far sources make a tile dearer): one prefix per batch, shared by all layers
         bal = csr.balance() if (rs16 and _BALANCE and E >= 400000 and not fl) else None
-        eargs = _lib.cg_args(dtype=dt, flags=fl | (_k3flag() if rs16 else 0), aggr=ctx.aggr, N=N, E=E, C=Ck, G=G, x=xk, edge_attr=edge_attr,
+        eargs = _lib.cg_args(dtype=dt, flags=fl | (_k3flag() if rs16 else 0) | getattr(ctx, "split", 0), aggr=ctx.aggr, N=N, E=E, C=Ck, G=G, x=xk, edge_attr=edge_attr,
                              rowptr=csr.rowptr, src=csr.src, tgt=csr.tgt, wpack=wpack, bpack=bpack, grad_out=gk, r_tgt=r_tgt, r_src=r_src,
                              r_src_dtype=_lib.MDL_BF16 if rs16 else _lib.MDL_F32, dwe=dwe, ld_dwe=ld_dwe, db=db, workspace=ws,
                              workspace_bytes=ws.numel(), balance=bal)
@@ -787,14 +792,14 @@ class _CGConvFn(torch.autograd.Function):
                 keep[1] = False                                                                     # handed back zeroed
             if direct:
                 return (dx, None, dW[:C].to(ctx.wdtypes[0]), db[:C].to(ctx.wdtypes[0]) if ctx.has_bias[0] else None,
-                        dW[C:].to(ctx.wdtypes[1]), db[C:].to(ctx.wdtypes[1]) if ctx.has_bias[1] else None, None, None, None, None)
+                        dW[C:].to(ctx.wdtypes[1]), db[C:].to(ctx.wdtypes[1]) if ctx.has_bias[1] else None, None, None, None, None, None)
             dW_f = torch.empty((C, 2 * C + G), dtype=torch.float32, device=x.device)
             dW_s = torch.empty_like(dW_f)
             db_f = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[0] else None
             db_s = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[1] else None
             check(_launch_timed("bwd_grads", lambda: lib().mdl_cgconv_assemble_grads(
                 ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s), stream())), "mdl_cgconv_assemble_grads")
-            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None, None, None
+            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None, None, None, None
         if dt == _lib.MDL_BF16 and Cp == 128 and C % 2 == 0 and N > 0:
             # wide layers (C = 100 / 128): the same products on the streaming kernels.  r_tgt / r_src keep their padded
             # [N, 2 Cp] layout (padded columns are exact zeros), so  dx = g + r_tgt Wn_t + r_src Wn_s  is two library GEMMs on
@@ -818,7 +823,7 @@ class _CGConvFn(torch.autograd.Function):
             db_s = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[1] else None
             check(lib().mdl_cgconv_assemble_grads(ptr(dwn), ptr(dwe), ptr(db), C, G, ptr(dW_f), ptr(dW_s), ptr(db_f), ptr(db_s),
                                                   stream()), "mdl_cgconv_assemble_grads")
-            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None, None, None
+            return dx, None, dW_f.to(ctx.wdtypes[0]), db_f, dW_s.to(ctx.wdtypes[1]), db_s, None, None, None, None, None
         Wn = torch.cat([wf32[:, :C], ws32[:, :C], wf32[:, C:2 * C], ws32[:, C:2 * C]], dim=0)      # [4C, C]
         rt = r_tgt.view(N, 2, Cp)[:, :, :C]                                                        # library GEMMs
         rs = r_src.view(N, 2, Cp)[:, :, :C]
@@ -831,7 +836,7 @@ class _CGConvFn(torch.autograd.Function):
         dW_s = torch.cat([dWn[C:2 * C], dWn[3 * C:4 * C], dwe_s], dim=1).to(ctx.wdtypes[1])
         db_f = db[:C].clone() if ctx.has_bias[0] else None
         db_s = db[Cp:Cp + C].clone() if ctx.has_bias[1] else None
-        return dx, None, dW_f, db_f, dW_s, db_s, None, None, None, None
+        return dx, None, dW_f, db_f, dW_s, db_s, None, None, None, None, None
 
 
 def cgconv_prepack(convs, x_dtype, device, want_node=True):
@@ -865,7 +870,7 @@ def cgconv_prepack(convs, x_dtype, device, want_node=True):
     return [(wbuf[k], bbuf[k], nbuf[k] if want_node else None, (C, G, dt)) for k in range(n)]
 
 
-def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None, bn_stats=None, packed=None):
+def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None, bn_stats=None, packed=None, split=False):
     """CGConv forward.  x [N,C], edge_index [2,E], edge_attr [E,G]; returns [N,C].
     bn_stats = (sums [2 R + 3, C] fp32 zero-filled, shift [C] fp32 or None): the kernel's epilogue also forms the statistics
     of its output for the BatchNorm behind the layer (callers check cgconv_bn_stats_ok first)."""
@@ -873,7 +878,7 @@ def cgconv(x, edge_index, edge_attr, w_f, b_f, w_s, b_s, aggr="mean", csr=None, 
         raise MdlError("cgconv: aggr must be mean or add")
     if csr is None:
         csr = csr_for(edge_index, x.shape[0])
-    return _CGConvFn.apply(x, edge_attr, w_f, b_f, w_s, b_s, csr, _lib.REDUCE[aggr], bn_stats, packed)
+    return _CGConvFn.apply(x, edge_attr, w_f, b_f, w_s, b_s, csr, _lib.REDUCE[aggr], bn_stats, packed, split)
 
 
 # BatchNorm statistics in the CGConv forward's epilogue (mdl_cgconv_fwd_ex, bn_sums): OPT-IN.  Measured on the bench batch

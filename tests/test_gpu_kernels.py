@@ -96,7 +96,7 @@ def test_scatter_matches_oracle(reduce, dtype, sorted_idx, C):
     close(src_d.grad, src_o.grad, *tol)
 
 
-def _cgconv_case(n, C, G, dtype, sort, seed, aggr="mean", empty_frac=0.1, window=40):
+def _cgconv_case(n, C, G, dtype, sort, seed, aggr="mean", empty_frac=0.1, window=40, split=False, tol=None):
     from matdeeplearn_amd import ops
     g = torch.Generator().manual_seed(seed)
     ei = rand_graph(n, seed, sort=sort, empty_frac=empty_frac, window=window)
@@ -118,9 +118,10 @@ def _cgconv_case(n, C, G, dtype, sort, seed, aggr="mean", empty_frac=0.1, window
     xd = x.to(d).to(dtype).requires_grad_(True)
     wfd, wsd, bfd, bsd = [t.to(d).clone().requires_grad_(True) for t in (wf, ws, bf, bs)]
     csr = ops.build_csr(ei.to(d), n, assume_sorted=sort)
-    out = ops.cgconv(xd, ei.to(d), ea.to(d).to(dtype), wfd, bfd, wsd, bsd, aggr, csr=csr)
+    out = ops.cgconv(xd, ei.to(d), ea.to(d).to(dtype), wfd, bfd, wsd, bsd, aggr, csr=csr, split=split)
     (out.float() * gout.to(d)).sum().backward()
-    tol = (2e-5, 2e-5) if dtype == torch.float32 else (3e-2, 3e-2)
+    if tol is None:
+        tol = (2e-5, 2e-5) if dtype == torch.float32 else (3e-2, 3e-2)
     close(out, ref, *tol)
     close(xd.grad, xo.grad, *tol)
     close(wfd.grad, wfo.grad, *tol)
@@ -140,6 +141,34 @@ def test_cgconv_matches_oracle(dtype, n, C, G, sort):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_cgconv_sum_aggr_and_isolated_nodes(dtype):
     _cgconv_case(150, 64, 50, dtype, True, seed=5, aggr="add", empty_frac=0.5)
+
+
+def test_cgconv_split_bf16_products_match_oracle():
+    """MDL_SPLIT_BF16 ("bf16x3": fp32 storage, the K = 2C + G product as three bf16 MFMAs on (hi, lo)-split operands) against
+    the fp32 oracle on UNROUNDED fp32 inputs: forward and every gradient to 2e-4 of the tensor scale — operands carry 16
+    significant bits (2^-17 each), i.e. ~1e-5 per product, two orders below the bf16 mode's 3e-2 — on several workgroups, partial
+    tiles, isolated nodes, far sources, sum and mean aggregation; and the flag falls back to the exact form off its shape."""
+    from matdeeplearn_amd import ops
+    t = (2e-4, 2e-4)
+    _cgconv_case(700, 64, 50, torch.float32, True, seed=31, empty_frac=0.05, split=True, tol=t)
+    _cgconv_case(2500, 64, 50, torch.float32, True, seed=33, empty_frac=0.3, split=True, tol=t)
+    _cgconv_case(90, 64, 50, torch.float32, True, seed=32, aggr="add", split=True, tol=t)
+    _cgconv_case(1500, 64, 50, torch.float32, True, seed=35, empty_frac=0.0, window=400, split=True, tol=t)
+    _cgconv_case(200, 64, 50, torch.float32, False, seed=34, split=True, tol=t)          # unsorted edge list
+    _cgconv_case(77, 32, 50, torch.float32, True, seed=36, split=True)                   # no split form at C = 32: exact, exact bound
+    # the split form really ran where it exists: its result differs from the exact form's by more than fp32 rounding
+    g = torch.Generator().manual_seed(3)
+    ei = rand_graph(300, 3, sort=True)
+    d = dev()
+    x = torch.randn(300, 64, generator=g).to(d)
+    ea = torch.rand(ei.shape[1], 50, generator=g).to(d)
+    w = [(torch.randn(64, 178, generator=g) * 0.2).to(d) for _ in range(2)]
+    b = [torch.zeros(64, device=d) for _ in range(2)]
+    csr = ops.build_csr(ei.to(d), 300, assume_sorted=True)
+    y0 = ops.cgconv(x, None, ea, w[0], b[0], w[1], b[1], "mean", csr=csr)
+    y1 = ops.cgconv(x, None, ea, w[0], b[0], w[1], b[1], "mean", csr=csr, split=True)
+    rel = float((y0 - y1).abs().max() / y0.abs().max())
+    assert 1e-7 < rel < 1e-4, rel
 
 
 @pytest.mark.parametrize("variant", ["per_wave", "edge_lane"])

@@ -168,6 +168,39 @@ def test_cfg2_cgcnn_model_fp32_and_bf16(bulk):
     assert np.isfinite([mae_ref, mae, mae16]).all()
 
 
+def test_cfg2_cgcnn_model_split_bf16_meets_the_north_star_tolerance(bulk):
+    """compute_dtype="bf16x3" (fp32 storage, the CGConv products on (hi, lo)-split bf16 operands, MDL_SPLIT_BF16) on the cfg2
+    workload against the CPU oracle at the same weights: eval prediction to 2e-4 of the prediction scale, |dMAE| < 1e-5
+    (north_star's criterion — the bf16 mode misses it by two orders), a finite training step whose loss matches the oracle's,
+    and the split form really ran (the prediction differs from the exact-fp32 product's by more than fp32 rounding)."""
+    from matdeeplearn_amd import models
+    kw = dict(dim1=64, dim2=64, pre_fc_count=1, gc_count=4, post_fc_count=3)
+    torch.manual_seed(0)
+    ref_model = omodels.CGCNN(bulk, **kw)
+    mx3 = models.CGCNN(bulk, compute_dtype="bf16x3", **kw)
+    m32 = models.CGCNN(bulk, compute_dtype="fp32", **kw)
+    assert mx3.split_products and not m32.split_products and mx3.compute_dtype == torch.float32
+    for m in (mx3, m32):
+        m.load_state_dict(ref_model.state_dict())
+        m.to(DEV)
+    bc, bg = _batches(bulk, np.arange(1024))
+    ref_model.train(); mx3.train(); m32.train()
+    lr = torch.nn.functional.mse_loss(ref_model(bc), bc.y)
+    lx = torch.nn.functional.mse_loss(mx3(bg), bg.y)
+    torch.nn.functional.mse_loss(m32(bg), bg.y)                 # (moves m32's BatchNorm buffers like the others')
+    lx.backward()
+    assert abs(float(lx) - float(lr)) < 1e-4 * max(1.0, abs(float(lr)))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mx3.parameters())
+    ref_model.eval(); mx3.eval(); m32.eval()
+    with torch.no_grad():
+        pr, px, p32 = ref_model(bc), mx3(bg), m32(bg)
+    _close(px, pr, 2e-4, "CGCNN bf16x3 eval prediction")
+    mae_ref, mae = float(torch.nn.functional.l1_loss(pr, bc.y)), float(torch.nn.functional.l1_loss(px, bg.y))
+    assert abs(mae - mae_ref) < 1e-5 * max(1.0, abs(mae_ref)), (mae, mae_ref)
+    d = float((px - p32).abs().max() / p32.abs().max())
+    assert d > 1e-7, "the split-product kernels did not run (prediction identical to the exact-fp32 form)"
+
+
 # ------------------------------------------------------------------------------------------------ cfg3
 @pytest.fixture(scope="module")
 def mof():

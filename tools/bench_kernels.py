@@ -36,7 +36,7 @@ print("N=%d E=%d" % (b.num_nodes, b.num_edges))
 ev = {"fwd": [], "bwd": [], "bwd_node": []}
 for it in range(a.iters + 2):
     ops.KERNEL_EVENTS = ev if it >= 2 else None
-    out = ops.cgconv(x, None, b.edge_attr, wf, bf, ws, bs, "mean", csr=b.csr)
+    out = ops.cgconv(x, None, b.edge_attr, wf, bf, ws, bs, "mean", csr=b.csr, split=os.environ.get("MDL_BK_SPLIT") == "1")
     if "bwd" in a.which:
         out.backward(torch.ones_like(out))
     if "rbf" in a.which:
