@@ -210,19 +210,185 @@ __global__ __launch_bounds__(64 * NW, 2) void cgconv_node_stream_kernel(const bf
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// x3 (MDL_SPLIT_BF16): the same pass on fp32 STORAGE with split-bf16 products (round 6).  r_tgt, r_src, x, grad_out and dx
+// are fp32; every tile row is split into a (hi, lo) bf16 pair while it is staged (v = hi + lo to 16 significant bits), the
+// LDS holds a hi and a lo copy of the R tile, the x tile and Wn^T (154 KB at C = 64: one 8-wave workgroup per CU), and every
+// product of the bf16 kernel runs three times: hi hi + lo hi + hi lo, fp32 accumulation.  Replaces, for the parity mode, the
+// three exact-fp32 library GEMMs + the concatenation of [r_tgt | r_src] (0.95 ms per layer at N = 2.1e5; fp32 matrix rate =
+// 1/16 of bf16) by one HBM-bound pass: N (2 Cp 4 + 2 Cp 4 + 3 C 4) bytes.
+// ------------------------------------------------------------------------------------------
+template <int CP, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void cgconv_node_x3_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+                                                                    const float* __restrict__ r_tgt, float* __restrict__ r_src,
+                                                                    const float* __restrict__ wn_t, float* __restrict__ dx,
+                                                                    float* __restrict__ dwn, int64_t N, int zero_src, int ld_out) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds4_t;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+    constexpr int TN = 64, K4 = 4 * CP, LD = K4 + 8, LX = CP + 8, NT = CP / 32, NTH = 64 * NW;
+    constexpr int RCH = 2 * CP / 4;          // 16-byte chunks (4 floats) per r_tgt / r_src row
+    constexpr int XCH = CP / 4;              // ... per x row
+    constexpr int NRL = TN * RCH / NTH;      // chunks per thread and array: 4 (CP 64, 8 waves)
+    constexpr int NXL = TN * XCH / NTH;      // 2
+    constexpr int MJ = (K4 / 32) * NT / NW;  // dWn blocks per wave: 2
+    static_assert(NRL >= 1 && NXL >= 1 && MJ >= 1 && NTH % RCH == 0 && NTH % XCH == 0 && 2 * NT <= NW, "shape / wave count");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* wl_h = reinterpret_cast<bf16_t*>(smem);      // Wn^T hi / lo [CP][LD]
+    bf16_t* wl_l = wl_h + CP * LD;
+    bf16_t* rl_h = wl_l + CP * LD;                       // R tile hi / lo [TN][LD]  (columns: r_tgt | r_src)
+    bf16_t* rl_l = rl_h + TN * LD;
+    bf16_t* xl_h = rl_l + TN * LD;                       // x tile hi / lo [TN][LX]
+    bf16_t* xl_l = xl_h + TN * LX;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto split4 = [](const f32x4& v, u32x2_t& hi, u32x2_t& lo) {
+        const unsigned ha = pk_bf16(v[0], v[1]), hb = pk_bf16(v[2], v[3]);
+        hi = u32x2_t{ha, hb};
+        lo = u32x2_t{pk_bf16(v[0] - __builtin_bit_cast(float, ha << 16), v[1] - __builtin_bit_cast(float, ha & 0xffff0000u)),
+                     pk_bf16(v[2] - __builtin_bit_cast(float, hb << 16), v[3] - __builtin_bit_cast(float, hb & 0xffff0000u))};
+    };
+    for (int q = tid; q < CP * (K4 / 4); q += NTH) {          // Wn^T (fp32 [CP][K4]) -> hi / lo LDS copies
+        const int row = q / (K4 / 4), c4 = q - row * (K4 / 4);
+        u32x2_t hi, lo;
+        split4(*reinterpret_cast<const f32x4*>(wn_t + row * K4 + c4 * 4), hi, lo);
+        *reinterpret_cast<u32x2_t*>(wl_h + row * LD + c4 * 4) = hi;
+        *reinterpret_cast<u32x2_t*>(wl_l + row * LD + c4 * 4) = lo;
+    }
+    f32x16 dw[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw[j][r] = 0.0f;
+
+    const int64_t n_tiles = (N + TN - 1) / TN;
+    f32x4 treg[NRL], sreg[NRL], xreg[NXL];
+    constexpr int RROWS = NTH / RCH, XROWS = NTH / XCH;
+    const int rrow0 = tid / RCH, rcc = tid % RCH, xrow0 = tid / XCH, xcc = tid % XCH;
+    const int ro = (rrow0 * (2 * CP) + 4 * rcc) * 4, xo = (xrow0 * CP + 4 * xcc) * 4;
+    auto rsrc = [](const void* base, int64_t bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0 ? 0 : (bytes < 0x7fffffffLL ? bytes : 0x7fffffffLL)), 0x00020000);
+    };
+    auto opaque = [](int v) { asm volatile("" : "+s"(v)); return v; };
+    auto load_tile = [&](int64_t tile) {
+        const int64_t nb = tile * TN, rem = N - nb;
+        const __amdgpu_buffer_rsrc_t tr = rsrc(r_tgt + nb * (2 * CP), rem * (2 * CP * 4));
+        const __amdgpu_buffer_rsrc_t sr = rsrc(r_src + nb * (2 * CP), rem * (2 * CP * 4));
+        const __amdgpu_buffer_rsrc_t xr = rsrc(x + nb * CP, rem * (CP * 4));
+#pragma unroll
+        for (int l = 0; l < NRL; ++l) treg[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tr, ro + opaque(l * (RROWS * 2 * CP * 4)), 0, 0));
+#pragma unroll
+        for (int l = 0; l < NRL; ++l) sreg[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sr, ro + opaque(l * (RROWS * 2 * CP * 4)), 0, 0));
+#pragma unroll
+        for (int l = 0; l < NXL; ++l) xreg[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, xo + opaque(l * (XROWS * CP * 4)), 0, 0));
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < n_tiles) load_tile(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int64_t nb = tile * TN;
+        __syncthreads();                                   // everyone is done reading the previous tile (and Wn is in)
+#pragma unroll
+        for (int l = 0; l < NRL; ++l) {
+            u32x2_t hi, lo;
+            split4(treg[l], hi, lo);
+            *reinterpret_cast<u32x2_t*>(rl_h + (rrow0 + l * RROWS) * LD + 4 * rcc) = hi;
+            *reinterpret_cast<u32x2_t*>(rl_l + (rrow0 + l * RROWS) * LD + 4 * rcc) = lo;
+            split4(sreg[l], hi, lo);
+            *reinterpret_cast<u32x2_t*>(rl_h + (rrow0 + l * RROWS) * LD + 2 * CP + 4 * rcc) = hi;
+            *reinterpret_cast<u32x2_t*>(rl_l + (rrow0 + l * RROWS) * LD + 2 * CP + 4 * rcc) = lo;
+        }
+        if (zero_src) {                                    // hand r_src back zeroed for the next edge pass (its only reader is here)
+            const __amdgpu_buffer_rsrc_t sz = rsrc(r_src + nb * (2 * CP), (N - nb) * (2 * CP * 4));
+#pragma unroll
+            for (int l = 0; l < NRL; ++l)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, sz, ro + opaque(l * (RROWS * 2 * CP * 4)), 0, 0);
+        }
+#pragma unroll
+        for (int l = 0; l < NXL; ++l) {
+            u32x2_t hi, lo;
+            split4(xreg[l], hi, lo);                       // rows past N are zeros
+            *reinterpret_cast<u32x2_t*>(xl_h + (xrow0 + l * XROWS) * LX + 4 * xcc) = hi;
+            *reinterpret_cast<u32x2_t*>(xl_l + (xrow0 + l * XROWS) * LX + 4 * xcc) = lo;
+        }
+        __syncthreads();
+        // ---- dx block (mt0, nt0) of waves 0 .. 2 NT - 1: rows = 32 nodes, K = 4Cp, cols = 32 features
+        const bool dxw = wv < 2 * NT;
+        const int mt0 = wv / NT, nt0 = wv - mt0 * NT;
+        const int64_t remg = N - nb - mt0 * 32;
+        const int go = (4 * h * CP + nt0 * 32 + i) * 4;
+        const bool more = tile + gridDim.x < n_tiles;
+        if (!dxw) {
+            if (more) load_tile(tile + gridDim.x);
+        } else {
+            float gv[16];
+            const __amdgpu_buffer_rsrc_t gr = rsrc(gout + (nb + mt0 * 32) * CP, (remg > 0 ? remg : 0) * (CP * 4));
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                gv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, go + ((r & 3) + 8 * (r >> 2)) * CP * 4, 0, 0));
+            if (more) load_tile(tile + gridDim.x);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < K4 / 16; ++kk) {
+                const int ao = (mt0 * 32 + i) * LD + 16 * kk + 8 * h, bo = (nt0 * 32 + i) * LD + 16 * kk + 8 * h;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(rl_h + ao), al = *reinterpret_cast<const bf16x8*>(rl_l + ao);
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wl_h + bo), bl = *reinterpret_cast<const bf16x8*>(wl_l + bo);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            }
+            const __amdgpu_buffer_rsrc_t dr = rsrc(dx + (nb + mt0 * 32) * CP, (remg > 0 ? remg : 0) * (CP * 4));
+#pragma unroll
+            for (int r = 0; r < 16; ++r)                                 // rows past N fall outside the resource: dropped
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gv[r] + acc[r]), dr, go + ((r & 3) + 8 * (r >> 2)) * CP * 4, 0, 0);
+        }
+        // ---- dWn blocks of this wave: rows = 32 columns of R, cols = 32 features, K = the tile's 64 nodes
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int blk = wv * MJ + j, mt = blk / NT, nt = blk - mt * NT;
+            const int t = i & 15;
+#pragma unroll
+            for (int ks = 0; ks < TN / 16; ++ks) {
+                const int pa = (16 * ks + 8 * h + (t >> 2)) * LD + mt * 32 + (i & 16) + 4 * (t & 3);
+                const int pb = (16 * ks + 8 * h + (t >> 2)) * LX + nt * 32 + (i & 16) + 4 * (t & 3);
+                auto frag = [&](const bf16_t* base, int off, int ld) {
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(base + off));
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(base + off + 4 * ld));
+                    return bf16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                };
+                const bf16x8 ah = frag(rl_h, pa, LD), al = frag(rl_l, pa, LD), bh = frag(xl_h, pb, LX), bl = frag(xl_l, pb, LX);
+                dw[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, dw[j], 0, 0, 0);
+                dw[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, dw[j], 0, 0, 0);
+                dw[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, dw[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+        const int blk = wv * MJ + j, mt = blk / NT, nt = blk - mt * NT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int R = mt * 32 + d_row(r, h), K = nt * 32 + i;
+            const int64_t at = ld_out > 0 ? (int64_t)(((R / CP) & 1) * CP + R % CP) * ld_out + ((R / CP) >> 1) * CP + K : (int64_t)R * CP + K;
+            unsafeAtomicAdd(dwn + at, dw[j][r]);
+        }
+    }
+}
+
 }  // namespace mdl
 
 namespace mdl {
 // wn_t [C][4Cp] (dtype bf16) = transpose of Wn = rows (f_tgt, s_tgt, f_src, s_src) of the two Linears' node columns
+template <typename TO>
 __global__ __launch_bounds__(256) void cgconv_pack_node_kernel(const float* __restrict__ wf, const float* __restrict__ ws, int C,
-                                                               int Cp, int ldw, bf16_t* __restrict__ wn_t) {
+                                                               int Cp, int ldw, TO* __restrict__ wn_t) {
     const int total = C * 4 * Cp;
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
         const int k = q / (4 * Cp), r = q - k * (4 * Cp);          // wn_t[k][r] = Wn[r][k]
         const int blk = r / Cp, c = r - blk * Cp;                  // blk: 0 f_tgt, 1 s_tgt, 2 f_src, 3 s_src
         float v = 0.0f;
         if (c < C) v = ((blk & 1) ? ws : wf)[c * ldw + (blk >> 1) * C + k];
-        wn_t[q] = f2bf(v);
+        if constexpr (std::is_same<TO, float>::value) wn_t[q] = v; else wn_t[q] = f2bf(v);
     }
 }
 // dW_f / dW_s [C][2C+G] and db_f / db_s [C] from the kernels' partial layouts (dwn [4Cp][C], dwe [2Cp][GP], db [2Cp])
@@ -251,10 +417,15 @@ __global__ __launch_bounds__(256) void cgconv_grads_kernel(const float* __restri
 extern "C" int mdl_cgconv_pack_node_weights(const float* w_f, const float* w_s, int C, int G, void* wn_t, int dtype,
                                             mdlStream_t stream) {
     using namespace mdl;
-    MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_cgconv_pack_node_weights: bf16 only");
+    // MDL_F32: the fp32 transpose the split-product node kernel (MDL_SPLIT_BF16) splits itself
+    MDL_REQUIRE(dtype == MDL_BF16 || dtype == MDL_F32, MDL_E_UNSUPP, "mdl_cgconv_pack_node_weights: dtype must be MDL_BF16 or MDL_F32");
     MDL_REQUIRE(w_f && w_s && wn_t && C >= 1 && G >= 0, MDL_E_ARG, "mdl_cgconv_pack_node_weights: bad arguments");
     const int Cp = (C + 31) / 32 * 32;
-    hipLaunchKernelGGL(cgconv_pack_node_kernel, dim3((unsigned)cdiv((int64_t)C * 4 * Cp, 256)), dim3(256), 0, (hipStream_t)stream, w_f,
+    if (dtype == MDL_F32)
+        hipLaunchKernelGGL(cgconv_pack_node_kernel<float>, dim3((unsigned)cdiv((int64_t)C * 4 * Cp, 256)), dim3(256), 0, (hipStream_t)stream,
+                           w_f, w_s, C, Cp, 2 * C + G, (float*)wn_t);
+    else
+    hipLaunchKernelGGL(cgconv_pack_node_kernel<bf16_t>, dim3((unsigned)cdiv((int64_t)C * 4 * Cp, 256)), dim3(256), 0, (hipStream_t)stream, w_f,
                        w_s, C, Cp, 2 * C + G, (bf16_t*)wn_t);
     return check_launch("mdl_cgconv_pack_node_weights");
 }
@@ -275,8 +446,32 @@ static int bwd_node_launch(const void* x, const void* grad_out, const void* r_tg
 extern "C" int mdl_cgconv_bwd_node_ex(const MdlCgNode* a, mdlStream_t stream) {
     MDL_REQUIRE(a && a->size == sizeof(MdlCgNode), MDL_E_ARG, "mdl_cgconv_bwd_node_ex: argument struct of another layout (size %u, expected %u)",
                 a ? a->size : 0u, (unsigned)sizeof(MdlCgNode));
-    MDL_REQUIRE((a->flags & ~(uint32_t)MDL_DETERMINISTIC) == 0, MDL_E_ARG, "mdl_cgconv_bwd_node_ex: unknown flag bits %#x", a->flags);
+    MDL_REQUIRE((a->flags & ~(uint32_t)(MDL_DETERMINISTIC | MDL_SPLIT_BF16)) == 0, MDL_E_ARG, "mdl_cgconv_bwd_node_ex: unknown flag bits %#x", a->flags);
     MDL_REQUIRE(a->r_src_dtype == MDL_F32 || a->r_src_dtype == MDL_BF16, MDL_E_ARG, "mdl_cgconv_bwd_node_ex: r_src_dtype must be MDL_F32 or MDL_BF16");
+    if (a->flags & MDL_SPLIT_BF16) {
+        // split-product node kernel: fp32 x / grad_out / r_tgt / r_src / dx, wn_t = the fp32 transpose (mdl_cgconv_pack_node_weights, MDL_F32)
+        using namespace mdl;
+        MDL_REQUIRE(a->dtype == MDL_F32 && a->r_src_dtype == MDL_F32 && a->C == 64 && !(a->flags & MDL_DETERMINISTIC), MDL_E_UNSUPP,
+                    "mdl_cgconv_bwd_node_ex: MDL_SPLIT_BF16 needs MDL_F32 storage, fp32 by-source sums, C = 64 (C=%d dtype=%d)", a->C, a->dtype);
+        MDL_REQUIRE(a->N >= 0 && (a->N == 0 || (a->x && a->grad_out && a->r_tgt && a->r_src && a->wn_t && a->dx && a->dwn)), MDL_E_ARG,
+                    "mdl_cgconv_bwd_node_ex: bad arguments");
+        MDL_REQUIRE(reinterpret_cast<uintptr_t>(a->wn_t) % 16 == 0 && reinterpret_cast<uintptr_t>(a->r_tgt) % 16 == 0 &&
+                        reinterpret_cast<uintptr_t>(a->r_src) % 16 == 0 && reinterpret_cast<uintptr_t>(a->x) % 16 == 0 &&
+                        reinterpret_cast<uintptr_t>(a->grad_out) % 4 == 0 && reinterpret_cast<uintptr_t>(a->dx) % 4 == 0, MDL_E_ARG,
+                    "mdl_cgconv_bwd_node_ex: 16-byte alignment required");
+        MDL_REQUIRE(a->ld_dwn == 0 || a->ld_dwn >= 2 * a->C, MDL_E_ARG, "mdl_cgconv_bwd_node_ex: ld_dwn (%d) below 2 C", a->ld_dwn);
+        if (a->N == 0) return MDL_OK;
+        constexpr int NWX = 8;
+        const int lds = (2 * 64 * (256 + 8) + 2 * 64 * (256 + 8) + 2 * 64 * (64 + 8)) * 2;
+        int64_t sgrid = cdiv(a->N, 64);
+        if (sgrid > 256) sgrid = 256;
+        auto kf = cgconv_node_x3_kernel<64, NWX>;
+        hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
+        if (e != hipSuccess) { set_error("mdl_cgconv_bwd_node_ex: LDS attribute (%d B): %s", lds, hipGetErrorString(e)); return MDL_E_LAUNCH; }
+        hipLaunchKernelGGL(kf, dim3((unsigned)sgrid), dim3(64 * NWX), lds, (hipStream_t)stream, (const float*)a->x, (const float*)a->grad_out,
+                           (const float*)a->r_tgt, static_cast<float*>(a->r_src), (const float*)a->wn_t, (float*)a->dx, a->dwn, a->N, a->zero_src, a->ld_dwn);
+        return check_launch("mdl_cgconv_bwd_node_ex");
+    }
     return bwd_node_launch(a->x, a->grad_out, a->r_tgt, static_cast<float*>(a->r_src), a->wn_t, a->dx, a->dwn, a->N, a->C,
                            a->dtype | (int)a->flags, a->zero_src, a->r_src_dtype == MDL_BF16, a->ld_dwn, stream);
 }

@@ -741,8 +741,10 @@ class _CGConvFn(torch.autograd.Function):
             gk = torch.nn.functional.pad(g, (0, Ck - C))
             x = x[:, :C]                                  # (the node-level part below works on the true width)
         r_tgt = torch.empty((N, 2 * Cp), dtype=x.dtype, device=x.device)          # by-target sums, compute dtype
-        node_hip = dt == _lib.MDL_BF16 and C == Cp and C in (32, 64)          # K3c consumes r_tgt / r_src
-        rs16 = (_RSRC16 and (node_hip or (Ck == 128 and dt == _lib.MDL_BF16)) and G == 50 and E > 0
+        sp = getattr(ctx, "split", 0)
+        node_x3 = bool(sp) and dt == _lib.MDL_F32 and C == 64                  # split-product node kernel (fp32 storage)
+        node_hip = (dt == _lib.MDL_BF16 and C == Cp and C in (32, 64)) or node_x3   # K3c consumes r_tgt / r_src
+        rs16 = (_RSRC16 and dt == _lib.MDL_BF16 and (node_hip or Ck == 128) and G == 50 and E > 0
                 and x.data_ptr() % 16 == 0 and edge_attr.data_ptr() % 4 == 0)
         nrs = N * 2 * Cp // 2 if rs16 else N * 2 * Cp                         # fp32 words of the by-source buffer
         keep = _take_rsrc(nrs, x.device) if node_hip else None
@@ -780,11 +782,11 @@ class _CGConvFn(torch.autograd.Function):
         if node_hip:
             wn_t, ctx.wn_t = getattr(ctx, "wn_t", None), None                                      # Wn^T (packed by the forward)
             if wn_t is None:
-                wn_t = torch.empty((C, 4 * Cp), dtype=torch.bfloat16, device=x.device)
+                wn_t = torch.empty((C, 4 * Cp), dtype=torch.float32 if node_x3 else torch.bfloat16, device=x.device)
                 check(lib().mdl_cgconv_pack_node_weights(ptr(wf32), ptr(ws32), C, G, ptr(wn_t), dt, stream()),
                       "mdl_cgconv_pack_node_weights")
             dx = torch.empty_like(x)
-            nargs = _lib.cg_node_args(dtype=dt, flags=fl, zero_src=1 if keep is not None else 0, N=N, C=C,
+            nargs = _lib.cg_node_args(dtype=dt, flags=fl | (sp if node_x3 else 0), zero_src=1 if keep is not None else 0, N=N, C=C,
                                       r_src_dtype=_lib.MDL_BF16 if rs16 else _lib.MDL_F32, ld_dwn=ldw if direct else 0, x=x, grad_out=g,
                                       r_tgt=r_tgt, r_src=r_src, wn_t=wn_t, dx=dx, dwn=dwn)
             check(_launch_timed("bwd_node", lambda: lib().mdl_cgconv_bwd_node_ex(nargs, stream())), "mdl_cgconv_bwd_node_ex")
