@@ -471,6 +471,14 @@ int mdl_cfconv_fwd(const void* rbf, const float* cut, const void* h, const int32
 int mdl_edge_mul(const void* a, const int32_t* ia, const void* b, const int32_t* ib, const float* scale, void* out,
                  int64_t E, int64_t F, int dtype, mdlStream_t stream);
 
+/* ---- split-product ("bf16x3") parity mode: operand preparation for the TN GEMM -------------------------
+ * hi[k] + lo[k] = src[k] to 16 significant bits (bf16 pair, both rounded to nearest even), so that a fp32 product runs on the
+ * bf16 matrix core as a_hi b_hi + a_lo b_hi + a_hi b_lo with fp32 accumulation.  The CGConv kernels split their operands in
+ * registers (MDL_SPLIT_BF16); this entry point prepares the operands of a node-level Linear's weight gradient dW = g^T x
+ * (the pre-FC layer, matdeeplearn/models/cgcnn.py:64-74,124-130 through autograd) for three mdl_gemm_tn launches.  n even,
+ * src 8-byte, hi / lo 4-byte aligned. */
+int mdl_split_bf16(const float* src, void* hi, void* lo, int64_t n, mdlStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,17 +17,20 @@ from .. import ops
 from ..nn import BatchNorm1d, Set2Set, lowp_copies as _lowp
 
 
-def dense(lin, h):
-    """nn.Linear in the dtype of h with fp32 master weights."""
+def dense(lin, h, split=False):
+    """nn.Linear in the dtype of h with fp32 master weights.  split (the bf16x3 mode): the weight gradient of a tall fp32 layer
+    on split bf16 operands (ops._LinearSplitTN)."""
     if h.dtype == lin.weight.dtype:
+        if split and ops.linear_split_ok(h, lin.weight):
+            return ops._LinearSplitTN.apply(h, lin.weight, lin.bias)
         return lin(h)
     return ops.linear(h, lin.weight, lin.bias, _lowp(lin))      # bf16, many rows: HIP TN GEMM for the weight gradient
 
 
-def dense_act(lin, h, act):
+def dense_act(lin, h, act, split=False):
     """getattr(F, act)(lin(h)); for bf16 activations with many rows the forward is one fused HIP kernel."""
     if h.dtype == lin.weight.dtype:
-        return getattr(F, act)(lin(h))
+        return getattr(F, act)(dense(lin, h, split))
     return ops.linear_act(h, lin.weight, lin.bias, act, _lowp(lin))
 
 
@@ -127,7 +130,7 @@ class GraphModel(nn.Module):
         if out.dtype == torch.bfloat16 and torch.is_grad_enabled():
             self._cast_dense(out.dtype)
         for lin in self.pre_lin_list:
-            out = dense_act(lin, out, self.act)
+            out = dense_act(lin, out, self.act, split=self.split_products)
         return out
 
     def _bn(self, i, out):
@@ -143,7 +146,7 @@ class GraphModel(nn.Module):
             # each are launch-bound on the pooled rows
             return ops.mlp_head(out, lins, [_lowp(lin) for lin in lins])
         for lin in self.post_lin_list:
-            out = dense_act(lin, out, self.act)
+            out = dense_act(lin, out, self.act, split=self.split_products)
         return dense(self.lin_out, out)
 
     def _pool(self, out, data):

@@ -1533,6 +1533,48 @@ def linear_act(x, weight, bias, act, lowp=None, in_act=None, out_pre=False, pre=
     return getattr(torch.nn.functional, act)(y)
 
 
+class _LinearSplitTN(torch.autograd.Function):
+    """F.linear on fp32 tensors whose WEIGHT GRADIENT dW = g^T x (contraction over the rows: N ~ 2e5 for a node-level layer) runs
+    as three bf16 TN-GEMM launches on (hi, lo)-split operands (mdl_split_bf16 + mdl_gemm_tn, fp32 accumulation) instead of the
+    library's fp32 product (0.6 ms for the pre-FC layer of the bench batch against 3 x 0.03): the "bf16x3" parity mode.  Forward
+    and dX stay the library's exact fp32 products."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        M, K = weight.shape
+        N = x.shape[0]
+        dx = g @ weight if ctx.needs_input_grad[0] else None
+
+        def split(t):
+            t = t.contiguous()
+            hi, lo = torch.empty_like(t, dtype=torch.bfloat16), torch.empty_like(t, dtype=torch.bfloat16)
+            check(lib().mdl_split_bf16(ptr(t), ptr(hi), ptr(lo), t.numel(), stream()), "mdl_split_bf16")
+            return hi, lo
+        xh, xl = split(x)
+        gh, gl = split(g)
+        dw = torch.zeros((M, K), dtype=torch.float32, device=x.device)
+        fl = _dflag()
+        for a, b in ((gl, xh), (gh, xl), (gh, xh)):
+            check(lib().mdl_gemm_tn(ptr(a), M, M, ptr(b), K, K, ptr(dw), N, _lib.MDL_BF16 | fl, stream()), "mdl_gemm_tn")
+        db = g.sum(0) if ctx.has_bias else None
+        return dx, dw.to(weight.dtype), db
+
+
+def linear_split_ok(x, weight):
+    """shapes of _LinearSplitTN: fp32 rows on a HIP device, enough of them, even widths inside mdl_gemm_tn's limits"""
+    M, K = weight.shape
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 1024
+            and M % 2 == 0 and K % 2 == 0 and M <= 128 and K <= 256 and weight.requires_grad and torch.is_grad_enabled())
+
+
 def linear(x, weight, bias, lowp=None):
     """F.linear in the dtype of x (fp32 master weights); bf16 inputs with many rows, out <= 128, in <= 256 take the
     HIP TN GEMM for dW, anything else the library autograd path.  `lowp` = (weight, bias) already cast to x.dtype."""
