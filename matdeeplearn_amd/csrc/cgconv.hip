@@ -430,11 +430,6 @@ template <int CP_, int VEC>
 struct XFrags<float, CP_, VEC, true> {
     static constexpr int NF = CP_ / 16;
     f32x4 t[NF][2], s[NF][2];
-    SplitFrag ts[NF], ss[NF];            // split ONCE per tile (split_all), used by every channel slice of the tile
-    __device__ __forceinline__ void split_all() {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) { ts[f] = split8(t[f][0], t[f][1]); ss[f] = split8(s[f][0], s[f][1]); }
-    }
     __device__ __forceinline__ void load(const float* x, int C, int my_tgt, int my_src, int h) {
         const float* xt = x + (int64_t)my_tgt * C + 8 * h;
         const float* xs = x + (int64_t)my_src * C + 8 * h;
@@ -544,13 +539,13 @@ __device__ __forceinline__ void pre_tile(const CgParams& p, const D& dm, const W
         constexpr int NF = CP_ / 16;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const SplitFrag a = xf.ts[f];
+            const SplitFrag a = split8(xf.t[f][0], xf.t[f][1]);   // (both channel slices of a tile split the same chunks: the compiler merges them)
             accf = mma_x3(a, ld_wfrag_x3(w.wbase, rowf, dm.WS, dm.KE + 16 * f, h), accf);
             accs = mma_x3(a, ld_wfrag_x3(w.wbase, rows, dm.WS, dm.KE + 16 * f, h), accs);
         }
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const SplitFrag a = xf.ss[f];
+            const SplitFrag a = split8(xf.s[f][0], xf.s[f][1]);
             accf = mma_x3(a, ld_wfrag_x3(w.wbase, rowf, dm.WS, dm.KE + dm.Cp + 16 * f, h), accf);
             accs = mma_x3(a, ld_wfrag_x3(w.wbase, rows, dm.WS, dm.KE + dm.Cp + 16 * f, h), accs);
         }
@@ -1221,7 +1216,6 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, ((sizeof(T) == 4 && CP_ != 0) ? MD
                 unsigned t4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) t4[j] = w.tsl[2 * j + h];
-                if constexpr (X3) xf.split_all();       // (the tile's x chunks were requested a tile ago: split once for all slices)
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl) {
                     f32x16 accf, accs;
@@ -1434,7 +1428,6 @@ __global__ __launch_bounds__(MDL_FWD_THREADS, ((sizeof(T) == 4 && CP_ != 0) ? MD
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
 #ifndef MDL_ABL_NOPRE
-        if constexpr (X3) xf.split_all();
         pre_tile<T, CP_, VEC, WM, NKW, 0, X3>(p, dm, w, lane, s, cur.tgt, cur.src, xf, wr, accf, accs);
 #else
         if constexpr (std::is_same<T, bf16_t>::value) {
@@ -1711,10 +1704,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accf[r] = bf; accs[r] = bs; }
             if constexpr (WSP != 0) pre_tile_wsp<CP_, 1, 0>(dm, w, lane, s, 0, pf, idf, accf, accs);
-            else {
-                if constexpr (X3) xf.split_all();
-                pre_tile<T, CP_, VEC, WM, NKW, 0, X3>(p, dm, w, lane, s, cur.tgt, cur.src, xf, wr, accf, accs);
-            }
+            else pre_tile<T, CP_, VEC, WM, NKW, 0, X3>(p, dm, w, lane, s, cur.tgt, cur.src, xf, wr, accf, accs);
             TPIN16(accf); TPIN16(accs);
             TMARK(3);
 
