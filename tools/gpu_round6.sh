@@ -9,6 +9,7 @@ NO_EXP=1 NO_BENCH=1 bash tools/gpu_suite.sh $TAG
 timeout 900 python bench.py 2> $OUT/bench_err.log | tail -1 > $OUT/bench_line.json; cut -c1-300 $OUT/bench_line.json
 bash tools/gpu_prof.sh $TAG/prof_cgcnn | tee $OUT/prof_cgcnn.txt | head -12
 bash tools/gpu_prof.sh $TAG/prof_schnet --model schnet --steps 20 --warmup 3 --settle-s 0.5 --settle-cap-s 3.0 | tee $OUT/prof_schnet.txt | head -8
+bash tools/gpu_prof.sh $TAG/prof_x3 --dtype bf16x3 --steps 10 --warmup 3 --settle-s 0.5 --settle-cap-s 2.0 | tee $OUT/prof_x3.txt | head -10
 cd $GRAFT_REPO_ROOT
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_small -o t -- python $GRAFT_REPO_ROOT/tools/bench_small.py > $OUT/small_under_rocprof.log 2>&1
