@@ -686,7 +686,8 @@ def main():
     # ---- the parity modes: same model, same batches, compute_dtype fp32 (exact products) and — CGCNN, whose conv kernels have
     # the form — bf16x3 (fp32 storage, the conv products as three bf16 MFMAs on (hi, lo)-split operands) ---------------------
     if world == 1 and args.dtype == "bf16" and (args.fp32_leg or not args.no_extras):
-        for mode in (("fp32", "bf16x3") if (cls_name == "CGCNN" and mkw.get("dim1") == 64) else ("fp32",)):
+        x3_ok = cls_name == "CGCNN" and (mkw.get("dim1") == 64 or 96 < mkw.get("dim1", 0) <= 128)   # widths the split kernels exist for
+        for mode in (("fp32", "bf16x3") if x3_ok else ("fp32",)):
             torch.manual_seed(args.seed)
             m32 = getattr(models, cls_name)(ds, compute_dtype=mode, **mkw).to(dev)
             m32.train()
@@ -759,11 +760,14 @@ def other_models(args):
                          "conv_kernel_share_of_step": j["config"].get("conv_kernel_share_of_step"),
                          "step_roofline_frac": (j.get("step_roofline") or {}).get("frac"),
                          "fp32_mode": {"ms_per_step": f32.get("ms_per_step"), "value": f32.get("value")},
-                         "val_mae_delta": cb.get("val_mae_delta"), "val_mae_delta_bf16": d16,
+                         "bf16x3_mode": ({"ms_per_step": j["bf16x3_mode"].get("ms_per_step"), "vs_bf16_step": j["bf16x3_mode"].get("vs_bf16_step")}
+                                         if j.get("bf16x3_mode") else None),
+                         "val_mae_delta": cb.get("val_mae_delta"), "val_mae_delta_bf16": d16, "val_mae_delta_bf16x3": cb.get("val_mae_delta_bf16x3"),
                          "pred_max_rel_delta_bf16": cb.get("pred_max_rel_delta_bf16"), "val_graphs": cb.get("val_graphs"),
                          # north_star's bound is |dMAE| < 1e-5 against the CPU path: which mode meets it, at what speed
                          "tolerance": {"north_star_val_mae_delta": 1e-5,
                                        "met_by": ("bf16" if d16 is not None and d16 < 1e-5 else
+                                                  "bf16x3" if cb.get("val_mae_delta_bf16x3") is not None and cb["val_mae_delta_bf16x3"] < 1e-5 else
                                                   "fp32" if cb.get("val_mae_delta") is not None and cb["val_mae_delta"] < 1e-5 else "none"),
                                        "bf16_stated": "see BASELINE.md section 5 (per-model bf16 tolerance)"},
                          "wall_s": round(time.time() - t0, 1)}
@@ -856,7 +860,7 @@ def cpu_baseline(args, ds, gpu_model, cls_name, mkw, timed_ids, va_idx):
         mae_cpu = float(torch.nn.functional.l1_loss(p_cpu, bc.y))
         scale = float(p_cpu.abs().max()) + 1e-12
         modes = [("fp32", "fp32", torch.float32), ("bf16", "bf16", torch.bfloat16)]
-        if cls_name == "CGCNN" and mkw.get("dim1") == 64:      # (the split-product kernels exist for C = 64, G = 50)
+        if cls_name == "CGCNN" and (mkw.get("dim1") == 64 or 96 < mkw.get("dim1", 0) <= 128):   # (widths the split-product kernels exist for)
             modes.insert(1, ("bf16x3", "bf16x3", torch.float32))
         for tag, cd, dt in modes:
             gm = getattr(models, cls_name)(ds, compute_dtype=cd, **mkw).to(ds.device)

@@ -1614,7 +1614,7 @@ __global__ __launch_bounds__(256, MDL_BWD_WAVES) void cgconv_bwd_kernel(CgParams
         nxt = cur;
         if (e0 + 32 < e1) nxt.template load<!ST>(p, e0 + 32, e1, i, n0);
         nn = nxt;
-        constexpr bool XDB = MDL_BWD_XDB != 0;
+        constexpr bool XDB = MDL_BWD_XDB != 0 && !(X3 && CP_ > 64);   // (x3 at 128 channels: two sets of fp32 x chunks are 256 registers)
         if constexpr (ST) ew.prefetch(p, lane, e0, min(32, e1 - e0), cur.ep);
         if constexpr (WSP != 0) pf.load(p.pt, p.ps, cur.tgt, cur.src, h, s);
         else if constexpr (CP_ != 0 && XDB) xf.load(x, dm.C, cur.tgt, cur.src, h);
@@ -2458,20 +2458,27 @@ static int cg_launch(bool bwd, CgParams& p, int dtype, hipStream_t st, const cha
     } else {
         if (x3) {
             // fp32 storage, split-bf16 products (MDL_SPLIT_BF16): the static C = 64, G = 50 kernels with the weights in LDS only
-            if (!(fast && w_lds && p.bias_col && !wsp && !det && reinterpret_cast<uintptr_t>(p.x) % 16 == 0)) {
-                set_error("%s: MDL_SPLIT_BF16 needs fp32, C = 64, G = 50, edge features in CSR order, 16-byte aligned x", name);
+            const bool x3_64 = fast && w_lds && d.Cp == 64;
+            const bool x3_128 = !p.eperm && p.G == 50 && p.C == 128 && d.Cp == 128 && w_lds && p.w_slice;   // (caller pads C = 100 to 128)
+            if (!((x3_64 || x3_128) && p.bias_col && !wsp && !det && reinterpret_cast<uintptr_t>(p.x) % 16 == 0)) {
+                set_error("%s: MDL_SPLIT_BF16 needs fp32, C = 64 or 128, G = 50, edge features in CSR order, 16-byte aligned x", name);
                 return MDL_E_UNSUPP;
             }
             hipError_t e;
-            if (bwd) {
-                auto kf = cgconv_bwd_kernel<T, 64, 50, 9, 1, 1, 0, true>;
-                e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
-                if (e == hipSuccess) hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
-            } else {
-                auto kf = cgconv_fwd_kernel<T, 64, 50, 9, 1, 1, false, 0, false, true>;
-                e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
-                if (e == hipSuccess) hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);
-            }
+#define MDL_CG_LAUNCH_X3(CP_)                                                                                                 \
+            do {                                                                                                              \
+                if (bwd) {                                                                                                    \
+                    auto kf = cgconv_bwd_kernel<T, CP_, 50, 9, 1, 1, 0, true>;                                                \
+                    e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                          \
+                    if (e == hipSuccess) hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);          \
+                } else {                                                                                                      \
+                    auto kf = cgconv_fwd_kernel<T, CP_, 50, 9, 1, 1, false, 0, false, true>;                                  \
+                    e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                          \
+                    if (e == hipSuccess) hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(waves * 64), lds, st, p);          \
+                }                                                                                                             \
+            } while (0)
+            if (x3_64) MDL_CG_LAUNCH_X3(64); else MDL_CG_LAUNCH_X3(128);
+#undef MDL_CG_LAUNCH_X3
             if (e != hipSuccess) { set_error("%s: LDS attribute (%d B): %s", name, lds, hipGetErrorString(e)); return MDL_E_LAUNCH; }
         }
         else if (fast && w_lds) MDL_CG_LAUNCH(64, 50, 9, 1, 1);
@@ -2543,7 +2550,9 @@ static int cg_check(const char* name, const void* x, const void* ea, const int32
 }  // namespace mdl
 
 // x3 (MDL_SPLIT_BF16 OR-ed into dtype, fp32 only): the static shape the split-product kernels exist for
-static bool cg_x3_ok(int C, int G, int dtype) { return dtype == MDL_F32 && C == 64 && G == 50; }
+// (C in (96, 128]: the static 128-channel kernels on zero-padded rows, one channel slice of W per workgroup — the reference's
+// default width 100, config.yml:123)
+static bool cg_x3_ok(int C, int G, int dtype) { return dtype == MDL_F32 && (C == 64 || (C > 96 && C <= 128)) && G == 50; }
 
 extern "C" size_t mdl_cgconv_wpack_bytes(int C, int G, int dtype) {
     using namespace mdl;

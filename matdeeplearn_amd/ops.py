@@ -678,8 +678,9 @@ class _CGConvFn(torch.autograd.Function):
         L = lib()
         # split-bf16 products on fp32 storage (MDL_SPLIT_BF16, the "bf16x3" parity mode): where the kernels have the shape
         # for it (C = 64, G = 50, CSR-ordered edge features); everything else of an fp32 tensor runs the exact form
-        sp = _lib.MDL_SPLIT_BF16 if (split and dt == _lib.MDL_F32 and C == 64 and G == 50 and E > 0 and not _DET
-                                     and x.data_ptr() % 16 == 0) else 0
+        # (C = 64; C in (96, 128]: the static 128-channel kernels on zero-padded rows — the reference's default width 100)
+        sp = _lib.MDL_SPLIT_BF16 if (split and dt == _lib.MDL_F32 and G == 50 and E > 0 and not _DET
+                                     and ((C == 64 and x.data_ptr() % 16 == 0) or (_PAD128 and 96 < C <= 128))) else 0
         ctx.split = sp
         wf32, ws32 = w_f.detach().float().contiguous(), w_s.detach().float().contiguous()
         bf32 = None if b_f is None else b_f.detach().float().contiguous()
@@ -691,7 +692,7 @@ class _CGConvFn(torch.autograd.Function):
         # zero-padded rows: the packed weights already have that layout (rows / K columns past C are zeros), so the padded
         # output columns hold the constant sigmoid(0) * softplus(0) and are cut off again; their gradients are zeros
         Ck = C
-        if _PAD128 and dt == _lib.MDL_BF16 and G == 50 and 96 < C < 128 and csr.eperm is None and E > 0:
+        if _PAD128 and (dt == _lib.MDL_BF16 or sp) and G == 50 and 96 < C < 128 and (csr.eperm is None or sp) and E > 0:
             Ck = 128
             x = torch.nn.functional.pad(x, (0, Ck - C))
         wn_t = None

@@ -156,6 +156,10 @@ def test_cgconv_split_bf16_products_match_oracle():
     _cgconv_case(1500, 64, 50, torch.float32, True, seed=35, empty_frac=0.0, window=400, split=True, tol=t)
     _cgconv_case(200, 64, 50, torch.float32, False, seed=34, split=True, tol=t)          # unsorted edge list
     _cgconv_case(77, 32, 50, torch.float32, True, seed=36, split=True)                   # no split form at C = 32: exact, exact bound
+    # the reference's default width (config.yml:123 dim1 = 100) and 128: the static 128-channel split kernels on zero-padded rows
+    _cgconv_case(900, 100, 50, torch.float32, True, seed=37, split=True, tol=t)
+    _cgconv_case(130, 100, 50, torch.float32, False, seed=38, split=True, tol=t)
+    _cgconv_case(65, 128, 50, torch.float32, True, seed=39, aggr="add", split=True, tol=t)
     # the split form really ran where it exists: its result differs from the exact form's by more than fp32 rounding
     g = torch.Generator().manual_seed(3)
     ei = rand_graph(300, 3, sort=True)
@@ -169,6 +173,36 @@ def test_cgconv_split_bf16_products_match_oracle():
     y1 = ops.cgconv(x, None, ea, w[0], b[0], w[1], b[1], "mean", csr=csr, split=True)
     rel = float((y0 - y1).abs().max() / y0.abs().max())
     assert 1e-7 < rel < 1e-4, rel
+
+
+def test_split_bf16_operands_and_the_split_weight_gradient():
+    """mdl_split_bf16 (raw C ABI): hi + lo reproduces an fp32 value to 2^-16 of its magnitude, hi is the round-to-nearest bf16 of
+    it; ops._LinearSplitTN (the bf16x3 mode's tall dense layer): forward and dX exact fp32, dW = g^T x over 5e4 rows on split
+    operands within 1e-4 of an fp64 product, db exact."""
+    from matdeeplearn_amd import _lib, ops
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    v = (torch.randn(4096, generator=g) * torch.exp(torch.randn(4096, generator=g) * 4)).to(d)
+    hi, lo = torch.empty_like(v, dtype=torch.bfloat16), torch.empty_like(v, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().mdl_split_bf16(_lib.ptr(v), _lib.ptr(hi), _lib.ptr(lo), v.numel(), _lib.stream()), "mdl_split_bf16")
+    assert torch.equal(hi, v.to(torch.bfloat16))
+    rec = hi.double() + lo.double()
+    assert float(((rec - v.double()).abs() / v.double().abs()).max()) < 2.0 ** -16
+    N, K, M = 50000, 114, 64
+    x = torch.randn(N, K, generator=g).to(d).requires_grad_(True)
+    w = (torch.randn(M, K, generator=g) * 0.1).to(d).requires_grad_(True)
+    b = torch.randn(M, generator=g).to(d).requires_grad_(True)
+    go = torch.randn(N, M, generator=g).to(d)
+    assert ops.linear_split_ok(x, w)
+    y = ops._LinearSplitTN.apply(x, w, b)
+    y.backward(go)
+    ref = torch.nn.functional.linear(x.detach(), w.detach(), b.detach())
+    assert torch.equal(y.detach(), ref)
+    dw64 = go.double().t() @ x.detach().double()
+    err = float((w.grad.double() - dw64).abs().max() / dw64.abs().max())
+    assert err < 1e-4, err
+    assert torch.allclose(x.grad, go @ w.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(b.grad, go.sum(0), rtol=1e-5, atol=1e-3)
 
 
 @pytest.mark.parametrize("variant", ["per_wave", "edge_lane"])
