@@ -686,8 +686,8 @@ def main():
     # ---- the parity modes: same model, same batches, compute_dtype fp32 (exact products) and — CGCNN, whose conv kernels have
     # the form — bf16x3 (fp32 storage, the conv products as three bf16 MFMAs on (hi, lo)-split operands) ---------------------
     if world == 1 and args.dtype == "bf16" and (args.fp32_leg or not args.no_extras):
-        x3_ok = cls_name == "CGCNN" and (mkw.get("dim1") == 64 or 96 < mkw.get("dim1", 0) <= 128)   # widths the split kernels exist for
-        for mode in (("fp32", "bf16x3") if x3_ok else ("fp32",)):
+        # (bf16x3: split conv kernels for CGCNN at C = 64 / (96, 128]; for every model the Linears' weight gradients on split operands)
+        for mode in ("fp32", "bf16x3"):
             torch.manual_seed(args.seed)
             m32 = getattr(models, cls_name)(ds, compute_dtype=mode, **mkw).to(dev)
             m32.train()
@@ -860,8 +860,7 @@ def cpu_baseline(args, ds, gpu_model, cls_name, mkw, timed_ids, va_idx):
         mae_cpu = float(torch.nn.functional.l1_loss(p_cpu, bc.y))
         scale = float(p_cpu.abs().max()) + 1e-12
         modes = [("fp32", "fp32", torch.float32), ("bf16", "bf16", torch.bfloat16)]
-        if cls_name == "CGCNN" and (mkw.get("dim1") == 64 or 96 < mkw.get("dim1", 0) <= 128):   # (widths the split-product kernels exist for)
-            modes.insert(1, ("bf16x3", "bf16x3", torch.float32))
+        modes.insert(1, ("bf16x3", "bf16x3", torch.float32))     # (exact fp32 forward for the models without split conv kernels)
         for tag, cd, dt in modes:
             gm = getattr(models, cls_name)(ds, compute_dtype=cd, **mkw).to(ds.device)
             gm.load_state_dict(gpu_model.state_dict())

@@ -78,6 +78,10 @@ class GraphModel(nn.Module):
         elif self.pool == "set2set" and self.pool_order == "late":
             setattr(self, set2set_names[0], Set2Set(self.output_dim, processing_steps=3, num_layers=1))
             self.lin_out_2 = nn.Linear(self.output_dim * 2, self.output_dim)
+        if self.split_products:
+            # bf16x3: the weight gradients of every Linear on split operands (the last step of every model's construction)
+            from ..nn import use_split_linears
+            use_split_linears(self)
 
     # ---- shared forward pieces ----------------------------------------------------------------
     def _inputs(self, data):

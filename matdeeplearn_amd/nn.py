@@ -54,6 +54,26 @@ class CGConv(nn.Module):
         return "%d, dim=%d, aggr=%s" % (self.channels, self.dim, self.aggr)
 
 
+class SplitLinear(nn.Linear):
+    """nn.Linear of a model in the bf16x3 mode (models/_base.py swaps the class of every Linear: same parameters, same
+    state_dict keys): forward and dX are the library's exact fp32 products; the WEIGHT GRADIENT of a tall input — g^T x with the
+    contraction over 1e5 .. 1e6 node or edge rows, which the library's fp32 path runs at ~5 TFLOP/s (half of MEGNet's exact-fp32
+    step) — runs as three bf16 TN-GEMM launches on (hi, lo)-split operands (ops._LinearSplitTN)."""
+
+    def forward(self, x):
+        if x.dim() == 2 and ops.linear_split_ok(x, self.weight):
+            return ops._LinearSplitTN.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
+def use_split_linears(model):
+    """bf16x3 mode: every plain nn.Linear of `model` becomes a SplitLinear (in place; nothing else changes)"""
+    for m in model.modules():
+        if type(m) is nn.Linear:
+            m.__class__ = SplitLinear
+    return model
+
+
 # ------------------------------------------------------------------------------------------------
 # SchNet: torch_geometric.nn.models.schnet.{ShiftedSoftplus, CFConv, InteractionBlock} (2.0.1) as
 # constructed at matdeeplearn/models/schnet.py:81 and called at schnet.py:134-143 (SURVEY A.3).

@@ -1573,7 +1573,8 @@ def linear_split_ok(x, weight):
     """shapes of _LinearSplitTN: fp32 rows on a HIP device, enough of them, even widths inside mdl_gemm_tn's limits"""
     M, K = weight.shape
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 1024
-            and M % 2 == 0 and K % 2 == 0 and M <= 128 and K <= 256 and weight.requires_grad and torch.is_grad_enabled())
+            and M % 2 == 0 and K % 2 == 0 and ((M <= 128 and K <= 256) or (M <= 160 and K <= 160))
+            and weight.requires_grad and torch.is_grad_enabled() and not _DET)
 
 
 def linear(x, weight, bias, lowp=None):

@@ -283,3 +283,41 @@ def test_product_megnet_matches_reference_goldens(tag, kw):
         ev = model(b).cpu()
     ref = torch.from_numpy(z[tag + "/pred_eval"])
     assert torch.allclose(ev, ref, rtol=1e-4, atol=1e-4 * (float(ref.abs().max()) + 1e-6))
+
+
+@pytest.mark.parametrize("name,kw", [("CGCNN", dict(dim1=64, dim2=32, gc_count=2, post_fc_count=1)),
+                                     ("SchNet", dict(dim1=32, dim2=32, dim3=50, gc_count=2, post_fc_count=1)),
+                                     ("MEGNet", dict(dim1=32, dim2=32, dim3=32, gc_count=2, gc_fc_count=1, post_fc_count=1)),
+                                     ("MPNN", dict(dim1=16, dim2=16, dim3=16, gc_count=1, post_fc_count=1)),
+                                     ("GCN", dict(dim1=32, dim2=32, gc_count=2, post_fc_count=1))])
+def test_bf16x3_mode_of_every_model_tracks_the_exact_fp32_mode(name, kw):
+    """compute_dtype="bf16x3" on every model class: same state_dict keys as fp32; the forward is the exact fp32 forward for the
+    four models without split conv kernels and the split conv products for CGCNN (C = 64): predictions within 1e-5 of the scale;
+    every parameter gradient — the Linears' weight gradients come from three bf16 TN GEMMs on split operands (nn.SplitLinear) —
+    within 2e-4 of the tensor's scale (+ 2e-5 of the model's largest gradient) of the exact mode's."""
+    from matdeeplearn_amd import models
+    from matdeeplearn_amd.process import synthetic_bulk
+    ds = synthetic_bulk(160, seed=12).to(torch.device("cuda:0"))
+    ids = np.arange(160)
+    torch.manual_seed(5)
+    m32 = getattr(models, name)(ds, compute_dtype="fp32", **kw).to("cuda:0").train()
+    mx3 = getattr(models, name)(ds, compute_dtype="bf16x3", **kw).to("cuda:0").train()
+    assert list(mx3.state_dict()) == list(m32.state_dict())
+    mx3.load_state_dict(m32.state_dict())
+    b = ds.collate(ids, edge_dtype=torch.float32, x_dtype=torch.float32)
+    assert b.num_nodes >= 1024                               # tall enough for the split weight gradient to be the path taken
+    p32, px3 = m32(b), mx3(b)
+    # (the four models without split conv kernels run the same fp32 forward kernels in both modes; their training-mode
+    # BatchNorm sums are atomically accumulated, so two runs agree to rounding, not to the bit)
+    assert float((p32 - px3).abs().max()) <= 1e-5 * (float(p32.abs().max()) + 1e-6)
+    torch.nn.functional.mse_loss(p32, b.y).backward()
+    torch.nn.functional.mse_loss(px3, b.y).backward()
+    g32 = dict(m32.named_parameters())
+    gmax = max(float(p.grad.abs().max()) for p in g32.values() if p.grad is not None)
+    for k, p in mx3.named_parameters():
+        r = g32[k].grad
+        if r is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        err = float((p.grad - r).abs().max())
+        assert err <= 2e-4 * float(r.abs().max()) + 2e-5 * gmax, (name, k, err, float(r.abs().max()), gmax)
