@@ -103,7 +103,11 @@ class GraphedStep:
             torch.cuda.synchronize(self.dev)
             self._zero_grad()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # thread-local capture mode: with a process group alive, its watchdog thread polls the events of earlier collectives
+            # (hipEventQuery) at its own pace — under the default GLOBAL mode such a call from ANOTHER thread during the capture is
+            # "operation not permitted when stream is capturing" and takes the process down (seen once in five runs of the RCCL
+            # world-1 test, round 6); only this thread's own calls belong to the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self._body()
             self.static_grads = [p.grad for p in self.params]
             with torch.no_grad():

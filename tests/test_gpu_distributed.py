@@ -139,6 +139,8 @@ def test_rccl_backend_executes_on_one_gpu():
     if os.path.isdir(out_dir):                     # keep the printed ready order / noise floor of this box
         with open(os.path.join(out_dir, "rccl_world1.log"), "w") as f:
             f.write(r.stdout[-20000:])
+            if "RCCL_OK" not in r.stdout:
+                f.write("\n---- stderr ----\n" + r.stderr[-6000:])
     assert "RCCL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
