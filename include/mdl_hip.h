@@ -467,6 +467,17 @@ int mdl_cfconv_pack_weights(const float* w1, const float* b1, const float* w2, c
 int mdl_cfconv_fwd(const void* rbf, const float* cut, const void* h, const int32_t* rowptr, const int32_t* src,
                    const int32_t* tgt, const void* wpack, void* out, void* a1, void* w, int64_t N, int64_t E, int F, int G,
                    int dtype, mdlStream_t stream);
+/* K4b (csrc/cfconv_bwd.hip) — the backward of the same block (matdeeplearn/models/schnet.py:131-145 through autograd) with the
+ * filter RECOMPUTED instead of stored.  The gradient w.r.t. h is mdl_cfconv_fwd itself on the by-source CSR with the output
+ * gradient in the place of h (rbf / cut rows in by-source order, src := target per slot, tgt := source per slot).  This entry
+ * point adds the parameter gradients of the filter network, fp32, into dw1 [F, G], db1 [F] or NULL, dw2 [F, F], db2 [F] or NULL
+ * (the caller zero-fills or accumulates) in one pass over the edges: dw_e = g[tgt_e] * h[src_e] * cut_e, a1_e recomputed,
+ * dW2 += dw^T a1, da = (dw W2) * ssp'(a1), dW1 += da^T rbf.  Nothing per edge is written.  g: [N, F] gradient w.r.t. the
+ * aggregated messages; rowptr[N] = number of edges that exist (rows of the edge arrays past it are ignored); the shapes of
+ * mdl_cfconv_supported; dtype | MDL_DETERMINISTIC: one workgroup, bit-reproducible sums. */
+int mdl_cfconv_bwd_w(const void* rbf, const float* cut, const void* h, const void* g, const int32_t* rowptr, const int32_t* src,
+                     const int32_t* tgt, const void* wpack, float* dw1, float* db1, float* dw2, float* db2, int64_t N, int64_t E,
+                     int F, int G, int dtype, mdlStream_t stream);
 /* out[e, :] = a[ia[e], :] * b[ib[e], :] * scale[e]   (gradient w.r.t. the per-edge filter w) */
 int mdl_edge_mul(const void* a, const int32_t* ia, const void* b, const int32_t* ib, const float* scale, void* out,
                  int64_t E, int64_t F, int dtype, mdlStream_t stream);

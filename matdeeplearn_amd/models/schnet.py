@@ -3,6 +3,7 @@ num_edge_features, dim3, cutoff) (:81); out = out + conv(out, edge_index, edge_w
 BatchNorm (:134-143), no activation between layers."""
 from torch import nn
 
+from .. import ops
 from ..nn import InteractionBlock, cosine_cutoff
 from ._base import GraphModel
 
@@ -23,6 +24,7 @@ class SchNet(GraphModel):
         x, edge_attr, csr = self._inputs(data)
         out = self._pre(x)
         cut = cosine_cutoff(data.edge_weight, self.conv_list[0].conv.cutoff) if len(self.conv_list) else None   # once per batch
+        by_source = ops.BySourceAttrs()                 # the backward's by-source copy of (edge_attr, cut): made once, by the last block
         for i, conv in enumerate(self.conv_list):
-            out = self._drop(self._bn(i, out + conv(out, None, data.edge_weight, edge_attr, csr=csr, cut=cut)))
+            out = self._drop(self._bn(i, out + conv(out, None, data.edge_weight, edge_attr, csr=csr, cut=cut, by_source=by_source)))
         return self._head(out, data)

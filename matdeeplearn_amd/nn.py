@@ -180,7 +180,7 @@ class CFConv(nn.Module):
         nn.init.xavier_uniform_(self.lin2.weight)
         self.lin2.bias.data.fill_(0)
 
-    def forward(self, x, edge_index, edge_weight, edge_attr, csr=None, cut=None):
+    def forward(self, x, edge_index, edge_weight, edge_attr, csr=None, cut=None, by_source=None):
         if csr is None:
             csr = ops.csr_for(edge_index, x.shape[0])
         c = cosine_cutoff(edge_weight, self.cutoff) if cut is None else cut           # [E] fp32
@@ -188,6 +188,10 @@ class CFConv(nn.Module):
         mods = list(self.nn)
         if (len(mods) == 3 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], ShiftedSoftplus) and isinstance(mods[2], nn.Linear)
                 and ops.cfconv_fused_ok(edge_attr, h, csr, mods[0], mods[2])):
+            if ops._CFCONV_RECOMPUTE and not c.requires_grad and not edge_attr.requires_grad:
+                # K4 + K4b: one autograd node, nothing stored per edge; the backward recomputes the filter (by_source: the edge
+                # features in by-source order, shared by the blocks of a model)
+                return _lin(self.lin2, ops.cfconv_recompute(edge_attr, c, h, csr, mods[0], mods[2], by_source))
             # K4: filter network, cutoff, h[src] * W and the segmented sum in ONE pass over the edges.  Under autograd the two
             # dense layers and the gather-multiply-reduce keep their nodes (the backward is theirs) — they receive the
             # activations the fused pass wrote instead of launching their own forward kernels.
@@ -220,8 +224,8 @@ class InteractionBlock(nn.Module):
         nn.init.xavier_uniform_(self.lin.weight)
         self.lin.bias.data.fill_(0)
 
-    def forward(self, x, edge_index, edge_weight, edge_attr, csr=None, cut=None):
-        return _lin(self.lin, self.act(self.conv(x, edge_index, edge_weight, edge_attr, csr=csr, cut=cut)))
+    def forward(self, x, edge_index, edge_weight, edge_attr, csr=None, cut=None, by_source=None):
+        return _lin(self.lin, self.act(self.conv(x, edge_index, edge_weight, edge_attr, csr=csr, cut=cut, by_source=by_source)))
 
 
 # ------------------------------------------------------------------------------------------------

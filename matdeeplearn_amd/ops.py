@@ -569,6 +569,7 @@ OPTIONS = {
     "cg_bn_stats": ("_CG_BN_STATS", "BatchNorm statistics in the CGConv forward's epilogue (measured time-neutral: off)"),
     "direct_grads": ("_DIRECT_GRADS", "K3 / K3c add into the final dW layout (measured slower at small batches: off)"),
     "cfconv_fused": ("_CFCONV_FUSED", "K4: the fused CFConv forward"),
+    "cfconv_recompute": ("_CFCONV_RECOMPUTE", "K4b: CFConv backward with the filter recomputed (no per-edge activations)"),
     "tn_colsum": ("_TN_COLSUM", "bias gradients out of the TN GEMM"),
     "dense_bwd": ("_DENSE_BWD", "dX + dW + db of a tall dense layer in one pass"),
     "dense_bwd_wide": ("_DENSE_BWD_WIDE", "... also when both widths exceed 128"),
@@ -1012,6 +1013,7 @@ def gather_mul_reduce(h, csr, w=None, scale=None, reduce="sum", pre=None):
 # K4 — the fused CFConv forward (csrc/cfconv.hip): filter network + cutoff + h[src] * W -> segmented sum in one pass
 # ------------------------------------------------------------------------------------------------
 _CFCONV_FUSED = True
+_CFCONV_RECOMPUTE = True
 
 
 def cfconv_fused_ok(rbf, h, csr, lin_a, lin_b):
@@ -1054,6 +1056,73 @@ def cfconv_fused(rbf, cut, h, csr, lin_a, lin_b, want_acts):
         ptr(rbf), ptr(cut), ptr(h), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(out), ptr(a1), ptr(w), N, E, F, G,
         dtype_code(h), stream())), "mdl_cfconv_fwd")
     return out, a1, w
+
+
+class BySourceAttrs:
+    """(rbf, cut) rows in by-source order for the backward of the recomputing CFConv (K4b): the same for every interaction block
+    of a model, so a model makes ONE of these per forward call and hands it to its blocks; the first backward to run gathers
+    (one mdl_gather_rows over [E, G] + one over [E]), the others reuse.  Lives exactly as long as the autograd graph of that
+    forward — nothing is keyed on tensor identity, so the in-place rewritten buffers of a HIP-graph replay are safe."""
+
+    def __init__(self):
+        self._v = None
+
+    def get(self, rbf, cut, eid_s):
+        if self._v is None:
+            idx = eid_s.long()
+            self._v = (rbf.index_select(0, idx), cut.index_select(0, idx))
+        return self._v
+
+
+class _CFConvRecompute(torch.autograd.Function):
+    """out = CFConv aggregation (mdl_cfconv_fwd, nothing stored per edge); backward: dh by the same kernel on the by-source CSR,
+    the filter network's parameter gradients by mdl_cfconv_bwd_w (csrc/cfconv_bwd.hip) — the filter is recomputed in both."""
+
+    @staticmethod
+    def forward(ctx, rbf, cut, h, w1, b1, w2, b2, csr, cache):
+        require_hip(rbf, h)
+        F, G = h.shape[1], rbf.shape[1]
+        dev = h.device
+        wpack = torch.empty(lib().mdl_cfconv_wpack_bytes(), dtype=torch.uint8, device=dev)
+        check(lib().mdl_cfconv_pack_weights(ptr(w1), ptr(b1), ptr(w2), ptr(b2), F, G, ptr(wpack), stream()), "mdl_cfconv_pack_weights")
+        out = torch.empty((csr.N, F), dtype=h.dtype, device=dev)
+        h = h.contiguous()
+        cut = cut.float().contiguous()
+        check(_launch_timed("cfconv_fwd", lambda: lib().mdl_cfconv_fwd(
+            ptr(rbf), ptr(cut), ptr(h), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(out), None, None, csr.N, csr.E,
+            F, G, dtype_code(h), stream())), "mdl_cfconv_fwd")
+        ctx.csr, ctx.cache, ctx.has_b = csr, cache, (b1 is not None, b2 is not None)
+        ctx.save_for_backward(rbf, cut, h, wpack)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rbf, cut, h, wpack = ctx.saved_tensors
+        csr = ctx.csr
+        N, E, F, G = csr.N, csr.E, h.shape[1], rbf.shape[1]
+        g = g.contiguous()
+        dh = dw1 = db1 = dw2 = db2 = None
+        if ctx.needs_input_grad[2]:
+            rowptr_s, col_s, eid_s, src_sorted = csr.transposed()
+            rbf_s, cut_s = (ctx.cache if ctx.cache is not None else BySourceAttrs()).get(rbf, cut, eid_s)
+            dh = torch.empty_like(h)
+            check(_launch_timed("cfconv_bwd_h", lambda: lib().mdl_cfconv_fwd(
+                ptr(rbf_s), ptr(cut_s), ptr(g), ptr(rowptr_s), ptr(col_s), ptr(src_sorted), ptr(wpack), ptr(dh), None, None, N, E, F, G,
+                dtype_code(h), stream())), "mdl_cfconv_fwd(T)")
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[5]:
+            buf = torch.zeros(F * G + F * F + 2 * F, dtype=torch.float32, device=h.device)
+            dw1, dw2 = buf[:F * G].view(F, G), buf[F * G:F * G + F * F].view(F, F)
+            db1 = buf[F * G + F * F:F * G + F * F + F] if ctx.has_b[0] else None
+            db2 = buf[F * G + F * F + F:] if ctx.has_b[1] else None
+            check(_launch_timed("cfconv_bwd_w", lambda: lib().mdl_cfconv_bwd_w(
+                ptr(rbf), ptr(cut), ptr(h), ptr(g), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(dw1), ptr(db1),
+                ptr(dw2), ptr(db2), N, E, F, G, dtype_code(h) | _dflag(), stream())), "mdl_cfconv_bwd_w")
+        return None, None, dh, dw1, db1, dw2, db2, None, None
+
+
+def cfconv_recompute(rbf, cut, h, csr, lin_a, lin_b, cache=None):
+    """K4 + K4b: the CFConv aggregation as ONE autograd node that stores nothing per edge (see cfconv_fused_ok for the shapes)."""
+    return _CFConvRecompute.apply(rbf, cut, h, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias, csr, cache)
 
 
 # ------------------------------------------------------------------------------------------------

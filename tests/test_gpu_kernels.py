@@ -1312,6 +1312,119 @@ def _cfconv_case(n, F, seed, empty_frac=0.1, max_in=20):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(3000, 150, 0.1, 20), (1500, 150, 0.5, 3), (2500, 130, 0.0, 40), (2000, 158, 0.1, 12)])
+def test_recomputing_cfconv_backward_matches_the_three_pass_sequence(shape, monkeypatch):
+    """K4 + K4b (ops.cfconv_recompute: the fused forward storing nothing per edge; backward = the same kernel on the by-source
+    CSR for dh + mdl_cfconv_bwd_w for the filter network's parameter gradients, filter recomputed in both) against the unfused
+    sequence (mdl_linear_act x 2 -> mdl_gather_mul_reduce and its autograd nodes) and against the fused forward with stored
+    activations: the block's output, x.grad and the gradient of EVERY parameter of the InteractionBlock; many isolated nodes,
+    in-degrees above one tile, filter widths at both ends of the supported range, with and without the by-source cache object.
+    Tolerance 3e-2 of each gradient's scale (bf16 activations in all three forms)."""
+    from matdeeplearn_amd import ops
+    n, F, empty, max_in = shape
+    conv, x, ei, dist, rbf, csr = _cfconv_case(n, F, 100 + n, empty, max_in)
+    gy = torch.randn(n, 100, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).to(dev())
+    res = {}
+    for mode in ("unfused", "stored", "recompute", "recompute_cached"):
+        monkeypatch.setattr(ops, "_CFCONV_FUSED", mode != "unfused")
+        monkeypatch.setattr(ops, "_CFCONV_RECOMPUTE", mode.startswith("recompute"))
+        ev = {"cfconv_fwd": [], "gmr_fwd": [], "cfconv_bwd_w": [], "cfconv_bwd_h": []}
+        ops.KERNEL_EVENTS = ev
+        xr = x.clone().requires_grad_(True)
+        conv.zero_grad(set_to_none=True)
+        kw = {"by_source": ops.BySourceAttrs()} if mode == "recompute_cached" else {}
+        y = conv(xr, ei, dist, rbf, csr=csr, **kw)
+        (y.float() * gy.float()).sum().backward()
+        ops.KERNEL_EVENTS = None
+        assert bool(ev["cfconv_bwd_w"]) == bool(ev["cfconv_bwd_h"]) == mode.startswith("recompute"), (mode, {k: len(v) for k, v in ev.items()})
+        assert bool(ev["gmr_fwd"]) == (mode == "unfused")
+        res[mode] = [y, xr.grad] + [p.grad for p in conv.parameters()]
+    names = ["y", "x.grad"] + [k for k, _ in conv.named_parameters()]
+    for mode in ("stored", "recompute", "recompute_cached"):
+        for nm, a, b in zip(names, res[mode], res["unfused"]):
+            assert a is not None and b is not None, (mode, nm)
+            try:
+                close(a, b, 3e-2, 3e-2)
+            except AssertionError as e:
+                raise AssertionError("%s / %s: %s" % (mode, nm, e))
+    assert torch.equal(res["recompute"][0], res["stored"][0])          # the same forward kernel, with and without the stores
+    assert torch.equal(res["recompute"][1], res["recompute_cached"][1])
+
+
+@pytest.mark.gpu
+def test_cfconv_weight_gradient_kernel_matches_fp64_and_ignores_padded_edges():
+    """mdl_cfconv_bwd_w through the raw C-ABI against fp64 arithmetic on the operands the kernel multiplies (bf16 inputs and
+    weights; dw, a1 and da rounded to bf16 where the kernel rounds them), on an edge array LONGER than the CSR covers (padded
+    static batch: the tail rows hold NaN features and must not be read into any sum); then dh = mdl_cfconv_fwd on the by-source
+    CSR against the per-edge loop; then the deterministic launch shape twice, bit-equal.  2e-2 of each gradient's scale."""
+    from matdeeplearn_amd import _lib, ops
+    d = dev()
+    L, P, st = _lib.lib(), _lib.ptr, _lib.stream
+    n, F, G, pad = 700, 150, 50, 77
+    g = torch.Generator().manual_seed(11)
+    ei = rand_graph(n, 23, sort=True, empty_frac=0.2, max_in=40)
+    E = ei.shape[1]
+    csr = ops.build_csr(ei.to(d), n, assume_sorted=True)
+    rbf = torch.rand(E + pad, G, generator=g).to(torch.bfloat16)
+    rbf[E:] = float("nan")
+    cut = torch.rand(E + pad, generator=g)
+    cut[E:] = float("nan")
+    h = torch.randn(n, F, generator=g).to(torch.bfloat16)
+    gout = torch.randn(n, F, generator=g).to(torch.bfloat16)
+    w1, b1 = torch.randn(F, G, generator=g) * 0.3, torch.randn(F, generator=g) * 0.2
+    w2, b2 = torch.randn(F, F, generator=g) * 0.1, torch.randn(F, generator=g) * 0.2
+    src = torch.cat([csr.src, torch.zeros(pad, dtype=torch.int32, device=d)])
+    tgt = torch.cat([csr.tgt, torch.zeros(pad, dtype=torch.int32, device=d)])
+    wpack = torch.empty(L.mdl_cfconv_wpack_bytes(), dtype=torch.uint8, device=d)
+    dv = [t.to(d).contiguous() for t in (rbf, cut, h, gout, w1, b1, w2, b2)]
+    _lib.check(L.mdl_cfconv_pack_weights(P(dv[4]), P(dv[5]), P(dv[6]), P(dv[7]), F, G, P(wpack), st()), "pack")
+
+    def run(flags):
+        outs = [torch.zeros(s_, dtype=torch.float32, device=d) for s_ in ((F, G), (F,), (F, F), (F,))]
+        _lib.check(L.mdl_cfconv_bwd_w(P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), P(csr.rowptr), P(src), P(tgt), P(wpack), P(outs[0]), P(outs[1]),
+                                      P(outs[2]), P(outs[3]), n, E + pad, F, G, _lib.MDL_BF16 | flags, st()), "cfconv_bwd_w")
+        return outs
+    dw1, db1, dw2, db2 = run(0)
+    bfr = lambda t: t.to(torch.bfloat16).double()
+    s_cpu, t_cpu = csr.src.cpu().long(), csr.tgt.cpu().long()
+    a1 = bfr(torch.nn.functional.softplus(bfr(rbf[:E]) @ bfr(w1).t() + bfr(b1)) - np.log(2.0))
+    dw = bfr(gout.double()[t_cpu] * h.double()[s_cpu] * cut[:E].double().view(-1, 1))
+    da = bfr((dw @ bfr(w2)) * (1.0 - torch.exp(-(a1 + np.log(2.0)))))
+    close(dw2, dw.t() @ a1, 2e-2, 2e-2)
+    close(db2, dw.sum(0), 2e-2, 2e-2)
+    close(dw1, da.t() @ bfr(rbf[:E]), 2e-2, 2e-2)
+    close(db1, da.sum(0), 2e-2, 2e-2)
+    # without bias outputs: the weight gradients alone
+    outs = [torch.zeros(F, G, device=d), torch.zeros(F, F, device=d)]
+    _lib.check(L.mdl_cfconv_bwd_w(P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), P(csr.rowptr), P(src), P(tgt), P(wpack), P(outs[0]), None,
+                                  P(outs[1]), None, n, E + pad, F, G, _lib.MDL_BF16, st()), "cfconv_bwd_w")
+    close(outs[0], dw1, 1e-3, 1e-3)
+    close(outs[1], dw2, 1e-3, 1e-3)
+    # dh: the forward kernel on the by-source CSR (g in the place of h), rbf / cut rows in by-source order
+    rowptr_s, col_s, eid_s, src_sorted = csr.transposed()
+    idx = eid_s.long()
+    rbf_s, cut_s = dv[0][:E].index_select(0, idx).contiguous(), dv[1][:E].index_select(0, idx).contiguous()
+    dh = torch.full((n, F), float("nan"), dtype=torch.bfloat16, device=d)
+    _lib.check(L.mdl_cfconv_fwd(P(rbf_s), P(cut_s), P(dv[3]), P(rowptr_s), P(col_s), P(src_sorted), P(wpack), P(dh), None, None, n, E,
+                                F, G, _lib.MDL_BF16, st()), "cfconv(T)")
+    w_ref = bfr(a1 @ bfr(w2).t() + bfr(b2))
+    dh_ref = torch.zeros(n, F, dtype=torch.float64)
+    dh_ref.index_add_(0, s_cpu, gout.double()[t_cpu] * w_ref * cut[:E].double().view(-1, 1))
+    close(dh, dh_ref, 2e-2, 2e-2)
+    # deterministic launch shape: bit-equal run to run, and equal to the parallel one within summation order
+    r1, r2 = run(_lib.MDL_DETERMINISTIC), run(_lib.MDL_DETERMINISTIC)
+    for a, b, c in zip(r1, r2, (dw1, db1, dw2, db2)):
+        assert torch.equal(a, b)
+        close(a, c, 1e-3, 1e-3)
+    # no edges at all: outputs untouched
+    z = torch.zeros(n + 1, dtype=torch.int32, device=d)
+    o = [torch.full((F, G), 7.0, device=d), torch.full((F, F), 7.0, device=d)]
+    _lib.check(L.mdl_cfconv_bwd_w(P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), P(z), P(src), P(tgt), P(wpack), P(o[0]), None, P(o[1]), None,
+                                  n, E + pad, F, G, _lib.MDL_BF16, st()), "cfconv_bwd_w")
+    assert float(o[0].min()) == 7.0 and float(o[1].max()) == 7.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3000, 150, 0.1, 20), (1500, 150, 0.5, 3), (2500, 130, 0.0, 40), (2000, 158, 0.1, 12)])
 def test_fused_cfconv_forward_matches_the_three_pass_sequence_and_trains_through_it(shape, monkeypatch):
     """K4 (mdl_cfconv_fwd: filter network -> cutoff -> h[src] * W -> segmented sum in one pass, csrc/cfconv.hip) against the
     sequence it replaces (mdl_linear_act x 2 -> mdl_gather_mul_reduce) on the same bf16 operands: the InteractionBlock's output,
@@ -1325,6 +1438,7 @@ def test_fused_cfconv_forward_matches_the_three_pass_sequence_and_trains_through
     assert csr.E >= 1024
     gy = torch.randn(n, 100, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).to(dev())
     res = {}
+    monkeypatch.setattr(ops, "_CFCONV_RECOMPUTE", False)              # the stored-activation form of the fused forward (kept as an option)
     for fused in (False, True):
         monkeypatch.setattr(ops, "_CFCONV_FUSED", fused)
         ev = {"cfconv_fwd": [], "gmr_fwd": []}
