@@ -474,10 +474,14 @@ int mdl_cfconv_fwd(const void* rbf, const float* cut, const void* h, const int32
  * (the caller zero-fills or accumulates) in one pass over the edges: dw_e = g[tgt_e] * h[src_e] * cut_e, a1_e recomputed,
  * dW2 += dw^T a1, da = (dw W2) * ssp'(a1), dW1 += da^T rbf.  Nothing per edge is written.  g: [N, F] gradient w.r.t. the
  * aggregated messages; rowptr[N] = number of edges that exist (rows of the edge arrays past it are ignored); the shapes of
- * mdl_cfconv_supported; dtype | MDL_DETERMINISTIC: one workgroup, bit-reproducible sums. */
+ * mdl_cfconv_supported; dtype | MDL_DETERMINISTIC: one workgroup, bit-reproducible sums.  scratch: NULL (the workgroups add
+ * their partial sums into the outputs with atomics) or mdl_cfconv_bwd_w_scratch_bytes() bytes, 16-byte aligned, contents
+ * undefined on entry and exit (the partial sums leave as plain stores and a second launch adds them up: 160 us less at
+ * SchNet_demo's batch). */
+size_t mdl_cfconv_bwd_w_scratch_bytes(void);
 int mdl_cfconv_bwd_w(const void* rbf, const float* cut, const void* h, const void* g, const int32_t* rowptr, const int32_t* src,
-                     const int32_t* tgt, const void* wpack, float* dw1, float* db1, float* dw2, float* db2, int64_t N, int64_t E,
-                     int F, int G, int dtype, mdlStream_t stream);
+                     const int32_t* tgt, const void* wpack, float* dw1, float* db1, float* dw2, float* db2, void* scratch, int64_t N,
+                     int64_t E, int F, int G, int dtype, mdlStream_t stream);
 /* out[e, :] = a[ia[e], :] * b[ib[e], :] * scale[e]   (gradient w.r.t. the per-edge filter w) */
 int mdl_edge_mul(const void* a, const int32_t* ia, const void* b, const int32_t* ib, const float* scale, void* out,
                  int64_t E, int64_t F, int dtype, mdlStream_t stream);

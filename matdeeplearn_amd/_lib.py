@@ -121,7 +121,8 @@ PROTOTYPES = {
     "mdl_cfconv_wpack_bytes": (_sz, []),
     "mdl_cfconv_pack_weights": (_i32, [_vp] * 4 + [_i32, _i32, _vp, _vp]),
     "mdl_cfconv_fwd": (_i32, [_vp] * 10 + [_i64, _i64, _i32, _i32, _i32, _vp]),
-    "mdl_cfconv_bwd_w": (_i32, [_vp] * 12 + [_i64, _i64, _i32, _i32, _i32, _vp]),
+    "mdl_cfconv_bwd_w_scratch_bytes": (_sz, []),
+    "mdl_cfconv_bwd_w": (_i32, [_vp] * 13 + [_i64, _i64, _i32, _i32, _i32, _vp]),
 }
 
 _lib = None

@@ -22,6 +22,11 @@
 
 #include "mdl_common.h"
 
+// experiment builds only (tools/build_variant.sh): MDL_CFB_SKIP = bit mask of phases left out, for timing ablations (results are then wrong)
+#ifndef MDL_CFB_SKIP
+#define MDL_CFB_SKIP 0
+#endif
+
 namespace mdl {
 namespace cfb {
 
@@ -61,8 +66,11 @@ struct Params {
     float* db1;              // [F] or nullptr
     float* dw2;              // [F, F]
     float* db2;              // [F] or nullptr
+    float* part;             // per-workgroup partial sums [grid][NBLK][1024] or nullptr (then: atomics into the outputs)
     int N, F;
 };
+constexpr int NBLK = NB * NB + 2 * NB;      // accumulator blocks per workgroup: 25 of dW2 (id = 5 row + col), 10 of dW1 (25 + b)
+constexpr int MAXGRID = 256, RED_SPLIT = 32;
 
 __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* base, int row, int ld, int k0, int h) {
     return *reinterpret_cast<const bf16x8*>(base + row * ld + k0 + 8 * h);
@@ -177,6 +185,10 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
         }
         cuc = vc;
         const int d0 = min(lane, FH - 1), d1 = min(tdw, FH - 1);
+        if (MDL_CFB_SKIP & 16) {            // (ablation: every row is node 0's)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) sn[r] = tn[r] = 0;
+        }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             h0[r] = reinterpret_cast<const unsigned*>(p.h + (int64_t)sn[r] * F)[d0];
@@ -232,34 +244,45 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
             request_idx(min(tile + 2 * (int64_t)gridDim.x, n_tiles - 1));
         }
 
-        // ---- S1: a1 = ssp(W1p . rbf^T) for this wave's blocks (edge block eb, unit block ub); lane = edge.  Rows of W1p are
-        // permuted (pi) so that registers 8 t .. 8 t + 7 of lane half h are units 16 t + 8 h .. + 7 of the block
+        // ---- S1: a1 = ssp(W1p . rbf^T); lane = edge.  Rows of W1p are permuted (pi) so that registers 8 t .. 8 t + 7 of lane half h
+        // are units 16 t + 8 h .. + 7 of the block.  Ten blocks (edge block eb, unit block ub) for eight waves: wave w takes
+        // (w & 1, w >> 1); the fifth unit block of edge block eb is computed by all four waves of that parity (4 MFMAs: cheap) and
+        // each applies the activation to a quarter of it — the 16 softplus values per lane are what a block costs, and a wave
+        // doing two blocks in a row was the critical path of the phase (120 of 530 us)
+        if (!(MDL_CFB_SKIP & 1)) {
+            const int eb = wv & 1, ub = wv >> 1;
+            f32x16 d, d4;
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-            const int bidx = wv + NW * bb;
-            if (bidx < 2 * NB) {
-                const int eb = bidx & 1, ub = bidx >> 1;
-                f32x16 d;
+            for (int r = 0; r < 16; ++r) d[r] = d4[r] = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) d[r] = 0.0f;
-#pragma unroll
-                for (int k = 0; k < KE / 16; ++k)
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * ub + i, ES, 16 * k, h), ld_frag(et, 32 * eb + i, ES, 16 * k, h), d, 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    u32x4 v;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        v[q] = pk_bf16(LN2_F * (GT::softplus_u(d[8 * t + 2 * q]) - 1.0f), LN2_F * (GT::softplus_u(d[8 * t + 2 * q + 1]) - 1.0f));
-                    if (ub == NB - 1 && t == 1 && h == 1) v[3] = (v[3] & 0x0000ffffu) | 0x3F800000u;      // unit FP - 1: the constant 1 (db2)
-                    *reinterpret_cast<u32x4*>(bl + (32 * eb + i) * LA + 32 * ub + 16 * t + 8 * h) = v;
-                }
+            for (int k = 0; k < KE / 16; ++k) {
+                const bf16x8 bfrag = ld_frag(et, 32 * eb + i, ES, 16 * k, h);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * ub + i, ES, 16 * k, h), bfrag, d, 0, 0, 0);
+                d4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * (NB - 1) + i, ES, 16 * k, h), bfrag, d4, 0, 0, 0);
             }
+            auto ssp2 = [](float t0, float t1) { return pk_bf16(LN2_F * (GT::softplus_u(t0) - 1.0f), LN2_F * (GT::softplus_u(t1) - 1.0f)); };
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ssp2(d[8 * t + 2 * q], d[8 * t + 2 * q + 1]);
+                *reinterpret_cast<u32x4*>(bl + (32 * eb + i) * LA + 32 * ub + 16 * t + 8 * h) = v;
+            }
+            // quarter ub of the fifth block: registers 4 ub .. 4 ub + 3 = units 128 + 16 (ub >> 1) + 8 h + 4 (ub & 1) .. + 3
+            float q0, q1, q2, q3;
+            if (ub == 0) { q0 = d4[0]; q1 = d4[1]; q2 = d4[2]; q3 = d4[3]; }
+            else if (ub == 1) { q0 = d4[4]; q1 = d4[5]; q2 = d4[6]; q3 = d4[7]; }
+            else if (ub == 2) { q0 = d4[8]; q1 = d4[9]; q2 = d4[10]; q3 = d4[11]; }
+            else { q0 = d4[12]; q1 = d4[13]; q2 = d4[14]; q3 = d4[15]; }
+            u32x2 v = u32x2{ssp2(q0, q1), ssp2(q2, q3)};
+            if (ub == 3 && h == 1) v[1] = (v[1] & 0x0000ffffu) | 0x3F800000u;                               // unit FP - 1: the constant 1 (db2)
+            *reinterpret_cast<u32x2*>(bl + (32 * eb + i) * LA + 32 * (NB - 1) + 16 * (ub >> 1) + 8 * h + 4 * (ub & 1)) = v;
         }
         __syncthreads();
 
         // ---- S2a: dW2 += dw^T . a1 (k = the tile's 64 edges)
-        if (cls2 == 0) tn_step<2, 2>(al, LA, r0, bl, LA, c0, i, h, acc);
+        if (MDL_CFB_SKIP & 2) { }
+        else if (cls2 == 0) tn_step<2, 2>(al, LA, r0, bl, LA, c0, i, h, acc);
         else if (cls2 == 1) tn_step<1, 4>(al, LA, r0, bl, LA, c0, i, h, acc);
         else if (cls2 == 2) tn_step<4, 1>(al, LA, r0, bl, LA, c0, i, h, acc);
         else if (cls2 == 3) tn_step<1, 1>(al, LA, r0, bl, LA, c0, i, h, acc);
@@ -267,7 +290,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
             const int bidx = wv + NW * bb;
-            if (bidx < 2 * NB) {
+            if (bidx < 2 * NB && !(MDL_CFB_SKIP & 4)) {
                 const int eb = bidx & 1, kb = bidx >> 1;
                 f32x16 d;
 #pragma unroll
@@ -294,12 +317,37 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
         __syncthreads();
 
         // ---- S3: dW1 += da^T . [rbf | 1]
-        tn_step<1, 1>(dl, LA, b1a >> 1, et, ES, b1a & 1, i, h, acc + 4);
-        if (b1b >= 0) tn_step<1, 1>(dl, LA, b1b >> 1, et, ES, b1b & 1, i, h, acc + 3);
+        if (!(MDL_CFB_SKIP & 8)) tn_step<1, 1>(dl, LA, b1a >> 1, et, ES, b1a & 1, i, h, acc + 4);
+        if (b1b >= 0 && !(MDL_CFB_SKIP & 8)) tn_step<1, 1>(dl, LA, b1b >> 1, et, ES, b1b & 1, i, h, acc + 3);
         // (the next tile's commit writes al and the OTHER rbf tile; bl / dl are rewritten behind the next barriers)
     }
 
-    // ---- flush: lane = column (k of dW2 / Gaussian of dW1), registers = rows (output unit m / unit)
+    if (MDL_CFB_SKIP & 32) return;
+    // ---- flush.  256 workgroups adding 35 blocks each into the same 33 k addresses with atomics cost 160 us of a 530-us launch
+    // (all workgroups finish together): with a scratch buffer the blocks leave as plain coalesced stores in accumulator layout
+    // (register r of a block: 64 consecutive floats) and cfconv_bwd_w_reduce_kernel sums them
+    if (p.part) {
+        float* const mine = p.part + (int64_t)blockIdx.x * (NBLK * 1024) + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < nblk2) {
+                float* dst = mine + (5 * (r0 + (j >> lnc)) + c0 + (j & ((1 << lnc) - 1))) * 1024;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[64 * r] = acc[j][r];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int b = j == 0 ? b1a : b1b;
+            if (b >= 0) {
+                float* dst = mine + (NB * NB + b) * 1024;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[64 * r] = acc[4 - j][r];
+            }
+        }
+        return;
+    }
+    // ---- flush with atomics: lane = column (k of dW2 / Gaussian of dW1), registers = rows (output unit m / unit)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j < nblk2) {
@@ -331,14 +379,52 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
     }
 }
 
+// sums the workgroups' partial blocks: one thread per accumulator element (block id, register, lane), the workgroup range cut in
+// RED_SPLIT pieces (gridDim.y) whose sums meet in the outputs with RED_SPLIT-way atomics
+__global__ __launch_bounds__(256) void cfconv_bwd_w_reduce_kernel(const float* __restrict__ part, int nwg, const int32_t* __restrict__ rowptr,
+                                                                   int N, int F, float* __restrict__ dw1, float* __restrict__ db1,
+                                                                   float* __restrict__ dw2, float* __restrict__ db2) {
+    nwg = min(nwg, (rowptr[N] + TE - 1) / TE);                      // workgroups without a tile (padded batch) wrote nothing
+    const int el = blockIdx.x * 256 + threadIdx.x;                  // < NBLK * 1024
+    const int id = el >> 10, r = (el >> 6) & 15, lane = el & 63, i = lane & 31, h = lane >> 5;
+    const int per = (nwg + RED_SPLIT - 1) / RED_SPLIT, w0 = blockIdx.y * per, w1 = min(nwg, w0 + per);
+    if (w0 >= w1) return;
+    // (eight workgroups' values per thread, all loads in flight at once: the pass is latency-bound otherwise — 4 pieces of 64
+    // measured 100 us for 37 MB)
+    const float* q = part + (int64_t)w0 * (NBLK * 1024) + el;
+    float v = 0.0f;
+    for (int w = w0; w < w1; w += 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = w + k < w1 ? q[(int64_t)k * (NBLK * 1024)] : 0.0f;
+        v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        q += 8 * (NBLK * 1024);
+    }
+    if (id < NB * NB) {
+        const int m = 32 * (id / NB) + d_row(r, h), col = 32 * (id % NB) + i;
+        if (m < F) {
+            if (col < F) unsafeAtomicAdd(dw2 + (int64_t)m * F + col, v);
+            else if (col == FP - 1 && db2) unsafeAtomicAdd(db2 + m, v);
+        }
+    } else {
+        const int b = id - NB * NB, u = 32 * (b >> 1) + d_row(r, h), col = 32 * (b & 1) + i;
+        if (u < F) {
+            if (col < G_) unsafeAtomicAdd(dw1 + (int64_t)u * G_ + col, v);
+            else if (col == G_ && db1) unsafeAtomicAdd(db1 + u, v);
+        }
+    }
+}
+
 }  // namespace cfb
 }  // namespace mdl
 
 using namespace mdl;
 
+extern "C" size_t mdl_cfconv_bwd_w_scratch_bytes(void) { return (size_t)cfb::MAXGRID * cfb::NBLK * 1024 * sizeof(float); }
+
 extern "C" int mdl_cfconv_bwd_w(const void* rbf, const float* cut, const void* h, const void* g, const int32_t* rowptr,
                                 const int32_t* src, const int32_t* tgt, const void* wpack, float* dw1, float* db1, float* dw2,
-                                float* db2, int64_t N, int64_t E, int F, int G, int dtype, mdlStream_t stream) {
+                                float* db2, void* scratch, int64_t N, int64_t E, int F, int G, int dtype, mdlStream_t stream) {
     const bool det = (dtype & MDL_DETERMINISTIC) != 0;      // one workgroup: every element gets its adds from one wave in tile order
     dtype &= MDL_DTYPE_MASK;
     MDL_REQUIRE(mdl_cfconv_supported(F, G, dtype), MDL_E_UNSUPP, "mdl_cfconv_bwd_w: bf16, G = 50 and even F in (128, 158] only (F = %d, G = %d, dtype %d)", F, G, dtype);
@@ -348,11 +434,16 @@ extern "C" int mdl_cfconv_bwd_w(const void* rbf, const float* cut, const void* h
     MDL_REQUIRE(((uintptr_t)rbf % 4) == 0 && ((uintptr_t)h % 4) == 0 && ((uintptr_t)g % 4) == 0 && ((uintptr_t)wpack % 16) == 0, MDL_E_ARG,
                 "mdl_cfconv_bwd_w: misaligned tensor");
     cfb::Params p{static_cast<const bf16_t*>(rbf), cut, static_cast<const bf16_t*>(h), static_cast<const bf16_t*>(g), rowptr, src, tgt,
-                  static_cast<const bf16_t*>(wpack), dw1, db1, dw2, db2, (int)N, F};
-    const int64_t grid = det ? 1 : std::min<int64_t>(256, std::max<int64_t>(1, cdiv(E, cfb::TE)));
+                  static_cast<const bf16_t*>(wpack), dw1, db1, dw2, db2, det ? nullptr : static_cast<float*>(scratch), (int)N, F};
+    MDL_REQUIRE(((uintptr_t)scratch % 16) == 0, MDL_E_ARG, "mdl_cfconv_bwd_w: misaligned scratch");
+    const int64_t grid = det ? 1 : std::min<int64_t>(cfb::MAXGRID, std::max<int64_t>(1, cdiv(E, cfb::TE)));
     auto kf = cfb::cfconv_bwd_w_kernel;
     hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), cfb::LDS);
     if (e != hipSuccess) { set_error("mdl_cfconv_bwd_w: LDS attribute (%d B): %s", cfb::LDS, hipGetErrorString(e)); return MDL_E_LAUNCH; }
     hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(cfb::NT), cfb::LDS, (hipStream_t)stream, p);
+    if (p.part) {
+        hipLaunchKernelGGL(cfb::cfconv_bwd_w_reduce_kernel, dim3(cfb::NBLK * 1024 / 256, cfb::RED_SPLIT), dim3(256), 0, (hipStream_t)stream,
+                           p.part, (int)grid, rowptr, (int)N, F, dw1, db1, dw2, db2);
+    }
     return check_launch("mdl_cfconv_bwd_w");
 }

@@ -1114,9 +1114,10 @@ class _CFConvRecompute(torch.autograd.Function):
             dw1, dw2 = buf[:F * G].view(F, G), buf[F * G:F * G + F * F].view(F, F)
             db1 = buf[F * G + F * F:F * G + F * F + F] if ctx.has_b[0] else None
             db2 = buf[F * G + F * F + F:] if ctx.has_b[1] else None
+            scratch = torch.empty(lib().mdl_cfconv_bwd_w_scratch_bytes(), dtype=torch.uint8, device=h.device)
             check(_launch_timed("cfconv_bwd_w", lambda: lib().mdl_cfconv_bwd_w(
                 ptr(rbf), ptr(cut), ptr(h), ptr(g), ptr(csr.rowptr), ptr(csr.src), ptr(csr.tgt), ptr(wpack), ptr(dw1), ptr(db1),
-                ptr(dw2), ptr(db2), N, E, F, G, dtype_code(h) | _dflag(), stream())), "mdl_cfconv_bwd_w")
+                ptr(dw2), ptr(db2), ptr(scratch), N, E, F, G, dtype_code(h) | _dflag(), stream())), "mdl_cfconv_bwd_w")
         return None, None, dh, dw1, db1, dw2, db2, None, None
 
 

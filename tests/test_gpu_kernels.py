@@ -1378,12 +1378,14 @@ def test_cfconv_weight_gradient_kernel_matches_fp64_and_ignores_padded_edges():
     dv = [t.to(d).contiguous() for t in (rbf, cut, h, gout, w1, b1, w2, b2)]
     _lib.check(L.mdl_cfconv_pack_weights(P(dv[4]), P(dv[5]), P(dv[6]), P(dv[7]), F, G, P(wpack), st()), "pack")
 
-    def run(flags):
+    scratch = torch.full((L.mdl_cfconv_bwd_w_scratch_bytes() // 4,), float("nan"), device=d)
+
+    def run(flags, scr=None):
         outs = [torch.zeros(s_, dtype=torch.float32, device=d) for s_ in ((F, G), (F,), (F, F), (F,))]
         _lib.check(L.mdl_cfconv_bwd_w(P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), P(csr.rowptr), P(src), P(tgt), P(wpack), P(outs[0]), P(outs[1]),
-                                      P(outs[2]), P(outs[3]), n, E + pad, F, G, _lib.MDL_BF16 | flags, st()), "cfconv_bwd_w")
+                                      P(outs[2]), P(outs[3]), P(scr), n, E + pad, F, G, _lib.MDL_BF16 | flags, st()), "cfconv_bwd_w")
         return outs
-    dw1, db1, dw2, db2 = run(0)
+    dw1, db1, dw2, db2 = run(0)                                # partial sums added with atomics
     bfr = lambda t: t.to(torch.bfloat16).double()
     s_cpu, t_cpu = csr.src.cpu().long(), csr.tgt.cpu().long()
     a1 = bfr(torch.nn.functional.softplus(bfr(rbf[:E]) @ bfr(w1).t() + bfr(b1)) - np.log(2.0))
@@ -1393,10 +1395,12 @@ def test_cfconv_weight_gradient_kernel_matches_fp64_and_ignores_padded_edges():
     close(db2, dw.sum(0), 2e-2, 2e-2)
     close(dw1, da.t() @ bfr(rbf[:E]), 2e-2, 2e-2)
     close(db1, da.sum(0), 2e-2, 2e-2)
+    for a, c in zip(run(0, scratch), (dw1, db1, dw2, db2)):    # the two-launch form (partial sums through the scratch buffer): the same sums
+        close(a, c, 1e-3, 1e-3)
     # without bias outputs: the weight gradients alone
     outs = [torch.zeros(F, G, device=d), torch.zeros(F, F, device=d)]
     _lib.check(L.mdl_cfconv_bwd_w(P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), P(csr.rowptr), P(src), P(tgt), P(wpack), P(outs[0]), None,
-                                  P(outs[1]), None, n, E + pad, F, G, _lib.MDL_BF16, st()), "cfconv_bwd_w")
+                                  P(outs[1]), None, P(scratch), n, E + pad, F, G, _lib.MDL_BF16, st()), "cfconv_bwd_w")
     close(outs[0], dw1, 1e-3, 1e-3)
     close(outs[1], dw2, 1e-3, 1e-3)
     # dh: the forward kernel on the by-source CSR (g in the place of h), rbf / cut rows in by-source order
@@ -1419,7 +1423,7 @@ def test_cfconv_weight_gradient_kernel_matches_fp64_and_ignores_padded_edges():
     z = torch.zeros(n + 1, dtype=torch.int32, device=d)
     o = [torch.full((F, G), 7.0, device=d), torch.full((F, F), 7.0, device=d)]
     _lib.check(L.mdl_cfconv_bwd_w(P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), P(z), P(src), P(tgt), P(wpack), P(o[0]), None, P(o[1]), None,
-                                  n, E + pad, F, G, _lib.MDL_BF16, st()), "cfconv_bwd_w")
+                                  P(scratch), n, E + pad, F, G, _lib.MDL_BF16, st()), "cfconv_bwd_w")
     assert float(o[0].min()) == 7.0 and float(o[1].max()) == 7.0
 
 

@@ -21,10 +21,11 @@ w2, b2 = torch.randn(F, F, generator=g) * 0.1, torch.randn(F, generator=g) * 0.2
 wpack = torch.empty(L.mdl_cfconv_wpack_bytes(), dtype=torch.uint8, device=d)
 dv = [t.to(d).contiguous() for t in (rbf, cut, h, gout, w1, b1, w2, b2)]
 _lib.check(L.mdl_cfconv_pack_weights(P(dv[4]), P(dv[5]), P(dv[6]), P(dv[7]), F, G, P(wpack), st()), "pack")
+scratch = None if os.environ.get('NOSCRATCH') else torch.empty(L.mdl_cfconv_bwd_w_scratch_bytes(), dtype=torch.uint8, device='cuda:0')
 outs = [torch.zeros(s_, dtype=torch.float32, device=d) for s_ in ((F, G), (F,), (F, F), (F,))]
 flags = _lib.MDL_DETERMINISTIC if os.environ.get("DET") else 0
 _lib.check(L.mdl_cfconv_bwd_w(P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), P(csr.rowptr), P(csr.src), P(csr.tgt), P(wpack), P(outs[0]), P(outs[1]),
-                              P(outs[2]), P(outs[3]), n, E, F, G, _lib.MDL_BF16 | flags, st()), "cfconv_bwd_w")
+                              P(outs[2]), P(outs[3]), P(scratch), n, E, F, G, _lib.MDL_BF16 | flags, st()), "cfconv_bwd_w")
 torch.cuda.synchronize()
 bfr = lambda t: t.to(torch.bfloat16).double()
 s_cpu, t_cpu = csr.src.cpu().long(), csr.tgt.cpu().long()
