@@ -181,6 +181,11 @@ class CFConv(nn.Module):
         self.lin2.bias.data.fill_(0)
 
     def forward(self, x, edge_index, edge_weight, edge_attr, csr=None, cut=None, by_source=None):
+        return _lin(self.lin2, self.aggregate(x, edge_index, edge_weight, edge_attr, csr=csr, cut=cut, by_source=by_source))
+
+    def aggregate(self, x, edge_index, edge_weight, edge_attr, csr=None, cut=None, by_source=None):
+        """sum_j lin1(x)_j * W(e_ij) * C(d_ij): the convolution in front of lin2 (InteractionBlock chains lin2 -> ssp -> lin as
+        ONE fused sequence behind it)"""
         if csr is None:
             csr = ops.csr_for(edge_index, x.shape[0])
         c = cosine_cutoff(edge_weight, self.cutoff) if cut is None else cut           # [E] fp32
@@ -191,7 +196,7 @@ class CFConv(nn.Module):
             if ops._CFCONV_RECOMPUTE and not c.requires_grad and not edge_attr.requires_grad:
                 # K4 + K4b: one autograd node, nothing stored per edge; the backward recomputes the filter (by_source: the edge
                 # features in by-source order, shared by the blocks of a model)
-                return _lin(self.lin2, ops.cfconv_recompute(edge_attr, c, h, csr, mods[0], mods[2], by_source))
+                return ops.cfconv_recompute(edge_attr, c, h, csr, mods[0], mods[2], by_source)
             # K4: filter network, cutoff, h[src] * W and the segmented sum in ONE pass over the edges.  Under autograd the two
             # dense layers and the gather-multiply-reduce keep their nodes (the backward is theirs) — they receive the
             # activations the fused pass wrote instead of launching their own forward kernels.
@@ -200,10 +205,9 @@ class CFConv(nn.Module):
             if train:
                 w = _seq(self.nn, edge_attr, pre=[a1, w])
                 agg = ops.gather_mul_reduce(h, csr, w=w, scale=c, reduce="sum", pre=agg)
-            return _lin(self.lin2, agg)
+            return agg
         w = _seq(self.nn, edge_attr)                                                  # filter  [E, F]
-        agg = ops.gather_mul_reduce(h, csr, w=w.to(h.dtype), scale=c, reduce="sum")
-        return _lin(self.lin2, agg)
+        return ops.gather_mul_reduce(h, csr, w=w.to(h.dtype), scale=c, reduce="sum")
 
 
 class InteractionBlock(nn.Module):
@@ -225,7 +229,10 @@ class InteractionBlock(nn.Module):
         self.lin.bias.data.fill_(0)
 
     def forward(self, x, edge_index, edge_weight, edge_attr, csr=None, cut=None, by_source=None):
-        return _lin(self.lin, self.act(self.conv(x, edge_index, edge_weight, edge_attr, csr=csr, cut=cut, by_source=by_source)))
+        # lin(ssp(lin2(agg))) as one chain: fused dense layers with the activation in the first one's epilogue and its derivative
+        # handed down from the second one's backward (no softplus / softplus_backward passes over [N, C])
+        agg = self.conv.aggregate(x, edge_index, edge_weight, edge_attr, csr=csr, cut=cut, by_source=by_source)
+        return _seq([self.conv.lin2, self.act, self.lin], agg)
 
 
 # ------------------------------------------------------------------------------------------------

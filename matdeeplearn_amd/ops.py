@@ -1069,8 +1069,10 @@ class BySourceAttrs:
 
     def get(self, rbf, cut, eid_s):
         if self._v is None:
-            idx = eid_s.long()
-            self._v = (rbf.index_select(0, idx), cut.index_select(0, idx))
+            rbf_s = torch.empty_like(rbf)
+            check(lib().mdl_gather_rows(ptr(rbf), ptr(eid_s), ptr(rbf_s), eid_s.numel(), rbf.shape[1], dtype_code(rbf), stream()),
+                  "mdl_gather_rows")                 # (torch's index_select on [E, 50] bf16 rows: 177 us against 60)
+            self._v = (rbf_s, cut.index_select(0, eid_s.long()))
         return self._v
 
 
