@@ -1112,7 +1112,7 @@ class _CFConvRecompute(torch.autograd.Function):
                 ptr(rbf_s), ptr(cut_s), ptr(g), ptr(rowptr_s), ptr(col_s), ptr(src_sorted), ptr(wpack), ptr(dh), None, None, N, E, F, G,
                 dtype_code(h), stream())), "mdl_cfconv_fwd(T)")
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[5]:
-            buf = torch.zeros(F * G + F * F + 2 * F, dtype=torch.float32, device=h.device)
+            buf = torch.zeros(F * G + F * F + 2 * F, dtype=torch.float32, device=h.device)    # (not the step arena: autograd may adopt these views as .grad)
             dw1, dw2 = buf[:F * G].view(F, G), buf[F * G:F * G + F * F].view(F, F)
             db1 = buf[F * G + F * F:F * G + F * F + F] if ctx.has_b[0] else None
             db2 = buf[F * G + F * F + F:] if ctx.has_b[1] else None
