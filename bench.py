@@ -364,7 +364,7 @@ def main():
     dp = FlatDataParallel(model, force=use_dist)
     opt = make_optimizer(model.parameters(), "AdamW", lr=0.002 * world)   # lr x world_size, training.py:388-389
 
-    ktimes = {"cgcnn": {"fwd": [], "bwd": [], "bwd_node": [], "bwd_grads": []}, "schnet": {"gmr_fwd": [], "cfconv_fwd": []}, "megnet": {"edge_linear": []},
+    ktimes = {"cgcnn": {"fwd": [], "bwd": [], "bwd_node": [], "bwd_grads": []}, "schnet": {"gmr_fwd": [], "cfconv_fwd": [], "cfconv_bwd_h": [], "cfconv_bwd_w": []}, "megnet": {"edge_linear": []},
               "gcn": {"gmr_fwd": []}, "mpnn": {"nnconv_fwd": []}}[args.model]
 
     prefetch = not args.no_prefetch
@@ -489,8 +489,14 @@ def main():
         ab = {"gmr_fwd": e_ev * (2 * F_ * s + 8) + n_ev * (F_ * s + 4),
               # K4 (fused forward, csrc/cfconv.hip), SURVEY 8d: E(G s + 4 + F s + 4) + N(2 F s + 4) — the training form also WRITES the two
               # activations the backward reads (2 E F s), which SURVEY's figure (filter recomputed in the backward) does not count
-              "cfconv_fwd": e_ev * (G * s + 4 + F_ * s + 4) + n_ev * (2 * F_ * s + 4)}
-        kname = {"gmr_fwd": "mdl_gather_mul_reduce", "cfconv_fwd": "mdl_cfconv_fwd (K4: filter network + cutoff + h[src] * W + segmented sum)"}
+              "cfconv_fwd": e_ev * (G * s + 4 + F_ * s + 4) + n_ev * (2 * F_ * s + 4),
+              # K4b (round 6: the backward with the filter recomputed): dh = the same kernel on the by-source CSR (the same bytes);
+              # parameter gradients = one pass reading rbf + indices + cutoff and gathering the g and h rows: E(G s + 12 + 2 F s)
+              "cfconv_bwd_h": e_ev * (G * s + 4 + F_ * s + 4) + n_ev * (2 * F_ * s + 4),
+              "cfconv_bwd_w": e_ev * (G * s + 12 + 2 * F_ * s)}
+        kname = {"gmr_fwd": "mdl_gather_mul_reduce", "cfconv_fwd": "mdl_cfconv_fwd (K4: filter network + cutoff + h[src] * W + segmented sum)",
+                 "cfconv_bwd_h": "mdl_cfconv_fwd on the by-source CSR (K4b: dh, filter recomputed)",
+                 "cfconv_bwd_w": "mdl_cfconv_bwd_w (K4b: dW1, db1, dW2, db2 of the filter network, filter recomputed; incl. its reduce launch)"}
     elif args.model == "gcn":                        # K4a with a scalar edge weight: E(F s + 8) + N(F s + 4)
         F_ = mkw["dim1"]
         ab = {"gmr_fwd": e_ev * (F_ * s + 8) + n_ev * (F_ * s + 4)}
@@ -610,6 +616,10 @@ def main():
             other = [k for k in have if k != dom]
             if other:
                 res["roofline_other"] = roof(other[0])
+            if len(other) > 1:                       # SchNet: K4 forward, K4b dh pass, K4b parameter-gradient pass
+                res["roofline_kernels"] = {k: {kk: vv for kk, vv in roof(k).items() if kk in ("kernel", "achieved", "frac", "avg_launch_us",
+                                                                                             "launches", "algorithmic_bytes_per_launch")}
+                                           for k in have}
 
     if world == 1 and not args.no_extras:
         from matdeeplearn_amd.training import GraphedStep

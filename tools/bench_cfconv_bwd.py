@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--graphs", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--F", type=int, default=150)
+ap.add_argument("--modes", default="recompute,stored,unfused,recompute")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ds = synthetic_mof(1200, seed=0).to(dev)
@@ -23,7 +24,7 @@ x = (torch.randn(b.num_nodes, 100, device=dev) * 0.5).to(torch.bfloat16)
 gy = torch.randn(b.num_nodes, 100, device=dev).to(torch.bfloat16)
 cut = mnn.cosine_cutoff(b.edge_weight, 8.0)
 b.csr.transposed()
-for mode in ("recompute", "stored", "unfused", "recompute"):
+for mode in a.modes.split(","):
     ops.configure(cfconv_fused=mode != "unfused", cfconv_recompute=mode == "recompute")
     ev = {k: [] for k in ("cfconv_fwd", "gmr_fwd", "cfconv_bwd_w", "cfconv_bwd_h")}
     t = []
