@@ -208,85 +208,73 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
         for (int j = 0; j < NRB; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b32(rr, 4u * (unsigned)(tid + NT * j), 0, 0);
     };
 
-    int64_t tile = blockIdx.x;
-    request_idx(tile);
-    request_rows(tile);
-    request_idx(min(tile + (int64_t)gridDim.x, n_tiles - 1));
-    int cur = 0;
-    for (; tile < n_tiles; tile += gridDim.x, cur ^= 1) {
-        bf16_t* const et = reinterpret_cast<bf16_t*>(smem + OFF_ET + cur * (TE * ES * 2));
-        // ---- S0: commit the staged operands: dw rows (fp32 products, rounded once) and the rbf tile
-        {
-            unsigned* al32 = reinterpret_cast<unsigned*>(al);
-            auto prod = [](unsigned gv, unsigned hv, float c) {
-                return pk_bf16(__uint_as_float(gv << 16) * __uint_as_float(hv << 16) * c,
-                               __uint_as_float(gv & 0xffff0000u) * __uint_as_float(hv & 0xffff0000u) * c);
-            };
+    // ---- the phases of a tile as lambdas (the loop below interleaves the phases of consecutive tiles)
+    auto commit_al = [&]() {                    // dw rows of the staged tile (fp32 products, rounded once) -> al
+        unsigned* al32 = reinterpret_cast<unsigned*>(al);
+        auto prod = [](unsigned gv, unsigned hv, float c) {
+            return pk_bf16(__uint_as_float(gv << 16) * __uint_as_float(hv << 16) * c,
+                           __uint_as_float(gv & 0xffff0000u) * __uint_as_float(hv & 0xffff0000u) * c);
+        };
 #pragma unroll
-            for (int r = 0; r < RPW; ++r)
-                if (lane < FH) al32[(RPW * wv + r) * (LA / 2) + lane] = prod(g0[r], h0[r], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cuc), r)));
+        for (int r = 0; r < RPW; ++r)
+            if (lane < FH) al32[(RPW * wv + r) * (LA / 2) + lane] = prod(g0[r], h0[r], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cuc), r)));
 #pragma unroll
-            for (int k = 0; k < RPW / 4; ++k) {
-                const float c = __shfl(cuc, 4 * k + tsel);
-                if (tdw < FH) al32[(RPW * wv + 4 * k + tsel) * (LA / 2) + tdw] = prod(g1[k], h1[k], c);
-            }
-            unsigned* et32 = reinterpret_cast<unsigned*>(et);
-#pragma unroll
-            for (int j = 0; j < NRB; ++j) {
-                const int d = tid + NT * j;
-                const int row = d / GH, col = d - row * GH;
-                if (d < TE * GH) et32[row * (ES / 2) + col] = rb[j];
-            }
+        for (int k = 0; k < RPW / 4; ++k) {
+            const float c = __shfl(cuc, 4 * k + tsel);
+            if (tdw < FH) al32[(RPW * wv + 4 * k + tsel) * (LA / 2) + tdw] = prod(g1[k], h1[k], c);
         }
-        __syncthreads();
-        if (tile + gridDim.x < n_tiles) {
-            request_rows(tile + gridDim.x);
-            request_idx(min(tile + 2 * (int64_t)gridDim.x, n_tiles - 1));
+    };
+    auto commit_et = [&](bf16_t* et) {          // the staged rbf dwords -> the rbf tile
+        unsigned* et32 = reinterpret_cast<unsigned*>(et);
+#pragma unroll
+        for (int j = 0; j < NRB; ++j) {
+            const int d = tid + NT * j;
+            const int row = d / GH, col = d - row * GH;
+            if (d < TE * GH) et32[row * (ES / 2) + col] = rb[j];
         }
-
-        // ---- S1: a1 = ssp(W1p . rbf^T); lane = edge.  Rows of W1p are permuted (pi) so that registers 8 t .. 8 t + 7 of lane half h
-        // are units 16 t + 8 h .. + 7 of the block.  Ten blocks (edge block eb, unit block ub) for eight waves: wave w takes
-        // (w & 1, w >> 1); the fifth unit block of edge block eb is computed by all four waves of that parity (4 MFMAs: cheap) and
-        // each applies the activation to a quarter of it — the 16 softplus values per lane are what a block costs, and a wave
-        // doing two blocks in a row was the critical path of the phase (120 of 530 us)
-        if (!(MDL_CFB_SKIP & 1)) {
-            const int eb = wv & 1, ub = wv >> 1;
-            f32x16 d, d4;
+    };
+    // S1: a1 = ssp(W1p . rbf^T); lane = edge.  Rows of W1p are permuted (pi) so that registers 8 t .. 8 t + 7 of lane half h are
+    // units 16 t + 8 h .. + 7 of the block.  Ten blocks (edge block eb, unit block ub) for eight waves: wave w takes (w & 1, w >> 1);
+    // the fifth unit block of edge block eb is computed by all four waves of that parity (4 MFMAs: cheap) and each applies the
+    // activation to a quarter of it
+    auto s1 = [&](const bf16_t* et) {
+        if (MDL_CFB_SKIP & 1) return;
+        const int eb = wv & 1, ub = wv >> 1;
+        f32x16 d, d4;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d[r] = d4[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) d[r] = d4[r] = 0.0f;
 #pragma unroll
-            for (int k = 0; k < KE / 16; ++k) {
-                const bf16x8 bfrag = ld_frag(et, 32 * eb + i, ES, 16 * k, h);
-                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * ub + i, ES, 16 * k, h), bfrag, d, 0, 0, 0);
-                d4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * (NB - 1) + i, ES, 16 * k, h), bfrag, d4, 0, 0, 0);
-            }
-            auto ssp2 = [](float t0, float t1) { return pk_bf16(LN2_F * (GT::softplus_u(t0) - 1.0f), LN2_F * (GT::softplus_u(t1) - 1.0f)); };
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                u32x4 v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = ssp2(d[8 * t + 2 * q], d[8 * t + 2 * q + 1]);
-                *reinterpret_cast<u32x4*>(bl + (32 * eb + i) * LA + 32 * ub + 16 * t + 8 * h) = v;
-            }
-            // quarter ub of the fifth block: registers 4 ub .. 4 ub + 3 = units 128 + 16 (ub >> 1) + 8 h + 4 (ub & 1) .. + 3
-            float q0, q1, q2, q3;
-            if (ub == 0) { q0 = d4[0]; q1 = d4[1]; q2 = d4[2]; q3 = d4[3]; }
-            else if (ub == 1) { q0 = d4[4]; q1 = d4[5]; q2 = d4[6]; q3 = d4[7]; }
-            else if (ub == 2) { q0 = d4[8]; q1 = d4[9]; q2 = d4[10]; q3 = d4[11]; }
-            else { q0 = d4[12]; q1 = d4[13]; q2 = d4[14]; q3 = d4[15]; }
-            u32x2 v = u32x2{ssp2(q0, q1), ssp2(q2, q3)};
-            if (ub == 3 && h == 1) v[1] = (v[1] & 0x0000ffffu) | 0x3F800000u;                               // unit FP - 1: the constant 1 (db2)
-            *reinterpret_cast<u32x2*>(bl + (32 * eb + i) * LA + 32 * (NB - 1) + 16 * (ub >> 1) + 8 * h + 4 * (ub & 1)) = v;
+        for (int k = 0; k < KE / 16; ++k) {
+            const bf16x8 bfrag = ld_frag(et, 32 * eb + i, ES, 16 * k, h);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * ub + i, ES, 16 * k, h), bfrag, d, 0, 0, 0);
+            d4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * (NB - 1) + i, ES, 16 * k, h), bfrag, d4, 0, 0, 0);
         }
-        __syncthreads();
-
-        // ---- S2a: dW2 += dw^T . a1 (k = the tile's 64 edges)
+        auto ssp2 = [](float t0, float t1) { return pk_bf16(LN2_F * (GT::softplus_u(t0) - 1.0f), LN2_F * (GT::softplus_u(t1) - 1.0f)); };
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = ssp2(d[8 * t + 2 * q], d[8 * t + 2 * q + 1]);
+            *reinterpret_cast<u32x4*>(bl + (32 * eb + i) * LA + 32 * ub + 16 * t + 8 * h) = v;
+        }
+        // quarter ub of the fifth block: registers 4 ub .. 4 ub + 3 = units 128 + 16 (ub >> 1) + 8 h + 4 (ub & 1) .. + 3
+        float q0, q1, q2, q3;
+        if (ub == 0) { q0 = d4[0]; q1 = d4[1]; q2 = d4[2]; q3 = d4[3]; }
+        else if (ub == 1) { q0 = d4[4]; q1 = d4[5]; q2 = d4[6]; q3 = d4[7]; }
+        else if (ub == 2) { q0 = d4[8]; q1 = d4[9]; q2 = d4[10]; q3 = d4[11]; }
+        else { q0 = d4[12]; q1 = d4[13]; q2 = d4[14]; q3 = d4[15]; }
+        u32x2 v = u32x2{ssp2(q0, q1), ssp2(q2, q3)};
+        if (ub == 3 && h == 1) v[1] = (v[1] & 0x0000ffffu) | 0x3F800000u;                               // unit FP - 1: the constant 1 (db2)
+        *reinterpret_cast<u32x2*>(bl + (32 * eb + i) * LA + 32 * (NB - 1) + 16 * (ub >> 1) + 8 * h + 4 * (ub & 1)) = v;
+    };
+    auto s2 = [&]() {
+        // S2a: dW2 += dw^T . a1 (k = the tile's 64 edges)
         if (MDL_CFB_SKIP & 2) { }
         else if (cls2 == 0) tn_step<2, 2>(al, LA, r0, bl, LA, c0, i, h, acc);
         else if (cls2 == 1) tn_step<1, 4>(al, LA, r0, bl, LA, c0, i, h, acc);
         else if (cls2 == 2) tn_step<4, 1>(al, LA, r0, bl, LA, c0, i, h, acc);
         else if (cls2 == 3) tn_step<1, 1>(al, LA, r0, bl, LA, c0, i, h, acc);
-        // ---- S2b: da = (W2^T . dw^T) .* ssp'(a1); lane = edge, rows of W2^T permuted like W1p's
+        // S2b: da = (W2^T . dw^T) .* ssp'(a1); lane = edge, rows of W2^T permuted like W1p's
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
             const int bidx = wv + NW * bb;
@@ -307,19 +295,62 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
                     for (int q = 0; q < 4; ++q) {
                         // ssp'(x) = sigmoid(x) = 1 - exp(-(y + ln 2)) from the rounded output y (what the unfused backward uses)
                         const float s0 = 1.0f - 0.5f * __builtin_amdgcn_exp2f(-LOG2E_F * __uint_as_float(y[q] << 16));
-                        const float s1 = 1.0f - 0.5f * __builtin_amdgcn_exp2f(-LOG2E_F * __uint_as_float(y[q] & 0xffff0000u));
-                        v[q] = pk_bf16(d[8 * t + 2 * q] * s0, d[8 * t + 2 * q + 1] * s1);
+                        const float s1v = 1.0f - 0.5f * __builtin_amdgcn_exp2f(-LOG2E_F * __uint_as_float(y[q] & 0xffff0000u));
+                        v[q] = pk_bf16(d[8 * t + 2 * q] * s0, d[8 * t + 2 * q + 1] * s1v);
                     }
                     *reinterpret_cast<u32x4*>(dl + off) = v;
                 }
             }
         }
-        __syncthreads();
+    };
+    auto s3 = [&](const bf16_t* et) {           // S3: dW1 += da^T . [rbf | 1]
+        if (MDL_CFB_SKIP & 8) return;
+        tn_step<1, 1>(dl, LA, b1a >> 1, et, ES, b1a & 1, i, h, acc + 4);
+        if (b1b >= 0) tn_step<1, 1>(dl, LA, b1b >> 1, et, ES, b1b & 1, i, h, acc + 3);
+    };
+    bf16_t* const et0 = reinterpret_cast<bf16_t*>(smem + OFF_ET);
+    bf16_t* const et1 = et0 + TE * ES;
 
-        // ---- S3: dW1 += da^T . [rbf | 1]
-        if (!(MDL_CFB_SKIP & 8)) tn_step<1, 1>(dl, LA, b1a >> 1, et, ES, b1a & 1, i, h, acc + 4);
-        if (b1b >= 0 && !(MDL_CFB_SKIP & 8)) tn_step<1, 1>(dl, LA, b1b >> 1, et, ES, b1b & 1, i, h, acc + 3);
-        // (the next tile's commit writes al and the OTHER rbf tile; bl / dl are rewritten behind the next barriers)
+    // ---- the tile loop.  Two workgroup barriers per tile; between them the phases of consecutive tiles are interleaved so that an
+    // interval mixes matrix work with vector work and with the staging traffic:
+    //   interval A:  dW2(t), da(t) -> dl                       | commit rbf(t+1) -> the other rbf tile
+    //   interval B:  dW1(t)  (dl, rbf(t))                      | commit dw(t+1) -> al, request rows / rbf (t+2), a1(t+1) -> bl
+    // (al and bl were last read in interval A, dl and the rbf tile of t are read in B and rewritten in the next A: every buffer has
+    // one barrier between its last reader and its next writer.)  Rows are requested a whole tile before they are committed.
+    const int64_t G = gridDim.x;
+    int64_t tile = blockIdx.x;
+    request_idx(tile);
+    request_rows(tile);
+    request_idx(min(tile + G, n_tiles - 1));
+    commit_et(et0);
+    commit_al();
+    __syncthreads();
+    if (tile + G < n_tiles) {
+        request_rows(tile + G);
+        request_idx(min(tile + 2 * G, n_tiles - 1));
+    }
+    s1(et0);
+    __syncthreads();
+    int cur = 0;
+    for (; tile < n_tiles; tile += G, cur ^= 1) {
+        bf16_t* const et = cur ? et1 : et0;
+        bf16_t* const etn = cur ? et0 : et1;
+        const bool more = tile + G < n_tiles;
+        // ---- interval A
+        s2();
+        if (more) commit_et(etn);
+        __syncthreads();
+        // ---- interval B
+        s3(et);
+        if (more) {
+            commit_al();
+            if (tile + 2 * G < n_tiles) {
+                request_rows(tile + 2 * G);
+                request_idx(min(tile + 3 * G, n_tiles - 1));
+            }
+            s1(etn);
+        }
+        __syncthreads();
     }
 
     if (MDL_CFB_SKIP & 32) return;
