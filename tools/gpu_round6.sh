@@ -18,3 +18,6 @@ rm -rf $OUT/prof_small
 cd $GRAFT_REPO_ROOT
 timeout 300 python tools/bench_small.py --steps 600 2>&1 | tail -1 | tee $OUT/small.log
 GRPS_SEL=4 bash tools/gpu_pmc.sh $TAG/pmc > $OUT/pmc.log 2>&1; cat $OUT/pmc/hbm_traffic.json 2>/dev/null | head -30
+# K4 / K4b (round 6, second half): micro-benchmark of the three forms of the CFConv block and the counters of the two kernels
+timeout 600 python tools/bench_cfconv_bwd.py 2>&1 | tail -5 | tee $OUT/bench_cfconv_bwd.log
+bash tools/gpu_pmc_k4b.sh $TAG/pmc_k4b > /dev/null 2>&1; tail -12 $OUT/pmc_k4b/summary.txt | cut -c1-400
