@@ -457,7 +457,7 @@ int mdl_gather_mul_reduce_dw(const void* g, const void* w, const float* scale, c
  * CSR slot; out: [N, F].  a1 / w: [E, F] — the two activations the backward consumes (mdl_gather_mul_reduce_dw, the dense
  * backward of the two layers) — or NULL for inference; rows past rowptr[N] (padded static batch) are zeroed.  The product uses
  * the bf16-ROUNDED filter, like the unfused sequence mdl_linear_act x 2 -> mdl_gather_mul_reduce.  bf16, G = 50, even F in
- * (128, 158] (SchNet_demo: 150); other shapes: MDL_E_UNSUPP (callers keep the unfused sequence).  wpack: the weights packed by
+ * [64, 158] (SchNet_demo: 150; the kernel is static at the padded width 96 / 128 / 160); other shapes: MDL_E_UNSUPP (callers keep the unfused sequence).  wpack: the weights packed by
  * mdl_cfconv_pack_weights (mdl_cfconv_wpack_bytes() bytes, 16-byte aligned) from the fp32 masters W1 [F, G], b1 [F] or NULL,
  * W2 [F, F], b2 [F] or NULL. */
 int mdl_cfconv_supported(int F, int G, int dtype);

@@ -32,24 +32,32 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds4_t;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int FP = 160, NBK = FP / 32;        // padded filter width; 32-unit blocks
 constexpr int G_ = 50, GH = G_ / 2;           // Gaussians per edge (the reference's edge features); dwords per rbf row
 constexpr int KE = 64, EKS = KE + 8;          // K of GEMM1 (G + bias column, padded); row stride of the rbf tile (halfwords)
-constexpr int W1S = KE + 8, W2S = FP + 8;     // row strides of the packed weights in LDS (halfwords)
+constexpr int W1S = KE + 8;                   // row stride of the packed layer-1 weights in LDS (halfwords)
 constexpr int DCS = 32 * 8 + 32;              // one chunk row of the message block: 32 edges x 8 bytes + pad
 #ifndef MDL_CF_NWAVE
 #define MDL_CF_NWAVE 8
 #endif
 constexpr int NWAVE = MDL_CF_NWAVE, NT = NWAVE * WAVE;
-constexpr int W1_BYTES = FP * W1S * 2, W2_BYTES = FP * W2S * 2;
 constexpr int NJ = (32 * GH + WAVE - 1) / WAVE;           // dwords of an rbf tile per lane
 constexpr int OFF_ET = 0, OFF_DP = 32 * EKS * 2, OFF_TSL = OFF_DP + 8 * DCS, OFF_STASH = OFF_TSL + 64;
 constexpr int WAVE_BYTES = OFF_STASH + NJ * WAVE * 4;     // (the stash: the NEXT tile's rbf dwords, parked in LDS once they have arrived)
-constexpr int LDS = W1_BYTES + W2_BYTES + NWAVE * WAVE_BYTES;
+// Filter width: the kernel is static at a padded width FP = 32 NBK with F <= FP - 2 (unit FP - 1 carries the bias of layer 2) and
+// F >= 32 (NBK - 1) (every block but the last lies inside the h rows): NBK = 3 for F in [64, 94], 4 for [96, 126], 5 for [128, 158]
+// (SchNet_demo: 150).  The packed weights' layout follows FP.
+template <int NBK_> struct Shape {
+    static constexpr int NBK = NBK_, FP = 32 * NBK_;
+    static constexpr int W2S = FP + 8;                    // row stride of the packed layer-2 weights in LDS (halfwords)
+    static constexpr int W1_BYTES = FP * W1S * 2, W2_BYTES = FP * W2S * 2;
+    static constexpr int LDS = W1_BYTES + W2_BYTES + NWAVE * WAVE_BYTES;
+    static_assert(W1_BYTES % 16 == 0 && W2_BYTES % 16 == 0, "alignment");
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+};
 constexpr float UP = 18446744073709551616.0f;             // 2^64: the messages travel scaled (folded into the cutoff factor)
 constexpr float RW = 4611686018427387904.0f;              // 2^62 = 2^126 / 2^64: scale of the one-hot sums
-static_assert(W1_BYTES % 16 == 0 && W2_BYTES % 16 == 0 && WAVE_BYTES % 16 == 0 && OFF_DP % 16 == 0 && OFF_TSL % 16 == 0, "alignment");
-static_assert(LDS <= 160 * 1024, "LDS budget");
+static_assert(WAVE_BYTES % 16 == 0 && OFF_DP % 16 == 0 && OFF_TSL % 16 == 0, "alignment");
+__host__ __device__ inline int nbk_for(int F) { return (F + 2 + 31) / 32; }
 
 #ifdef MDL_CF_TIMING      // experiment builds only: per-phase cycle counters of wave 0 of workgroup 0 (tools/bench_cfconv.py prints them)
 __device__ long long g_cf_dbg[16];
@@ -105,8 +113,11 @@ __device__ __forceinline__ int lower_bound_cost(const int32_t* __restrict__ rowp
     return __builtin_amdgcn_readfirstlane(lo);
 }
 
+template <int NBK>
 __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
     typedef Gate<true> GT;
+    typedef Shape<NBK> SH;
+    constexpr int FP = SH::FP, W2S = SH::W2S, W1_BYTES = SH::W1_BYTES, W2_BYTES = SH::W2_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, t16 = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -438,6 +449,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_fwd_kernel(Params p) {
 __global__ __launch_bounds__(256) void cfconv_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
                                                           const float* __restrict__ w2, const float* __restrict__ b2, int F,
                                                           bf16_t* __restrict__ wpack) {
+    const int FP = 32 * nbk_for(F), W2S = FP + 8;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     auto pi = [](int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); };     // row of a 32-row block -> unit of the block
     if (idx < FP * W1S) {
@@ -476,26 +488,37 @@ extern "C" int mdl_debug_read_cf(long long* host16) {
     return e == hipSuccess ? 0 : 1;
 }
 #endif
-extern "C" size_t mdl_cfconv_wpack_bytes(void) { return (size_t)cf::W1_BYTES + cf::W2_BYTES; }
+extern "C" size_t mdl_cfconv_wpack_bytes(void) { return (size_t)cf::Shape<5>::W1_BYTES + cf::Shape<5>::W2_BYTES; }     // (the widest layout)
 
 extern "C" int mdl_cfconv_supported(int F, int G, int dtype) {
-    return dtype == MDL_BF16 && G == cf::G_ && F > 128 && F <= cf::FP - 2 && F % 2 == 0;
+    return dtype == MDL_BF16 && G == cf::G_ && F >= 64 && F <= 158 && F % 2 == 0;
 }
 
 extern "C" int mdl_cfconv_pack_weights(const float* w1, const float* b1, const float* w2, const float* b2, int F, int G, void* wpack,
                                        mdlStream_t stream) {
-    MDL_REQUIRE(mdl_cfconv_supported(F, G, MDL_BF16), MDL_E_UNSUPP, "mdl_cfconv_pack_weights: F = %d, G = %d (supported: G = 50, even F in (128, 158])", F, G);
+    MDL_REQUIRE(mdl_cfconv_supported(F, G, MDL_BF16), MDL_E_UNSUPP, "mdl_cfconv_pack_weights: F = %d, G = %d (supported: G = 50, even F in [64, 158])", F, G);
     MDL_REQUIRE(w1 && w2 && wpack, MDL_E_ARG, "mdl_cfconv_pack_weights: null weights");
-    const int total = cf::FP * cf::W1S + cf::FP * cf::W2S;
+    const int FP = 32 * cf::nbk_for(F);
+    const int total = FP * cf::W1S + FP * (FP + 8);
     hipLaunchKernelGGL(cf::cfconv_pack_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, F,
                        static_cast<bf16_t*>(wpack));
     return check_launch("mdl_cfconv_pack_weights");
 }
 
+template <int NBK>
+static int cfconv_launch(const cf::Params& p, int64_t grid, hipStream_t st) {
+    auto kf = cf::cfconv_fwd_kernel<NBK>;
+    constexpr int lds = cf::Shape<NBK>::LDS;
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
+    if (e != hipSuccess) { set_error("mdl_cfconv_fwd: LDS attribute (%d B): %s", lds, hipGetErrorString(e)); return MDL_E_LAUNCH; }
+    hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(cf::NT), lds, st, p);
+    return check_launch("mdl_cfconv_fwd");
+}
+
 extern "C" int mdl_cfconv_fwd(const void* rbf, const float* cut, const void* h, const int32_t* rowptr, const int32_t* src,
                               const int32_t* tgt, const void* wpack, void* out, void* a1, void* w, int64_t N, int64_t E, int F, int G,
                               int dtype, mdlStream_t stream) {
-    MDL_REQUIRE(mdl_cfconv_supported(F, G, dtype), MDL_E_UNSUPP, "mdl_cfconv_fwd: bf16, G = 50 and even F in (128, 158] only (F = %d, G = %d, dtype %d)", F, G, dtype);
+    MDL_REQUIRE(mdl_cfconv_supported(F, G, dtype), MDL_E_UNSUPP, "mdl_cfconv_fwd: bf16, G = 50 and even F in [64, 158] only (F = %d, G = %d, dtype %d)", F, G, dtype);
     MDL_REQUIRE(N >= 0 && E >= 0 && N < (1ll << 31) && E * (int64_t)F < (1ll << 40) && E < (1ll << 31), MDL_E_ARG, "mdl_cfconv_fwd: sizes out of range");
     if (N == 0) return MDL_OK;
     MDL_REQUIRE(rowptr && out && wpack && h, MDL_E_ARG, "mdl_cfconv_fwd: null argument");
@@ -506,9 +529,9 @@ extern "C" int mdl_cfconv_fwd(const void* rbf, const float* cut, const void* h, 
                  static_cast<bf16_t*>(out), static_cast<bf16_t*>(a1), static_cast<bf16_t*>(w), (int)N, (int)E, F};
     // one 8-wave workgroup per CU; small problems: about two tiles per wave at least
     const int64_t grid = std::min<int64_t>(256, std::max<int64_t>(1, cdiv(E + N, 32 * cf::NWAVE * 2)));
-    auto kf = cf::cfconv_fwd_kernel;
-    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), cf::LDS);
-    if (e != hipSuccess) { set_error("mdl_cfconv_fwd: LDS attribute (%d B): %s", cf::LDS, hipGetErrorString(e)); return MDL_E_LAUNCH; }
-    hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(cf::NT), cf::LDS, (hipStream_t)stream, p);
-    return check_launch("mdl_cfconv_fwd");
+    switch (cf::nbk_for(F)) {
+        case 3: return cfconv_launch<3>(p, grid, (hipStream_t)stream);
+        case 4: return cfconv_launch<4>(p, grid, (hipStream_t)stream);
+        default: return cfconv_launch<5>(p, grid, (hipStream_t)stream);
+    }
 }

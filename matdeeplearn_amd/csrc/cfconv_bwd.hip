@@ -67,7 +67,7 @@ struct Params {
     float* dw2;              // [F, F]
     float* db2;              // [F] or nullptr
     float* part;             // per-workgroup partial sums [grid][NBLK][1024] or nullptr (then: atomics into the outputs)
-    int N, F;
+    int N, F, nbk;           // nbk: 32-unit blocks of the packed weights' layout (the forward's padded width FP_w = 32 nbk <= FP)
 };
 constexpr int NBLK = NB * NB + 2 * NB;      // accumulator blocks per workgroup: 25 of dW2 (id = 5 row + col), 10 of dW1 (25 + b)
 constexpr int MAXGRID = 256, RED_SPLIT = 32;
@@ -120,23 +120,25 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
     const int64_t n_tiles = ((int64_t)Et + TE - 1) / TE;
     if ((int64_t)blockIdx.x >= n_tiles) return;
 
-    // ---- one-time setup: W1p verbatim, W2^T (row rho of a 32-row block of k = the a1 unit pi(rho), columns m natural; the bias
-    // slot FP - 1 of W2p's K axis is not a unit: zero), tiles zeroed, the constant-1 column of both rbf tiles
+    // ---- one-time setup: everything zeroed; W1p verbatim (FP_w of its FP rows exist in the packed layout of a narrower filter);
+    // W2^T (row rho of a 32-row block of k = the a1 unit pi(rho), columns m natural; the bias slot FP_w - 1 of W2p's K axis is
+    // not a unit: zero); the constant-1 column of both rbf tiles
     {
-        const u32x4* gsrc = reinterpret_cast<const u32x4*>(p.wpack);
-        u32x4* l = reinterpret_cast<u32x4*>(smem + OFF_W1);
-        for (int q = tid; q < FP * ES * 2 / 16; q += NT) l[q] = gsrc[q];
-        unsigned* z = reinterpret_cast<unsigned*>(smem + OFF_WT);
-        for (int q = tid; q < (LDS - OFF_WT) / 4; q += NT) z[q] = 0u;
+        unsigned* z = reinterpret_cast<unsigned*>(smem);
+        for (int q = tid; q < LDS / 4; q += NT) z[q] = 0u;
     }
     __syncthreads();
     {
-        const bf16_t* w2p = p.wpack + FP * ES;
-        for (int q = tid; q < FP * FP; q += NT) {
-            const int prow = q / FP, pos = q - prow * FP;                 // W2p[prow][pos]: output unit m = pi(prow), input unit k = pos
+        const int FPw = 32 * p.nbk, W2Sw = FPw + 8;
+        const u32x4* gsrc = reinterpret_cast<const u32x4*>(p.wpack);
+        u32x4* l = reinterpret_cast<u32x4*>(smem + OFF_W1);
+        for (int q = tid; q < FPw * ES * 2 / 16; q += NT) l[q] = gsrc[q];
+        const bf16_t* w2p = p.wpack + FPw * ES;
+        for (int q = tid; q < FPw * FPw; q += NT) {
+            const int prow = q / FPw, pos = q - prow * FPw;               // W2p[prow][pos]: output unit m = pi(prow), input unit k = pos
             const int m = (prow & ~31) | pi32(prow & 31);
             const int krow = (pos & ~31) | pi32(pos & 31);
-            wt[krow * LA + m] = pos == FP - 1 ? (bf16_t)0 : w2p[prow * W2S + pos];
+            wt[krow * LA + m] = pos == FPw - 1 ? (bf16_t)0 : w2p[prow * W2Sw + pos];
         }
         for (int q = tid; q < 2 * TE; q += NT) reinterpret_cast<bf16_t*>(smem + OFF_ET)[q * ES + G_] = 0x3F80;
     }
@@ -458,14 +460,15 @@ extern "C" int mdl_cfconv_bwd_w(const void* rbf, const float* cut, const void* h
                                 float* db2, void* scratch, int64_t N, int64_t E, int F, int G, int dtype, mdlStream_t stream) {
     const bool det = (dtype & MDL_DETERMINISTIC) != 0;      // one workgroup: every element gets its adds from one wave in tile order
     dtype &= MDL_DTYPE_MASK;
-    MDL_REQUIRE(mdl_cfconv_supported(F, G, dtype), MDL_E_UNSUPP, "mdl_cfconv_bwd_w: bf16, G = 50 and even F in (128, 158] only (F = %d, G = %d, dtype %d)", F, G, dtype);
+    MDL_REQUIRE(mdl_cfconv_supported(F, G, dtype), MDL_E_UNSUPP, "mdl_cfconv_bwd_w: bf16, G = 50 and even F in [64, 158] only (F = %d, G = %d, dtype %d)", F, G, dtype);
     MDL_REQUIRE(N >= 0 && E >= 0 && N < (1ll << 31) && E < (1ll << 31) - 64, MDL_E_ARG, "mdl_cfconv_bwd_w: sizes out of range");
     if (N == 0 || E == 0) return MDL_OK;
     MDL_REQUIRE(rbf && cut && h && g && rowptr && src && tgt && wpack && dw1 && dw2, MDL_E_ARG, "mdl_cfconv_bwd_w: null argument");
     MDL_REQUIRE(((uintptr_t)rbf % 4) == 0 && ((uintptr_t)h % 4) == 0 && ((uintptr_t)g % 4) == 0 && ((uintptr_t)wpack % 16) == 0, MDL_E_ARG,
                 "mdl_cfconv_bwd_w: misaligned tensor");
     cfb::Params p{static_cast<const bf16_t*>(rbf), cut, static_cast<const bf16_t*>(h), static_cast<const bf16_t*>(g), rowptr, src, tgt,
-                  static_cast<const bf16_t*>(wpack), dw1, db1, dw2, db2, det ? nullptr : static_cast<float*>(scratch), (int)N, F};
+                  static_cast<const bf16_t*>(wpack), dw1, db1, dw2, db2, det ? nullptr : static_cast<float*>(scratch), (int)N, F,
+                  (F + 2 + 31) / 32};
     MDL_REQUIRE(((uintptr_t)scratch % 16) == 0, MDL_E_ARG, "mdl_cfconv_bwd_w: misaligned scratch");
     const int64_t grid = det ? 1 : std::min<int64_t>(cfb::MAXGRID, std::max<int64_t>(1, cdiv(E, cfb::TE)));
     auto kf = cfb::cfconv_bwd_w_kernel;

@@ -193,7 +193,8 @@ class CFConv(nn.Module):
         mods = list(self.nn)
         if (len(mods) == 3 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], ShiftedSoftplus) and isinstance(mods[2], nn.Linear)
                 and ops.cfconv_fused_ok(edge_attr, h, csr, mods[0], mods[2])):
-            if ops._CFCONV_RECOMPUTE and not c.requires_grad and not edge_attr.requires_grad:
+            if (ops._CFCONV_RECOMPUTE and h.shape[1] >= ops._CFCONV_RECOMPUTE_MIN_F and not c.requires_grad
+                    and not edge_attr.requires_grad):
                 # K4 + K4b: one autograd node, nothing stored per edge; the backward recomputes the filter (by_source: the edge
                 # features in by-source order, shared by the blocks of a model)
                 return ops.cfconv_recompute(edge_attr, c, h, csr, mods[0], mods[2], by_source)

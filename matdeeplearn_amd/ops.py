@@ -1014,6 +1014,10 @@ def gather_mul_reduce(h, csr, w=None, scale=None, reduce="sum", pre=None):
 # ------------------------------------------------------------------------------------------------
 _CFCONV_FUSED = True
 _CFCONV_RECOMPUTE = True
+# K4b runs at the padded width 160 whatever the filter width, so below ~112 units the stored-activation backward is the faster
+# one (forward + backward of the block, E = 1.46 M: F = 64: 942 us recomputing / 684 stored / 739 unfused; 100: 1077 / 1047 /
+# 1107; 128: 1207 / 1283 / 1343; 150: 1290 / 1697 / 1794 — profiles/r06d_k4_k4b_forms.txt)
+_CFCONV_RECOMPUTE_MIN_F = 112
 
 
 def cfconv_fused_ok(rbf, h, csr, lin_a, lin_b):

@@ -1311,7 +1311,8 @@ def _cfconv_case(n, F, seed, empty_frac=0.1, max_in=20):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(3000, 150, 0.1, 20), (1500, 150, 0.5, 3), (2500, 130, 0.0, 40), (2000, 158, 0.1, 12)])
+@pytest.mark.parametrize("shape", [(3000, 150, 0.1, 20), (1500, 150, 0.5, 3), (2500, 130, 0.0, 40), (2000, 158, 0.1, 12),
+                                   (2000, 64, 0.1, 20), (2000, 100, 0.2, 35), (2000, 128, 0.1, 12), (1500, 94, 0.1, 12), (1500, 96, 0.1, 12)])
 def test_recomputing_cfconv_backward_matches_the_three_pass_sequence(shape, monkeypatch):
     """K4 + K4b (ops.cfconv_recompute: the fused forward storing nothing per edge; backward = the same kernel on the by-source
     CSR for dh + mdl_cfconv_bwd_w for the filter network's parameter gradients, filter recomputed in both) against the unfused
@@ -1327,6 +1328,7 @@ def test_recomputing_cfconv_backward_matches_the_three_pass_sequence(shape, monk
     for mode in ("unfused", "stored", "recompute", "recompute_cached"):
         monkeypatch.setattr(ops, "_CFCONV_FUSED", mode != "unfused")
         monkeypatch.setattr(ops, "_CFCONV_RECOMPUTE", mode.startswith("recompute"))
+        monkeypatch.setattr(ops, "_CFCONV_RECOMPUTE_MIN_F", 0)            # (the default dispatch keeps the stored form below 112 units)
         ev = {"cfconv_fwd": [], "gmr_fwd": [], "cfconv_bwd_w": [], "cfconv_bwd_h": []}
         ops.KERNEL_EVENTS = ev
         xr = x.clone().requires_grad_(True)
@@ -1351,7 +1353,8 @@ def test_recomputing_cfconv_backward_matches_the_three_pass_sequence(shape, monk
 
 
 @pytest.mark.gpu
-def test_cfconv_weight_gradient_kernel_matches_fp64_and_ignores_padded_edges():
+@pytest.mark.parametrize("F", [150, 64, 100, 128])
+def test_cfconv_weight_gradient_kernel_matches_fp64_and_ignores_padded_edges(F):
     """mdl_cfconv_bwd_w through the raw C-ABI against fp64 arithmetic on the operands the kernel multiplies (bf16 inputs and
     weights; dw, a1 and da rounded to bf16 where the kernel rounds them), on an edge array LONGER than the CSR covers (padded
     static batch: the tail rows hold NaN features and must not be read into any sum); then dh = mdl_cfconv_fwd on the by-source
@@ -1359,7 +1362,7 @@ def test_cfconv_weight_gradient_kernel_matches_fp64_and_ignores_padded_edges():
     from matdeeplearn_amd import _lib, ops
     d = dev()
     L, P, st = _lib.lib(), _lib.ptr, _lib.stream
-    n, F, G, pad = 700, 150, 50, 77
+    n, G, pad = 700, 50, 77
     g = torch.Generator().manual_seed(11)
     ei = rand_graph(n, 23, sort=True, empty_frac=0.2, max_in=40)
     E = ei.shape[1]
@@ -1428,7 +1431,8 @@ def test_cfconv_weight_gradient_kernel_matches_fp64_and_ignores_padded_edges():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(3000, 150, 0.1, 20), (1500, 150, 0.5, 3), (2500, 130, 0.0, 40), (2000, 158, 0.1, 12)])
+@pytest.mark.parametrize("shape", [(3000, 150, 0.1, 20), (1500, 150, 0.5, 3), (2500, 130, 0.0, 40), (2000, 158, 0.1, 12),
+                                   (2000, 64, 0.1, 20), (2000, 100, 0.2, 35), (2000, 128, 0.1, 12)])
 def test_fused_cfconv_forward_matches_the_three_pass_sequence_and_trains_through_it(shape, monkeypatch):
     """K4 (mdl_cfconv_fwd: filter network -> cutoff -> h[src] * W -> segmented sum in one pass, csrc/cfconv.hip) against the
     sequence it replaces (mdl_linear_act x 2 -> mdl_gather_mul_reduce) on the same bf16 operands: the InteractionBlock's output,
@@ -1464,7 +1468,8 @@ def test_fused_cfconv_forward_matches_the_three_pass_sequence_and_trains_through
 
 
 @pytest.mark.gpu
-def test_fused_cfconv_matches_the_fp64_loop_oracle_and_zeroes_padded_rows():
+@pytest.mark.parametrize("F", [150, 64, 100, 128, 94, 96])
+def test_fused_cfconv_matches_the_fp64_loop_oracle_and_zeroes_padded_rows(F):
     """mdl_cfconv_fwd through the raw C-ABI against the literal per-edge loop of the oracle (fp64, on the bf16-rounded operands)
     — out, and the two activations it stores — on an edge array LONGER than the CSR covers (a padded static batch): the rows
     past rowptr[N] of both activations are written as zeros.  Tolerance 2e-2 of the output scale (bf16 activations between
@@ -1472,7 +1477,7 @@ def test_fused_cfconv_matches_the_fp64_loop_oracle_and_zeroes_padded_rows():
     from matdeeplearn_amd import _lib, ops
     d = dev()
     L, P, st = _lib.lib(), _lib.ptr, _lib.stream
-    n, F, G, pad = 400, 150, 50, 77
+    n, G, pad = 400, 50, 77
     g = torch.Generator().manual_seed(3)
     ei = rand_graph(n, 21, sort=True, empty_frac=0.2, max_in=40)
     E = ei.shape[1]
@@ -1509,4 +1514,5 @@ def test_fused_cfconv_matches_the_fp64_loop_oracle_and_zeroes_padded_rows():
     _lib.check(L.mdl_cfconv_fwd(P(dv[0]), P(dv[1]), P(dv[2]), P(csr.rowptr), P(src), P(tgt), P(wpack), P(out2), None, None, n, E + pad,
                                 F, G, _lib.MDL_BF16, st()), "cfconv")
     assert torch.equal(out, out2)
-    assert L.mdl_cfconv_supported(128, 50, _lib.MDL_BF16) == 0 and L.mdl_cfconv_supported(150, 50, _lib.MDL_F32) == 0
+    assert L.mdl_cfconv_supported(150, 50, _lib.MDL_F32) == 0 and L.mdl_cfconv_supported(150, 64, _lib.MDL_BF16) == 0
+    assert [L.mdl_cfconv_supported(f, 50, _lib.MDL_BF16) for f in (62, 64, 100, 101, 128, 158, 160)] == [0, 1, 1, 0, 1, 1, 0]
