@@ -35,23 +35,27 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds4_t;
 
-constexpr int FP = 160, NB = FP / 32;          // padded filter width; 32-unit blocks
 constexpr int G_ = 50, GH = G_ / 2;            // Gaussians per edge; dwords per rbf row
 constexpr int KE = 64, ES = KE + 8;            // K of GEMM1 (G + bias column, padded); row stride of the rbf tile / W1p (halfwords)
-constexpr int W2S = FP + 8;                    // row stride of W2p in the packed weights (cfconv.hip)
-constexpr int LA = FP + 8;                     // row stride of the [edge][unit] tiles and of W2^T (halfwords)
 constexpr int TE = 64;                         // edges per tile
 constexpr int NW = 8, NT = NW * WAVE, RPW = TE / NW;
-constexpr int OFF_W1 = 0;
-constexpr int OFF_WT = OFF_W1 + FP * ES * 2;   // W2^T [k][m]
-constexpr int OFF_AL = OFF_WT + FP * LA * 2;   // dw  [edge][unit]
-constexpr int OFF_BL = OFF_AL + TE * LA * 2;   // a1  [edge][unit]
-constexpr int OFF_DL = OFF_BL + TE * LA * 2;   // da  [edge][unit]
-constexpr int OFF_ET = OFF_DL + TE * LA * 2;   // two rbf tiles [edge][ES]
-constexpr int LDS = OFF_ET + 2 * TE * ES * 2;
 constexpr int NRB = (TE * GH + NT - 1) / NT;   // rbf dwords of a tile per thread
-static_assert(LDS <= 160 * 1024, "LDS budget");
-static_assert(OFF_WT % 16 == 0 && OFF_AL % 16 == 0 && OFF_BL % 16 == 0 && OFF_DL % 16 == 0 && OFF_ET % 16 == 0 && (LA * 2) % 16 == 0 && (ES * 2) % 16 == 0, "alignment");
+// static at the padded filter width FP = 32 NB of the forward kernel (cfconv.hip: NB = 3 for F in [64, 94], 4 for [96, 126], 5 for [128, 158])
+template <int NB_> struct Shape {
+    static constexpr int NB = NB_, FP = 32 * NB_;
+    static constexpr int W2S = FP + 8;                    // row stride of W2p in the packed weights (cfconv.hip)
+    static constexpr int LA = FP + 8;                     // row stride of the [edge][unit] tiles and of W2^T (halfwords)
+    static constexpr int OFF_W1 = 0;
+    static constexpr int OFF_WT = OFF_W1 + FP * ES * 2;   // W2^T [k][m]
+    static constexpr int OFF_AL = OFF_WT + FP * LA * 2;   // dw  [edge][unit]
+    static constexpr int OFF_BL = OFF_AL + TE * LA * 2;   // a1  [edge][unit]
+    static constexpr int OFF_DL = OFF_BL + TE * LA * 2;   // da  [edge][unit]
+    static constexpr int OFF_ET = OFF_DL + TE * LA * 2;   // two rbf tiles [edge][ES]
+    static constexpr int LDS = OFF_ET + 2 * TE * ES * 2;
+    static constexpr int NBLK = NB * NB + 2 * NB;         // accumulator blocks per workgroup: NB^2 of dW2 (id = NB row + col), 2 NB of dW1 (NB^2 + b)
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static_assert(OFF_WT % 16 == 0 && OFF_AL % 16 == 0 && OFF_BL % 16 == 0 && OFF_DL % 16 == 0 && OFF_ET % 16 == 0 && (LA * 2) % 16 == 0 && (ES * 2) % 16 == 0, "alignment");
+};
 
 struct Params {
     const bf16_t* rbf;       // [E, G] edge features, CSR order
@@ -67,9 +71,8 @@ struct Params {
     float* dw2;              // [F, F]
     float* db2;              // [F] or nullptr
     float* part;             // per-workgroup partial sums [grid][NBLK][1024] or nullptr (then: atomics into the outputs)
-    int N, F, nbk;           // nbk: 32-unit blocks of the packed weights' layout (the forward's padded width FP_w = 32 nbk <= FP)
+    int N, F;
 };
-constexpr int NBLK = NB * NB + 2 * NB;      // accumulator blocks per workgroup: 25 of dW2 (id = 5 row + col), 10 of dW1 (25 + b)
 constexpr int MAXGRID = 256, RED_SPLIT = 32;
 
 __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* base, int row, int ld, int k0, int h) {
@@ -104,8 +107,12 @@ __device__ __forceinline__ void tn_step(const bf16_t* x, int ldx, int r0, const 
     }
 }
 
+template <int NB>
 __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
     typedef Gate<true> GT;
+    typedef Shape<NB> S;
+    constexpr int FP = S::FP, LA = S::LA, W2S = S::W2S, LDS = S::LDS, NBLK = S::NBLK;
+    constexpr int OFF_W1 = S::OFF_W1, OFF_WT = S::OFF_WT, OFF_AL = S::OFF_AL, OFF_BL = S::OFF_BL, OFF_DL = S::OFF_DL, OFF_ET = S::OFF_ET;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,16 +127,15 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
     const int64_t n_tiles = ((int64_t)Et + TE - 1) / TE;
     if ((int64_t)blockIdx.x >= n_tiles) return;
 
-    // ---- one-time setup: everything zeroed; W1p verbatim (FP_w of its FP rows exist in the packed layout of a narrower filter);
-    // W2^T (row rho of a 32-row block of k = the a1 unit pi(rho), columns m natural; the bias slot FP_w - 1 of W2p's K axis is
-    // not a unit: zero); the constant-1 column of both rbf tiles
+    // ---- one-time setup: everything zeroed; W1p verbatim; W2^T (row rho of a 32-row block of k = the a1 unit pi(rho), columns m
+    // natural; the bias slot FP - 1 of W2p's K axis is not a unit: zero); the constant-1 column of both rbf tiles
     {
         unsigned* z = reinterpret_cast<unsigned*>(smem);
         for (int q = tid; q < LDS / 4; q += NT) z[q] = 0u;
     }
     __syncthreads();
     {
-        const int FPw = 32 * p.nbk, W2Sw = FPw + 8;
+        constexpr int FPw = FP, W2Sw = W2S;
         const u32x4* gsrc = reinterpret_cast<const u32x4*>(p.wpack);
         u32x4* l = reinterpret_cast<u32x4*>(smem + OFF_W1);
         for (int q = tid; q < FPw * ES * 2 / 16; q += NT) l[q] = gsrc[q];
@@ -147,12 +153,18 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
     // ---- which accumulator blocks this wave owns.  dW2 (5 x 5 blocks, rows m / columns k): waves 2..5 a 2 x 2 square, wave 6 row 4
     // x columns 0..3, wave 7 rows 0..3 x column 4, wave 0 the corner (4, 4), wave 1 none — waves 0 and 1 carry the ninth and tenth
     // block of GEMM1 / da instead.  dW1 (5 x 2 blocks): waves 2..7 one block, waves 0 and 1 two.
-    // (class: 0 = 2 x 2, 1 = 1 x 4, 2 = 4 x 1, 3 = one block, 4 = none; block j of the rectangle is (r0 + (j >> lnc), c0 + (j & (nc - 1))))
-    const int cls2 = wv >= 2 && wv <= 5 ? 0 : (wv == 6 ? 1 : (wv == 7 ? 2 : (wv == 0 ? 3 : 4)));
-    const int r0 = cls2 == 0 ? 2 * ((wv - 2) >> 1) : (cls2 == 1 || cls2 == 3 ? 4 : 0);
-    const int c0 = cls2 == 0 ? 2 * ((wv - 2) & 1) : (cls2 == 2 || cls2 == 3 ? 4 : 0);
-    const int lnc = cls2 == 0 ? 1 : (cls2 == 1 ? 2 : 0), nblk2 = cls2 <= 2 ? 4 : (cls2 == 3 ? 1 : 0);
-    const int b1a = wv >= 2 ? wv - 2 : 6 + 2 * wv, b1b = wv >= 2 ? -1 : 7 + 2 * wv;       // dW1 blocks: (unit block = b >> 1, Gaussian block = b & 1)
+    // (class: 0 = 2 x 2, 1 = 1 x 4, 2 = 4 x 1, 3 = one block, 4 = none, 5 = 1 x 2; block j of the rectangle is (r0 + (j >> lnc), c0 + (j & (nc - 1))))
+    // NB = 4: 16 + 8 blocks — every wave a 1 x 2 piece of dW2 and one dW1 block.  NB = 3: 9 + 6 blocks — waves 0..6 one dW2 block,
+    // wave 7 the 1 x 2 piece (2, 1..2); waves 0..5 one dW1 block.
+    const int cls5 = wv >= 2 && wv <= 5 ? 0 : (wv == 6 ? 1 : (wv == 7 ? 2 : (wv == 0 ? 3 : 4)));
+    const int cls2 = NB == 5 ? cls5 : (NB == 4 ? 5 : (wv == 7 ? 5 : 3));
+    const int r0 = NB == 5 ? (cls5 == 0 ? 2 * ((wv - 2) >> 1) : (cls5 == 1 || cls5 == 3 ? 4 : 0)) : (NB == 4 ? wv >> 1 : (wv == 7 ? 2 : wv / 3));
+    const int c0 = NB == 5 ? (cls5 == 0 ? 2 * ((wv - 2) & 1) : (cls5 == 2 || cls5 == 3 ? 4 : 0)) : (NB == 4 ? 2 * (wv & 1) : (wv == 7 ? 1 : wv % 3));
+    const int lnc = NB == 5 ? (cls5 == 0 ? 1 : (cls5 == 1 ? 2 : 0)) : (NB == 4 ? 1 : (wv == 7 ? 1 : 0));
+    const int nblk2 = NB == 5 ? (cls5 <= 2 ? 4 : (cls5 == 3 ? 1 : 0)) : (NB == 4 ? 2 : (wv == 7 ? 2 : 1));
+    // dW1 blocks: (unit block = b >> 1, Gaussian block = b & 1)
+    const int b1a = NB == 5 ? (wv >= 2 ? wv - 2 : 6 + 2 * wv) : (NB == 4 ? wv : (wv < 6 ? wv : -1));
+    const int b1b = NB == 5 ? (wv >= 2 ? -1 : 7 + 2 * wv) : -1;
     // five accumulator tiles per wave: dW2 blocks in acc[0 .. nblk2 - 1], the first dW1 block in acc[4], the second one (waves 0
     // and 1, which own at most one dW2 block) in acc[3]
     f32x16 acc[5];
@@ -241,33 +253,50 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
     // activation to a quarter of it
     auto s1 = [&](const bf16_t* et) {
         if (MDL_CFB_SKIP & 1) return;
-        const int eb = wv & 1, ub = wv >> 1;
-        f32x16 d, d4;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d[r] = d4[r] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < KE / 16; ++k) {
-            const bf16x8 bfrag = ld_frag(et, 32 * eb + i, ES, 16 * k, h);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * ub + i, ES, 16 * k, h), bfrag, d, 0, 0, 0);
-            d4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * (NB - 1) + i, ES, 16 * k, h), bfrag, d4, 0, 0, 0);
-        }
         auto ssp2 = [](float t0, float t1) { return pk_bf16(LN2_F * (GT::softplus_u(t0) - 1.0f), LN2_F * (GT::softplus_u(t1) - 1.0f)); };
+        const int eb = wv & 1, ub = wv >> 1;
+        if constexpr (NB == 5) {
+            f32x16 d, d4;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            u32x4 v;
+            for (int r = 0; r < 16; ++r) d[r] = d4[r] = 0.0f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = ssp2(d[8 * t + 2 * q], d[8 * t + 2 * q + 1]);
-            *reinterpret_cast<u32x4*>(bl + (32 * eb + i) * LA + 32 * ub + 16 * t + 8 * h) = v;
+            for (int k = 0; k < KE / 16; ++k) {
+                const bf16x8 bfrag = ld_frag(et, 32 * eb + i, ES, 16 * k, h);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * ub + i, ES, 16 * k, h), bfrag, d, 0, 0, 0);
+                d4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * (NB - 1) + i, ES, 16 * k, h), bfrag, d4, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ssp2(d[8 * t + 2 * q], d[8 * t + 2 * q + 1]);
+                *reinterpret_cast<u32x4*>(bl + (32 * eb + i) * LA + 32 * ub + 16 * t + 8 * h) = v;
+            }
+            // quarter ub of the fifth block: registers 4 ub .. 4 ub + 3 = units 128 + 16 (ub >> 1) + 8 h + 4 (ub & 1) .. + 3
+            float q0, q1, q2, q3;
+            if (ub == 0) { q0 = d4[0]; q1 = d4[1]; q2 = d4[2]; q3 = d4[3]; }
+            else if (ub == 1) { q0 = d4[4]; q1 = d4[5]; q2 = d4[6]; q3 = d4[7]; }
+            else if (ub == 2) { q0 = d4[8]; q1 = d4[9]; q2 = d4[10]; q3 = d4[11]; }
+            else { q0 = d4[12]; q1 = d4[13]; q2 = d4[14]; q3 = d4[15]; }
+            u32x2 v = u32x2{ssp2(q0, q1), ssp2(q2, q3)};
+            if (ub == 3 && h == 1) v[1] = (v[1] & 0x0000ffffu) | 0x3F800000u;                           // unit FP - 1: the constant 1 (db2)
+            *reinterpret_cast<u32x2*>(bl + (32 * eb + i) * LA + 32 * (NB - 1) + 16 * (ub >> 1) + 8 * h + 4 * (ub & 1)) = v;
+        } else if (ub < NB) {                                    // 2 NB <= 8 blocks: one per wave (NB = 3: waves 6, 7 have none)
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KE / 16; ++k)
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(w1l, 32 * ub + i, ES, 16 * k, h), ld_frag(et, 32 * eb + i, ES, 16 * k, h), d, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ssp2(d[8 * t + 2 * q], d[8 * t + 2 * q + 1]);
+                if (ub == NB - 1 && t == 1 && h == 1) v[3] = (v[3] & 0x0000ffffu) | 0x3F800000u;        // unit FP - 1: the constant 1 (db2)
+                *reinterpret_cast<u32x4*>(bl + (32 * eb + i) * LA + 32 * ub + 16 * t + 8 * h) = v;
+            }
         }
-        // quarter ub of the fifth block: registers 4 ub .. 4 ub + 3 = units 128 + 16 (ub >> 1) + 8 h + 4 (ub & 1) .. + 3
-        float q0, q1, q2, q3;
-        if (ub == 0) { q0 = d4[0]; q1 = d4[1]; q2 = d4[2]; q3 = d4[3]; }
-        else if (ub == 1) { q0 = d4[4]; q1 = d4[5]; q2 = d4[6]; q3 = d4[7]; }
-        else if (ub == 2) { q0 = d4[8]; q1 = d4[9]; q2 = d4[10]; q3 = d4[11]; }
-        else { q0 = d4[12]; q1 = d4[13]; q2 = d4[14]; q3 = d4[15]; }
-        u32x2 v = u32x2{ssp2(q0, q1), ssp2(q2, q3)};
-        if (ub == 3 && h == 1) v[1] = (v[1] & 0x0000ffffu) | 0x3F800000u;                               // unit FP - 1: the constant 1 (db2)
-        *reinterpret_cast<u32x2*>(bl + (32 * eb + i) * LA + 32 * (NB - 1) + 16 * (ub >> 1) + 8 * h + 4 * (ub & 1)) = v;
     };
     auto s2 = [&]() {
         // S2a: dW2 += dw^T . a1 (k = the tile's 64 edges)
@@ -276,6 +305,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
         else if (cls2 == 1) tn_step<1, 4>(al, LA, r0, bl, LA, c0, i, h, acc);
         else if (cls2 == 2) tn_step<4, 1>(al, LA, r0, bl, LA, c0, i, h, acc);
         else if (cls2 == 3) tn_step<1, 1>(al, LA, r0, bl, LA, c0, i, h, acc);
+        else if (cls2 == 5) tn_step<1, 2>(al, LA, r0, bl, LA, c0, i, h, acc);
         // S2b: da = (W2^T . dw^T) .* ssp'(a1); lane = edge, rows of W2^T permuted like W1p's
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
@@ -307,7 +337,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
     };
     auto s3 = [&](const bf16_t* et) {           // S3: dW1 += da^T . [rbf | 1]
         if (MDL_CFB_SKIP & 8) return;
-        tn_step<1, 1>(dl, LA, b1a >> 1, et, ES, b1a & 1, i, h, acc + 4);
+        if (NB >= 4 || b1a >= 0) tn_step<1, 1>(dl, LA, b1a >> 1, et, ES, b1a & 1, i, h, acc + 4);
         if (b1b >= 0) tn_step<1, 1>(dl, LA, b1b >> 1, et, ES, b1b & 1, i, h, acc + 3);
     };
     bf16_t* const et0 = reinterpret_cast<bf16_t*>(smem + OFF_ET);
@@ -364,7 +394,7 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (j < nblk2) {
-                float* dst = mine + (5 * (r0 + (j >> lnc)) + c0 + (j & ((1 << lnc) - 1))) * 1024;
+                float* dst = mine + (NB * (r0 + (j >> lnc)) + c0 + (j & ((1 << lnc) - 1))) * 1024;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dst[64 * r] = acc[j][r];
             }
@@ -415,8 +445,9 @@ __global__ __launch_bounds__(NT, 2) void cfconv_bwd_w_kernel(Params p) {
 // sums the workgroups' partial blocks: one thread per accumulator element (block id, register, lane), the workgroup range cut in
 // RED_SPLIT pieces (gridDim.y) whose sums meet in the outputs with RED_SPLIT-way atomics
 __global__ __launch_bounds__(256) void cfconv_bwd_w_reduce_kernel(const float* __restrict__ part, int nwg, const int32_t* __restrict__ rowptr,
-                                                                   int N, int F, float* __restrict__ dw1, float* __restrict__ db1,
+                                                                   int N, int F, int NB, float* __restrict__ dw1, float* __restrict__ db1,
                                                                    float* __restrict__ dw2, float* __restrict__ db2) {
+    const int NBLK = NB * NB + 2 * NB, FP = 32 * NB;
     nwg = min(nwg, (rowptr[N] + TE - 1) / TE);                      // workgroups without a tile (padded batch) wrote nothing
     const int el = blockIdx.x * 256 + threadIdx.x;                  // < NBLK * 1024
     const int id = el >> 10, r = (el >> 6) & 15, lane = el & 63, i = lane & 31, h = lane >> 5;
@@ -453,7 +484,20 @@ __global__ __launch_bounds__(256) void cfconv_bwd_w_reduce_kernel(const float* _
 
 using namespace mdl;
 
-extern "C" size_t mdl_cfconv_bwd_w_scratch_bytes(void) { return (size_t)cfb::MAXGRID * cfb::NBLK * 1024 * sizeof(float); }
+extern "C" size_t mdl_cfconv_bwd_w_scratch_bytes(void) { return (size_t)cfb::MAXGRID * cfb::Shape<5>::NBLK * 1024 * sizeof(float); }
+
+template <int NB>
+static int cfconv_bwd_w_launch(const cfb::Params& p, int64_t grid, int64_t N, const int32_t* rowptr, hipStream_t st) {
+    auto kf = cfb::cfconv_bwd_w_kernel<NB>;
+    constexpr int lds = cfb::Shape<NB>::LDS;
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);
+    if (e != hipSuccess) { set_error("mdl_cfconv_bwd_w: LDS attribute (%d B): %s", lds, hipGetErrorString(e)); return MDL_E_LAUNCH; }
+    hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(cfb::NT), lds, st, p);
+    if (p.part)
+        hipLaunchKernelGGL(cfb::cfconv_bwd_w_reduce_kernel, dim3(cfb::Shape<NB>::NBLK * 1024 / 256, cfb::RED_SPLIT), dim3(256), 0, st, p.part,
+                           (int)grid, rowptr, (int)N, p.F, NB, p.dw1, p.db1, p.dw2, p.db2);
+    return check_launch("mdl_cfconv_bwd_w");
+}
 
 extern "C" int mdl_cfconv_bwd_w(const void* rbf, const float* cut, const void* h, const void* g, const int32_t* rowptr,
                                 const int32_t* src, const int32_t* tgt, const void* wpack, float* dw1, float* db1, float* dw2,
@@ -464,20 +508,14 @@ extern "C" int mdl_cfconv_bwd_w(const void* rbf, const float* cut, const void* h
     MDL_REQUIRE(N >= 0 && E >= 0 && N < (1ll << 31) && E < (1ll << 31) - 64, MDL_E_ARG, "mdl_cfconv_bwd_w: sizes out of range");
     if (N == 0 || E == 0) return MDL_OK;
     MDL_REQUIRE(rbf && cut && h && g && rowptr && src && tgt && wpack && dw1 && dw2, MDL_E_ARG, "mdl_cfconv_bwd_w: null argument");
-    MDL_REQUIRE(((uintptr_t)rbf % 4) == 0 && ((uintptr_t)h % 4) == 0 && ((uintptr_t)g % 4) == 0 && ((uintptr_t)wpack % 16) == 0, MDL_E_ARG,
-                "mdl_cfconv_bwd_w: misaligned tensor");
+    MDL_REQUIRE(((uintptr_t)rbf % 4) == 0 && ((uintptr_t)h % 4) == 0 && ((uintptr_t)g % 4) == 0 && ((uintptr_t)wpack % 16) == 0 &&
+                    ((uintptr_t)scratch % 16) == 0, MDL_E_ARG, "mdl_cfconv_bwd_w: misaligned tensor");
     cfb::Params p{static_cast<const bf16_t*>(rbf), cut, static_cast<const bf16_t*>(h), static_cast<const bf16_t*>(g), rowptr, src, tgt,
-                  static_cast<const bf16_t*>(wpack), dw1, db1, dw2, db2, det ? nullptr : static_cast<float*>(scratch), (int)N, F,
-                  (F + 2 + 31) / 32};
-    MDL_REQUIRE(((uintptr_t)scratch % 16) == 0, MDL_E_ARG, "mdl_cfconv_bwd_w: misaligned scratch");
+                  static_cast<const bf16_t*>(wpack), dw1, db1, dw2, db2, det ? nullptr : static_cast<float*>(scratch), (int)N, F};
     const int64_t grid = det ? 1 : std::min<int64_t>(cfb::MAXGRID, std::max<int64_t>(1, cdiv(E, cfb::TE)));
-    auto kf = cfb::cfconv_bwd_w_kernel;
-    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), cfb::LDS);
-    if (e != hipSuccess) { set_error("mdl_cfconv_bwd_w: LDS attribute (%d B): %s", cfb::LDS, hipGetErrorString(e)); return MDL_E_LAUNCH; }
-    hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(cfb::NT), cfb::LDS, (hipStream_t)stream, p);
-    if (p.part) {
-        hipLaunchKernelGGL(cfb::cfconv_bwd_w_reduce_kernel, dim3(cfb::NBLK * 1024 / 256, cfb::RED_SPLIT), dim3(256), 0, (hipStream_t)stream,
-                           p.part, (int)grid, rowptr, (int)N, F, dw1, db1, dw2, db2);
+    switch ((F + 2 + 31) / 32) {                              // the padded width of the packed weights (cfconv.hip: nbk_for)
+        case 3: return cfconv_bwd_w_launch<3>(p, grid, N, rowptr, (hipStream_t)stream);
+        case 4: return cfconv_bwd_w_launch<4>(p, grid, N, rowptr, (hipStream_t)stream);
+        default: return cfconv_bwd_w_launch<5>(p, grid, N, rowptr, (hipStream_t)stream);
     }
-    return check_launch("mdl_cfconv_bwd_w");
 }

@@ -1014,10 +1014,11 @@ def gather_mul_reduce(h, csr, w=None, scale=None, reduce="sum", pre=None):
 # ------------------------------------------------------------------------------------------------
 _CFCONV_FUSED = True
 _CFCONV_RECOMPUTE = True
-# K4b runs at the padded width 160 whatever the filter width, so below ~112 units the stored-activation backward is the faster
-# one (forward + backward of the block, E = 1.46 M: F = 64: 942 us recomputing / 684 stored / 739 unfused; 100: 1077 / 1047 /
-# 1107; 128: 1207 / 1283 / 1343; 150: 1290 / 1697 / 1794 — profiles/r06d_k4_k4b_forms.txt)
-_CFCONV_RECOMPUTE_MIN_F = 112
+# Forward + backward of the block at E = 1.46 M (profiles/r06d_k4_k4b_forms.txt; K4 and K4b both static at the padded width 96 /
+# 128 / 160): F = 64: 864 us recomputing / 696 stored / 748 unfused; 80: 899 / 886 / 952; 100: 1048 / 1076 / 1126; 112: 1055 / 1115 /
+# 1175; 128: 1215 / 1313 / 1343; 150: 1254 / 1686 / 1794 — the recomputing backward from the 128-wide instantiation on (it also keeps
+# 2 E F s bytes of activations per layer out of memory), stored activations below
+_CFCONV_RECOMPUTE_MIN_F = 96
 
 
 def cfconv_fused_ok(rbf, h, csr, lin_a, lin_b):

@@ -1328,7 +1328,7 @@ def test_recomputing_cfconv_backward_matches_the_three_pass_sequence(shape, monk
     for mode in ("unfused", "stored", "recompute", "recompute_cached"):
         monkeypatch.setattr(ops, "_CFCONV_FUSED", mode != "unfused")
         monkeypatch.setattr(ops, "_CFCONV_RECOMPUTE", mode.startswith("recompute"))
-        monkeypatch.setattr(ops, "_CFCONV_RECOMPUTE_MIN_F", 0)            # (the default dispatch keeps the stored form below 112 units)
+        monkeypatch.setattr(ops, "_CFCONV_RECOMPUTE_MIN_F", 0)            # (the default dispatch keeps the stored form below 96 units)
         ev = {"cfconv_fwd": [], "gmr_fwd": [], "cfconv_bwd_w": [], "cfconv_bwd_h": []}
         ops.KERNEL_EVENTS = ev
         xr = x.clone().requires_grad_(True)

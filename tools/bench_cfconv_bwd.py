@@ -26,6 +26,7 @@ cut = mnn.cosine_cutoff(b.edge_weight, 8.0)
 b.csr.transposed()
 for mode in a.modes.split(","):
     ops.configure(cfconv_fused=mode != "unfused", cfconv_recompute=mode == "recompute")
+    ops._CFCONV_RECOMPUTE_MIN_F = 0                   # (time the requested form whatever the default dispatch would pick at this width)
     ev = {k: [] for k in ("cfconv_fwd", "gmr_fwd", "cfconv_bwd_w", "cfconv_bwd_h")}
     t = []
     for it in range(a.iters + 3):
