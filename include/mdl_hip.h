@@ -423,6 +423,17 @@ int mdl_gemm_tn_act(const void* a, int64_t lda, int M, const void* y, int64_t ld
 int mdl_dense_bwd(const void* g, int64_t ldg, int M, const void* y, int64_t ldy, int act, const void* x, int64_t ldx, int K,
                   const void* w, void* dx, int64_t lddx, int xout, void* gm, float* dw, float* db, int64_t N, int dtype,
                   mdlStream_t stream);
+/* The streaming TN products end with one fp32 atomic per output element and WORKGROUP, and a launch's atomics retire at ~160 G/s
+ * whatever their addresses (256 workgroups x 25 blocks: 42 us beside 16 us of product on 1.1e5 rows).  The _ex forms take
+ * `scratch` = mdl_tn_scratch_bytes() bytes (16-byte aligned, contents undefined on entry and exit) or NULL: with it the blocks
+ * leave as plain stores and a second launch adds them into dw / db (c / colsum).  Everything else as the forms without it, which
+ * are the _ex forms with scratch = NULL. */
+size_t mdl_tn_scratch_bytes(void);
+int mdl_dense_bwd_ex(const void* g, int64_t ldg, int M, const void* y, int64_t ldy, int act, const void* x, int64_t ldx, int K,
+                     const void* w, void* dx, int64_t lddx, int xout, void* gm, float* dw, float* db, void* scratch, int64_t N,
+                     int dtype, mdlStream_t stream);
+int mdl_gemm_tn_ex(const void* a, int64_t lda, int M, const void* y, int64_t ldy, int act, const void* b, int64_t ldb, int K,
+                   float* c, float* colsum, void* scratch, int64_t N, int dtype, mdlStream_t stream);
 
 /* ---- generic gather / edge-weighted gather-reduce (SchNet CFConv, GCNConv, MEGNet, NNConv) ------
  * Replace the index_select + elementwise + torch_scatter sequence of PyG MessagePassing.propagate at

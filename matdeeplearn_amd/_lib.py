@@ -102,6 +102,8 @@ PROTOTYPES = {
     "mdl_bn_bwd_apply_relu_n": (_i32, [_vp] * 6 + [_i64, _i32, _vp, _i32, _vp]),
     "mdl_linear_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_dense_bwd": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "mdl_dense_bwd_ex": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "mdl_tn_scratch_bytes": (_sz, []),
     "mdl_linear_act_stats": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mdl_linear_act_in": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mdl_ssp_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
@@ -113,6 +115,7 @@ PROTOTYPES = {
     "mdl_split_bf16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "mdl_gemm_tn_colsum": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "mdl_gemm_tn_act": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
+    "mdl_gemm_tn_ex": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mdl_gather_rows": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "mdl_gather_mul_reduce": (_i32, [_vp] * 7 + [_i64, _i64, _i32, _i32, _vp]),
     "mdl_gather_mul_reduce_dw": (_i32, [_vp] * 9 + [_i64, _i64, _i32, _vp]),

@@ -16,6 +16,12 @@ namespace mdl {
 extern "C" int mdl_dense_bwd(const void* g, int64_t ldg, int M, const void* y, int64_t ldy, int act, const void* x, int64_t ldx,
                              int K, const void* w, void* dx, int64_t lddx, int xout, void* gm, float* dw, float* db,
                              int64_t N, int dtype, mdlStream_t stream) {
+    return mdl_dense_bwd_ex(g, ldg, M, y, ldy, act, x, ldx, K, w, dx, lddx, xout, gm, dw, db, nullptr, N, dtype, stream);
+}
+
+extern "C" int mdl_dense_bwd_ex(const void* g, int64_t ldg, int M, const void* y, int64_t ldy, int act, const void* x, int64_t ldx,
+                                int K, const void* w, void* dx, int64_t lddx, int xout, void* gm, float* dw, float* db, void* scratch,
+                                int64_t N, int dtype, mdlStream_t stream) {
     using namespace mdl;
     const bool det = (dtype & MDL_DETERMINISTIC) != 0;      // one workgroup: every dw / db element gets one add from one wave
     dtype &= MDL_DTYPE_MASK;
@@ -40,13 +46,15 @@ extern "C" int mdl_dense_bwd(const void* g, int64_t ldg, int M, const void* y, i
     int64_t grid = cdiv(N, 64);
     if (grid > grid_cap) grid = grid_cap;
     const int lds = (64 * (32 * mt + 8) + 64 * (32 * nt + 8) + 32 * nt * (32 * mt + 8)) * 2;
+    // scratch: dW / db blocks as plain stores + a reduce launch instead of atomics from every workgroup (gemm_tn_stream.inc `part`)
+    float* part = (scratch && !det && grid >= 32 && reinterpret_cast<uintptr_t>(scratch) % 16 == 0) ? static_cast<float*>(scratch) : nullptr;
 #define MDL_DB_K(MT_, NT_, A_, NW_)                                                                                          \
     do {                                                                                                                     \
         auto kf = gemm_tn_stream_kernel<MT_, NT_, A_, true, NW_>;                                                            \
         hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                          \
         if (e != hipSuccess) { set_error("mdl_dense_bwd: LDS attribute (%d B): %s", lds, hipGetErrorString(e)); return MDL_E_LAUNCH; } \
         hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * NW_), lds, st, (const bf16_t*)g, (int)ldg, M, (const bf16_t*)x, \
-                           (int)ldx, K, dw, db, N, (const bf16_t*)y, (int)ldy, (const bf16_t*)w, (bf16_t*)dx, (int)lddx, xout, (bf16_t*)gm); \
+                           (int)ldx, K, dw, db, N, (const bf16_t*)y, (int)ldy, (const bf16_t*)w, (bf16_t*)dx, (int)lddx, xout, (bf16_t*)gm, part); \
     } while (0)
 // waves per workgroup (measured on 1.5e6 rows, tools/bench_dense.py): a 5-tile side needs 8 (one 4-wave workgroup per CU ran
 // 150 x 150 in 611 us, 8 waves in 434); 4-tile shapes take 8 without an activation staging (288 -> 225 us) and 4 with one
@@ -63,5 +71,6 @@ extern "C" int mdl_dense_bwd(const void* g, int64_t ldg, int M, const void* y, i
     else { if (nt == 2) MDL_DB(5, 2); else if (nt == 4) MDL_DB(5, 4); else MDL_DB(5, 5); }
 #undef MDL_DB
 #undef MDL_DB_K
+    if (part) hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(mt * nt * 4), 16), dim3(256), 0, st, part, (int)grid, nt, mt * nt, M, K, dw, db);
     return check_launch("mdl_dense_bwd");
 }

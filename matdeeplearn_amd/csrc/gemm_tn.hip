@@ -98,8 +98,15 @@ extern "C" int mdl_gemm_tn_colsum(const void* a, int64_t lda, int M, const void*
     return mdl_gemm_tn_act(a, lda, M, nullptr, 0, 0, b, ldb, K, c, colsum, N, dtype, stream);
 }
 
+extern "C" size_t mdl_tn_scratch_bytes(void) { return (size_t)512 * 25 * 1024 * sizeof(float); }
+
 extern "C" int mdl_gemm_tn_act(const void* a, int64_t lda, int M, const void* y, int64_t ldy, int act, const void* b,
                                int64_t ldb, int K, float* c, float* colsum, int64_t N, int dtype, mdlStream_t stream) {
+    return mdl_gemm_tn_ex(a, lda, M, y, ldy, act, b, ldb, K, c, colsum, nullptr, N, dtype, stream);
+}
+
+extern "C" int mdl_gemm_tn_ex(const void* a, int64_t lda, int M, const void* y, int64_t ldy, int act, const void* b,
+                              int64_t ldb, int K, float* c, float* colsum, void* scratch, int64_t N, int dtype, mdlStream_t stream) {
     using namespace mdl;
     // MDL_DETERMINISTIC: one workgroup — every element of c / colsum then gets ONE add from one wave (no cross-block order)
     const bool det = (dtype & MDL_DETERMINISTIC) != 0;
@@ -126,20 +133,25 @@ extern "C" int mdl_gemm_tn_act(const void* a, int64_t lda, int M, const void* y,
             const int grid_cap = det ? 1 : ((N >= (1 << 20) && mt * nt < 25) ? 512 : 256);
             int64_t sgrid = cdiv(N, 64);
             if (sgrid > grid_cap) sgrid = grid_cap;
+            // scratch: the blocks leave as plain stores and a second launch adds them (the streaming kernel's `part`); not worth a
+            // launch for a handful of workgroups, not reproducible enough for the deterministic shape
+            float* part = (scratch && !det && sgrid >= 32 && reinterpret_cast<uintptr_t>(scratch) % 16 == 0) ? static_cast<float*>(scratch) : nullptr;
 #define MDL_TNS(MT_, NT_)                                                                                                   \
     do {                                                                                                                    \
         if (act == 0) hipLaunchKernelGGL((gemm_tn_stream_kernel<MT_, NT_, 0, false, MDL_TN_NW(MT_, NT_)>), dim3((unsigned)sgrid), dim3(64 * MDL_TN_NW(MT_, NT_)), 0, st,      \
-            (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, colsum, N, (const bf16_t*)nullptr, 0);          \
+            (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, colsum, N, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, (bf16_t*)nullptr, 0, 0, (bf16_t*)nullptr, part); \
         else if (act == 1) hipLaunchKernelGGL((gemm_tn_stream_kernel<MT_, NT_, 1, false, MDL_TN_NW(MT_, NT_)>), dim3((unsigned)sgrid), dim3(64 * MDL_TN_NW(MT_, NT_)), 0, st, \
-            (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, colsum, N, (const bf16_t*)y, (int)ldy);         \
+            (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, colsum, N, (const bf16_t*)y, (int)ldy, (const bf16_t*)nullptr, (bf16_t*)nullptr, 0, 0, (bf16_t*)nullptr, part); \
         else hipLaunchKernelGGL((gemm_tn_stream_kernel<MT_, NT_, 2, false, MDL_TN_NW(MT_, NT_)>), dim3((unsigned)sgrid), dim3(64 * MDL_TN_NW(MT_, NT_)), 0, st,               \
-            (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, colsum, N, (const bf16_t*)y, (int)ldy);         \
+            (const bf16_t*)a, (int)lda, M, (const bf16_t*)b, (int)ldb, K, c, colsum, N, (const bf16_t*)y, (int)ldy, (const bf16_t*)nullptr, (bf16_t*)nullptr, 0, 0, (bf16_t*)nullptr, part); \
     } while (0)
             if (mt == 1) { if (nt == 1) MDL_TNS(1, 1); else if (nt == 2) MDL_TNS(1, 2); else if (nt == 4) MDL_TNS(1, 4); else MDL_TNS(1, 5); }
             else if (mt == 2) { if (nt == 1) MDL_TNS(2, 1); else if (nt == 2) MDL_TNS(2, 2); else if (nt == 4) MDL_TNS(2, 4); else MDL_TNS(2, 5); }
             else if (mt == 4) { if (nt == 1) MDL_TNS(4, 1); else if (nt == 2) MDL_TNS(4, 2); else if (nt == 4) MDL_TNS(4, 4); else MDL_TNS(4, 5); }
             else { if (nt == 1) MDL_TNS(5, 1); else if (nt == 2) MDL_TNS(5, 2); else if (nt == 4) MDL_TNS(5, 4); else MDL_TNS(5, 5); }
 #undef MDL_TNS
+            if (part)
+                hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(mt * nt * 4), 16), dim3(256), 0, st, part, (int)sgrid, nt, mt * nt, M, K, c, colsum);
             return check_launch("mdl_gemm_tn");
         }
     }

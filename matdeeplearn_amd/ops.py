@@ -530,6 +530,28 @@ def _workspace(device, nbytes):
     return t
 
 
+_TN_SCRATCH = True     # partial sums of the streaming TN products through a scratch buffer + reduce launch instead of atomics
+_TNS = {}
+
+
+def _tn_scratch(device):
+    """Per device and stream: mdl_tn_scratch_bytes() bytes for the _ex forms of the TN products (launches on one stream are
+    ordered, so every layer shares it; allocated once — before any HIP-graph capture, by the warm-up steps)."""
+    if not _TN_SCRATCH:
+        return None
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _TNS.get(key)
+    if t is None:
+        t = _TNS[key] = torch.empty(lib().mdl_tn_scratch_bytes(), dtype=torch.uint8, device=device)
+    return t
+
+
+def _gemm_tn(a, lda, M, y, ldy, act, b, ldb, K, c, colsum, N, flags, device):
+    """mdl_gemm_tn / _colsum / _act in their scratch form (c [M, K] += (a .* act'(y))^T b, colsum += column sums)"""
+    return lib().mdl_gemm_tn_ex(ptr(a), lda, M, ptr(y), ldy, act, ptr(b), ldb, K, ptr(c), ptr(colsum), ptr(_tn_scratch(device)), N, flags,
+                                stream())
+
+
 # Deterministic mode (include/mdl_hip.h, MDL_DETERMINISTIC): the kernels that combine per-workgroup partial sums with
 # floating-point atomics — the CGConv backward edge pass and node kernel, the TN GEMM, the BatchNorm sums, the fused head —
 # are launched in a shape in which every sum gets its terms from ONE wave in program order: bit-reproducible from run to run,
@@ -575,6 +597,7 @@ OPTIONS = {
     "dense_bwd_wide": ("_DENSE_BWD_WIDE", "... also when both widths exceed 128"),
     "mlp_head": ("_MLP_HEAD", "post-FC head as one launch per direction"),
     "linear_wide": ("_LINEAR_WIDE", "NNConv's Y = x W2r on the streaming kernel"),
+    "tn_scratch": ("_TN_SCRATCH", "weight-gradient blocks of the TN products as plain stores + a reduce launch (off: atomics from every workgroup)"),
 }
 
 
@@ -819,8 +842,8 @@ class _CGConvFn(torch.autograd.Function):
             dx.addmm_(rs_b, wsrc.to(torch.bfloat16))
             xc = x.contiguous()
             for blk, r in enumerate((r_tgt[:, :Cp], r_tgt[:, Cp:], rs_b[:, :Cp], rs_b[:, Cp:])):
-                check(lib().mdl_gemm_tn(ptr(r), r.stride(0), Cp, ptr(xc), xc.stride(0), C, ptr(dwn[blk * Cp:(blk + 1) * Cp]), N,
-                                        dt | fl, stream()), "mdl_gemm_tn")
+                check(_gemm_tn(r, r.stride(0), Cp, None, 0, 0, xc, xc.stride(0), C, dwn[blk * Cp:(blk + 1) * Cp], None, N, dt | fl,
+                               x.device), "mdl_gemm_tn")
             dW_f = torch.empty((C, 2 * C + G), dtype=torch.float32, device=x.device)
             dW_s = torch.empty_like(dW_f)
             db_f = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias[0] else None
@@ -1277,9 +1300,9 @@ def _dense_bwd(ctx, g, x, w, act_y=None, xout=0, want_gm=False):
     dx = torch.empty((N, K), dtype=g.dtype, device=g.device)
     gm = torch.empty((N, M), dtype=g.dtype, device=g.device) if want_gm else None
     code, y = act_y if act_y is not None else (0, None)
-    check(lib().mdl_dense_bwd(ptr(g), g.stride(0), M, ptr(y), 0 if y is None else y.stride(0), code, ptr(x), x.stride(0), K,
-                              ptr(w), ptr(dx), K, xout, ptr(gm), ptr(dw), ptr(dbv) if ctx.has_bias else None, N,
-                              dtype_code(g) | _dflag(), stream()), "mdl_dense_bwd")
+    check(lib().mdl_dense_bwd_ex(ptr(g), g.stride(0), M, ptr(y), 0 if y is None else y.stride(0), code, ptr(x), x.stride(0), K,
+                                 ptr(w), ptr(dx), K, xout, ptr(gm), ptr(dw), ptr(dbv) if ctx.has_bias else None,
+                                 ptr(_tn_scratch(g.device)), N, dtype_code(g) | _dflag(), stream()), "mdl_dense_bwd")
     out = (dx, dw.to(ctx.wdtype), dbv.to(ctx.wdtype) if ctx.has_bias else None)
     return out + (gm,) if want_gm else out
 
@@ -1304,9 +1327,8 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
     if act_y is not None:
         buf = _zeros_grad(M * K + M, g.device)
         dw, dbv = buf[:M * K].view(M, K), buf[M * K:]
-        check(lib().mdl_gemm_tn_act(ptr(g), g.stride(0), M, ptr(act_y[1]), act_y[1].stride(0), act_y[0], ptr(x), x.stride(0), K,
-                                    ptr(dw), ptr(dbv) if ctx.has_bias else None, g.shape[0], dtype_code(g) | _dflag(), stream()),
-              "mdl_gemm_tn_act")
+        check(_gemm_tn(g, g.stride(0), M, act_y[1], act_y[1].stride(0), act_y[0], x, x.stride(0), K, dw,
+                       dbv if ctx.has_bias else None, g.shape[0], dtype_code(g) | _dflag(), g.device), "mdl_gemm_tn_act")
         dx = _dx_hip(g, w, act_y) if ctx.needs_input_grad[0] else None
         return dx, dw.to(ctx.wdtype), (dbv.to(ctx.wdtype) if ctx.has_bias else None)
     dx = _dx_hip(g, w) if ctx.needs_input_grad[0] else None
@@ -1322,8 +1344,8 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
             c = buf[off:off + K * (m1 - m0)].view(K, m1 - m0)
             off += K * (m1 - m0)
             gs = g[:, m0:m1]
-            check(lib().mdl_gemm_tn_colsum(ptr(x), x.stride(0), K, ptr(gs), g.stride(0), m1 - m0, ptr(c), None, g.shape[0],
-                                           dtype_code(g) | _dflag(), stream()), "mdl_gemm_tn_colsum")
+            check(_gemm_tn(x, x.stride(0), K, None, 0, 0, gs, g.stride(0), m1 - m0, c, None, g.shape[0], dtype_code(g) | _dflag(), g.device),
+                  "mdl_gemm_tn_colsum")
             parts.append(c)
         dw = torch.cat(parts, dim=1).t()
         db = g.sum(dim=0, dtype=torch.float32).to(ctx.wdtype) if ctx.has_bias else None
@@ -1336,11 +1358,11 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
         buf = _zeros_grad(M * K + M, g.device)
         d1, d2, dbv = buf[:M * kh].view(M, kh), buf[M * kh:M * K].view(M, K - kh), buf[M * K:]
         fused_db = ctx.has_bias and kh <= 158
-        check(lib().mdl_gemm_tn_colsum(ptr(g), g.stride(0), M, ptr(x), x.stride(0), kh, ptr(d1), ptr(dbv) if fused_db else None,
-                                       g.shape[0], dtype_code(g) | _dflag(), stream()), "mdl_gemm_tn_colsum")
+        check(_gemm_tn(g, g.stride(0), M, None, 0, 0, x, x.stride(0), kh, d1, dbv if fused_db else None, g.shape[0],
+                       dtype_code(g) | _dflag(), g.device), "mdl_gemm_tn_colsum")
         x2 = x[:, kh:]
-        check(lib().mdl_gemm_tn_colsum(ptr(g), g.stride(0), M, ptr(x2), x.stride(0), K - kh, ptr(d2), None, g.shape[0],
-                                       dtype_code(g) | _dflag(), stream()), "mdl_gemm_tn_colsum")
+        check(_gemm_tn(g, g.stride(0), M, None, 0, 0, x2, x.stride(0), K - kh, d2, None, g.shape[0], dtype_code(g) | _dflag(), g.device),
+              "mdl_gemm_tn_colsum")
         dw = torch.cat([d1, d2], dim=1)
         db = None
         if ctx.has_bias:
@@ -1355,8 +1377,8 @@ def _linear_tn_grads(ctx, g, x, w, act_y=None):
                 and ga.stride(0) % 2 == 0 and x.data_ptr() % 4 == 0 and ga.data_ptr() % 4 == 0)
     buf = _zeros_grad(Ma * K + Ma, g.device)                                       # dW | db: zero-filled (one fill per step)
     dw, dbv = buf[:Ma * K].view(Ma, K), buf[Ma * K:]
-    check(lib().mdl_gemm_tn_colsum(ptr(ga), ga.stride(0), Ma, ptr(x), x.stride(0), K, ptr(dw), ptr(dbv) if fused_db else None,
-                                   g.shape[0], dtype_code(g) | _dflag(), stream()), "mdl_gemm_tn_colsum")
+    check(_gemm_tn(ga, ga.stride(0), Ma, None, 0, 0, x, x.stride(0), K, dw, dbv if fused_db else None, g.shape[0],
+                   dtype_code(g) | _dflag(), g.device), "mdl_gemm_tn_colsum")
     dw = dw[:M]
     db = None
     if ctx.has_bias:                          # bias gradient = column sums of g: out of the same pass when the shape allows
@@ -1641,7 +1663,7 @@ class _LinearSplitTN(torch.autograd.Function):
         dw = torch.zeros((M, K), dtype=torch.float32, device=x.device)
         fl = _dflag()
         for a, b in ((gl, xh), (gh, xl), (gh, xh)):
-            check(lib().mdl_gemm_tn(ptr(a), M, M, ptr(b), K, K, ptr(dw), N, _lib.MDL_BF16 | fl, stream()), "mdl_gemm_tn")
+            check(_gemm_tn(a, M, M, None, 0, 0, b, K, K, dw, None, N, _lib.MDL_BF16 | fl, x.device), "mdl_gemm_tn")
         db = g.sum(0) if ctx.has_bias else None
         return dx, dw.to(weight.dtype), db
 
@@ -1866,8 +1888,9 @@ class _LinearReluBN(torch.autograd.Function):
         buf = _zeros_grad(M * K + M, x.device)
         dw, dbv = buf[:M * K].view(M, K), buf[M * K:]
         dx = torch.empty((N, K), dtype=x.dtype, device=x.device)
-        check(lib().mdl_dense_bwd(ptr(gp), M, M, None, 0, 0, ptr(x), x.stride(0), K, ptr(w), ptr(dx), K, 0, None, ptr(dw),
-                                  ptr(dbv) if ctx.has_bias else None, N, dt | _dflag(), stream()), "mdl_dense_bwd")
+        check(lib().mdl_dense_bwd_ex(ptr(gp), M, M, None, 0, 0, ptr(x), x.stride(0), K, ptr(w), ptr(dx), K, 0, None, ptr(dw),
+                                     ptr(dbv) if ctx.has_bias else None, ptr(_tn_scratch(x.device)), N, dt | _dflag(), stream()),
+              "mdl_dense_bwd")
         dts = []
         for t in range(ctx.ntab):
             need = ctx.needs_input_grad[12 + t] and ctx.rows[t] is not None

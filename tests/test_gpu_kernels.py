@@ -1516,3 +1516,39 @@ def test_fused_cfconv_matches_the_fp64_loop_oracle_and_zeroes_padded_rows(F):
     assert torch.equal(out, out2)
     assert L.mdl_cfconv_supported(150, 50, _lib.MDL_F32) == 0 and L.mdl_cfconv_supported(150, 64, _lib.MDL_BF16) == 0
     assert [L.mdl_cfconv_supported(f, 50, _lib.MDL_BF16) for f in (62, 64, 100, 101, 128, 158, 160)] == [0, 1, 1, 0, 1, 1, 0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(70000, 100, 100, 1), (70001, 150, 150, 2), (3000, 64, 114, 0), (40000, 150, 50, 0), (2100, 100, 100, 1)])
+def test_tn_products_with_a_scratch_buffer_match_the_atomic_flush(shape):
+    """mdl_gemm_tn_ex / mdl_dense_bwd_ex with `scratch` (the workgroups' accumulator blocks leave as plain stores and
+    tn_reduce_kernel adds them) against the same entry points with scratch = NULL (atomics from every workgroup): dW, db, the
+    column sums — and dX, which does not depend on the flush — on row counts that are not multiples of the tile, with the scratch
+    buffer full of NaN on entry.  Same sums in another order: 1e-4 of the scale (fp32 accumulation of ~1e3 bf16 products per term)."""
+    from matdeeplearn_amd import _lib
+    d = dev()
+    L, P, st = _lib.lib(), _lib.ptr, _lib.stream
+    N, M, K, act = shape
+    g_ = torch.Generator().manual_seed(N + M)
+    g = torch.randn(N, M, generator=g_).to(torch.bfloat16).to(d)
+    y = torch.randn(N, M, generator=g_).to(torch.bfloat16).to(d)
+    x = torch.randn(N, K, generator=g_).to(torch.bfloat16).to(d)
+    w = (torch.randn(M, K, generator=g_) * 0.1).to(torch.bfloat16).to(d)
+    scratch = torch.full((L.mdl_tn_scratch_bytes() // 4,), float("nan"), device=d)
+    res = []
+    for scr in (None, scratch):
+        c, cs = torch.zeros(M, K, device=d), torch.zeros(M, device=d)
+        _lib.check(L.mdl_gemm_tn_ex(P(g), M, M, P(y) if act else None, M, act, P(x), K, K, P(c), P(cs) if K <= 158 else None, P(scr), N,
+                                    _lib.MDL_BF16, st()), "gemm_tn_ex")
+        out = [c, cs]
+        if 34 <= M <= 160 and 34 <= K <= 158:
+            dx = torch.full((N, K), float("nan"), dtype=torch.bfloat16, device=d)
+            dw, db = torch.zeros(M, K, device=d), torch.zeros(M, device=d)
+            _lib.check(L.mdl_dense_bwd_ex(P(g), M, M, P(y) if act else None, M, act, P(x), K, K, P(w), P(dx), K, 0, None, P(dw), P(db), P(scr),
+                                          N, _lib.MDL_BF16, st()), "dense_bwd_ex")
+            out += [dw, db, dx]
+        res.append(out)
+    for a, b in zip(res[1], res[0]):
+        assert torch.isfinite(a.float()).all()
+        close(a, b, 1e-4, 1e-4)
+    assert torch.equal(res[1][-1], res[0][-1]) or len(res[0]) == 2          # dX: the same arithmetic either way

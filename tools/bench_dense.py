@@ -44,3 +44,18 @@ for rows in rows_list:
         t("dense_bwd %d<-%d act %d xout %d rows %d" % (K, M, act, xout, rows),
           lambda: L.mdl_dense_bwd(P(g), M, M, P(y) if act else None, M, act, P(x), K, K, P(w), P(dx), K, xout, None, P(dw), P(db), rows,
                                   _lib.MDL_BF16, st()), rows * ((2 if act else 1) * M + 2 * K) * 2)
+# the _ex forms (partial sums through the scratch buffer + reduce launch) against the forms above
+scr = torch.empty(L.mdl_tn_scratch_bytes(), dtype=torch.uint8, device=d)
+for rows in rows_list:
+    for (M, K) in ((150, 150), (100, 100), (64, 114)):
+        a = torch.randn(rows, M, device=d).to(torch.bfloat16); b = torch.randn(rows, K, device=d).to(torch.bfloat16)
+        c = torch.zeros(M, K, device=d); cs = torch.zeros(M, device=d)
+        t("gemm_tn_ex %dx%d rows %d" % (M, K, rows), lambda: L.mdl_gemm_tn_ex(P(a), a.stride(0), M, None, 0, 0, P(b), b.stride(0), K, P(c), P(cs), P(scr), rows, _lib.MDL_BF16, st()),
+          rows * (M + K) * 2)
+    for (K, M, act, xout) in ((100, 100, 1, 0), (100, 100, 0, 1), (150, 150, 0, 2)):
+        g = torch.randn(rows, M, device=d).to(torch.bfloat16); y = torch.randn(rows, M, device=d).to(torch.bfloat16)
+        x = torch.randn(rows, K, device=d).to(torch.bfloat16); w = torch.randn(M, K, device=d).to(torch.bfloat16)
+        dx = torch.empty(rows, K, device=d, dtype=torch.bfloat16); dw = torch.zeros(M, K, device=d); db = torch.zeros(M, device=d)
+        t("dense_bwd_ex %d<-%d act %d xout %d rows %d" % (K, M, act, xout, rows),
+          lambda: L.mdl_dense_bwd_ex(P(g), M, M, P(y) if act else None, M, act, P(x), K, K, P(w), P(dx), K, xout, None, P(dw), P(db), P(scr), rows,
+                                     _lib.MDL_BF16, st()), rows * ((2 if act else 1) * M + 2 * K) * 2)
