@@ -205,6 +205,9 @@ __global__ __launch_bounds__(64 * NW, 2) void cgconv_node_stream_kernel(const bf
             // ld_out > 0 (MdlCgNode.ld_dwn): straight into the two Linears' stacked weight gradient [2C][ld_out] (rows f | s, columns
             // target | source | edge): block b of rows goes to rows (b & 1) C + c, columns (b >> 1) C + K — no assembly pass
             const int64_t at = ld_out > 0 ? (int64_t)(((R / CP) & 1) * CP + R % CP) * ld_out + ((R / CP) >> 1) * CP + K : (int64_t)R * CP + K;
+#ifdef MDL_NODE_NOFLUSH      // experiment builds only: what the atomics of the flush cost
+            if (N < 0)
+#endif
             unsafeAtomicAdd(dwn + at, dw[j][r]);
         }
     }
@@ -370,6 +373,9 @@ __global__ __launch_bounds__(64 * NW, 1) void cgconv_node_x3_kernel(const float*
         for (int r = 0; r < 16; ++r) {
             const int R = mt * 32 + d_row(r, h), K = nt * 32 + i;
             const int64_t at = ld_out > 0 ? (int64_t)(((R / CP) & 1) * CP + R % CP) * ld_out + ((R / CP) >> 1) * CP + K : (int64_t)R * CP + K;
+#ifdef MDL_NODE_NOFLUSH      // experiment builds only: what the atomics of the flush cost
+            if (N < 0)
+#endif
             unsafeAtomicAdd(dwn + at, dw[j][r]);
         }
     }
