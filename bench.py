@@ -388,7 +388,7 @@ def main():
             with ops.zero_arena(dev):               # one zero fill per step for the kernels' small accumulators
                 out = model(batch)
                 loss = ops.loss("l1_loss", out, batch.y)
-                loss.backward()
+                ops.backward(loss)
             ops.KERNEL_EVENTS = None
             if dp.reduce_grads_async(force=use_dist):
                 dp.finish()

@@ -65,6 +65,10 @@ enum {
  *                      exact-fp32 MFMA, which has 1/16 of the bf16 rate.  Relative error 2^-16 per product: a PARITY
  *                      mode between bf16 (2^-9) and exact fp32 — the reference computes fp32 throughout
  *                      (training.py:34-54).  C = 64, G = 50, edge features in CSR order only.
+ *   MDL_MLP_F32_IO     mdl_mlp_head_fwd / _bwd only: the head's LAST output y (fwd) and its gradient gy (bwd) are fp32 rows —
+ *                      the model's `out.float()` (the reference's fp32 prediction, cgcnn.py:169-174) and the cast of the
+ *                      loss gradient back to bf16 cost a launch each, a tenth of the glue of a batch-100 step.  y holds the
+ *                      bf16-rounded values the bf16 output would have held.
  * The struct entry points (MdlCgConv, MdlCgNode) carry their flags in a field of their own; the positional entry points of
  * the dense / BatchNorm kernels take them OR-ed into `dtype`. */
 #define MDL_DTYPE_MASK 0xff
@@ -73,6 +77,7 @@ enum {
 #define MDL_K3_EDGE_LANE 0x400
 #define MDL_BN_SHIFT_ROW 0x800
 #define MDL_SPLIT_BF16 0x1000
+#define MDL_MLP_F32_IO 0x2000
 
 typedef void* mdlStream_t; /* hipStream_t */
 
@@ -269,6 +274,16 @@ int mdl_assemble_batch(const int64_t* ids, const int64_t* noff, const int64_t* e
                        const float* dist, const float* dist_norm, const int32_t* lrowptr, const float* y_all,
                        void* x, int64_t* batch, int32_t* rowptr, int32_t* src, int32_t* tgt, float* ew, float* dn,
                        float* y, int B, int F, int T, int target_index, int dtype, mdlStream_t stream);
+/* The same into the PADDED buffers of a static batch (n_cap nodes, e_cap edge slots: HIP-graph replays of the training step at
+ * the reference's batch size, config.yml:136) with mdl_pad_batch_tail and mdl_pad_edge_tail (below) done by extra workgroups of
+ * the same launch, and pool_seg [n_cap] (may be NULL) = `batch` as int32 — four launches of a launch-bound step as one.
+ * col_s / eid_s / src_s: the by-source arrays whose tails are padded too (all three or all NULL). */
+int mdl_assemble_batch_padded(const int64_t* ids, const int64_t* noff, const int64_t* eoff, const int64_t* node_ptr,
+                              const int64_t* edge_ptr, const float* x_all, const int32_t* src_l, const int32_t* tgt_l,
+                              const float* dist, const float* dist_norm, const int32_t* lrowptr, const float* y_all,
+                              void* x, int64_t* batch, int32_t* rowptr, int32_t* src, int32_t* tgt, float* ew, float* dn,
+                              float* y, int B, int F, int T, int target_index, int dtype, int64_t n_cap, int64_t e_cap,
+                              int32_t* pool_seg, int32_t* col_s, int32_t* eid_s, int32_t* src_s, mdlStream_t stream);
 
 /* dx = g * sigmoid(pre) for y = softplus(pre) - ln 2 given y (the SchNet activation; sigmoid(pre) = 1 - exp(-(y + ln 2))): one
  * bf16 pass instead of six library elementwise launches.  n = number of elements (even). */
@@ -330,6 +345,11 @@ int mdl_pad_edge_tail(const int64_t* noff, const int64_t* eoff, int B, int64_t n
  * (kind 1, F.mse_loss); grad[i] = d loss / d pred[i].  fp32.  Replaces the eight elementwise / reduction launches of
  * `getattr(F, loss)(output, data.y)` + its autograd (matdeeplearn/training/training.py:44-47). */
 int mdl_loss_fwd_bwd(const float* pred, const float* y, int64_t n, int kind, float* loss, float* grad, mdlStream_t stream);
+/* same over the first n of n_total predictions (y [n]; grad [n_total], exact zeros past n): the padded static batch of the
+ * HIP-graph step carries a dummy graph behind the batch's B graphs, and `output[:B]` in front of the loss would put a slice
+ * node (zero fill + copy in the backward) between the model and the loss. */
+int mdl_loss_fwd_bwd_rows(const float* pred, const float* y, int64_t n, int64_t n_total, int kind, float* loss, float* grad,
+                          mdlStream_t stream);
 
 /* ---- training-mode BatchNorm1d over rows, x: [N, C] row-major ------------------------------------
  * Replaces torch.nn.BatchNorm1d as applied after every conv layer (matdeeplearn/models/cgcnn.py:85-87,143)
@@ -380,8 +400,9 @@ int mdl_linear_act_in(const void* x, const void* y, int xact, const void* w, con
  * 155-174) — as ONE launch per direction: h_0 = relu(x w_0^T + b_0), ..., y = h_{NL-2} w_{NL-1}^T + b_{NL-1}.
  * bf16; 1 <= NL <= 4 dense layers, every width <= 64 (hidden widths and K0 even), ReLU between the layers, none after the last.
  * w / b / h / dw / db are HOST arrays of NL device pointers (b and db entries may be NULL).
- *   fwd: h[l] receives layer l's output [N, M[l]] (h[NL-1] = y); the hidden ones are what the backward needs.
- *   bwd: h[l] (l < NL-1) = the saved hidden outputs, gy = dL/dy [N, M[NL-1]]; dw[l] [M[l], K_l] and db[l] [M[l]] are fp32,
+ *   fwd: h[l] receives layer l's output [N, M[l]] (h[NL-1] = y, fp32 rows under dtype | MDL_MLP_F32_IO); the hidden ones are
+ *        what the backward needs.
+ *   bwd: h[l] (l < NL-1) = the saved hidden outputs, gy = dL/dy [N, M[NL-1]] (fp32 rows under MDL_MLP_F32_IO); dw[l] [M[l], K_l] and db[l] [M[l]] are fp32,
  *        zero-filled by the caller and accumulated with atomics; dx [N, K0] may be NULL. */
 int mdl_mlp_head_fwd(const void* x, const void* const* w, const void* const* b, void* const* h, int64_t N, int K0, int NL,
                      const int* M, int dtype, mdlStream_t stream);

@@ -21,6 +21,7 @@ MDL_F32, MDL_BF16 = 0, 1
 MDL_SUM, MDL_MEAN, MDL_MAX = 0, 1, 2
 # execution flags (include/mdl_hip.h): the `flags` field of the struct entry points, OR-ed into `dtype` for the positional ones
 MDL_DTYPE_MASK, MDL_DETERMINISTIC, MDL_K3_PER_WAVE, MDL_K3_EDGE_LANE = 0xFF, 0x100, 0x200, 0x400
+MDL_MLP_F32_IO = 0x2000        # mdl_mlp_head_fwd / _bwd: the last output / its gradient as fp32 rows
 MDL_SPLIT_BF16 = 0x1000        # CGConv kernels on fp32 storage: the K = 2C + G product as three bf16 MFMAs on (hi, lo) operands
 MDL_BN_SHIFT_ROW = 0x800       # mdl_bn_apply_n: sums about the shift row their producer stored behind the totals rows
 MDL_BN_REPLICAS = 16
@@ -88,12 +89,14 @@ PROTOTYPES = {
     "mdl_cgconv_pack_node_weights": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "mdl_cgconv_assemble_grads": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mdl_assemble_batch": (_i32, [_vp] * 20 + [_i32, _i32, _i32, _i32, _i32, _vp]),
+    "mdl_assemble_batch_padded": (_i32, [_vp] * 20 + [_i32, _i32, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mdl_nnconv_msg_fwd": (_i32, [_vp] * 5 + [_i64, _i32, _i32, _i32, _vp]),
     "mdl_nnconv_msg_bwd": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _vp]),
     "mdl_pad_batch_tail": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "mdl_assemble_transposed": (_i32, [_vp] * 13 + [_i32, _i64, _vp]),
     "mdl_pad_edge_tail": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mdl_loss_fwd_bwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "mdl_loss_fwd_bwd_rows": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "mdl_bn_sums_rows": (_i32, []),
     "mdl_bn_stats_n": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "mdl_bn_apply_n": (_i32, [_vp] * 8 + [_i64, _i32, _f32, _f32, _vp, _i32, _vp]),

@@ -32,11 +32,37 @@ struct AsmParams {
     float* dn;                 // out [E] normalised distance
     float* y;                  // out [B]
     int F, T, target_index, B;
+    // padded static batch (mdl_assemble_batch_padded; n_cap = 0 otherwise): the blocks past B close the tails in the same launch
+    int64_t n_cap, e_cap;
+    int32_t* pool_seg;         // out [n_cap] int32 copy of `batch` (the pooling index's segment ids) or null
+    int32_t* col_s;            // by-source arrays [e_cap] whose tails are padded too, or null
+    int32_t* eid_s;
+    int32_t* src_s;
 };
+
+constexpr int ASM_TAIL_BLOCKS = 64;
 
 template <typename T>
 __global__ __launch_bounds__(256) void assemble_kernel(AsmParams p) {
     const int g = blockIdx.x;
+    if (g >= p.B) {
+        // tail of a padded static batch (what pad_tail_kernel / pad_edge_tail_kernel below do as launches of their own): padding
+        // nodes own no edges and sit in the dummy graph B, unused edge slots point at the first padding node
+        const int64_t N = p.noff[p.B], E = p.eoff[p.B];
+        const int64_t t0 = (int64_t)(g - p.B) * blockDim.x + threadIdx.x, ts = (int64_t)ASM_TAIL_BLOCKS * blockDim.x;
+        for (int64_t n = N + t0; n < p.n_cap; n += ts) {
+            p.batch[n] = p.B;
+            p.rowptr[n + 1] = (int32_t)E;
+            if (p.pool_seg) p.pool_seg[n] = p.B;
+        }
+        const int32_t pad = (int32_t)(N < p.n_cap ? N : p.n_cap - 1);
+        for (int64_t e = E + t0; e < p.e_cap; e += ts) {
+            p.src[e] = pad;
+            p.tgt[e] = pad;
+            if (p.col_s) { p.col_s[e] = pad; p.src_s[e] = pad; p.eid_s[e] = (int32_t)e; }
+        }
+        return;
+    }
     const int64_t gid = p.ids[g];
     const int64_t n0s = p.node_ptr[gid], nn = p.node_ptr[gid + 1] - n0s;
     const int64_t e0s = p.edge_ptr[gid], ne = p.edge_ptr[gid + 1] - e0s;
@@ -58,6 +84,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams p) {
     for (int64_t j = threadIdx.x; j < nn; j += blockDim.x) {
         p.batch[no + j] = g;
         p.rowptr[no + j] = (int32_t)(eo + p.lrowptr[n0s + j]);
+        if (p.pool_seg) p.pool_seg[no + j] = g;
     }
     const int32_t shift = (int32_t)no;
     for (int64_t k0 = threadIdx.x; k0 < ne; k0 += 2 * blockDim.x) {
@@ -187,10 +214,32 @@ extern "C" int mdl_assemble_batch(const int64_t* ids, const int64_t* noff, const
     MDL_REQUIRE(ids && noff && eoff && node_ptr && edge_ptr && x_all && lrowptr && y_all && x && batch && rowptr && y,
                 MDL_E_ARG, "mdl_assemble_batch: null pointer");
     AsmParams p = {ids, noff, eoff, node_ptr, edge_ptr, x_all, src_l, tgt_l, dist, dist_norm, lrowptr, y_all,
-                   x, batch, rowptr, src, tgt, ew, dn, y, F, T, target_index, B};
+                   x, batch, rowptr, src, tgt, ew, dn, y, F, T, target_index, B, 0, 0, nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MDL_F32) hipLaunchKernelGGL((assemble_kernel<float>), dim3((unsigned)B), dim3(256), 0, st, p);
     else if (dtype == MDL_BF16) hipLaunchKernelGGL((assemble_kernel<bf16_t>), dim3((unsigned)B), dim3(256), 0, st, p);
     else { set_error("mdl_assemble_batch: unsupported dtype %d", dtype); return MDL_E_UNSUPP; }
     return check_launch("mdl_assemble_batch");
+}
+
+// mdl_assemble_batch + mdl_pad_batch_tail + mdl_pad_edge_tail (+ the int32 copy of `batch` the pooling index reads) as ONE launch
+extern "C" int mdl_assemble_batch_padded(const int64_t* ids, const int64_t* noff, const int64_t* eoff, const int64_t* node_ptr,
+                                         const int64_t* edge_ptr, const float* x_all, const int32_t* src_l, const int32_t* tgt_l,
+                                         const float* dist, const float* dist_norm, const int32_t* lrowptr, const float* y_all,
+                                         void* x, int64_t* batch, int32_t* rowptr, int32_t* src, int32_t* tgt, float* ew, float* dn,
+                                         float* y, int B, int F, int T, int target_index, int dtype, int64_t n_cap, int64_t e_cap,
+                                         int32_t* pool_seg, int32_t* col_s, int32_t* eid_s, int32_t* src_s, mdlStream_t stream) {
+    using namespace mdl;
+    MDL_REQUIRE(B >= 1 && F >= 1 && T >= 1 && target_index >= 0 && target_index < T && n_cap >= 1 && e_cap >= 0, MDL_E_ARG,
+                "mdl_assemble_batch_padded: bad sizes");
+    MDL_REQUIRE(ids && noff && eoff && node_ptr && edge_ptr && x_all && lrowptr && y_all && x && batch && rowptr && y && src && tgt &&
+                    (!col_s || (eid_s && src_s)), MDL_E_ARG, "mdl_assemble_batch_padded: null pointer");
+    AsmParams p = {ids, noff, eoff, node_ptr, edge_ptr, x_all, src_l, tgt_l, dist, dist_norm, lrowptr, y_all,
+                   x, batch, rowptr, src, tgt, ew, dn, y, F, T, target_index, B, n_cap, e_cap, pool_seg, col_s, eid_s, src_s};
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(B + ASM_TAIL_BLOCKS));
+    if (dtype == MDL_F32) hipLaunchKernelGGL((assemble_kernel<float>), grid, dim3(256), 0, st, p);
+    else if (dtype == MDL_BF16) hipLaunchKernelGGL((assemble_kernel<bf16_t>), grid, dim3(256), 0, st, p);
+    else { set_error("mdl_assemble_batch_padded: unsupported dtype %d", dtype); return MDL_E_UNSUPP; }
+    return check_launch("mdl_assemble_batch_padded");
 }

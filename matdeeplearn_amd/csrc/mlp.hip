@@ -26,26 +26,60 @@ struct MlpArgs {
     int64_t N;
     int K0, NL;
     int M[MLP_MAXL];
+    int f32io;                      // MDL_MLP_F32_IO: fwd writes the LAST layer's output as fp32 rows, bwd reads gy as fp32 rows
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* mlp_lds4_t;
 
-// rows [r0, r0 + 64) of src [N, K] (bf16, dense rows, even K) -> tile [64][MLP_LD], zero-filled past N and past K
+// rows [r0, r0 + 64) of src [N, K] (bf16, dense rows) -> tile [64][MLP_LD], zero-filled past N and past K.
+// Every load of a staging call is issued before the first LDS store (clamped, branch-free addresses: element 0 stands in for
+// what lies outside) — a loop of load -> wait -> store is a chain of 8-16 memory round trips per tile, which at the reference's
+// batch size (two tiles of work per workgroup) was most of the two kernels' time.
 __device__ __forceinline__ void mlp_stage(bf16_t* tile, const bf16_t* src, int64_t r0, int64_t N, int K, int tid) {
     if (K & 1) {                                                       // odd width (a 1-column output): element by element
-        for (int q = tid; q < 64 * 64; q += 256) {
-            const int row = q >> 6, c = q & 63;
-            tile[row * MLP_LD + c] = (r0 + row < N && c < K) ? src[(r0 + row) * (int64_t)K + c] : (bf16_t)0;
+        bf16_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int q = tid + 256 * u, row = q >> 6, c = q & 63;
+            const bool ok = r0 + row < N && c < K;
+            v[u] = src[ok ? (r0 + row) * (int64_t)K + c : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int q = tid + 256 * u, row = q >> 6, c = q & 63;
+            tile[row * MLP_LD + c] = (r0 + row < N && c < K) ? v[u] : (bf16_t)0;
         }
         return;
     }
     const int k2 = K >> 1;
-    for (int q = tid; q < 64 * 32; q += 256) {
-        const int row = q >> 5, d = q & 31;
-        unsigned v = 0u;
-        if (r0 + row < N && d < k2) v = *reinterpret_cast<const unsigned*>(src + (r0 + row) * (int64_t)K + 2 * d);
-        *reinterpret_cast<unsigned*>(tile + row * MLP_LD + 2 * d) = v;
+    unsigned v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int q = tid + 256 * u, row = q >> 5, d = q & 31;
+        const bool ok = r0 + row < N && d < k2;
+        v[u] = *reinterpret_cast<const unsigned*>(src + (ok ? (r0 + row) * (int64_t)K + 2 * d : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int q = tid + 256 * u, row = q >> 5, d = q & 31;
+        *reinterpret_cast<unsigned*>(tile + row * MLP_LD + 2 * d) = (r0 + row < N && d < k2) ? v[u] : 0u;
+    }
+}
+
+// the same from fp32 rows (the output gradient under MDL_MLP_F32_IO), rounded to bf16 as the cast in front of the kernel did
+__device__ __forceinline__ void mlp_stage_f32(bf16_t* tile, const float* src, int64_t r0, int64_t N, int K, int tid) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int q = tid + 256 * u, row = q >> 6, c = q & 63;
+        const bool ok = r0 + row < N && c < K;
+        v[u] = src[ok ? (r0 + row) * (int64_t)K + c : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int q = tid + 256 * u, row = q >> 6, c = q & 63;
+        tile[row * MLP_LD + c] = (r0 + row < N && c < K) ? f2bf(v[u]) : (bf16_t)0;
     }
 }
 
@@ -70,13 +104,27 @@ __global__ __launch_bounds__(256, 2) void mlp_head_fwd_kernel(MlpArgs p) {
     bf16_t* tb = ta + 64 * MLP_LD;
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = wv & 1, nt = wv >> 1;
-    for (int l = 0; l < p.NL; ++l) {
-        const int K = l ? p.M[l - 1] : p.K0, M = p.M[l];
-        for (int q = tid; q < 64 * 32; q += 256) {
-            const int row = q >> 5, d = q & 31;
-            unsigned v = 0u;
-            if (row < M && 2 * d < K) v = *reinterpret_cast<const unsigned*>(p.w[l] + (int64_t)row * K + 2 * d);
-            *reinterpret_cast<unsigned*>(wl + (l * 64 + row) * MLP_LD + 2 * d) = v;
+    {   // weights -> LDS: every layer's loads in flight before the first store (see mlp_stage)
+        unsigned wv_[MLP_MAXL][8];
+#pragma unroll
+        for (int l = 0; l < MLP_MAXL; ++l) {
+            const int K = l < p.NL ? (l ? p.M[l - 1] : p.K0) : 0, M = l < p.NL ? p.M[l] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = tid + 256 * u, row = q >> 5, d = q & 31;
+                unsigned v = 0u;
+                if (row < M && 2 * d < K) v = *reinterpret_cast<const unsigned*>(p.w[l] + (int64_t)row * K + 2 * d);
+                wv_[l][u] = v;
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < MLP_MAXL; ++l) {
+            if (l >= p.NL) break;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = tid + 256 * u, row = q >> 5, d = q & 31;
+                *reinterpret_cast<unsigned*>(wl + (l * 64 + row) * MLP_LD + 2 * d) = wv_[l][u];
+            }
         }
     }
     const int64_t n_tiles = (p.N + 63) / 64;
@@ -93,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void mlp_head_fwd_kernel(MlpArgs p) {
             const f32x16 acc = mlp_block(tin, wl + l * 64 * MLP_LD, mt, nt, i, h, bias);
             const bool relu = l + 1 < p.NL;
             bf16_t* const out = p.h[l];
+            float* const out32 = (!relu && p.f32io) ? reinterpret_cast<float*>(p.h[l]) : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mt * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
@@ -100,7 +149,10 @@ __global__ __launch_bounds__(256, 2) void mlp_head_fwd_kernel(MlpArgs p) {
                 if (relu) v = v > 0.0f ? v : 0.0f;
                 const bf16_t hv = f2bf(v);
                 tout[row * MLP_LD + col] = hv;                         // (columns past M: zero weights rows -> bias 0 -> relu(0) = 0)
-                if (col < M && r0 + row < p.N) out[(r0 + row) * (int64_t)M + col] = hv;
+                if (col < M && r0 + row < p.N) {
+                    if (out32) out32[(r0 + row) * (int64_t)M + col] = bf2f(hv);     // (the value the bf16 output + cast gave)
+                    else out[(r0 + row) * (int64_t)M + col] = hv;
+                }
             }
             __syncthreads();
             bf16_t* t = tin; tin = tout; tout = t;
@@ -157,7 +209,8 @@ __global__ __launch_bounds__(256, 1) void mlp_head_bwd_kernel(MlpArgs p) {
         __syncthreads();
         for (int l = 0; l < p.NL; ++l)
             mlp_stage(tin + l * 64 * MLP_LD, l ? p.h[l - 1] : p.x, r0, p.N, l ? p.M[l - 1] : p.K0, tid);
-        mlp_stage(da, p.gy, r0, p.N, p.M[p.NL - 1], tid);
+        if (p.f32io) mlp_stage_f32(da, reinterpret_cast<const float*>(p.gy), r0, p.N, p.M[p.NL - 1], tid);
+        else mlp_stage(da, p.gy, r0, p.N, p.M[p.NL - 1], tid);
         __syncthreads();
         bf16_t* dcur = da;
         bf16_t* dnext = dbuf;
@@ -245,7 +298,8 @@ static int mlp_check(const char* name, const MlpArgs& a, int dtype) {
 
 }  // namespace mdl
 
-// w / b / h: NL pointers each (b entries may be NULL); h[l] receives layer l's output [N, M[l]] (h[NL-1] = y)
+// w / b / h: NL pointers each (b entries may be NULL); h[l] receives layer l's output [N, M[l]] (h[NL-1] = y; with
+// dtype | MDL_MLP_F32_IO that last one is an fp32 buffer — the prediction the fp32 loss reads, no cast launch behind the head)
 extern "C" int mdl_mlp_head_fwd(const void* x, const void* const* w, const void* const* b, void* const* h, int64_t N, int K0,
                                 int NL, const int* M, int dtype, mdlStream_t stream) {
     using namespace mdl;
@@ -253,6 +307,8 @@ extern "C" int mdl_mlp_head_fwd(const void* x, const void* const* w, const void*
     a.x = (const bf16_t*)x; a.N = N; a.K0 = K0; a.NL = NL;
     MDL_REQUIRE(NL >= 1 && NL <= MLP_MAXL && w && b && h && M, MDL_E_ARG, "mdl_mlp_head_fwd: bad arguments");
     for (int l = 0; l < NL; ++l) { a.w[l] = (const bf16_t*)w[l]; a.b[l] = (const bf16_t*)b[l]; a.h[l] = (bf16_t*)h[l]; a.M[l] = M[l]; }
+    a.f32io = (dtype & MDL_MLP_F32_IO) != 0;
+    dtype &= MDL_DTYPE_MASK;
     int rc = mlp_check("mdl_mlp_head_fwd", a, dtype);
     if (rc) return rc;
     for (int l = 0; l < NL; ++l) MDL_REQUIRE(N == 0 || a.h[l], MDL_E_ARG, "mdl_mlp_head_fwd: null output %d", l);
@@ -266,7 +322,7 @@ extern "C" int mdl_mlp_head_fwd(const void* x, const void* const* w, const void*
     return check_launch("mdl_mlp_head_fwd");
 }
 
-// h: the NL-1 saved hidden outputs (h[l] = output of layer l, l < NL-1); gy [N, M[NL-1]]; dw[l] [M[l], K_l] / db[l] [M[l]] fp32,
+// h: the NL-1 saved hidden outputs (h[l] = output of layer l, l < NL-1); gy [N, M[NL-1]] (fp32 rows with MDL_MLP_F32_IO); dw[l] [M[l], K_l] / db[l] [M[l]] fp32,
 // zero-filled by the caller (db entries and dx may be NULL)
 extern "C" int mdl_mlp_head_bwd(const void* x, const void* const* w, const void* const* h, const void* gy, void* dx,
                                 float* const* dw, float* const* db, int64_t N, int K0, int NL, const int* M, int dtype,
@@ -280,10 +336,11 @@ extern "C" int mdl_mlp_head_bwd(const void* x, const void* const* w, const void*
         a.h[l] = l + 1 < NL ? (bf16_t*)const_cast<void*>(h[l]) : nullptr;
     }
     const bool det = (dtype & MDL_DETERMINISTIC) != 0;      // one workgroup: one add per dw / db element
+    a.f32io = (dtype & MDL_MLP_F32_IO) != 0;
     dtype &= MDL_DTYPE_MASK;
     int rc = mlp_check("mdl_mlp_head_bwd", a, dtype);
     if (rc) return rc;
-    MDL_REQUIRE(N == 0 || (gy && reinterpret_cast<uintptr_t>(gy) % (M[NL - 1] % 2 ? 2 : 4) == 0), MDL_E_ARG,
+    MDL_REQUIRE(N == 0 || (gy && reinterpret_cast<uintptr_t>(gy) % ((M[NL - 1] % 2 && !a.f32io) ? 2 : 4) == 0), MDL_E_ARG,
                 "mdl_mlp_head_bwd: null / misaligned gy");
     for (int l = 0; l < NL; ++l) {
         MDL_REQUIRE(N == 0 || a.dw[l], MDL_E_ARG, "mdl_mlp_head_bwd: null dw %d", l);

@@ -143,12 +143,14 @@ class GraphModel(nn.Module):
     def _drop(self, out):
         return F.dropout(out, p=self.dropout_rate, training=self.training)
 
-    def _post(self, out):
+    def _post(self, out, final=False):
+        """final: the head's output is the model's prediction (early pooling) — the fused head then writes it as the fp32 tensor
+        `out.float()` would make of its bf16 output (no cast launch forward, none in front of its backward)."""
         lins = list(self.post_lin_list) + [self.lin_out]
         if out.dtype != self.lin_out.weight.dtype and ops.mlp_head_ok(out, lins, self.act):
             # the whole head in one launch per direction (csrc/mlp.hip): separately its ~20 launches of a few microseconds
             # each are launch-bound on the pooled rows
-            return ops.mlp_head(out, lins, [_lowp(lin) for lin in lins])
+            return ops.mlp_head(out, lins, [_lowp(lin) for lin in lins], f32_out=final)
         for lin in self.post_lin_list:
             out = dense_act(lin, out, self.act, split=self.split_products)
         return dense(self.lin_out, out)
@@ -161,7 +163,7 @@ class GraphModel(nn.Module):
 
     def _head(self, out, data):
         if self.pool_order == "early":
-            out = self._post(self._pool(out, data).to(out.dtype))
+            out = self._post(self._pool(out, data).to(out.dtype), final=True)
         else:
             out = self._post(out)
             if self.pool == "set2set":

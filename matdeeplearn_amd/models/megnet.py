@@ -200,7 +200,7 @@ class MEGNet(GraphModel):
                 x_pool = ops.scatter(x, data.batch, 0, nb, self.pool_reduce, assume_sorted=True)
                 e_pool = ops.scatter(ops.scatter(e, ei[0], 0, n, self.pool_reduce), data.batch, 0, nb, self.pool_reduce,
                                      assume_sorted=True)
-            out = self._post(torch.cat([x_pool, e_pool, u], dim=1))
+            out = self._post(torch.cat([x_pool, e_pool, u], dim=1), final=True)
         else:
             out = self._post(x)
             if self.pool == "set2set":

@@ -311,8 +311,10 @@ class _SegmentReduce(torch.autograd.Function):
         g = g.contiguous()
         argmax = ctx.saved_tensors[0] if ctx.reduce == _lib.MDL_MAX else None
         # rows outside every segment (the unused tail of a padded static batch) must get exact zeros: they feed dense
-        # per-row kernels (weight-gradient GEMMs) that run over all rows
-        alloc = torch.zeros if (ctx.reduce == _lib.MDL_MAX or si.partial) else torch.empty
+        # per-row kernels (weight-gradient GEMMs) that run over all rows.  The sum / mean kernels write EVERY row from g[seg[row]],
+        # and a padded row's segment id is the dummy graph / the first padding node, whose gradient row is exactly zero by the
+        # static batch's invariant — so only the max form (which writes the argmax rows alone) needs the fill launch
+        alloc = torch.zeros if ctx.reduce == _lib.MDL_MAX else torch.empty
         gs = alloc(ctx.shape, dtype=g.dtype, device=g.device)
         check(lib().mdl_segment_reduce_bwd(ptr(g), ptr(si.rowptr), ptr(si.seg), ptr(si.perm), ptr(argmax), ptr(gs),
                                            si.N, si.E, C, ctx.reduce, dtype_code(g), stream()),
@@ -1510,7 +1512,7 @@ class _MlpHead(torch.autograd.Function):
     head on the pooled graph rows.  params = (W_0, b_0, ..., W_last, b_last) fp32 masters; lowp = their bf16 copies or None."""
 
     @staticmethod
-    def forward(ctx, x, lowp, *params):
+    def forward(ctx, x, lowp, f32_out, *params):
         import ctypes
         NL = len(params) // 2
         ws = [(params[2 * l].to(x.dtype) if lowp is None or lowp[l] is None else lowp[l][0]).contiguous() for l in range(NL)]
@@ -1518,12 +1520,16 @@ class _MlpHead(torch.autograd.Function):
               (params[2 * l + 1].to(x.dtype) if lowp is None or lowp[l] is None else lowp[l][1]) for l in range(NL)]
         N, K0 = x.shape
         M = [int(w.shape[0]) for w in ws]
-        hs = [torch.empty((N, m), dtype=x.dtype, device=x.device) for m in M]
+        # f32_out: the prediction as fp32 rows (the values the bf16 output holds) — the model's `out.float()` behind the head and
+        # the cast of the loss gradient in front of its backward are then no launches (MDL_MLP_F32_IO)
+        hs = [torch.empty((N, m), dtype=torch.float32 if (f32_out and l == NL - 1) else x.dtype, device=x.device)
+              for l, m in enumerate(M)]
         Ma = (ctypes.c_int * NL)(*M)
-        check(lib().mdl_mlp_head_fwd(ptr(x), _ptr_array(ws), _ptr_array(bs), _ptr_array(hs), N, K0, NL, Ma, dtype_code(x), stream()),
-              "mdl_mlp_head_fwd")
+        io = _lib.MDL_MLP_F32_IO if f32_out else 0
+        check(lib().mdl_mlp_head_fwd(ptr(x), _ptr_array(ws), _ptr_array(bs), _ptr_array(hs), N, K0, NL, Ma, dtype_code(x) | io,
+                                     stream()), "mdl_mlp_head_fwd")
         ctx.save_for_backward(x, *ws, *hs[:-1])
-        ctx.NL, ctx.M, ctx.K0 = NL, M, K0
+        ctx.NL, ctx.M, ctx.K0, ctx.io = NL, M, K0, io
         ctx.has_bias = [params[2 * l + 1] is not None for l in range(NL)]
         ctx.wdtypes = [params[2 * l].dtype for l in range(NL)]
         return hs[-1]
@@ -1536,6 +1542,8 @@ class _MlpHead(torch.autograd.Function):
         x, ws, hs = saved[0], list(saved[1:1 + NL]), list(saved[1 + NL:])
         N = x.shape[0]
         gy = gy.contiguous()
+        if gy.dtype != (torch.float32 if ctx.io else x.dtype):
+            gy = gy.to(torch.float32 if ctx.io else x.dtype)
         Ks = [K0] + M[:-1]
         dws, dbs = [], []
         for l in range(NL):
@@ -1545,12 +1553,12 @@ class _MlpHead(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         Ma = (ctypes.c_int * NL)(*M)
         check(lib().mdl_mlp_head_bwd(ptr(x), _ptr_array(ws), _ptr_array(hs + [None]), ptr(gy), ptr(dx), _ptr_array(dws), _ptr_array(dbs),
-                                     N, K0, NL, Ma, dtype_code(x) | _dflag(), stream()), "mdl_mlp_head_bwd")
+                                     N, K0, NL, Ma, dtype_code(x) | _dflag() | ctx.io, stream()), "mdl_mlp_head_bwd")
         grads = []
         for l in range(NL):
             grads.append(dws[l].to(ctx.wdtypes[l]))
             grads.append(dbs[l].to(ctx.wdtypes[l]) if ctx.has_bias[l] else None)
-        return (dx, None) + tuple(grads)
+        return (dx, None, None) + tuple(grads)
 
 
 def mlp_head_ok(x, lins, act):
@@ -1568,12 +1576,13 @@ def mlp_head_ok(x, lins, act):
     return True
 
 
-def mlp_head(x, lins, lowp=None):
-    """lins: the nn.Linear modules of the chain (ReLU after every one but the last)"""
+def mlp_head(x, lins, lowp=None, f32_out=False):
+    """lins: the nn.Linear modules of the chain (ReLU after every one but the last); f32_out: the last layer's output as fp32 rows
+    (the bf16-rounded values; for a head whose output is the model's fp32 prediction)"""
     params = []
     for lin in lins:
         params += [lin.weight, lin.bias]
-    return _MlpHead.apply(x, lowp, *params)
+    return _MlpHead.apply(x, lowp, bool(f32_out), *params)
 
 
 class _LinearWide(torch.autograd.Function):
@@ -1691,13 +1700,45 @@ def linear(x, weight, bias, lowp=None):
 # ------------------------------------------------------------------------------------------------
 # training loss: value and gradient in one launch
 # ------------------------------------------------------------------------------------------------
+_UNIT = {}
+
+
+def unit_grad(device):
+    """The constant fp32 scalar 1.0 on `device`, for `loss.backward(gradient=ops.unit_grad(dev))`: autograd's own root gradient is a
+    fresh ones_like (a fill launch) that the fused loss then multiplies its stored gradient with (a second one); the loss node
+    recognises THIS tensor by its address and hands its gradient on as it is.  Never written to."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _UNIT.get(key)
+    if t is None:
+        t = _UNIT[key] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
+def backward(loss):
+    """loss.backward() with the constant unit root gradient (see unit_grad) when the loss is an fp32 device scalar"""
+    if loss.is_cuda and loss.dtype == torch.float32 and loss.dim() == 0:
+        loss.backward(gradient=unit_grad(loss.device))
+    else:
+        loss.backward()
+
+
+def _is_unit(g):
+    t = _UNIT.get((g.device.type, g.device.index))
+    return t is not None and g.data_ptr() == t.data_ptr() and g.dim() == 0
+
+
 class _FusedLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, kind):
+    def forward(ctx, pred, target, kind, rows):
         p = pred.contiguous()
         y = target.contiguous()
         out = torch.empty(1 + p.numel(), dtype=torch.float32, device=p.device)          # loss | gradient
-        check(lib().mdl_loss_fwd_bwd(ptr(p), ptr(y), p.numel(), kind, ptr(out), ptr(out[1:]), stream()), "mdl_loss_fwd_bwd")
+        if rows is None:
+            check(lib().mdl_loss_fwd_bwd(ptr(p), ptr(y), p.numel(), kind, ptr(out), ptr(out[1:]), stream()), "mdl_loss_fwd_bwd")
+        else:
+            check(lib().mdl_loss_fwd_bwd_rows(ptr(p), ptr(y), int(rows), p.numel(), kind, ptr(out), ptr(out[1:]), stream()),
+                  "mdl_loss_fwd_bwd_rows")
         ctx.save_for_backward(out)
         ctx.shape = tuple(pred.shape)
         return out[0]
@@ -1705,16 +1746,25 @@ class _FusedLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (out,) = ctx.saved_tensors
-        return (out[1:] * g).view(ctx.shape), None, None
+        grad = out[1:] if _is_unit(g) else out[1:] * g
+        return grad.view(ctx.shape), None, None, None
 
 
-def loss(name, pred, target):
+def loss(name, pred, target, rows=None):
     """getattr(F, name)(pred, target) as the reference's train() evaluates it (training.py:44-47).  l1_loss / mse_loss on
-    fp32 HIP tensors of equal shape compute the value and d loss / d pred in one launch; anything else is torch's."""
+    fp32 HIP tensors of equal shape compute the value and d loss / d pred in one launch; anything else is torch's.
+    rows: the loss of pred[:rows] against target (`rows` elements) with the gradient of the remaining predictions written as
+    zeros by the same launch (the padded static batch's dummy graph) — no slice node between the model and the loss."""
     kind = {"l1_loss": 0, "mse_loss": 1}.get(name)
+    if rows is not None:
+        rows = int(rows)
+        if (kind is not None and pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.dim() == 1
+                and target.dim() == 1 and target.numel() == rows and 1 <= rows <= pred.numel() and not target.requires_grad):
+            return _FusedLoss.apply(pred, target, kind, rows)
+        pred = pred[:rows]
     if (kind is not None and pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32
             and pred.shape == target.shape and pred.numel() >= 1 and not target.requires_grad):
-        return _FusedLoss.apply(pred, target, kind)
+        return _FusedLoss.apply(pred, target, kind, None)
     return getattr(torch.nn.functional, name)(pred, target)
 
 

@@ -591,24 +591,25 @@ class StaticBatch:
         d = ds._dev
         p = _lib.ptr
         ids_d, noff_d, eoff_d = self.pack[:B], self.pack[B:2 * B + 1], self.pack[2 * B + 1:]
-        _lib.check(_lib.lib().mdl_assemble_batch(
+        # K8 with the tails of the padded buffers closed by extra workgroups of the same launch (padding nodes: no edges, dummy graph
+        # B; unused edge slots -> the first padding node) and the pooling index's int32 segment ids written beside `batch`: one
+        # launch where round 5 had four (mdl_assemble_batch, mdl_pad_batch_tail, mdl_pad_edge_tail, an int64 -> int32 copy)
+        bs = self.by_source
+        _lib.check(_lib.lib().mdl_assemble_batch_padded(
             p(ids_d), p(noff_d), p(eoff_d), p(d["node_ptr"]), p(d["edge_ptr"]), p(d["x"]), p(d["src"]), p(d["tgt"]),
             p(d["dist"]), p(d["dist_norm"]), p(d["lrowptr"]), p(d["y"]), p(self.x), p(self.batch_idx), p(self.rowptr),
             p(self.src), p(self.tgt), p(self.ew), p(self.dn), p(self.y), B, ds.num_features, ds.y.shape[1],
-            int(ds.target_index), _lib.dtype_code(self.x), _lib.stream()), "mdl_assemble_batch")
-        _lib.check(_lib.lib().mdl_pad_batch_tail(p(noff_d), p(eoff_d), B, self.n_cap, p(self.rowptr), p(self.batch_idx),
-                                                 _lib.stream()), "mdl_pad_batch_tail")
-        if self.by_source:
+            int(ds.target_index), _lib.dtype_code(self.x), self.n_cap, self.e_cap, p(self.pool_seg),
+            p(self.col_s) if bs else None, p(self.eid_s) if bs else None, p(self.src_s) if bs else None, _lib.stream()),
+            "mdl_assemble_batch_padded")
+        if bs:
             eperm_s, lrowptr_s = ds.by_source()
             _lib.check(_lib.lib().mdl_assemble_transposed(
                 p(ids_d), p(noff_d), p(eoff_d), p(d["node_ptr"]), p(d["edge_ptr"]), p(d["src"]), p(d["tgt"]), p(eperm_s),
                 p(lrowptr_s), p(self.rowptr_s), p(self.col_s), p(self.eid_s), p(self.src_s), B, self.n_cap, _lib.stream()),
                 "mdl_assemble_transposed")
-        _lib.check(_lib.lib().mdl_pad_edge_tail(p(noff_d), p(eoff_d), B, self.n_cap, self.e_cap, p(self.src), p(self.tgt),
-                                                p(self.col_s), p(self.eid_s), p(self.src_s), _lib.stream()), "mdl_pad_edge_tail")
         self.batch._edge_index_stale = True       # the int64 [2, e_cap] view: refilled when (and if) a model reads batch.edge_index
         ops.rbf_expand(self.dn, 0.0, 1.0, ds.num_edge_features, 0.2, offsets=d["offsets"], out=self.edge_attr)
-        self.pool_seg.copy_(self.batch_idx)       # (its row pointers arrived with the ids: StaticBatch.load)
         # the static CSR outlives the batch: its work-balance prefix (CGConv backward) is rebuilt with the batch, in place
         self.batch.csr.refresh_balance()
         return self.batch

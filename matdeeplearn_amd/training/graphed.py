@@ -64,8 +64,10 @@ class GraphedStep:
         batch = sb.assemble()
         with ops.true_rows(batch.true_rows), ops.zero_arena(self.dev):
             out = self.model(batch)
-            loss = ops.loss(self.loss_name, out[:self.B], sb.y)
-            loss.backward()
+            # the dummy graph's prediction (row B) is outside the loss: its gradient is written as zero by the loss kernel itself,
+            # and the root gradient is the constant the loss node hands through (no slice / fill / multiply launches)
+            loss = ops.loss(self.loss_name, out, sb.y, rows=self.B) if out.dim() == 1 else ops.loss(self.loss_name, out[:self.B], sb.y)
+            ops.backward(loss)
         self.loss_value.copy_(loss.detach())
         if self.opt_in_graph:
             self.opt.step()
@@ -169,7 +171,7 @@ class GraphedStep:
         with ops.zero_arena(self.dev):
             out = self.model(batch)
             loss = ops.loss(self.loss_name, out, batch.y)
-            loss.backward()
+            ops.backward(loss)
         self.loss_value.copy_(loss.detach())
         self._finish_eager()
         self.eager_steps += 1

@@ -86,7 +86,7 @@ def train(model, optimizer, loader, loss_method, rank=None, dp=None, stats=None)
         with _step_arena(output_device(data)):
             output = model(data)
             loss = ops.loss(loss_method, output, data.y)
-            loss.backward()
+            ops.backward(loss)
         loss_all = loss_all + loss.detach() * output.size(0)
         if dp is not None:
             dp.reduce_grads()

@@ -1167,6 +1167,120 @@ def test_fused_post_fc_head_matches_the_layer_by_layer_path(shape):
         assert frob(a, c) <= max(3e-2, 1.2 * frob(b, c))
 
 
+@pytest.mark.parametrize("shape", [(101, 64, (64, 64, 64, 1)), (8193, 64, (64, 64, 64, 1)), (257, 16, (64, 8)), (1, 64, (64, 1))])
+def test_fused_head_with_fp32_prediction_equals_the_bf16_head_and_its_casts(shape):
+    """MDL_MLP_F32_IO (round 6): the head's last output as fp32 rows and its gradient read as fp32 rows — bit-identical to the
+    bf16 head with `.float()` behind it and the bf16 cast of the gradient in front of its backward (the two launches it removes)."""
+    from matdeeplearn_amd import ops
+    d = dev()
+    N, K0, widths = shape
+    g = torch.Generator().manual_seed(7 * N + K0)
+    lins, k = [], K0
+    for m in widths:
+        lin = torch.nn.Linear(k, m)
+        with torch.no_grad():
+            lin.weight.copy_(torch.randn(m, k, generator=g) * (1.5 / k ** 0.5))
+            lin.bias.copy_(torch.randn(m, generator=g) * 0.2)
+        lins.append(lin.to(d))
+        k = m
+    x0 = torch.randn(N, K0, generator=g).to(d).to(torch.bfloat16)
+    gy = torch.randn(N, widths[-1], generator=g).to(d)                        # an fp32 gradient (what the fp32 loss hands back)
+    res = []
+    with ops.deterministic():                                                 # one workgroup: the weight-gradient sums in one order
+        for f32 in (False, True):
+            for lin in lins:
+                lin.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            y = ops.mlp_head(x, lins, f32_out=f32)
+            assert y.dtype == (torch.float32 if f32 else torch.bfloat16)
+            y.float().backward(gy)
+            res.append((y.detach().float(), x.grad.clone(), [lin.weight.grad.clone() for lin in lins], [lin.bias.grad.clone() for lin in lins]))
+    (y0, dx0, dw0, db0), (y1, dx1, dw1, db1) = res
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    for a, b in zip(dw0 + db0, dw1 + db1):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["l1_loss", "mse_loss"])
+@pytest.mark.parametrize("n,total", [(100, 101), (1, 2), (8192, 8193), (300, 300), (5, 4000)])
+def test_fused_loss_over_the_first_rows_matches_the_sliced_loss(name, n, total):
+    """ops.loss(..., rows=n) — mdl_loss_fwd_bwd_rows: the loss of pred[:n] with exact zeros as the gradient of the rows behind
+    (the padded static batch's dummy graph) — against torch's loss of the slice; with the constant unit root gradient
+    (ops.backward) and with a scaled one."""
+    from matdeeplearn_amd import ops
+    g = torch.Generator().manual_seed(n + total)
+    p = torch.randn(total, generator=g)
+    y = torch.randn(n, generator=g)
+    if n > 4:
+        y[3] = p[3]
+    for scale in (None, 3.0):
+        pd = p.to(dev()).requires_grad_(True)
+        out = ops.loss(name, pd, y.to(dev()), rows=n)
+        if scale is None:
+            ops.backward(out)
+        else:
+            (out * scale).backward()
+        pr = p.clone().requires_grad_(True)
+        ref = getattr(torch.nn.functional, name)(pr[:n], y)
+        (ref * (scale or 1.0)).backward()
+        close(out, ref, 1e-5, 1e-6)
+        close(pd.grad, pr.grad, 1e-6, 1e-9)
+        assert not pd.grad[n:].any()
+    # the unit root gradient is recognised by its address only: an equal-valued tensor takes the multiply and gives the same values
+    pd = p.to(dev()).requires_grad_(True)
+    ops.loss(name, pd, y.to(dev()), rows=n).backward(gradient=torch.ones((), device=dev()))
+    close(pd.grad, pr.grad / (scale or 1.0), 1e-6, 1e-9)
+    assert float(ops.unit_grad(dev())) == 1.0
+
+
+@pytest.mark.parametrize("by_source", [False, True])
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16])
+def test_padded_batch_assembly_in_one_launch_matches_the_separate_launches(by_source, x_dtype):
+    """mdl_assemble_batch_padded (K8 + both tail paddings + the pooling index's int32 segment ids as ONE launch: what
+    StaticBatch.assemble runs inside the captured step) against mdl_assemble_batch, mdl_pad_batch_tail, mdl_pad_edge_tail and the
+    int64 -> int32 copy it replaces — every buffer bit-equal, stale contents of an earlier, larger batch overwritten."""
+    from matdeeplearn_amd import _lib
+    from matdeeplearn_amd.process import StaticBatch, synthetic_bulk
+    d = dev()
+    ds = synthetic_bulk(300, seed=5).to(d)
+    B = 37
+    order = np.argsort(ds.node_ptr[1:] - ds.node_ptr[:-1])
+    big = order[-B:]
+    n_cap = int((ds.node_ptr[big + 1] - ds.node_ptr[big]).sum()) + 77
+    e_cap = int((ds.edge_ptr[1:] - ds.edge_ptr[:-1]).max()) * B + 301
+    sb = StaticBatch(ds, B, n_cap, e_cap, x_dtype=x_dtype, edge_dtype=x_dtype, by_source=by_source)
+    rng = np.random.default_rng(3)
+    p = _lib.ptr
+    for ids in (order[-B:], order[:B], rng.choice(300, size=B, replace=False)):      # a large batch first: its tail must not survive
+        assert sb.fits(ids)
+        sb.load(ids)
+        batch = sb.assemble()
+        torch.cuda.synchronize()
+        dd = ds._dev
+        x = torch.zeros_like(sb.x); bi = torch.full_like(sb.batch_idx, -7); rp = torch.full_like(sb.rowptr, -7)
+        src = torch.full_like(sb.src, -7); tgt = torch.full_like(sb.tgt, -7); ew = torch.zeros_like(sb.ew); dn = torch.zeros_like(sb.dn)
+        y = torch.zeros_like(sb.y)
+        cs, es, ss = (torch.full_like(sb.col_s, -7) for _ in range(3))
+        ids_d, noff_d, eoff_d = sb.pack[:B], sb.pack[B:2 * B + 1], sb.pack[2 * B + 1:]
+        _lib.check(_lib.lib().mdl_assemble_batch(
+            p(ids_d), p(noff_d), p(eoff_d), p(dd["node_ptr"]), p(dd["edge_ptr"]), p(dd["x"]), p(dd["src"]), p(dd["tgt"]),
+            p(dd["dist"]), p(dd["dist_norm"]), p(dd["lrowptr"]), p(dd["y"]), p(x), p(bi), p(rp), p(src), p(tgt), p(ew), p(dn), p(y),
+            B, ds.num_features, ds.y.shape[1], int(ds.target_index), _lib.dtype_code(x), _lib.stream()), "mdl_assemble_batch")
+        _lib.check(_lib.lib().mdl_pad_batch_tail(p(noff_d), p(eoff_d), B, n_cap, p(rp), p(bi), _lib.stream()), "mdl_pad_batch_tail")
+        _lib.check(_lib.lib().mdl_pad_edge_tail(p(noff_d), p(eoff_d), B, n_cap, e_cap, p(src), p(tgt), p(cs) if by_source else None,
+                                                p(es) if by_source else None, p(ss) if by_source else None, _lib.stream()),
+                   "mdl_pad_edge_tail")
+        N, E = sb.true_nodes, sb.true_edges
+        assert torch.equal(sb.x[:N], x[:N]) and torch.equal(sb.batch_idx, bi) and torch.equal(sb.rowptr, rp) and torch.equal(sb.y, y)
+        assert torch.equal(sb.src, src) and torch.equal(sb.tgt, tgt) and torch.equal(sb.ew[:E], ew[:E]) and torch.equal(sb.dn[:E], dn[:E])
+        assert torch.equal(sb.pool_seg, bi.to(torch.int32))
+        assert int(sb.rowptr[N]) == E and int(sb.rowptr[-1]) == E and int(sb.batch_idx[N]) == B and int(sb.src[-1]) == min(N, n_cap - 1)
+        if by_source:
+            assert torch.equal(sb.col_s[E:], cs[E:]) and torch.equal(sb.eid_s[E:], es[E:]) and torch.equal(sb.src_s[E:], ss[E:])
+            assert int(sb.rowptr_s[N]) == E and int(sb.rowptr_s[-1]) == E
+        assert batch.pool_index.seg.data_ptr() == sb.pool_seg.data_ptr()
+
+
 # ---------------------------------------------------------------------------------------------
 # BatchNorm statistics formed by the PRODUCER of the rows (round 5): the CGConv forward's epilogue (mdl_cgconv_fwd_ex) and
 # the dense layer's (mdl_linear_act_stats), about a per-column shift, normalised by mdl_bn_apply_n(MDL_BN_SHIFT_ROW)
