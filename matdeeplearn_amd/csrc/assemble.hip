@@ -69,40 +69,74 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams p) {
     const int64_t no = p.noff[g], eo = p.eoff[g];
     T* __restrict__ xo = static_cast<T*>(p.x) + no * p.F;
     const float* __restrict__ xi = p.x_all + n0s * p.F;
-    // A block moves only ~3000 feature elements and ~330 edges: with one load in flight per thread the copy is a chain of
-    // memory round trips.  Four independent (clamped) loads are issued before the first store of every trip.
-    constexpr int U = 4;
+    // A block moves only ~3000 feature elements and ~330 edges: every loop of load -> store is a chain of memory round trips
+    // (~2 us each on a cold 0.8-GB dataset), and at the reference's batch size the kernel IS that chain.  So the loads of the
+    // first trip of every array — the edge arrays (two trips' worth), the row pointers and six feature elements per thread — are
+    // all issued (clamped) before the first store; a typical graph then needs one more feature trip.
+    constexpr int U = 6;
     const int64_t nx = nn * p.F;
-    for (int64_t q0 = threadIdx.x; q0 < nx; q0 += U * blockDim.x) {
+    const int32_t shift = (int32_t)no;
+    const int t = threadIdx.x, bd = blockDim.x;
+    int32_t sv[2], tv[2];
+    float dv[2], nv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t k = e0s + min((int64_t)t + u * bd, ne > 0 ? ne - 1 : 0);
+        const bool ok = ne > 0;
+        sv[u] = ok ? p.src_l[k] : 0; tv[u] = ok ? p.tgt_l[k] : 0; dv[u] = ok ? p.dist[k] : 0.0f; nv[u] = ok ? p.dist_norm[k] : 0.0f;
+    }
+    const int32_t lr = t < nn ? p.lrowptr[n0s + t] : 0;
+    float v0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v0[u] = nx > 0 ? xi[min((int64_t)t + u * bd, nx - 1)] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t k = (int64_t)t + u * bd;
+        if (k < ne) {
+            p.src[eo + k] = sv[u] + shift;
+            p.tgt[eo + k] = tv[u] + shift;
+            p.ew[eo + k] = dv[u];
+            p.dn[eo + k] = nv[u];
+        }
+    }
+    if (t < nn) {
+        p.batch[no + t] = g;
+        p.rowptr[no + t] = (int32_t)(eo + lr);
+        if (p.pool_seg) p.pool_seg[no + t] = g;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if ((int64_t)t + u * bd < nx) Elem<T>::st(xo + t + u * bd, v0[u]);
+    // the rest (large graphs)
+    for (int64_t q0 = (int64_t)t + U * bd; q0 < nx; q0 += U * bd) {
         float v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = xi[min(q0 + u * blockDim.x, nx - 1)];
+        for (int u = 0; u < U; ++u) v[u] = xi[min(q0 + u * bd, nx - 1)];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (q0 + u * blockDim.x < nx) Elem<T>::st(xo + q0 + u * blockDim.x, v[u]);
+            if (q0 + u * bd < nx) Elem<T>::st(xo + q0 + u * bd, v[u]);
     }
-    for (int64_t j = threadIdx.x; j < nn; j += blockDim.x) {
+    for (int64_t j = (int64_t)t + bd; j < nn; j += bd) {
         p.batch[no + j] = g;
         p.rowptr[no + j] = (int32_t)(eo + p.lrowptr[n0s + j]);
         if (p.pool_seg) p.pool_seg[no + j] = g;
     }
-    const int32_t shift = (int32_t)no;
-    for (int64_t k0 = threadIdx.x; k0 < ne; k0 += 2 * blockDim.x) {
-        int32_t sv[2], tv[2];
-        float dv[2], nv[2];
+    for (int64_t k0 = (int64_t)t + 2 * bd; k0 < ne; k0 += 2 * bd) {
+        int32_t sw[2], tw[2];
+        float dw[2], nw[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int64_t k = e0s + min(k0 + u * blockDim.x, ne - 1);
-            sv[u] = p.src_l[k]; tv[u] = p.tgt_l[k]; dv[u] = p.dist[k]; nv[u] = p.dist_norm[k];
+            const int64_t k = e0s + min(k0 + u * bd, ne - 1);
+            sw[u] = p.src_l[k]; tw[u] = p.tgt_l[k]; dw[u] = p.dist[k]; nw[u] = p.dist_norm[k];
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int64_t k = k0 + u * blockDim.x;
+            const int64_t k = k0 + u * bd;
             if (k < ne) {
-                p.src[eo + k] = sv[u] + shift;
-                p.tgt[eo + k] = tv[u] + shift;
-                p.ew[eo + k] = dv[u];
-                p.dn[eo + k] = nv[u];
+                p.src[eo + k] = sw[u] + shift;
+                p.tgt[eo + k] = tw[u] + shift;
+                p.ew[eo + k] = dw[u];
+                p.dn[eo + k] = nw[u];
             }
         }
     }

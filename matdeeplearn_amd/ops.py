@@ -536,10 +536,15 @@ _TN_SCRATCH = True     # partial sums of the streaming TN products through a scr
 _TNS = {}
 
 
-def _tn_scratch(device):
+_TN_SCRATCH_MIN_ROWS = 32768
+
+
+def _tn_scratch(device, rows=None):
     """Per device and stream: mdl_tn_scratch_bytes() bytes for the _ex forms of the TN products (launches on one stream are
-    ordered, so every layer shares it; allocated once — before any HIP-graph capture, by the warm-up steps)."""
-    if not _TN_SCRATCH:
+    ordered, so every layer shares it; allocated once — before any HIP-graph capture, by the warm-up steps).  None (= atomics
+    from the few workgroups there are) for a product over few rows: at the reference's batch size the reduce launch costs more
+    than the handful of atomics it replaces."""
+    if not _TN_SCRATCH or (rows is not None and rows < _TN_SCRATCH_MIN_ROWS):
         return None
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     t = _TNS.get(key)
@@ -550,7 +555,7 @@ def _tn_scratch(device):
 
 def _gemm_tn(a, lda, M, y, ldy, act, b, ldb, K, c, colsum, N, flags, device):
     """mdl_gemm_tn / _colsum / _act in their scratch form (c [M, K] += (a .* act'(y))^T b, colsum += column sums)"""
-    return lib().mdl_gemm_tn_ex(ptr(a), lda, M, ptr(y), ldy, act, ptr(b), ldb, K, ptr(c), ptr(colsum), ptr(_tn_scratch(device)), N, flags,
+    return lib().mdl_gemm_tn_ex(ptr(a), lda, M, ptr(y), ldy, act, ptr(b), ldb, K, ptr(c), ptr(colsum), ptr(_tn_scratch(device, N)), N, flags,
                                 stream())
 
 
@@ -1304,7 +1309,7 @@ def _dense_bwd(ctx, g, x, w, act_y=None, xout=0, want_gm=False):
     code, y = act_y if act_y is not None else (0, None)
     check(lib().mdl_dense_bwd_ex(ptr(g), g.stride(0), M, ptr(y), 0 if y is None else y.stride(0), code, ptr(x), x.stride(0), K,
                                  ptr(w), ptr(dx), K, xout, ptr(gm), ptr(dw), ptr(dbv) if ctx.has_bias else None,
-                                 ptr(_tn_scratch(g.device)), N, dtype_code(g) | _dflag(), stream()), "mdl_dense_bwd")
+                                 ptr(_tn_scratch(g.device, N)), N, dtype_code(g) | _dflag(), stream()), "mdl_dense_bwd")
     out = (dx, dw.to(ctx.wdtype), dbv.to(ctx.wdtype) if ctx.has_bias else None)
     return out + (gm,) if want_gm else out
 
@@ -1730,10 +1735,12 @@ def _is_unit(g):
 
 class _FusedLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, kind, rows):
+    def forward(ctx, pred, target, kind, rows, buf):
         p = pred.contiguous()
         y = target.contiguous()
-        out = torch.empty(1 + p.numel(), dtype=torch.float32, device=p.device)          # loss | gradient
+        # loss | gradient; buf: the caller's persistent fp32 buffer of >= 1 + numel elements (GraphedStep reads the loss value of
+        # a replayed step from its first element — no copy launch at the end of the step)
+        out = torch.empty(1 + p.numel(), dtype=torch.float32, device=p.device) if buf is None else buf[:1 + p.numel()]
         if rows is None:
             check(lib().mdl_loss_fwd_bwd(ptr(p), ptr(y), p.numel(), kind, ptr(out), ptr(out[1:]), stream()), "mdl_loss_fwd_bwd")
         else:
@@ -1747,24 +1754,29 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, g):
         (out,) = ctx.saved_tensors
         grad = out[1:] if _is_unit(g) else out[1:] * g
-        return grad.view(ctx.shape), None, None, None
+        return grad.view(ctx.shape), None, None, None, None
 
 
-def loss(name, pred, target, rows=None):
+def loss(name, pred, target, rows=None, buf=None):
     """getattr(F, name)(pred, target) as the reference's train() evaluates it (training.py:44-47).  l1_loss / mse_loss on
     fp32 HIP tensors of equal shape compute the value and d loss / d pred in one launch; anything else is torch's.
     rows: the loss of pred[:rows] against target (`rows` elements) with the gradient of the remaining predictions written as
-    zeros by the same launch (the padded static batch's dummy graph) — no slice node between the model and the loss."""
+    zeros by the same launch (the padded static batch's dummy graph) — no slice node between the model and the loss.
+    buf: optional persistent fp32 device buffer (>= 1 + pred.numel() elements, contiguous) that receives [loss | gradient] when the
+    fused kernel runs; the returned loss is then a view of buf[0]."""
+    if buf is not None and not (buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous() and buf.dim() == 1
+                                and buf.numel() >= 1 + pred.numel() and buf.device == pred.device):
+        buf = None
     kind = {"l1_loss": 0, "mse_loss": 1}.get(name)
     if rows is not None:
         rows = int(rows)
         if (kind is not None and pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.dim() == 1
                 and target.dim() == 1 and target.numel() == rows and 1 <= rows <= pred.numel() and not target.requires_grad):
-            return _FusedLoss.apply(pred, target, kind, rows)
+            return _FusedLoss.apply(pred, target, kind, rows, buf)
         pred = pred[:rows]
     if (kind is not None and pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32
             and pred.shape == target.shape and pred.numel() >= 1 and not target.requires_grad):
-        return _FusedLoss.apply(pred, target, kind, None)
+        return _FusedLoss.apply(pred, target, kind, None, buf)
     return getattr(torch.nn.functional, name)(pred, target)
 
 
@@ -1939,7 +1951,7 @@ class _LinearReluBN(torch.autograd.Function):
         dw, dbv = buf[:M * K].view(M, K), buf[M * K:]
         dx = torch.empty((N, K), dtype=x.dtype, device=x.device)
         check(lib().mdl_dense_bwd_ex(ptr(gp), M, M, None, 0, 0, ptr(x), x.stride(0), K, ptr(w), ptr(dx), K, 0, None, ptr(dw),
-                                     ptr(dbv) if ctx.has_bias else None, ptr(_tn_scratch(x.device)), N, dt | _dflag(), stream()),
+                                     ptr(dbv) if ctx.has_bias else None, ptr(_tn_scratch(x.device, N)), N, dt | _dflag(), stream()),
               "mdl_dense_bwd")
         dts = []
         for t in range(ctx.ntab):

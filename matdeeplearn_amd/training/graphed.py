@@ -51,7 +51,9 @@ class GraphedStep:
             raise ops.MdlError("GraphedStep: the optimizer step is captured, so its learning rate must be a device tensor (a "
                                "float would be frozen into the graph and every scheduler update ignored by the replays): "
                                "training.make_optimizer(..., capturable=True) builds it that way")
-        self.loss_value = torch.zeros((), dtype=torch.float32, device=self.dev)
+        # [loss | d loss / d prediction] of the fused loss kernel: the step's loss is read from its first element
+        self._loss_buf = torch.zeros(2 + self.B + 1, dtype=torch.float32, device=self.dev)
+        self.loss_value = self._loss_buf[0]
         self.graph = None
         self.bn_layers = [m for m in model.modules() if isinstance(m, BatchNorm1d)]
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -66,9 +68,11 @@ class GraphedStep:
             out = self.model(batch)
             # the dummy graph's prediction (row B) is outside the loss: its gradient is written as zero by the loss kernel itself,
             # and the root gradient is the constant the loss node hands through (no slice / fill / multiply launches)
-            loss = ops.loss(self.loss_name, out, sb.y, rows=self.B) if out.dim() == 1 else ops.loss(self.loss_name, out[:self.B], sb.y)
+            loss = (ops.loss(self.loss_name, out, sb.y, rows=self.B, buf=self._loss_buf) if out.dim() == 1
+                    else ops.loss(self.loss_name, out[:self.B], sb.y))
             ops.backward(loss)
-        self.loss_value.copy_(loss.detach())
+        if loss.data_ptr() != self.loss_value.data_ptr():
+            self.loss_value.copy_(loss.detach())
         if self.opt_in_graph:
             self.opt.step()
 
@@ -170,9 +174,10 @@ class GraphedStep:
         self._zero_grad()
         with ops.zero_arena(self.dev):
             out = self.model(batch)
-            loss = ops.loss(self.loss_name, out, batch.y)
+            loss = ops.loss(self.loss_name, out, batch.y, buf=self._loss_buf)
             ops.backward(loss)
-        self.loss_value.copy_(loss.detach())
+        if loss.data_ptr() != self.loss_value.data_ptr():
+            self.loss_value.copy_(loss.detach())
         self._finish_eager()
         self.eager_steps += 1
         return batch.num_edges, batch.num_nodes
