@@ -18,7 +18,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 # per-file extras: the edge-per-lane CGConv backward wants its MFMA results in VGPRs (see csrc/cgconv.hip)
 FILE_FLAGS = {"cgconv_ep.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "cfconv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 # translation units that #include another .hip file
-FILE_DEPS = {"cgconv_ep.hip": ["cgconv.hip"]}
+FILE_DEPS = {}
 
 
 def _hipcc():
