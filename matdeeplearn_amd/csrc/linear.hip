@@ -26,6 +26,10 @@
 // MPNN -8 %; 150 -> 150 217 -> 263 us)
 // The gathering forms (K6) keep 4 as well: with the table rows in flight they need 137-148 registers, so an 8-wave workgroup
 // would be alone on its CU (228 -> ~275 us on the MEGNet bench batch).
+#ifndef MDL_WIDE_NT
+#define MDL_WIDE_NT 6      // mdl_linear_wide: 32-column blocks per workgroup — 192 columns = 384 B of a bf16 output row: whole 128-byte
+                           // lines, so no line is shared by workgroups of two XCDs (5 -> 6: 513 -> 456 us for NNConv's Y; 4: 506, 8: 494)
+#endif
 #define MDL_LIN_NW(KP_, G_) (((KP_) == 160 || (G_) != 0) ? 4 : 8)
 
 namespace mdl {
@@ -470,26 +474,27 @@ extern "C" int mdl_mlp2(const void* x, const void* w1, const void* b1, int act1,
 #endif
 
 // out[N, M] = x[N, K] w[M, K]^T for a WIDE output (M in the thousands: NNConv's Y = x W2r, mpnn.py:83-88 — C_out * d3 = 10^4
-// columns per node): the layer is a write stream of N * M * 2 bytes; column blocks of 160 run as the second grid dimension of
+// columns per node): the layer is a write stream of N * M * 2 bytes; column blocks of 32 * MDL_WIDE_NT = 192 run as the second grid dimension of
 // the streaming kernel, each workgroup keeping its block of w in LDS for ~1/64 of the rows.
 extern "C" int mdl_linear_wide(const void* x, const void* w, void* out, int64_t N, int K, int64_t M, int dtype, mdlStream_t stream) {
     using namespace mdl;
     MDL_REQUIRE(dtype == MDL_BF16, MDL_E_UNSUPP, "mdl_linear_wide: bf16 only");
-    MDL_REQUIRE(K >= 4 && K <= 160 && K % 2 == 0 && M >= 1 && M <= 160 * 65535LL && M * 2 * 64 < 0x7fffffffLL, MDL_E_UNSUPP,
+    MDL_REQUIRE(K >= 4 && K <= 160 && K % 2 == 0 && M >= 1 && M <= 32 * MDL_WIDE_NT * 65535LL && M * 2 * 64 < 0x7fffffffLL, MDL_E_UNSUPP,
                 "mdl_linear_wide: need even 4<=K<=160 (got K=%d M=%lld)", K, (long long)M);
     MDL_REQUIRE(N >= 0 && (N == 0 || (x && w && out)), MDL_E_ARG, "mdl_linear_wide: bad arguments");
     MDL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(w) % 4 == 0 &&
                 reinterpret_cast<uintptr_t>(out) % 2 == 0, MDL_E_ARG, "mdl_linear_wide: misaligned pointer");
     if (N == 0) return MDL_OK;
     const int kp = K <= 64 ? 64 : (K <= 128 ? 128 : 160);
-    const unsigned gy = (unsigned)((M + 159) / 160);
+    constexpr int WNT = MDL_WIDE_NT;                 // 32-column blocks per workgroup
+    const unsigned gy = (unsigned)((M + 32 * WNT - 1) / (32 * WNT));
     int64_t gx = cdiv(N, 64);
     if (gx > 64) gx = 64;
-    const int lds = (32 * 5 + 64) * (kp + 8) * 2;
+    const int lds = (32 * WNT + 64) * (kp + 8) * 2;
     const GatherAdd ga{};
 #define MDL_WIDE(KP_)                                                                                                 \
     do {                                                                                                              \
-        auto kf = linear_act_kernel<KP_, 5, 0, 0>;                                                                \
+        auto kf = linear_act_kernel<KP_, WNT, 0, 0>;                                                              \
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(kf), lds);                                            \
         hipLaunchKernelGGL(kf, dim3(gy, (unsigned)gx), dim3(64 * MDL_LIN_NW(KP_, 0)), lds, (hipStream_t)stream, (const bf16_t*)x,         \
                            (const bf16_t*)w, (const bf16_t*)nullptr, (bf16_t*)out, N, K, (int)M, 0, ga,               \

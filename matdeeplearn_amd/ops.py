@@ -1591,7 +1591,7 @@ def mlp_head(x, lins, lowp=None, f32_out=False):
 
 
 class _LinearWide(torch.autograd.Function):
-    """y = x @ w for a wide w [K, M] (M in the thousands): forward as a streaming HIP kernel over 160-column blocks
+    """y = x @ w for a wide w [K, M] (M in the thousands): forward as a streaming HIP kernel over 192-column blocks
     (mdl_linear_wide), backward = the two library products autograd would form."""
 
     @staticmethod

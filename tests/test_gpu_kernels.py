@@ -462,6 +462,27 @@ def test_nnconv_contraction_matches_oracle(dtype, n, Ci, Co, D3):
         close(p.grad, og[k].grad, *tol)
 
 
+@pytest.mark.parametrize("N,K,M", [(1500, 100, 10000), (1024, 64, 641), (2077, 160, 1000), (4099, 24, 2400), (1100, 100, 192)])
+def test_wide_output_dense_layer_matches_the_library_product(N, K, M):
+    """mdl_linear_wide (ops.matmul_wide: NNConv's Y = x W2r — thousands of output columns in 192-column blocks per workgroup)
+    against the library's x @ w on the same bf16 operands: ragged row counts, a last column block of 1 .. 191 columns, K below
+    and at the kernel's maximum; and its autograd (the two library products) against torch's."""
+    from matdeeplearn_amd import ops
+    g = torch.Generator().manual_seed(N + M)
+    x = torch.randn(N, K, generator=g).to(dev()).to(torch.bfloat16)
+    w = (torch.randn(K, M, generator=g) * (1.0 / K ** 0.5)).to(dev()).to(torch.bfloat16)
+    xa = x.clone().requires_grad_(True)
+    wa = w.clone().requires_grad_(True)
+    out = ops._LinearWide.apply(xa, wa)
+    ref = x.float() @ w.float()
+    assert out.shape == (N, M) and out.dtype == torch.bfloat16
+    close(out, ref, 1e-2, 1e-2)                                              # one bf16 rounding of an fp32-accumulated sum
+    gy = torch.randn(N, M, generator=g).to(dev()).to(torch.bfloat16)
+    out.backward(gy)
+    close(xa.grad, gy.float() @ w.float().t(), 2e-2, 2e-2)
+    close(wa.grad, x.float().t() @ gy.float(), 2e-2, 2e-2)
+
+
 @pytest.mark.parametrize("E,d", [(5003, 100), (1500, 64), (70, 24)])
 def test_megnet_edge_block_first_layer_without_concatenation(E, d):
     """K6 (ops.linear_gather_act) against the reference's formulation relu(Linear(cat[x[row], x[col], e, u[b]])) in fp32 on
