@@ -66,9 +66,20 @@ __global__ __launch_bounds__(64 * MDL_LIN_NW(KP, GATHER), 2) void linear_act_ker
     // (wide layers are launched with the COLUMN block as the fast grid dimension: the workgroups that run together then cover
     // whole rows of `out` — 20 KB contiguous per row for NNConv's Y — instead of a 320-byte segment of many rows)
     const bool wide = ldo > 0;                       // (only mdl_linear_wide passes ldo)
-    const unsigned bx = wide ? blockIdx.y : blockIdx.x, gdx = wide ? gridDim.y : gridDim.x;
+    unsigned bx = wide ? blockIdx.y : blockIdx.x, cbx = blockIdx.x;
+    const unsigned gdx = wide ? gridDim.y : gridDim.x;
+    if (wide && (gridDim.y & 7u) == 0u) {
+        // XCD-aware tile map: workgroups are dealt to the 8 XCDs round-robin in dispatch order, and the column blocks of one row
+        // chunk write NEIGHBOURING segments of the same output rows — with rows that are not a multiple of 128 bytes (NNConv's
+        // Y: 20,000 B) most segment boundaries fall inside a cache line, which two XCDs' L2s would each hold half of.  All column
+        // blocks of a row chunk therefore go to ONE XCD (consecutive slots there): its L2 merges the shared lines and serves the
+        // chunk's x tile to all of them.
+        const unsigned f = blockIdx.y * gridDim.x + blockIdx.x, xcd = f & 7u, k = f >> 3;
+        cbx = k % gridDim.x;
+        bx = xcd + 8u * (k / gridDim.x);
+    }
     if (wide) {
-        const int c0 = (int)blockIdx.x * 32 * NT;
+        const int c0 = (int)cbx * 32 * NT;
         w += (int64_t)c0 * K;
         if (bias) bias += c0;
         out += c0;
@@ -489,7 +500,14 @@ extern "C" int mdl_linear_wide(const void* x, const void* w, void* out, int64_t 
     constexpr int WNT = MDL_WIDE_NT;                 // 32-column blocks per workgroup
     const unsigned gy = (unsigned)((M + 32 * WNT - 1) / (32 * WNT));
     int64_t gx = cdiv(N, 64);
+#ifdef MDL_WIDE_ROUNDS
+    {   // experiment: row chunks so that the launch is MDL_WIDE_ROUNDS rounds of 512 resident workgroups
+        int64_t cap = std::max<int64_t>(1, (512LL * MDL_WIDE_ROUNDS) / gy);
+        if (gx > cap) gx = cap;
+    }
+#else
     if (gx > 64) gx = 64;
+#endif
     const int lds = (32 * WNT + 64) * (kp + 8) * 2;
     const GatherAdd ga{};
 #define MDL_WIDE(KP_)                                                                                                 \
