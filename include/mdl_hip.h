@@ -409,6 +409,19 @@ int mdl_mlp_head_fwd(const void* x, const void* const* w, const void* const* b, 
 int mdl_mlp_head_bwd(const void* x, const void* const* w, const void* const* h, const void* gy, void* dx, float* const* dw,
                      float* const* db, int64_t N, int K0, int NL, const int* M, int dtype, mdlStream_t stream);
 
+/* The gate arithmetic of one step of a single-layer GRU — the reference's MPNN runs `out, h = self.gru_list[i](m.unsqueeze(0), h)`
+ * after every NNConv layer (matdeeplearn/models/mpnn.py:160-161): gi = W_ih m + b_ih and gh = W_hh h + b_hh are dense layers of this
+ * library ([N, 3C] in `dtype`, torch's gate order r | z | n); these two entry points replace the ~12 forward and ~25 backward
+ * elementwise / chunk / cat / cast launches of the gates written out with tensor operations:
+ *   fwd: r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r gh_n), h_out = n + z (h - n)   (fp32 arithmetic;
+ *        h, h_out [N, C] fp32; out_lp [N, C] in `dtype` = the copy of h_out the next layer reads, may be NULL);
+ *   bwd: from g_h = dL/dh_out (fp32) and g_lp = dL/dout_lp (`dtype`) — either may be NULL, not both — with r, z, n recomputed:
+ *        dgi, dgh [N, 3C] in `dtype` (the output gradients of the two dense layers), dh [N, C] fp32. */
+int mdl_gru_gates_fwd(const void* gi, const void* gh, const float* h, float* h_out, void* out_lp, int64_t N, int C, int dtype,
+                      mdlStream_t stream);
+int mdl_gru_gates_bwd(const void* gi, const void* gh, const float* h, const float* g_h, const void* g_lp, void* dgi, void* dgh,
+                      float* dh, int64_t N, int C, int dtype, mdlStream_t stream);
+
 /* out[N, M] = x[N, K] w[M, K]^T for a wide output (M in the thousands; bf16, even K <= 160): NNConv's per-node operand
  * Y = x W2r of the re-associated message (matdeeplearn/models/mpnn.py:83-88 — C_out * d3 = 10^4 columns), a write stream of
  * N * M * 2 bytes that the library ran as a 256x256x32 macro-tile GEMM (771 us for 6.1e4 x 100 x 1e4). */

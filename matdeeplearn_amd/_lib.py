@@ -114,6 +114,8 @@ PROTOTYPES = {
     "mdl_linear_wide": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp]),
     "mdl_mlp_head_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "mdl_mlp_head_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
+    "mdl_gru_gates_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "mdl_gru_gates_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "mdl_gemm_tn": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp]),
     "mdl_split_bf16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "mdl_gemm_tn_colsum": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),

@@ -15,21 +15,26 @@ def gru_step(gru, x, h):
     products in the dtype of x, the gate arithmetic in fp32 (torch's gate order r | z | n; n uses r * (W_hn h + b_hn)).
     The library call goes through MIOpen's RNN path, which for sequence length 1 spends ~7 ms per layer on 6e4 rows in
     fp32 GEMMs and tensor-op kernels — a third of the MPNN step; the parameters stay those of the nn.GRU module
-    (state_dict keys gru_list.{i}.weight_ih_l0, ...)."""
+    (state_dict keys gru_list.{i}.weight_ih_l0, ...).  Returns (h_new fp32, h_new in the dtype of x): on a HIP device the gates are
+    one launch per direction (ops.gru_gates, csrc/gru.hip) instead of ~12 + ~25 elementwise / chunk / cat / cast launches."""
     cd = x.dtype
     if cd == torch.bfloat16 and x.is_cuda:
         # (ops.linear: the gate matrices' weight gradients — [3C, C] with the contraction over 6e4 rows — on the TN GEMM)
-        gi = ops.linear(x, gru.weight_ih_l0, gru.bias_ih_l0).float()
-        gh = ops.linear(h.to(cd), gru.weight_hh_l0, gru.bias_hh_l0).float()
+        gi = ops.linear(x, gru.weight_ih_l0, gru.bias_ih_l0)
+        gh = ops.linear(h.to(cd), gru.weight_hh_l0, gru.bias_hh_l0)
     else:
-        gi = F.linear(x, gru.weight_ih_l0.to(cd), gru.bias_ih_l0.to(cd)).float()
-        gh = F.linear(h.to(cd), gru.weight_hh_l0.to(cd), gru.bias_hh_l0.to(cd)).float()
+        gi = F.linear(x, gru.weight_ih_l0.to(cd), gru.bias_ih_l0.to(cd))
+        gh = F.linear(h.to(cd), gru.weight_hh_l0.to(cd), gru.bias_hh_l0.to(cd))
+    if ops.gru_gates_ok(gi, gh, h):
+        return ops.gru_gates(gi, gh, h)
+    gi, gh = gi.float(), gh.float()
     i_r, i_z, i_n = gi.chunk(3, dim=1)
     h_r, h_z, h_n = gh.chunk(3, dim=1)
     r = torch.sigmoid(i_r + h_r)
     z = torch.sigmoid(i_z + h_z)
     n = torch.tanh(i_n + r * h_n)
-    return n + z * (h - n)                                    # (1 - z) * n + z * h
+    h_new = n + z * (h - n)                                   # (1 - z) * n + z * h
+    return h_new, h_new.to(cd)
 
 
 class MPNN(GraphModel):
@@ -57,8 +62,8 @@ class MPNN(GraphModel):
             m = self._drop(getattr(F, self.act)(m))
             gru = self.gru_list[i]
             if gru.num_layers == 1 and not gru.bidirectional and gru.bias:
-                h = gru_step(gru, m, h)
+                h, out = gru_step(gru, m, h)
             else:
                 h = gru(m.float().unsqueeze(0), h.unsqueeze(0))[1].squeeze(0)
-            out = h.to(cd)
+                out = h.to(cd)
         return self._head(out, data)

@@ -1703,6 +1703,59 @@ def linear(x, weight, bias, lowp=None):
 
 
 # ------------------------------------------------------------------------------------------------
+# GRU gates (MPNN): one launch per direction instead of ~12 + ~25 elementwise / chunk / cat / cast launches
+# ------------------------------------------------------------------------------------------------
+class _GRUGates(torch.autograd.Function):
+    """(h_new fp32, out) from gi, gh [N, 3C] (gate order r | z | n) and the state h [N, C] fp32 — mpnn.py:160-161; `out` is
+    h_new in the dtype of gi (the tensor the next layer reads).  Backward recomputes the gates (csrc/gru.hip)."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, h):
+        N, C3 = gi.shape
+        C = C3 // 3
+        gi, gh, h = gi.contiguous(), gh.contiguous(), h.contiguous()
+        h_new = torch.empty((N, C), dtype=torch.float32, device=gi.device)
+        lp = gi.dtype != torch.float32
+        out = torch.empty((N, C), dtype=gi.dtype, device=gi.device) if lp else None
+        check(lib().mdl_gru_gates_fwd(ptr(gi), ptr(gh), ptr(h), ptr(h_new), ptr(out), N, C, dtype_code(gi), stream()), "mdl_gru_gates_fwd")
+        ctx.save_for_backward(gi, gh, h)
+        ctx.lp = lp
+        if lp:
+            return h_new, out
+        dummy = h_new.new_empty(0)            # (fp32: callers use the first output for both roles — gru_gates below)
+        ctx.mark_non_differentiable(dummy)
+        return h_new, dummy
+
+    @staticmethod
+    def backward(ctx, g_h, g_out):
+        gi, gh, h = ctx.saved_tensors
+        N, C3 = gi.shape
+        C = C3 // 3
+        if not ctx.lp:
+            g_out = None
+        g_h = None if g_h is None else g_h.contiguous().float()
+        g_out = None if g_out is None else g_out.contiguous().to(gi.dtype)
+        if g_h is None and g_out is None:
+            return None, None, None
+        dgi, dgh = torch.empty_like(gi), torch.empty_like(gh)
+        dh = torch.empty_like(h)
+        check(lib().mdl_gru_gates_bwd(ptr(gi), ptr(gh), ptr(h), ptr(g_h), ptr(g_out), ptr(dgi), ptr(dgh), ptr(dh), N, C,
+                                      dtype_code(gi), stream()), "mdl_gru_gates_bwd")
+        return dgi, dgh, dh
+
+
+def gru_gates_ok(gi, gh, h):
+    return (gi.is_cuda and gi.dim() == 2 and gi.shape == gh.shape and gi.dtype == gh.dtype and gi.dtype in (torch.float32, torch.bfloat16)
+            and gi.shape[1] % 3 == 0 and h.dtype == torch.float32 and h.shape == (gi.shape[0], gi.shape[1] // 3) and gi.shape[0] > 0)
+
+
+def gru_gates(gi, gh, h):
+    """One GRU step's gates: returns (h_new [N, C] fp32, out [N, C] in gi's dtype — the same tensor as h_new for fp32)."""
+    h_new, out = _GRUGates.apply(gi, gh, h)
+    return (h_new, out) if gi.dtype != torch.float32 else (h_new, h_new)
+
+
+# ------------------------------------------------------------------------------------------------
 # training loss: value and gradient in one launch
 # ------------------------------------------------------------------------------------------------
 _UNIT = {}

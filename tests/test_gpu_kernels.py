@@ -462,6 +462,54 @@ def test_nnconv_contraction_matches_oracle(dtype, n, Ci, Co, D3):
         close(p.grad, og[k].grad, *tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C", [(3001, 100), (257, 64), (5, 7), (1, 4), (1200, 30)])
+def test_fused_gru_gates_match_the_written_out_step_and_torch_gru(dtype, N, C):
+    """csrc/gru.hip (ops.gru_gates: the gate arithmetic of one GRU step as one launch per direction, mpnn.py:160-161) against the
+    written-out tensor form on the same (rounded) gi / gh in fp32 — both outputs and, with gradients arriving at BOTH outputs,
+    d gi, d gh, d h — and, in fp32, the whole step against torch.nn.GRU; vector (C % 4 == 0) and scalar widths."""
+    from matdeeplearn_amd import ops
+    from matdeeplearn_amd.models.mpnn import gru_step
+    d = dev()
+    g = torch.Generator().manual_seed(N * 7 + C)
+    gi0 = (torch.randn(N, 3 * C, generator=g) * 1.5).to(d).to(dtype)
+    gh0 = (torch.randn(N, 3 * C, generator=g) * 1.5).to(d).to(dtype)
+    h0 = torch.randn(N, C, generator=g).to(d)
+    w1 = torch.randn(N, C, generator=g).to(d)
+    w2 = torch.randn(N, C, generator=g).to(d).to(dtype)
+    assert ops.gru_gates_ok(gi0, gh0, h0)
+    gi, gh, h = (t.clone().requires_grad_(True) for t in (gi0, gh0, h0))
+    hn, out = ops.gru_gates(gi, gh, h)
+    assert hn.dtype == torch.float32 and out.dtype == dtype and out.shape == hn.shape
+    ((hn * w1).sum() + (out.float() * w2.float()).sum()).backward()
+    gir, ghr, hr = (t.clone().float().requires_grad_(True) for t in (gi0, gh0, h0))
+    i_r, i_z, i_n = gir.chunk(3, dim=1)
+    h_r, h_z, h_n = ghr.chunk(3, dim=1)
+    r = torch.sigmoid(i_r + h_r); z = torch.sigmoid(i_z + h_z); n = torch.tanh(i_n + r * h_n)
+    ref = n + z * (hr - n)
+    ref_out = ref.to(dtype)
+    ((ref * w1).sum() + (ref_out.float() * w2.float()).sum()).backward()
+    close(hn, ref, 2e-6, 2e-6)
+    assert torch.equal(out, hn.to(dtype))
+    tol = (2e-5, 2e-5) if dtype == torch.float32 else (1e-2, 1e-2)          # (bf16: d gi / d gh are rounded once on the way out)
+    close(gi.grad, gir.grad, *tol)
+    close(gh.grad, ghr.grad, *tol)
+    close(h.grad, hr.grad, 2e-5, 2e-5)
+    if dtype == torch.float32:
+        torch.manual_seed(C)
+        gru = torch.nn.GRU(C, C).to(d)
+        x = torch.randn(N, C, generator=g).to(d).requires_grad_(True)
+        hs = h0.clone().requires_grad_(True)
+        o_ref = gru(x.unsqueeze(0), hs.unsqueeze(0))[1].squeeze(0)
+        g_ref = torch.autograd.grad((o_ref * w1).sum(), [x, hs] + list(gru.parameters()))
+        o, o2 = gru_step(gru, x, hs)
+        assert o2 is o
+        g_hip = torch.autograd.grad((o * w1).sum(), [x, hs] + list(gru.parameters()))
+        close(o, o_ref, 1e-5, 1e-5)
+        for a, b in zip(g_hip, g_ref):
+            close(a, b, 1e-4, 1e-4)
+
+
 @pytest.mark.parametrize("N,K,M", [(1500, 100, 10000), (1024, 64, 641), (2077, 160, 1000), (4099, 24, 2400), (1100, 100, 192)])
 def test_wide_output_dense_layer_matches_the_library_product(N, K, M):
     """mdl_linear_wide (ops.matmul_wide: NNConv's Y = x W2r — thousands of output columns in 192-column blocks per workgroup)

@@ -716,7 +716,8 @@ def test_written_out_gru_step_is_torch_gru():
     assert torch.equal(out_ref.squeeze(0), h_ref.squeeze(0))
     w = torch.randn(n, c)
     g_ref = torch.autograd.grad((h_ref.squeeze(0) * w).sum(), [x, h] + list(gru.parameters()))
-    out = gru_step(gru, x, h)
+    out, out_cd = gru_step(gru, x, h)                  # (the state, and the state in the compute dtype: the same values in fp32)
+    assert torch.equal(out, out_cd)
     g = torch.autograd.grad((out * w).sum(), [x, h] + list(gru.parameters()))
     assert torch.allclose(out, h_ref.squeeze(0), rtol=1e-5, atol=1e-6)
     for a, b in zip(g, g_ref):
