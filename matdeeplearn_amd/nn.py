@@ -320,9 +320,16 @@ class NNConv(nn.Module):
             w2 = last.weight.view(ci, co * d3).to(x.dtype)
             Y = ops.matmul_wide(x, w2)                                    # [N, C_out*d3]: the only large dense product
             m = ops.nnconv_msg(Y, hdn.to(x.dtype), csr, co)
-            if last.bias is not None:
+            linear_aggr = self.aggr in ("mean", "add", "sum")
+            if last.bias is not None and not linear_aggr:
                 m = m + ops.gather(x @ last.bias.view(ci, co).to(x.dtype), csr.row)
             out = ops.scatter(m, csr.col, 0, x.shape[0], self.aggr)
+            if last.bias is not None and linear_aggr:
+                # the bias of the edge network's last layer contributes x_j B2 (B2 = bias.view(C_in, C_out)) to every message: a
+                # per-NODE row gathered by source.  Sum and mean distribute over it, so it is aggregated on its own — K4a reads the
+                # [N, C_out] rows per edge from L2 — instead of as an [E, C_out] gather + add in front of the scatter (and a
+                # by-source segment sum + an [E, C_out] gradient copy behind it): ~90 us per layer at cfg5's 8e5 edges
+                out = out + ops.gather_mul_reduce(x @ last.bias.view(ci, co).to(x.dtype), csr, reduce=self.aggr)
             if self.lin is not None:
                 out = out + _lin(self.lin, x)
             if self.bias is not None:
