@@ -671,6 +671,13 @@ class DeviceLoader:
         n = len(self.indices) if self.world_size == 1 else -(-len(self.indices) // self.world_size)
         return -(-n // self.batch_size)
 
+    def batch_ids(self):
+        """The epoch's batches as graph-id arrays, in the order __iter__ assembles them (training.GraphedStep takes ids: it
+        assembles the batch inside its captured step)."""
+        idx = self._order()
+        for i in range(0, len(idx), self.batch_size):
+            yield idx[i:i + self.batch_size]
+
     def __iter__(self):
         idx = self._order()
         starts = list(range(0, len(idx), self.batch_size))

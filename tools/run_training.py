@@ -43,11 +43,15 @@ def main():
     ap.add_argument("--data", default="pt10")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--epochs", type=int, default=None)
+    ap.add_argument("--graph-replay", default=None, choices=["auto", "True", "False"],
+                    help="Training.graph_replay: run the training steps as HIP-graph replays (auto: for small batches)")
     a = ap.parse_args()
     job, processing, training, mp = load_config(a.config, "Training", a.model)
     if a.epochs:
         mp["epochs"] = a.epochs
     mp["compute_dtype"] = a.dtype
+    if a.graph_replay:
+        training["graph_replay"] = a.graph_replay
     ds = load_dataset(a.data, processing).to("cuda")
     edge_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     out = train_regular("cuda", 1, ds, job, training, mp, edge_dtype=edge_dtype)
@@ -55,7 +59,9 @@ def main():
     edges = sum(x.get("edges", 0) for x in h[1:])
     secs = sum(x["time"] for x in h[1:])
     if secs > 0:
-        print("train edges/s (epochs 2..): %.3e" % (edges / secs))
+        steps = sum(-(-x.get("graphs", 0) // mp.get("batch_size", 100)) for x in h[1:])
+        print("train edges/s (epochs 2..): %.3e   %.3f ms per step incl. validation (%d steps, %s)"
+              % (edges / secs, secs / max(steps, 1) * 1e3, steps, "replayed" if "replays" in h[-1] else "eager"))
 
 
 if __name__ == "__main__":
