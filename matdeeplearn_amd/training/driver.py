@@ -88,7 +88,7 @@ def graph_replay_wanted(mode, dataset, model, train_loader, rbf, distributed, op
     optional `graph_replay` key: "True" / "False" / "auto" (default).  auto = a single-process job on a HIP-resident dataset with
     the kernel RBF expansion, one of this package's models, an Adam-family optimizer, a fused loss, and batches small enough for
     the host to be the bottleneck (< 4e5 edges per batch: the reference's batch_size 100 is 3e4) — at the bench batch the eager
-    step is device-bound and the padded replay 1-2 % slower."""
+    step is device-bound and the padded replay 1-2 % slower; models that pool with Set2Set stay eager."""
     mode = str(mode)
     if mode == "False" or train_loader is None:
         return False
@@ -104,6 +104,8 @@ def graph_replay_wanted(mode, dataset, model, train_loader, rbf, distributed, op
         return True
     if not ok or distributed:
         return False
+    if getattr(model, "pool", None) == "set2set":
+        return False        # (Set2Set runs torch's LSTM through the library's RNN path: not captured by default; "True" tries it)
     idx = np.asarray(train_loader.indices)
     mean_edges = float((np.asarray(dataset.edge_ptr)[idx + 1] - np.asarray(dataset.edge_ptr)[idx]).mean())
     return mean_edges * train_loader.batch_size < 4e5
