@@ -727,16 +727,16 @@ class _CGConvFn(torch.autograd.Function):
             Ck = 128
             x = torch.nn.functional.pad(x, (0, Ck - C))
         wn_t = None
-        if packed is not None and packed[3] == (C, G, dt) and Ck == C:
+        if packed is not None and packed[3] == (C, G, dt):
             wpack, bpack, wn_t = packed[:3]               # packed with the model's other layers (cgconv_prepack): no launch here
         else:
             wpack = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             bpack = torch.empty(2 * _rup(C, 32), dtype=torch.float32, device=x.device)
         # a training step on the K3c shapes packs the backward node kernel's operand in the same launch
-        if packed is not None and packed[3] == (C, G, dt) and Ck == C:
+        if packed is not None and packed[3] == (C, G, dt):
             pass
-        elif dt == _lib.MDL_BF16 and C in (32, 64) and any(ctx.needs_input_grad):
-            wn_t = torch.empty((C, 4 * C), dtype=torch.bfloat16, device=x.device)
+        elif dt == _lib.MDL_BF16 and (C in (32, 64) or Ck == 128) and any(ctx.needs_input_grad):
+            wn_t = torch.empty((C, 4 * _rup(C, 32)), dtype=torch.bfloat16, device=x.device)
             check(L.mdl_cgconv_pack_weights_node(ptr(wf32), ptr(bf32), ptr(ws32), ptr(bs32), C, G, ptr(wpack), ptr(bpack),
                                                  ptr(wn_t), dt, stream()), "mdl_cgconv_pack_weights_node")
         else:
@@ -841,12 +841,16 @@ class _CGConvFn(torch.autograd.Function):
             # launches (128 rows each) into the [4 Cp, C] layout mdl_cgconv_assemble_grads reads — the library's
             # (4C x N)(N x C) form of that contraction ran 531 us per layer on a 64x64x256 macro tile
             rs_b = r_src.to(torch.bfloat16)
-            wt = torch.zeros((2 * Cp, C), dtype=torch.float32, device=x.device)
-            wsrc = torch.zeros_like(wt)
-            wt[:C], wt[Cp:Cp + C] = wf32[:, :C], ws32[:, :C]
-            wsrc[:C], wsrc[Cp:Cp + C] = wf32[:, C:2 * C], ws32[:, C:2 * C]
-            dx = torch.addmm(g, r_tgt, wt.to(torch.bfloat16))
-            dx.addmm_(rs_b, wsrc.to(torch.bfloat16))
+            # Wn^T [C, 4 Cp] (columns f_tgt | s_tgt | f_src | s_src, zero-padded to Cp each) comes packed with the forward's weights
+            # (one launch for all layers: cgconv_prepack) — round 6; before, the two zero-padded operands were built here with
+            # eight fill / slice-copy / cast launches per layer
+            wn_t, ctx.wn_t = getattr(ctx, "wn_t", None), None
+            if wn_t is None:
+                wn_t = torch.empty((C, 4 * Cp), dtype=torch.bfloat16, device=x.device)
+                check(lib().mdl_cgconv_pack_node_weights(ptr(wf32), ptr(ws32), C, G, ptr(wn_t), dt, stream()),
+                      "mdl_cgconv_pack_node_weights")
+            dx = torch.addmm(g, r_tgt, wn_t[:, :2 * Cp].t())
+            dx.addmm_(rs_b, wn_t[:, 2 * Cp:].t())
             xc = x.contiguous()
             for blk, r in enumerate((r_tgt[:, :Cp], r_tgt[:, Cp:], rs_b[:, :Cp], rs_b[:, Cp:])):
                 check(_gemm_tn(r, r.stride(0), Cp, None, 0, 0, xc, xc.stride(0), C, dwn[blk * Cp:(blk + 1) * Cp], None, N, dt | fl,
@@ -885,7 +889,7 @@ def cgconv_prepack(convs, x_dtype, device, want_node=True):
     if any(c.channels != C or c.dim != G or c.lin_f.weight.dtype != torch.float32 or not c.lin_f.weight.is_contiguous()
            or not c.lin_s.weight.is_contiguous() or (c.lin_f.bias is None) != (convs[0].lin_f.bias is None) for c in convs):
         return None
-    if not (dt == _lib.MDL_BF16 and C in (32, 64)):
+    if not (dt == _lib.MDL_BF16 and (C in (32, 64) or (_PAD128 and G == 50 and 96 < C < 128))):
         return None
     L = lib()
     nbytes = L.mdl_cgconv_wpack_bytes(C, G, dt)
@@ -894,7 +898,7 @@ def cgconv_prepack(convs, x_dtype, device, want_node=True):
     n = len(convs)
     wbuf = torch.empty((n, nbytes), dtype=torch.uint8, device=device)
     bbuf = torch.empty((n, 2 * _rup(C, 32)), dtype=torch.float32, device=device)
-    nbuf = torch.empty((n, C, 4 * C), dtype=torch.bfloat16, device=device) if want_node else None
+    nbuf = torch.empty((n, C, 4 * _rup(C, 32)), dtype=torch.bfloat16, device=device) if want_node else None
     tab = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
     has_b = convs[0].lin_f.bias is not None
     check(L.mdl_cgconv_pack_weights_multi(

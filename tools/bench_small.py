@@ -13,12 +13,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=100)
 ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--graphs", type=int, default=4096)
+ap.add_argument("--dim", type=int, default=64, help="dim1 (100 = the reference's default width, config.yml:123)")
+ap.add_argument("--dim2", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ds = synthetic_bulk(a.graphs, seed=0).to(dev)
 rng = np.random.default_rng(0)
 torch.manual_seed(0)
-m = models.CGCNN(ds, dim1=64, dim2=64, gc_count=4, post_fc_count=3, compute_dtype="bf16").to(dev)
+m = models.CGCNN(ds, dim1=a.dim, dim2=a.dim2 or a.dim, gc_count=4, post_fc_count=3, compute_dtype="bf16").to(dev)
 o = make_optimizer(m.parameters(), "AdamW", lr=0.002, capturable=True)
 gs = GraphedStep(ds, m, o, a.batch, compute_dtype=torch.bfloat16)
 ids = [rng.choice(len(ds), size=a.batch, replace=False) for _ in range(64)]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which torch-level operations (not HIP-library kernels) a model's training step still launches, with input shapes and device time:
-torch.profiler over a few steps of a bench workload.  usage: python tools/glue_profile.py megnet|mpnn|schnet|gcn|cgcnn [batch]"""
+torch.profiler over a few steps of a bench workload.  usage: python tools/glue_profile.py megnet|mpnn|schnet|gcn|cgcnn [batch [dim1 dim2]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,6 +16,8 @@ dev = torch.device("cuda:0")
 ds = getattr(process, gen_name)(min(n_graphs, 4 * B), seed=0).to(dev)
 torch.manual_seed(0)
 kw = dict(mkw or dict(dim1=64, dim2=64, gc_count=4, post_fc_count=3))
+if len(sys.argv) > 4:
+    kw.update(dim1=int(sys.argv[3]), dim2=int(sys.argv[4]))
 m = getattr(models, cls_name)(ds, compute_dtype="bf16", **kw).to(dev)
 opt = make_optimizer(m.parameters(), "AdamW", lr=0.002)
 rng = np.random.default_rng(0)
@@ -48,5 +50,5 @@ for e in prof.key_averages(group_by_input_shape=True):
         rows.append((t / 3.0, e.count / 3.0, e.key, str(e.input_shapes)[:110]))
 rows.sort(reverse=True)
 print("%-9s %-7s %-42s %s" % ("us/step", "n/step", "op", "input shapes"))
-for t, n, k, sh in rows[:45]:
+for t, n, k, sh in rows[:int(os.environ.get("GLUE_ROWS", "45"))]:
     print("%9.1f %7.1f %-42s %s" % (t, n, k[:42], sh))

@@ -3,7 +3,7 @@
 set -u
 TAG=${1:-small_trace}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/p -o t -- python $GRAFT_REPO_ROOT/tools/bench_small.py --steps 40 > $OUT/run.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/p -o t -- python $GRAFT_REPO_ROOT/tools/bench_small.py --steps 40 ${SMALL_ARGS:-} > $OUT/run.log 2>&1
 f=$(find $OUT/p -name "*kernel_trace.csv" | head -1)
 python - "$f" > $OUT/small_trace.txt <<'PY'
 import csv, sys
