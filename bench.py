@@ -693,6 +693,32 @@ def main():
                                          "ms_per_step": res["ref_batch_100"]["eager"]["ms_per_step"], "mode": "eager",
                                          "graph_error": repr(exc)[:300]})
 
+        # ... and through the reference's own job entry (training.train_regular = training.py:377-539: epochs, validation, scheduler):
+        # the step replays by itself at this batch size (Training.graph_replay: auto); the eager job beside it
+        if args.model == "cgcnn" and args.dtype == "bf16":
+            try:
+                from matdeeplearn_amd.training import train_regular
+                sub = np.asarray(tr_idx)[:4096 + 512]
+                tjob = dict(job_name="bench", seed=args.seed, save_model="False", write_output="False")
+                tmp = dict(model="CGCNN", epochs=4, lr=0.002, batch_size=rb, optimizer="AdamW", optimizer_args={},
+                           scheduler="ReduceLROnPlateau", scheduler_args={"mode": "min", "factor": 0.8, "patience": 10},
+                           compute_dtype="bf16", **{k: v for k, v in mkw.items()})
+                splits = (sub[:4096], sub[4096:4096 + 256], sub[4096 + 256:])
+                thr = {}
+                for mode in ("auto", "False"):
+                    ttr = dict(target_index=int(getattr(ds, "target_index", 0)), loss="l1_loss", train_ratio=0.8, val_ratio=0.05,
+                               test_ratio=0.15, verbosity=0, graph_replay=mode)
+                    r = train_regular("cuda", 1, ds, tjob, ttr, tmp, splits=splits, edge_dtype=cdt, log=lambda *a: None)
+                    h = r["history"][1:]
+                    secs, st = sum(x["time"] for x in h), sum(-(-x["graphs"] // rb) for x in h)
+                    thr[mode] = {"ms_per_step_incl_validation": round(secs / max(st, 1) * 1e3, 4), "steps": st,
+                                 "value": round(sum(x["edges"] for x in h) / max(secs, 1e-9), 1), "unit": "edges/s",
+                                 "mode": "hip-graph replay" if "replays" in h[-1] else "eager", "train_error": round(h[-1]["train"], 5)}
+                res["ref_batch_100"]["through_train_regular"] = {"graph_replay_auto": thr["auto"], "graph_replay_off": thr["False"],
+                                                                 "train_graphs": 4096, "val_graphs": 256, "epochs_timed": 3}
+            except Exception as exc:
+                res["ref_batch_100"]["through_train_regular"] = {"error": repr(exc)[:300]}
+
     # ---- the parity modes: same model, same batches, compute_dtype fp32 (exact products) and — CGCNN, whose conv kernels have
     # the form — bf16x3 (fp32 storage, the conv products as three bf16 MFMAs on (hi, lo)-split operands) ---------------------
     if world == 1 and args.dtype == "bf16" and (args.fp32_leg or not args.no_extras):
