@@ -148,14 +148,87 @@ class GraphedStep:
             self.dp.reduce_grads()
         self.opt.step()
 
+    def _stale_lowp(self):
+        """The captured optimizer step rewrites the parameters without Python noticing (no version counter moves on a replay), so
+        the per-layer bf16 copies that the captured forward made at the START of the step would still pass for current: drop the
+        record — an eager forward behind a replay (validation, the final evaluation of a job) casts the masters itself."""
+        for lin in getattr(self.model, "_dense_layers", None) or ():
+            lin._mdl_lowp = None
+
     def _replay(self):
         self.graph.replay()
         self._bump_bn(1)
         self.replays += 1
+        if self.opt_in_graph:
+            self._stale_lowp()
         if not self.opt_in_graph:
             for p, g in zip(self.params, self.static_grads):       # the graph writes into ITS gradient tensors
                 p.grad = g
             self._finish_eager()
+
+    # ---- forward-only evaluation on the same static buffers (validation between the epochs) ------------------------------
+    def _eval_body(self):
+        sb = self.sb
+        batch = sb.assemble()
+        with torch.no_grad(), ops.true_rows(batch.true_rows), ops.zero_arena(self.dev):
+            # (the bf16 copies of the dense weights are refreshed by the TRAINING forward, i.e. they predate the last optimizer step:
+            # the evaluation casts the current masters itself)
+            if self.cdt == torch.bfloat16 and hasattr(self.model, "_cast_dense"):
+                self.model._cast_dense(self.cdt)
+            out = self.model(batch)
+            if out.dim() == 1 and out.dtype == torch.float32:
+                ops.loss(self.loss_name, out, sb.y, rows=self.B, buf=self._eval_buf)
+            else:
+                self._eval_buf[0].copy_(getattr(F, self.loss_name)(out[:self.B].float(), sb.y.view_as(out[:self.B])))
+
+    def capture_eval(self, ids):
+        """Capture the forward-only step (eval mode: BatchNorm on its running statistics, no dropout)."""
+        self._eval_buf = torch.zeros(2 + self.B + 1, dtype=torch.float32, device=self.dev)
+        was = self.model.training
+        self.model.eval()
+        for m in self.bn_layers:                                   # (the host-side step counters reach their buffers OUTSIDE the capture)
+            m._sync_counter()
+        prev = ops.NO_INDEX_CACHE
+        ops.NO_INDEX_CACHE = True
+        try:
+            self.sb.load(ids)
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._eval_body()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            torch.cuda.synchronize(self.dev)
+            self.eval_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.eval_graph, capture_error_mode="thread_local"):
+                self._eval_body()
+        finally:
+            ops.NO_INDEX_CACHE = prev
+            self.model.train(was)
+        return self
+
+    def eval_loss(self, ids):
+        """Mean loss of the graphs `ids` under the current weights in eval mode, as a device scalar that stays valid until the next
+        call (a view of the evaluation's persistent buffer): ONE replay for a full batch that fits the static capacity, the eager
+        forward otherwise.  The model is left in the mode it was in."""
+        if self.sb.fits(ids):
+            if getattr(self, "eval_graph", None) is None:
+                self.capture_eval(ids)
+            for m in self.bn_layers:
+                m._sync_counter()
+            self.sb.load(ids)
+            self.eval_graph.replay()
+            self.eval_replays = getattr(self, "eval_replays", 0) + 1
+            return self._eval_buf[0]
+        was = self.model.training
+        self.model.eval()
+        try:
+            with torch.no_grad():
+                batch = self.ds.collate(ids, edge_dtype=self.cdt, x_dtype=self.cdt)
+                out = self.model(batch)
+                return getattr(F, self.loss_name)(out, batch.y.view_as(out))
+        finally:
+            self.model.train(was)
 
     # ---- public step ------------------------------------------------------------------------------------------------
     def step(self, ids):

@@ -115,6 +115,17 @@ def train(model, optimizer, loader, loss_method, rank=None, dp=None, stats=None,
     return loss_all / max(count, 1)
 
 
+def evaluate_graphed(loader, graphed):
+    """evaluate(loader, model, loss) for the trainer's validation pass with the forward-only step replayed (training.GraphedStep.
+    eval_loss): the sample-weighted mean loss as a device scalar.  No rows of predictions — the final evaluation of a job, which
+    writes them, stays eager."""
+    loss_all, count = 0, 0
+    for ids in loader.batch_ids():
+        loss_all = loss_all + graphed.eval_loss(ids) * len(ids)
+        count += len(ids)
+    return loss_all / max(count, 1)
+
+
 def evaluate(loader, model, loss_method, rank=None, out=False, sharded=False):
     """Eval-mode pass; with out=True also returns rows (id, target, prediction) like training.py:68-90.
     sharded=True (every rank of the process group calls it on ITS shard of the split, loader may be None for an empty shard):
@@ -185,7 +196,10 @@ def trainer(rank, world_size, model, optimizer, scheduler, loss, train_loader, v
             val_error = evaluate(val_loader, model, loss, rank=rank, sharded=True)
             val_error = None if val_error is None else float(val_error)
         elif val_loader is not None and (not distributed or dist.get_rank() == 0):
-            val_error = float(evaluate(val_loader, model, loss, rank=rank))
+            if graphed is not None and not distributed and hasattr(val_loader, "batch_ids"):
+                val_error = float(evaluate_graphed(val_loader, graphed))
+            else:
+                val_error = float(evaluate(val_loader, model, loss, rank=rank))
         if val_error is not None:
             if val_error < best_val:                            # training.py:144-166 (NaN never passes)
                 best_val = val_error

@@ -71,6 +71,56 @@ def test_train_regular_replays_the_step_at_small_batches_and_matches_the_eager_j
         train_regular("cuda", 1, _pt10().to("cuda"), job, dict(training, graph_replay="True"), dict(mp, optimizer="SGD"), log=quiet, edge_dtype=ed)
 
 
+@pytest.mark.parametrize("name", ["CGCNN", "SchNet", "MEGNet"])
+def test_evaluation_behind_replayed_steps_sees_the_current_weights_and_replays_too(name):
+    """(a) The captured optimizer step rewrites the parameters without moving a version counter: an EAGER forward behind replays
+    must not reuse the bf16 weight copies the captured forward made before that step (GraphedStep drops their record).
+    (b) GraphedStep.eval_loss — the forward-only step in eval mode as ONE replay, what train_regular's validation runs — equals the
+    eager evaluation of the same graphs, before and after more training steps; a ragged batch takes the eager path."""
+    import torch.nn.functional as F
+    from matdeeplearn_amd import models
+    from matdeeplearn_amd.process import synthetic_bulk
+    from matdeeplearn_amd.training import GraphedStep, make_optimizer
+    d = torch.device("cuda")
+    ds = synthetic_bulk(256, seed=3).to(d)
+    torch.manual_seed(0)
+    kw = dict(dim1=64, dim2=64, gc_count=2, post_fc_count=2, compute_dtype="bf16")
+    if name != "CGCNN":
+        kw.update(dim3=64)
+    m = getattr(models, name)(ds, **kw).to(d)
+    opt = make_optimizer(m.parameters(), "AdamW", lr=0.01, capturable=True)
+    B = 24
+    gs = GraphedStep(ds, m, opt, B, compute_dtype=torch.bfloat16)
+    rng = np.random.default_rng(1)
+    ids_eval = rng.choice(256, size=B, replace=False)
+
+    def eager_eval(ids):
+        m.eval()
+        with torch.no_grad():
+            b = ds.collate(ids, edge_dtype=torch.bfloat16, x_dtype=torch.bfloat16)
+            out = m(b)
+            loss = F.l1_loss(out, b.y.view_as(out))
+        m.train()
+        return out.clone(), float(loss)
+
+    for rnd in range(2):
+        for _ in range(4):
+            gs.step(rng.choice(256, size=B, replace=False))
+        assert gs.replays >= 4 * (rnd + 1) - 1
+        out_a, loss_a = eager_eval(ids_eval)
+        for lin in m._dense_layers:                            # what a correct cache policy must make redundant
+            lin._mdl_lowp = None
+        out_b, loss_b = eager_eval(ids_eval)
+        assert torch.equal(out_a, out_b), "an eager forward behind replayed steps used stale bf16 weight copies"
+        loss_g = float(gs.eval_loss(ids_eval))
+        assert abs(loss_g - loss_a) <= 2e-3 * max(1.0, abs(loss_a)), (loss_g, loss_a)
+        assert m.training
+    assert gs.eval_replays == 2
+    ragged = ids_eval[:B - 5]
+    assert abs(float(gs.eval_loss(ragged)) - eager_eval(ragged)[1]) <= 1e-6 * max(1.0, abs(eager_eval(ragged)[1]))
+    assert gs.eval_replays == 2
+
+
 def test_bf16_models_train_finite():
     from matdeeplearn_amd import models
     from matdeeplearn_amd.process import synthetic_bulk
