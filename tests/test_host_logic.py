@@ -515,6 +515,38 @@ def test_drivers_regular_cv_ensemble_predict(pt10, tmp_path, monkeypatch):
     assert rep["errors"].shape == (2, 3)
 
 
+def test_graph_replay_key_off_the_device_and_loader_batch_ids(pt10):
+    """Training.graph_replay (driver.graph_replay_wanted): a dataset that is not resident on a HIP device never replays in auto
+    mode — the CPU jobs of this suite stay what they were — and "True" says why it cannot instead of falling back silently;
+    DeviceLoader.batch_ids() hands out the id batches in the order __iter__ assembles them (shuffled per epoch, rank-sharded)."""
+    from matdeeplearn_amd.process import DeviceLoader
+    from matdeeplearn_amd.training import train_regular
+    from matdeeplearn_amd.training.driver import graph_replay_wanted
+    from oracle import ops as oops
+    ld = DeviceLoader(pt10, np.arange(150), 40, shuffle=True, seed=3, rbf=lambda d: oops.rbf_expand(d))
+    model = _oracle_factory("CGCNN")(data=pt10, dim1=8, dim2=8, gc_count=1, post_fc_count=1)
+    for mode in ("auto", "False"):
+        assert graph_replay_wanted(mode, pt10, model, ld, None, False, "AdamW", "l1_loss") is False
+    with pytest.raises(ValueError):
+        graph_replay_wanted("True", pt10, model, ld, None, False, "AdamW", "l1_loss")
+    training = dict(target_index=0, loss="l1_loss", train_ratio=0.8, val_ratio=0.05, test_ratio=0.15, verbosity=0, graph_replay="True")
+    mp = dict(model="CGCNN", dim1=8, dim2=8, gc_count=1, post_fc_count=1, epochs=1, lr=0.005, batch_size=50, optimizer="AdamW",
+              optimizer_args={}, scheduler="ReduceLROnPlateau", scheduler_args={"mode": "min", "factor": 0.8, "patience": 10})
+    with pytest.raises(ValueError):
+        train_regular("cpu", 1, pt10, dict(job_name="t", seed=1, save_model="False", write_output="False"), training, mp,
+                      model_factory=_oracle_factory, rbf=lambda d: oops.rbf_expand(d), log=lambda *a: None)
+    for epoch in (0, 1):
+        ld.set_epoch(epoch)
+        got = [ids.tolist() for ids in ld.batch_ids()]
+        assert [len(g) for g in got] == [40, 40, 40, 30] and sorted(sum(got, [])) == list(range(150))
+        ys = np.asarray(pt10.y)[:, 0]
+        for ids, b in zip(got, ld):                                  # the assembled batches hold exactly these graphs, in this order
+            assert np.array_equal(np.asarray(b.y).reshape(-1), ys[np.asarray(ids)])
+    ld2 = [DeviceLoader(pt10, np.arange(150), 40, shuffle=True, seed=3, rank=r, world_size=2) for r in (0, 1)]
+    parts = [sum((ids.tolist() for ids in l.batch_ids()), []) for l in ld2]
+    assert len(parts[0]) == len(parts[1]) == 75 and sorted(parts[0] + parts[1]) == list(range(150))
+
+
 def test_load_reference_style_config(tmp_path):
     from matdeeplearn_amd.training import load_config
     cfg = tmp_path / "config.yml"
