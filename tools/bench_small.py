@@ -15,12 +15,18 @@ ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--graphs", type=int, default=4096)
 ap.add_argument("--dim", type=int, default=64, help="dim1 (100 = the reference's default width, config.yml:123)")
 ap.add_argument("--dim2", type=int, default=0)
+ap.add_argument("--model", default="CGCNN", help="CGCNN | SchNet | MEGNet | GCN | MPNN with the reference's *_demo widths (dim 100)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ds = synthetic_bulk(a.graphs, seed=0).to(dev)
 rng = np.random.default_rng(0)
 torch.manual_seed(0)
-m = models.CGCNN(ds, dim1=a.dim, dim2=a.dim2 or a.dim, gc_count=4, post_fc_count=3, compute_dtype="bf16").to(dev)
+if a.model == "CGCNN":
+    m = models.CGCNN(ds, dim1=a.dim, dim2=a.dim2 or a.dim, gc_count=4, post_fc_count=3, compute_dtype="bf16").to(dev)
+else:
+    kw = {"SchNet": dict(dim1=100, dim2=100, dim3=150, cutoff=8), "MEGNet": dict(dim1=100, dim2=100, dim3=100, gc_fc_count=1),
+          "GCN": dict(dim1=100, dim2=150), "MPNN": dict(dim1=100, dim2=100, dim3=100)}[a.model]
+    m = getattr(models, a.model)(ds, pre_fc_count=1, gc_count=4, post_fc_count=3, compute_dtype="bf16", **kw).to(dev)
 o = make_optimizer(m.parameters(), "AdamW", lr=0.002, capturable=True)
 gs = GraphedStep(ds, m, o, a.batch, compute_dtype=torch.bfloat16)
 ids = [rng.choice(len(ds), size=a.batch, replace=False) for _ in range(64)]

@@ -17,7 +17,7 @@ prev_end = t0
 print("step of %d launches, %.1f us from first start to next step's first start" % (b - a, (int(rows[b]["Start_Timestamp"]) - t0) / 1e3))
 for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print("%8.1f  +gap %6.1f  dur %6.1f  q%s  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?"), r["Kernel_Name"][:110]))
+    print("%8.1f  +gap %6.1f  dur %6.1f  q%s  g%s  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?"), r.get("Grid_Size", r.get("Grid_Size_X", "?")), r["Kernel_Name"][:110]))
     prev_end = max(prev_end, e)
 PY
 rm -rf $OUT/p
