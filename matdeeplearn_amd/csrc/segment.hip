@@ -7,6 +7,10 @@
 // Algorithmic bytes: E*C*s (read) + N*C*s (write) + 4*(N+1).
 #include "mdl_common.h"
 
+#ifndef MDL_SEG_SMALL
+#define MDL_SEG_SMALL 1      // 0: the lane-group kernel for every size (A/B)
+#endif
+
 namespace mdl {
 
 __global__ __launch_bounds__(256) void csr_rowptr_kernel(const int32_t* __restrict__ idx, int64_t E, int64_t N,
@@ -136,6 +140,53 @@ __global__ __launch_bounds__(256) void seg_fwd_vec_kernel(const T* __restrict__ 
     }
 }
 
+// FEW segments (a batch of ~100 graphs pooled to graph rows, the reference's batch size: config.yml:136): with one lane group per
+// (segment, channel group) the launch is a few thousand threads that each walk their segment's rows as a chain of memory round
+// trips (13 for a graph of 26 nodes, 160 for a graph's 330 edges).  Here a WORKGROUP owns a segment: 256 / CG row lanes per
+// channel group take the rows b + r, b + r + RL, ... (two in flight each), the partial sums meet in LDS.  Same sums in another order.
+template <typename T, int REDUCE, int W>
+__global__ __launch_bounds__(256) void seg_fwd_small_kernel(const T* __restrict__ src, const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ perm, T* __restrict__ out, int CG) {
+    typedef VecW<T, W> V;
+    __shared__ float red[256 * W];
+    const int n = blockIdx.x, t = threadIdx.x;
+    const int RL = 256 / CG;                                   // CG <= 256
+    const int cg = t % CG, r = t / CG;
+    const int b = rowptr[n], e = rowptr[n + 1];
+    float acc[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) acc[q] = 0.0f;
+    if (r < RL) {
+        const T* base = src + (int64_t)cg * W;
+        const int64_t ld = (int64_t)CG * W;
+        for (int k = b + r; k < e; k += 2 * RL) {
+            float v0[W], v1[W];
+            const int k1 = min(k + RL, e - 1);
+            V::ld(base + (int64_t)(perm ? perm[k] : k) * ld, v0);
+            V::ld(base + (int64_t)(perm ? perm[k1] : k1) * ld, v1);
+            const bool two = k + RL < e;
+#pragma unroll
+            for (int q = 0; q < W; ++q) acc[q] += v0[q] + (two ? v1[q] : 0.0f);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < W; ++q) red[t * W + q] = acc[q];
+    __syncthreads();
+    if (t < CG) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) acc[q] = 0.0f;
+        for (int j = 0; j < RL; ++j)
+#pragma unroll
+            for (int q = 0; q < W; ++q) acc[q] += red[(j * CG + t) * W + q];
+        if (REDUCE == MDL_MEAN) {
+            const float cnt = (float)max(e - b, 1);
+#pragma unroll
+            for (int q = 0; q < W; ++q) acc[q] = acc[q] / cnt;
+        }
+        V::st(out + ((int64_t)n * CG + t) * W, acc);
+    }
+}
+
 template <typename T, int REDUCE, int W>
 __global__ __launch_bounds__(256) void seg_bwd_vec_kernel(const T* __restrict__ go, const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ seg, const int32_t* __restrict__ perm,
@@ -192,6 +243,20 @@ static int seg_fwd(const T* src, const int32_t* rowptr, const int32_t* perm, T* 
         const int CG = (int)(C / vw);
         dim3 gv(grid_for(N * CG * 4)), bv(256);
         if (reduce != MDL_SUM && reduce != MDL_MEAN) { set_error("mdl_segment_reduce_fwd: bad reduce %d", reduce); return MDL_E_ARG; }
+        // few segments (fewer lane groups than the device has lanes for): a workgroup per segment (seg_fwd_small_kernel)
+        if (MDL_SEG_SMALL && N * CG < 65536 && N <= 65535 && CG <= 256) {
+            dim3 gs((unsigned)N);
+            if constexpr (sizeof(T) == 2) {
+                if (vw == 4) {
+                    if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_fwd_small_kernel<T, MDL_SUM, 4>), gs, bv, 0, st, src, rowptr, perm, out, CG);
+                    else hipLaunchKernelGGL((seg_fwd_small_kernel<T, MDL_MEAN, 4>), gs, bv, 0, st, src, rowptr, perm, out, CG);
+                    return check_launch("mdl_segment_reduce_fwd");
+                }
+            }
+            if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_fwd_small_kernel<T, MDL_SUM, Vec<T>::W>), gs, bv, 0, st, src, rowptr, perm, out, CG);
+            else hipLaunchKernelGGL((seg_fwd_small_kernel<T, MDL_MEAN, Vec<T>::W>), gs, bv, 0, st, src, rowptr, perm, out, CG);
+            return check_launch("mdl_segment_reduce_fwd");
+        }
         if constexpr (sizeof(T) == 2) {
             if (vw == 4) {
                 if (reduce == MDL_SUM) hipLaunchKernelGGL((seg_fwd_vec_kernel<T, MDL_SUM, 4>), gv, bv, 0, st, src, rowptr, perm, out, N, CG);
