@@ -138,7 +138,7 @@ def _seq(seq, h, pre=None):
         give = (fused and act in ("relu", "ssp") and nxt is not None and nxt[1] is not False and torch.is_grad_enabled()
                 and nxt[0].weight.requires_grad and nxt[0].in_features == m.out_features
                 and ops._hip_shape_ok(nxt[0].out_features, nxt[0].in_features)
-                and (nxt[1] != "ssp" or nxt[0].out_features % 2 == 0) and h.shape[0] >= 1024)
+                and (nxt[1] != "ssp" or nxt[0].out_features % 2 == 0) and h.shape[0] >= ops._DENSE_MIN_ROWS)
         prev_act = layers[j - 1][1] if handed else None
         if fused:
             h = _lin(m, h, act, in_act=prev_act, out_pre=give, pre=pre.pop(0) if pre else None)

@@ -537,6 +537,9 @@ _TNS = {}
 
 
 _TN_SCRATCH_MIN_ROWS = 32768
+# rows from which a bf16 dense layer (forward, dX, the one-pass backward, the TN weight gradient) takes the streaming HIP kernels
+# instead of the library's GEMMs
+_DENSE_MIN_ROWS = 64        # (1024 until round 6: at ~100 graph rows — the reference's batch size — the library's GEMMs cost 11-12 us each against 5-6)
 
 
 def _tn_scratch(device, rows=None):
@@ -1072,7 +1075,7 @@ def cfconv_fused_ok(rbf, h, csr, lin_a, lin_b):
         return False
     if torch.is_grad_enabled() and (lin_a.weight.requires_grad or lin_b.weight.requires_grad or h.requires_grad):
         # the autograd nodes this forward stands in for: _LinearActTN (ssp, derivative handed down) -> _LinearActTN -> K4a
-        return (linear_act_fused_ok(rbf, lin_a.weight, "ssp") and _hip_shape_ok(F, F) and rbf.shape[0] >= 1024
+        return (linear_act_fused_ok(rbf, lin_a.weight, "ssp") and _hip_shape_ok(F, F) and rbf.shape[0] >= _DENSE_MIN_ROWS
                 and lin_a.weight.requires_grad and lin_b.weight.requires_grad)
     return True
 
@@ -1259,7 +1262,7 @@ def _hip_shape_ok(M, K):
 
 def _dx_hip_ok(g, w):
     M, K = w.shape
-    return (g.dtype == torch.bfloat16 and g.is_cuda and g.shape[0] >= 1024 and g.is_contiguous() and g.data_ptr() % 16 == 0
+    return (g.dtype == torch.bfloat16 and g.is_cuda and g.shape[0] >= _DENSE_MIN_ROWS and g.is_contiguous() and g.data_ptr() % 16 == 0
             and _hip_shape_ok(K, M) and M % 2 == 0)
 
 
@@ -1292,7 +1295,7 @@ def _dense_bwd_ok(ctx, g, x, w, y=None):
     rows."""
     M, K = ctx.shape
     kb = K + (1 if ctx.has_bias else 0)
-    return (_DENSE_BWD and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16 and g.is_cuda and g.shape[0] >= 1024
+    return (_DENSE_BWD and ctx.needs_input_grad[0] and g.dtype == torch.bfloat16 and g.is_cuda and g.shape[0] >= _DENSE_MIN_ROWS
             and 34 <= M <= 160 and 34 <= K and kb <= 160 and M % 2 == 0 and K % 2 == 0 and (_DENSE_BWD_WIDE or not (M > 128 and kb > 128))
             and g.stride(1) == 1 and x.stride(1) == 1 and g.stride(0) % 2 == 0 and x.stride(0) % 2 == 0
             and g.data_ptr() % 4 == 0 and x.data_ptr() % 4 == 0 and w.is_contiguous() and w.dtype == torch.bfloat16
@@ -1629,7 +1632,7 @@ def linear_act_fused_ok(x, weight, act):
     """the fused dense layer (_LinearActTN) takes (x, weight, act)"""
     # (ssp: the one-pass softplus backward works on element PAIRS — an odd width would reach it with an odd element count)
     return (act in ("relu", "ssp", None) and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
-            and x.shape[0] >= 1024 and _hip_shape_ok(weight.shape[0], weight.shape[1])
+            and x.shape[0] >= _DENSE_MIN_ROWS and _hip_shape_ok(weight.shape[0], weight.shape[1])
             and (act != "ssp" or weight.shape[0] % 2 == 0)
             and x.data_ptr() % 16 == 0 and weight.requires_grad)
 
@@ -1697,7 +1700,7 @@ def linear_split_ok(x, weight):
 def linear(x, weight, bias, lowp=None):
     """F.linear in the dtype of x (fp32 master weights); bf16 inputs with many rows, out <= 128, in <= 256 take the
     HIP TN GEMM for dW, anything else the library autograd path.  `lowp` = (weight, bias) already cast to x.dtype."""
-    if (x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] >= 1024
+    if (x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] >= _DENSE_MIN_ROWS
             and (weight.shape[0] <= 128 or _hip_shape_ok(weight.shape[0], weight.shape[1]) or _tn_wide_out_ok(x, weight))
             and (weight.shape[1] <= 256 or _tn_split_ok(x, weight)) and weight.requires_grad):
         if lowp is not None and lowp[0].dtype == x.dtype:
@@ -2023,7 +2026,7 @@ def linear_relu_bn_ok(x, weight, has_bias, gathered=None):
     shapes (even widths in [34, 160], not both above 128), at most three gathered tables."""
     M, K = weight.shape
     kb = K + (1 if has_bias else 0)
-    return (_DENSE_BWD and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.shape[0] >= 1024
+    return (_DENSE_BWD and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.shape[0] >= _DENSE_MIN_ROWS
             and x.requires_grad and torch.is_grad_enabled() and weight.requires_grad
             and 34 <= M <= (128 if gathered else 160) and 34 <= K and kb <= 160 and M % 2 == 0 and K % 2 == 0
             and not (M > 128 and kb > 128) and M % 4 == 0 and x.data_ptr() % 16 == 0 and (gathered is None or len(gathered) <= 3))

@@ -7,7 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from matdeeplearn_amd import models
 from matdeeplearn_amd.process import synthetic_bulk
 from matdeeplearn_amd.training import GraphedStep, make_optimizer
-import _ab; _ab.apply()      # (tools/_ab.py: MDL_HIP_LIB / MDL_OPS of the A/B scripts -> explicit calls)
+import _ab; _ab.apply()
+if os.environ.get("MDL_DENSE_MIN_ROWS"):      # (tool-level A/B of ops._DENSE_MIN_ROWS)
+    from matdeeplearn_amd import ops as _ops
+    _ops._DENSE_MIN_ROWS = int(os.environ["MDL_DENSE_MIN_ROWS"])      # (tools/_ab.py: MDL_HIP_LIB / MDL_OPS of the A/B scripts -> explicit calls)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=100)
