@@ -536,7 +536,7 @@ _TN_SCRATCH = True     # partial sums of the streaming TN products through a scr
 _TNS = {}
 
 
-_TN_SCRATCH_MIN_ROWS = 32768
+_TN_SCRATCH_MIN_ROWS = 4096      # (measured, tools/bench_dense.py: atomics win at 2.6 k rows — 8.2 vs 10.8 us —, the scratch form from 8 k — 13.8 vs 17.8)
 # rows from which a bf16 dense layer (forward, dX, the one-pass backward, the TN weight gradient) takes the streaming HIP kernels
 # instead of the library's GEMMs
 _DENSE_MIN_ROWS = 64        # (1024 until round 6: at ~100 graph rows — the reference's batch size — the library's GEMMs cost 11-12 us each against 5-6)
